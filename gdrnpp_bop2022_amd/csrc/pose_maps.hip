@@ -1,0 +1,262 @@
+// Map-space kernels of the GDRNPP post-processing — SURVEY.md §8 rows a3.4, a3.5, a4, a6, a8.2, a13.
+//
+//   gdrnpp_decode_correspondences  engine_utils.py:295-333 (get_out_coor regression branch,
+//                                  get_out_mask L1 / BCE) + gdrn_evaluator.py:115-153
+//                                  (get_img_model_points_with_coords2d)
+//   gdrnpp_pose_from_pred_centroid_z
+//                                  rot_reps.py:34-55, pose_from_pred_centroid_z.py:56-154,
+//                                  core/utils/utils.py:31-75 (allocentric_to_egocentric) with
+//                                  transforms3d.axangles.axangle2mat restated
+//   gdrnpp_zoom_K                  camera_geometry.py:6-21 as called at engine_utils.py:260-264
+//   gdrnpp_pack_pose_records       fixed 64-byte record replacing the pickled dict list of
+//                                  gdrn_evaluator.py:636-665 for the all-gather (§8e)
+//
+// Selection masks / correspondence order are bit-exact: every compare uses the
+// same fp32 operands the NumPy code forms (NEP-50 float32 semantics for the
+// `0.0001*extent` and `mask>thr` scalars), IEEE division, no FMA.
+#include "common.hpp"
+#include <cfloat>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+// ---------------------------------------------------------------------------------------
+// decode + compaction: one workgroup per ROI.  Wave w owns the contiguous pixel range
+// [w*chunk, (w+1)*chunk); lane l of iteration k handles pixel w*chunk + 64k + l, so every
+// wave-level access is one coalesced 256-byte row.  Row-major order of the boolean-mask
+// gather is reproduced by ballot + popcount ranks with a 4-entry cross-wave scan.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void decode_corr_kernel(
+    const float* __restrict__ coor_x, const float* __restrict__ coor_y, const float* __restrict__ coor_z,
+    const float* __restrict__ mask_raw, const float* __restrict__ coord2d, const float* __restrict__ extent,
+    const float* __restrict__ imwh, float* __restrict__ out_mask, int* __restrict__ count,
+    int* __restrict__ sel_idx, float* __restrict__ img_pts, float* __restrict__ mdl_pts, int hw, int mask_type,
+    float mask_thr) {
+  __shared__ float s_min[kWaves], s_max[kWaves];
+  __shared__ int s_cnt[kWaves];
+  const int bi = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* cx = coor_x + (size_t)bi * hw;
+  const float* cy = coor_y + (size_t)bi * hw;
+  const float* cz = coor_z + (size_t)bi * hw;
+  const float* mk = mask_raw + (size_t)bi * hw;
+  const float* c2 = coord2d + (size_t)bi * 2 * hw;
+  const float e0 = extent[bi * 3], e1 = extent[bi * 3 + 1], e2 = extent[bi * 3 + 2];
+  const float imW = imwh[bi * 2], imH = imwh[bi * 2 + 1];
+
+  float mmin = 0.f, mden = 1.f;
+  if (mask_type == 0) {
+    float lo = FLT_MAX, hi = -FLT_MAX;
+    bool has_nan = false;
+    for (int i = threadIdx.x; i < hw; i += kThreads) {
+      float v = mk[i];
+      has_nan |= (v != v);
+      lo = fminf(lo, v);
+      hi = fmaxf(hi, v);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo = fminf(lo, __shfl_xor(lo, off, 64));
+      hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    }
+    const bool any_nan = __any(has_nan);
+    if (lane == 0) { s_min[wave] = any_nan ? NAN : lo; s_max[wave] = any_nan ? NAN : hi; }
+    __syncthreads();
+    lo = s_min[0]; hi = s_max[0];
+    for (int w = 1; w < kWaves; ++w) {  // torch.max/min propagate NaN
+      lo = (s_min[w] != s_min[w] || lo != lo) ? NAN : fminf(lo, s_min[w]);
+      hi = (s_max[w] != s_max[w] || hi != hi) ? NAN : fmaxf(hi, s_max[w]);
+    }
+    mmin = lo;
+    mden = hi - lo;  // no epsilon (engine_utils.py:325): constant map -> 0/0 = NaN -> nothing selected
+  }
+
+  const float t0 = 0.0001f * e0, t1 = 0.0001f * e1, t2 = 0.0001f * e2;
+  const int chunk = ((hw + kThreads - 1) / kThreads) * 64;  // pixels per wave, multiple of 64
+  const int begin = wave * chunk, end = min(hw, begin + chunk);
+
+  // pass 1: count
+  int my_cnt = 0;
+  for (int p0 = begin; p0 < end; p0 += 64) {
+    const int p = p0 + lane;
+    bool sel = false;
+    if (p < end) {
+      float m = mk[p];
+      if (mask_type == 0) m = (m - mmin) / mden;
+      else m = 1.f / (1.f + expf(-m));
+      if (out_mask) out_mask[(size_t)bi * hw + p] = m;
+      const float x = (cx[p] - 0.5f) * e0, y = (cy[p] - 0.5f) * e1, z = (cz[p] - 0.5f) * e2;
+      sel = (m > mask_thr) && (fabsf(x) > t0) && (fabsf(y) > t1) && (fabsf(z) > t2);
+    }
+    my_cnt += __popcll(__ballot(sel));
+  }
+  if (lane == 0) s_cnt[wave] = my_cnt;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < kWaves; ++w) {
+    if (w < wave) base += s_cnt[w];
+    total += s_cnt[w];
+  }
+  if (threadIdx.x == 0) count[bi] = total;
+
+  // pass 2: ranks + scatter (same arithmetic as pass 1; inputs come from L1/L2)
+  for (int p0 = begin; p0 < end; p0 += 64) {
+    const int p = p0 + lane;
+    bool sel = false;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (p < end) {
+      float m = mk[p];
+      if (mask_type == 0) m = (m - mmin) / mden;
+      else m = 1.f / (1.f + expf(-m));
+      x = (cx[p] - 0.5f) * e0; y = (cy[p] - 0.5f) * e1; z = (cz[p] - 0.5f) * e2;
+      sel = (m > mask_thr) && (fabsf(x) > t0) && (fabsf(y) > t1) && (fabsf(z) > t2);
+    }
+    const unsigned long long bal = __ballot(sel);
+    if (sel) {
+      const int r = base + __popcll(bal & ((1ull << lane) - 1ull));
+      const size_t o = (size_t)bi * hw + r;
+      if (sel_idx) sel_idx[o] = p;
+      img_pts[o * 2] = c2[p] * imW;
+      img_pts[o * 2 + 1] = c2[hw + p] * imH;
+      mdl_pts[o * 3] = x; mdl_pts[o * 3 + 1] = y; mdl_pts[o * 3 + 2] = z;
+    }
+    base += __popcll(bal);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ void pose_from_pred_kernel(const float* __restrict__ rot6d, const float* __restrict__ t_,
+                                      const float* __restrict__ cams, const float* __restrict__ centers,
+                                      const float* __restrict__ whs, const float* __restrict__ resize_ratios,
+                                      float* __restrict__ rot, float* __restrict__ trans, int b, int z_type,
+                                      int is_allo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b) return;
+  // rot6d_to_mat_batch (rot_reps.py:34-55): x = normalize(a), z = normalize(x X b), y = z X x; columns (x,y,z)
+  const float* d6 = rot6d + 6 * (size_t)i;
+  float ax = d6[0], ay = d6[1], az = d6[2], bx = d6[3], by = d6[4], bz = d6[5];
+  float na = fmaxf(sqrtf((ax * ax + ay * ay) + az * az), 1e-12f);  // F.normalize eps
+  float x0 = ax / na, x1 = ay / na, x2 = az / na;
+  float z0 = x1 * bz - x2 * by, z1 = x2 * bx - x0 * bz, z2 = x0 * by - x1 * bx;
+  float nz = fmaxf(sqrtf((z0 * z0 + z1 * z1) + z2 * z2), 1e-12f);
+  z0 /= nz; z1 /= nz; z2 /= nz;
+  float y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0;
+  float Ra[9] = {x0, y0, z0, x1, y1, z1, x2, y2, z2};
+
+  // pose_from_predictions_test (pose_from_pred_centroid_z.py:73-110), fp32 like the torch ops
+  const float* K = cams + 9 * (size_t)i;
+  const float cxp = t_[3 * i] * whs[2 * i] + centers[2 * i];
+  const float cyp = t_[3 * i + 1] * whs[2 * i + 1] + centers[2 * i + 1];
+  const float z = (z_type == 0) ? t_[3 * i + 2] * resize_ratios[i] : t_[3 * i + 2];
+  const float tx = z * (cxp - K[2]) / K[0];
+  const float ty = z * (cyp - K[5]) / K[4];
+  trans[3 * i] = tx; trans[3 * i + 1] = ty; trans[3 * i + 2] = z;
+
+  float* Ro = rot + 9 * (size_t)i;
+  if (!is_allo) {
+    for (int k = 0; k < 9; ++k) Ro[k] = Ra[k];
+    return;
+  }
+  // allocentric_to_egocentric (utils.py:48-62): float32 obj_ray, float64 angle/axis/matrix, fp32 store
+  const float nt = sqrtf((tx * tx + ty * ty) + z * z);
+  const float ox = tx / nt, oy = ty / nt, oz = z / nt;
+  const double angle = acos((double)oz);
+  if (angle > 0) {
+    double ux = -(double)oy, uy = (double)ox, uz = 0.0;  // cross((0,0,1), obj_ray)
+    const double n = sqrt(ux * ux + uy * uy + uz * uz);
+    ux /= n; uy /= n; uz /= n;
+    const double c = cos(angle), s = sin(angle), C = 1 - c;
+    const double xs = ux * s, ys = uy * s, zs = uz * s;
+    const double xC = ux * C, yC = uy * C, zC = uz * C;
+    const double xyC = ux * yC, yzC = uy * zC, zxC = uz * xC;
+    const double M[9] = {ux * xC + c, xyC - zs, zxC + ys, xyC + zs, uy * yC + c, yzC - xs, zxC - ys, yzC + xs, uz * zC + c};
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) {
+        double acc = 0.0;
+        for (int k = 0; k < 3; ++k) acc += M[r * 3 + k] * (double)Ra[k * 3 + cc];
+        Ro[r * 3 + cc] = (float)acc;
+      }
+  } else {
+    for (int k = 0; k < 9; ++k) Ro[k] = Ra[k];
+  }
+}
+
+__global__ void zoom_K_kernel(const float* __restrict__ K, const float* __restrict__ centers,
+                              const float* __restrict__ scales, float* __restrict__ Kc, int b, float out_res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b) return;
+  const float* k = K + 9 * (size_t)i;
+  float* o = Kc + 9 * (size_t)i;
+  const float s = scales[i];
+  const float x0 = centers[2 * i] - s / 2, y0 = centers[2 * i + 1] - s / 2;
+  const float r = out_res / s;
+  o[0] = k[0] * r; o[1] = k[1] * r; o[2] = (k[2] - x0) * r;
+  o[3] = k[3] * r; o[4] = k[4] * r; o[5] = (k[5] - y0) * r;
+  o[6] = k[6]; o[7] = k[7]; o[8] = k[8];
+}
+
+__global__ void pack_records_kernel(const float* __restrict__ R, const double* __restrict__ t_ref,
+                                    const float* __restrict__ t_net, const float* __restrict__ score,
+                                    const int* __restrict__ obj_id, const int* __restrict__ roi_id,
+                                    float* __restrict__ rec, int b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b) return;
+  float* o = rec + 16 * (size_t)i;
+  for (int k = 0; k < 9; ++k) o[k] = R[9 * (size_t)i + k];
+  for (int k = 0; k < 3; ++k) o[9 + k] = t_ref ? (float)t_ref[3 * (size_t)i + k] : t_net[3 * (size_t)i + k];
+  o[12] = score ? score[i] : 1.f;
+  o[13] = obj_id ? (float)obj_id[i] : -1.f;
+  o[14] = roi_id ? (float)roi_id[i] : (float)i;
+  o[15] = 1.f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gdrnpp_decode_correspondences(const float* coor_x, const float* coor_y, const float* coor_z,
+                                  const float* mask_raw, const float* coord2d, const float* extent,
+                                  const float* imwh, float* out_mask, int* count, int* sel_idx, float* img_pts,
+                                  float* mdl_pts, int b, int hw, int mask_type, float mask_thr, void* stream) {
+  GDRNPP_REQUIRE(coor_x && coor_y && coor_z && mask_raw && coord2d && extent && imwh && count && img_pts && mdl_pts,
+                 GDRNPP_EINVAL, "gdrnpp_decode_correspondences: null pointer");
+  GDRNPP_REQUIRE(b > 0 && hw > 0, GDRNPP_EINVAL, "gdrnpp_decode_correspondences: b=%d hw=%d", b, hw);
+  GDRNPP_REQUIRE(mask_type == 0 || mask_type == 1, GDRNPP_EINVAL, "gdrnpp_decode_correspondences: mask_type=%d",
+                 mask_type);
+  hipLaunchKernelGGL(decode_corr_kernel, dim3(b), dim3(kThreads), 0, (hipStream_t)stream, coor_x, coor_y, coor_z,
+                     mask_raw, coord2d, extent, imwh, out_mask, count, sel_idx, img_pts, mdl_pts, hw, mask_type,
+                     mask_thr);
+  return gdrnpp::check_launch("gdrnpp_decode_correspondences");
+}
+
+int gdrnpp_pose_from_pred_centroid_z(const float* rot6d, const float* t_, const float* cams, const float* centers,
+                                     const float* whs, const float* resize_ratios, float* rot, float* trans, int b,
+                                     int z_type, int is_allo, void* stream) {
+  GDRNPP_REQUIRE(rot6d && t_ && cams && centers && whs && resize_ratios && rot && trans, GDRNPP_EINVAL,
+                 "gdrnpp_pose_from_pred_centroid_z: null pointer");
+  GDRNPP_REQUIRE(b > 0 && (z_type == 0 || z_type == 1), GDRNPP_EINVAL,
+                 "gdrnpp_pose_from_pred_centroid_z: b=%d z_type=%d", b, z_type);
+  hipLaunchKernelGGL(pose_from_pred_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot6d, t_, cams,
+                     centers, whs, resize_ratios, rot, trans, b, z_type, is_allo);
+  return gdrnpp::check_launch("gdrnpp_pose_from_pred_centroid_z");
+}
+
+int gdrnpp_zoom_K(const float* K, const float* centers, const float* scales, float* K_crop, int b, float out_res,
+                  void* stream) {
+  GDRNPP_REQUIRE(K && centers && scales && K_crop && b > 0, GDRNPP_EINVAL, "gdrnpp_zoom_K: bad arguments");
+  hipLaunchKernelGGL(zoom_K_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, K, centers, scales,
+                     K_crop, b, out_res);
+  return gdrnpp::check_launch("gdrnpp_zoom_K");
+}
+
+int gdrnpp_pack_pose_records(const float* R, const double* t_refined, const float* t_net, const float* score,
+                             const int* obj_id, const int* roi_id, float* rec, int b, void* stream) {
+  GDRNPP_REQUIRE(R && rec && (t_refined || t_net) && b > 0, GDRNPP_EINVAL, "gdrnpp_pack_pose_records: bad arguments");
+  hipLaunchKernelGGL(pack_records_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, R, t_refined, t_net,
+                     score, obj_id, roi_id, rec, b);
+  return gdrnpp::check_launch("gdrnpp_pack_pose_records");
+}
+
+}  // extern "C"

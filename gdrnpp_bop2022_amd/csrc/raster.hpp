@@ -1,0 +1,93 @@
+// Depth rasteriser shared by gdrnpp_render_depth and gdrnpp_depth_refine (gfx950).
+//
+// Replaces the OpenGL pipeline of lib/render_vispy/renderer.py for the 64x64 ROI render:
+//   projective_matrix :461-477, draw_model :363-407 (model matrix diag(1,-1,-1,1)*[R|t]),
+//   finish :155-182 (z-buffer -> metric depth, background 0, vertical flip).
+// Derived geometry (SURVEY.md §8a notes): GL pixel (row j, col i) is sampled at the OpenCV
+// image point (u,v) = (i+0.5, j+0.5) under K_crop; the linearised depth equals the camera-space
+// Z of the nearest surface hit, kept only for z_near <= Z <= z_far, both faces (no culling).
+//
+// Formulation (no GL, no per-pixel division by vertex w): with h_i = K * (R v_i + t) the
+// homogeneous pixel-space vertices and q = (u, v, 1),
+//     w0 = q . (h1 x h2),  w1 = q . (h2 x h0),  w2 = q . (h0 x h1),  D = h0 . (h1 x h2)
+// the ray through q hits the triangle iff w0,w1,w2 share a sign, and there Z = D / (w0+w1+w2)
+// (exactly the perspective-correct depth GL interpolates).  This also handles triangles that
+// cross the camera plane, which GL handles by clipping.
+// All arithmetic is fp64 with a fixed evaluation order and no FMA, identical to
+// oracle/raster_oracle.c, so coverage and depth are bit-exact against the oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gdrnpp {
+
+struct TriSetup {
+  double e0[3], e1[3], e2[3];  // edge planes (cross products)
+  double D;
+  int i_lo, i_hi, j_lo, j_hi;  // conservative pixel bbox (inclusive); empty if i_lo > i_hi
+};
+
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// K, R row-major (already widened to double); t double
+__device__ __forceinline__ void project_vertex(const float* __restrict__ v, const double* K, const double* R,
+                                               const double* t, double* h) {
+  const double x = v[0], y = v[1], z = v[2];
+  const double X = ((R[0] * x + R[1] * y) + R[2] * z) + t[0];
+  const double Y = ((R[3] * x + R[4] * y) + R[5] * z) + t[1];
+  const double Z = ((R[6] * x + R[7] * y) + R[8] * z) + t[2];
+  h[0] = (K[0] * X + K[1] * Y) + K[2] * Z;
+  h[1] = (K[3] * X + K[4] * Y) + K[5] * Z;
+  h[2] = (K[6] * X + K[7] * Y) + K[8] * Z;
+}
+
+__device__ __forceinline__ int clampi(double v, int lo, int hi) {
+  v = fmax(v, (double)lo);
+  v = fmin(v, (double)hi);
+  return (int)v;
+}
+
+__device__ __forceinline__ void setup_triangle(const double* h0, const double* h1, const double* h2, int res_w,
+                                               int res_h, TriSetup& s) {
+  cross3(h1, h2, s.e0);
+  cross3(h2, h0, s.e1);
+  cross3(h0, h1, s.e2);
+  s.D = (h0[0] * s.e0[0] + h0[1] * s.e0[1]) + h0[2] * s.e0[2];
+  if (h0[2] > 0.0 && h1[2] > 0.0 && h2[2] > 0.0) {
+    const double u0 = h0[0] / h0[2], u1 = h1[0] / h1[2], u2 = h2[0] / h2[2];
+    const double v0 = h0[1] / h0[2], v1 = h1[1] / h1[2], v2 = h2[1] / h2[2];
+    const double umin = fmin(u0, fmin(u1, u2)), umax = fmax(u0, fmax(u1, u2));
+    const double vmin = fmin(v0, fmin(v1, v2)), vmax = fmax(v0, fmax(v1, v2));
+    // pixel centre i+0.5 in [umin,umax]  =>  i in [umin-0.5, umax-0.5]; widened by floor/ceil
+    s.i_lo = clampi(floor(umin - 0.5), 0, res_w);       // res_w => empty after the hi clamp
+    s.i_hi = clampi(ceil(umax - 0.5), -1, res_w - 1);
+    s.j_lo = clampi(floor(vmin - 0.5), 0, res_h);
+    s.j_hi = clampi(ceil(vmax - 0.5), -1, res_h - 1);
+  } else {
+    s.i_lo = 0; s.i_hi = res_w - 1; s.j_lo = 0; s.j_hi = res_h - 1;
+  }
+  if (!(s.D != 0.0)) { s.i_lo = 1; s.i_hi = 0; }  // degenerate (or NaN) triangle
+}
+
+// depth of the triangle at pixel (i,j); returns false when the pixel centre is not covered
+__device__ __forceinline__ bool sample_triangle(const TriSetup& s, int i, int j, double z_near, double z_far,
+                                                double& Z, double* lam) {
+  const double u = (double)i + 0.5, v = (double)j + 0.5;
+  const double w0 = (s.e0[0] * u + s.e0[1] * v) + s.e0[2];
+  const double w1 = (s.e1[0] * u + s.e1[1] * v) + s.e1[2];
+  const double w2 = (s.e2[0] * u + s.e2[1] * v) + s.e2[2];
+  const bool pos = (w0 >= 0.0) && (w1 >= 0.0) && (w2 >= 0.0);
+  const bool neg = (w0 <= 0.0) && (w1 <= 0.0) && (w2 <= 0.0);
+  if (!(pos || neg)) return false;
+  const double sum = (w0 + w1) + w2;
+  if (sum == 0.0) return false;
+  Z = s.D / sum;
+  if (!(Z >= z_near && Z <= z_far)) return false;
+  if (lam) { lam[0] = w0 / sum; lam[1] = w1 / sum; lam[2] = w2 / sum; }
+  return true;
+}
+
+}  // namespace gdrnpp

@@ -1,0 +1,276 @@
+"""ctypes binding of ``libgdrnpp_hip.so`` (the C ABI declared in ``include/gdrnpp_hip.h``).
+
+PyTorch is used here only as the owner of device memory and streams: every wrapper checks
+device / dtype / contiguity, then hands raw ``data_ptr()``s and the current HIP stream to the
+C entry point.  There is NO CPU fallback: if the shared library is missing or a call returns a
+non-zero status, a ``RuntimeError`` is raised (reference behaviour for misuse is
+``TORCH_CHECK`` -> ``RuntimeError``, ransac_voting.cpp:7-19).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libgdrnpp_hip.so")
+
+_lib = None
+
+
+class gdrnpp_meshes(ctypes.Structure):
+    _fields_ = [
+        ("verts", c_void_p),
+        ("faces", c_void_p),
+        ("vert_off", c_void_p),
+        ("face_off", c_void_p),
+        ("n_obj", c_int),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol of include/gdrnpp_hip.h
+_P = c_void_p
+SIGNATURES = {
+    "gdrnpp_version": (c_int, []),
+    "gdrnpp_last_error": (c_char_p, []),
+    "farthest_point_sampling": (None, [_P, _P, c_int, c_int]),
+    "farthest_point_sampling_init_center": (None, [_P, _P, c_int, c_int]),
+    "uncertainty_pnp": (None, [_P, _P, _P, _P, _P, _P, c_int]),
+    "gdrnpp_fps_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gdrnpp_fps": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "gdrnpp_nnd_forward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "gdrnpp_nnd_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "gdrnpp_generate_hypothesis": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "gdrnpp_voting_for_hypothesis": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "gdrnpp_generate_hypothesis_vanishing_point": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "gdrnpp_voting_for_hypothesis_vanishing_point": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "gdrnpp_vote_count": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
+    "gdrnpp_uncertainty_pnp_batched": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "gdrnpp_decode_correspondences": (
+        c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "gdrnpp_pose_from_pred_centroid_z": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "gdrnpp_zoom_K": (c_int, [_P, _P, _P, _P, c_int, c_float, _P]),
+    "gdrnpp_render_depth": (
+        c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "gdrnpp_depth_refine": (
+        c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
+                c_int, c_int, c_float, c_float, _P]),
+    "gdrnpp_pack_pose_records": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+}
+
+
+def load(path: str | None = None) -> ctypes.CDLL:
+    """Load the shared library and bind every declared symbol (no compute, no GPU needed)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"gdrnpp_bop2022_amd: HIP extension {p} is missing — run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C gdrnpp_bop2022_amd/csrc`).  There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().gdrnpp_last_error()
+        raise RuntimeError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype: torch.dtype, name: str) -> int:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA(HIP) tensor")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------
+class MeshSet:
+    """All object models of a dataset, flat and resident in HBM (``gdrnpp_meshes``)."""
+
+    def __init__(self, vertices: list, faces: list, device="cuda"):
+        import numpy as np
+
+        assert len(vertices) == len(faces) and len(vertices) > 0
+        v_off, f_off = [0], [0]
+        for v, f in zip(vertices, faces):
+            v_off.append(v_off[-1] + int(len(v)))
+            f_off.append(f_off[-1] + int(len(f)))
+        self.n_obj = len(vertices)
+        self.verts = torch.from_numpy(np.ascontiguousarray(np.concatenate(vertices, 0), np.float32)).to(device)
+        self.faces = torch.from_numpy(np.ascontiguousarray(np.concatenate(faces, 0), np.int32)).to(device)
+        self.vert_off = torch.tensor(v_off, dtype=torch.int32, device=device)
+        self.face_off = torch.tensor(f_off, dtype=torch.int32, device=device)
+        self.n_verts = v_off[1:]
+        self.n_faces = f_off[1:]
+        self._c = gdrnpp_meshes(self.verts.data_ptr(), self.faces.data_ptr(), self.vert_off.data_ptr(),
+                                self.face_off.data_ptr(), self.n_obj)
+
+    @property
+    def c(self):
+        return ctypes.byref(self._c)
+
+    def bytes_per_render(self, obj: int) -> int:
+        return 12 * (self.n_verts[obj] - (self.n_verts[obj - 1] if obj else 0)) + 12 * (
+            self.n_faces[obj] - (self.n_faces[obj - 1] if obj else 0))
+
+
+# ------------------------------------------------------------------------------------------
+def fps(pts: torch.Tensor, sn: int, init_center: bool = True, start_idx: torch.Tensor | None = None) -> torch.Tensor:
+    """pts f32[b,pn,3] -> idxs i32[b,sn]."""
+    lib = load()
+    assert pts.dim() == 3 and pts.shape[2] == 3
+    b, pn, _ = pts.shape
+    idxs = torch.empty((b, sn), dtype=torch.int32, device=pts.device)
+    ws_bytes = lib.gdrnpp_fps_workspace_bytes(b, pn)
+    ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=pts.device)
+    sp = _dev(start_idx, torch.int32, "start_idx") if start_idx is not None else None
+    _check(lib.gdrnpp_fps(_dev(pts, torch.float32, "pts"), idxs.data_ptr(), sp, b, pn, sn, 1 if init_center else 0,
+                          ws.data_ptr(), _stream()), "gdrnpp_fps")
+    return idxs
+
+
+def nnd_forward(xyz1, xyz2, dist1, dist2, idx1, idx2) -> int:
+    lib = load()
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    _check(lib.gdrnpp_nnd_forward(_dev(xyz1, torch.float32, "xyz1"), _dev(xyz2, torch.float32, "xyz2"),
+                                  _dev(dist1, torch.float32, "dist1"), _dev(dist2, torch.float32, "dist2"),
+                                  _dev(idx1, torch.int32, "idx1"), _dev(idx2, torch.int32, "idx2"), b, n, m,
+                                  _stream()), "gdrnpp_nnd_forward")
+    return 1
+
+
+def nnd_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2) -> int:
+    lib = load()
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    _check(lib.gdrnpp_nnd_backward(_dev(xyz1, torch.float32, "xyz1"), _dev(xyz2, torch.float32, "xyz2"),
+                                   _dev(gradxyz1, torch.float32, "gradxyz1"),
+                                   _dev(gradxyz2, torch.float32, "gradxyz2"),
+                                   _dev(graddist1, torch.float32, "graddist1"),
+                                   _dev(graddist2, torch.float32, "graddist2"), _dev(idx1, torch.int32, "idx1"),
+                                   _dev(idx2, torch.int32, "idx2"), b, n, m, _stream()), "gdrnpp_nnd_backward")
+    return 1
+
+
+def uncertainty_pnp_batched(pts2d, pts3d, wgt2d, K, init_rt, return_info: bool = False):
+    lib = load()
+    b, pn, _ = pts2d.shape
+    out = torch.empty((b, 6), dtype=torch.float64, device=pts2d.device)
+    info = torch.zeros((b, 2), dtype=torch.int32, device=pts2d.device)
+    _check(lib.gdrnpp_uncertainty_pnp_batched(_dev(pts2d, torch.float64, "pts2d"), _dev(pts3d, torch.float64, "pts3d"),
+                                              _dev(wgt2d, torch.float64, "wgt2d"), _dev(K, torch.float64, "K"),
+                                              _dev(init_rt, torch.float64, "init_rt"), out.data_ptr(),
+                                              info.data_ptr(), b, pn, _stream()), "gdrnpp_uncertainty_pnp_batched")
+    return (out, info) if return_info else out
+
+
+def decode_correspondences(coor_x, coor_y, coor_z, mask_raw, coord2d, extent, im_wh, mask_type: int = 0,
+                           mask_thr: float = 0.5, want_mask: bool = True):
+    """Maps [b,1,h,w] (or [b,h,w]) -> (count i32[b], sel_idx i32[b,hw], img_pts f32[b,hw,2], mdl_pts f32[b,hw,3],
+    out_mask f32[b,1,h,w] | None).  Rows >= count[b] are undefined."""
+    lib = load()
+    b = coor_x.shape[0]
+    hw = coor_x[0].numel()
+    dev = coor_x.device
+    count = torch.empty((b,), dtype=torch.int32, device=dev)
+    sel_idx = torch.empty((b, hw), dtype=torch.int32, device=dev)
+    img_pts = torch.empty((b, hw, 2), dtype=torch.float32, device=dev)
+    mdl_pts = torch.empty((b, hw, 3), dtype=torch.float32, device=dev)
+    out_mask = torch.empty_like(mask_raw) if want_mask else None
+    _check(lib.gdrnpp_decode_correspondences(
+        _dev(coor_x, torch.float32, "coor_x"), _dev(coor_y, torch.float32, "coor_y"),
+        _dev(coor_z, torch.float32, "coor_z"), _dev(mask_raw, torch.float32, "mask"),
+        _dev(coord2d, torch.float32, "coord2d"), _dev(extent, torch.float32, "extent"),
+        _dev(im_wh, torch.float32, "im_wh"), out_mask.data_ptr() if want_mask else None, count.data_ptr(),
+        sel_idx.data_ptr(), img_pts.data_ptr(), mdl_pts.data_ptr(), b, hw, mask_type, float(mask_thr), _stream()),
+        "gdrnpp_decode_correspondences")
+    return count, sel_idx, img_pts, mdl_pts, out_mask
+
+
+def pose_from_pred_centroid_z(rot6d, t_, cams, centers, whs, resize_ratios, z_type: str = "REL", is_allo: bool = True):
+    lib = load()
+    b = rot6d.shape[0]
+    rot = torch.empty((b, 3, 3), dtype=torch.float32, device=rot6d.device)
+    trans = torch.empty((b, 3), dtype=torch.float32, device=rot6d.device)
+    _check(lib.gdrnpp_pose_from_pred_centroid_z(
+        _dev(rot6d, torch.float32, "rot6d"), _dev(t_, torch.float32, "t_"), _dev(cams, torch.float32, "cams"),
+        _dev(centers, torch.float32, "centers"), _dev(whs, torch.float32, "whs"),
+        _dev(resize_ratios, torch.float32, "resize_ratios"), rot.data_ptr(), trans.data_ptr(), b,
+        {"REL": 0, "ABS": 1}[z_type], 1 if is_allo else 0, _stream()), "gdrnpp_pose_from_pred_centroid_z")
+    return rot, trans
+
+
+def zoom_K(K, centers, scales, out_res: float):
+    lib = load()
+    b = K.shape[0]
+    out = torch.empty_like(K)
+    _check(lib.gdrnpp_zoom_K(_dev(K, torch.float32, "K"), _dev(centers, torch.float32, "centers"),
+                             _dev(scales, torch.float32, "scales"), out.data_ptr(), b, float(out_res), _stream()),
+           "gdrnpp_zoom_K")
+    return out
+
+
+def render_depth(meshes: MeshSet, obj, K, R, t, res: int, z_near: float = 0.1, z_far: float = 100.0,
+                 want_xyz: bool = False):
+    lib = load()
+    b = obj.shape[0]
+    depth = torch.empty((b, res, res), dtype=torch.float32, device=obj.device)
+    xyz = torch.empty((b, res, res, 3), dtype=torch.float32, device=obj.device) if want_xyz else None
+    _check(lib.gdrnpp_render_depth(meshes.c, _dev(obj, torch.int32, "obj"), _dev(K, torch.float32, "K"),
+                                   _dev(R, torch.float32, "R"), _dev(t, torch.float32, "t"), depth.data_ptr(),
+                                   xyz.data_ptr() if want_xyz else None, b, res, z_near, z_far, _stream()),
+           "gdrnpp_render_depth")
+    return (depth, xyz) if want_xyz else depth
+
+
+def depth_refine(meshes: MeshSet, obj, coor_x, coor_y, coor_z, mask_raw, roi_depth, K_crop, R, t, res: int = 64,
+                 iters: int = 2, threshold: float = 0.8, mask_type: int = 0, use_coor_z: bool = False,
+                 z_near: float = 0.1, z_far: float = 100.0, debug: bool = False, out: torch.Tensor | None = None):
+    """-> t_refined f64[b,3] (and the per-iteration renders f32[b,iters,res,res] when debug)."""
+    lib = load()
+    b = obj.shape[0]
+    t_out = out if out is not None else torch.empty((b, 3), dtype=torch.float64, device=obj.device)
+    dbg = torch.zeros((b, iters, res, res), dtype=torch.float32, device=obj.device) if debug else None
+    assert roi_depth.shape[-1] == 4 * res and roi_depth.shape[-2] == 4 * res
+    _check(lib.gdrnpp_depth_refine(
+        meshes.c, _dev(obj, torch.int32, "obj"), _dev(coor_x, torch.float32, "coor_x"),
+        _dev(coor_y, torch.float32, "coor_y"), _dev(coor_z, torch.float32, "coor_z"),
+        _dev(mask_raw, torch.float32, "mask"), _dev(roi_depth, torch.float32, "roi_depth"),
+        _dev(K_crop, torch.float32, "K_crop"), _dev(R, torch.float32, "R"), _dev(t, torch.float32, "t"),
+        _dev(t_out, torch.float64, "t_out"), dbg.data_ptr() if debug else None, b, res, iters, float(threshold),
+        mask_type, 1 if use_coor_z else 0, z_near, z_far, _stream()), "gdrnpp_depth_refine")
+    return (t_out, dbg) if debug else t_out
+
+
+def pack_pose_records(R, t_refined, t_net, score, obj_id, roi_id):
+    lib = load()
+    b = R.shape[0]
+    rec = torch.empty((b, 16), dtype=torch.float32, device=R.device)
+    _check(lib.gdrnpp_pack_pose_records(
+        _dev(R, torch.float32, "R"), _dev(t_refined, torch.float64, "t_refined") if t_refined is not None else None,
+        _dev(t_net, torch.float32, "t_net") if t_net is not None else None,
+        _dev(score, torch.float32, "score") if score is not None else None,
+        _dev(obj_id, torch.int32, "obj_id") if obj_id is not None else None,
+        _dev(roi_id, torch.int32, "roi_id") if roi_id is not None else None, rec.data_ptr(), b, _stream()),
+        "gdrnpp_pack_pose_records")
+    return rec

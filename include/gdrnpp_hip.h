@@ -1,0 +1,210 @@
+/*
+ * gdrnpp_hip.h — flat C ABI of libgdrnpp_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the GDRNPP inference hot path
+ * (SURVEY.md §8b).  Two groups of entry points:
+ *
+ *  (1) Reference-ABI symbols: byte-for-byte the prototypes the reference's
+ *      cffi modules bind (host pointers, synchronous, no status):
+ *        core/csrc/fps/src/ext.h:1-14
+ *        core/csrc/uncertainty_pnp/src/ext.h:1-9
+ *  (2) gdrnpp_* symbols: device-pointer, stream-ordered, batched entry points
+ *      that replace the reference's torch extensions (ransac_voting.cpp:112-117,
+ *      nnd_cuda.cpp:86-89) and its per-ROI CPU/GL post-processing
+ *      (gdrn_evaluator.py:115-153,461-573, engine_utils.py:295-333,
+ *      pose_from_pred_centroid_z.py:56-154, lib/render_vispy/renderer.py).
+ *
+ * Conventions for group (2):
+ *   - every pointer is a DEVICE pointer unless its name starts with h_;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return 0 = ok, negative = argument error (GDRNPP_E*), positive = hipError_t;
+ *   - no allocation inside; scratch is passed in, sized by *_workspace_bytes();
+ *   - no global state; safe from several host threads on different streams.
+ */
+#ifndef GDRNPP_HIP_H_
+#define GDRNPP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDRNPP_EINVAL (-1) /* bad size / null pointer */
+#define GDRNPP_ELIMIT (-2) /* size above what the kernel supports */
+
+/* library/ABI version: major*10000 + minor*100 + patch */
+int gdrnpp_version(void);
+/* message for the last non-zero status returned on this host thread */
+const char* gdrnpp_last_error(void);
+
+/* ------------------------------------------------------------------------ */
+/* (1) reference-ABI symbols (host pointers)                                 */
+/* ------------------------------------------------------------------------ */
+
+/* core/csrc/fps/src/ext.h:1-6 — random start point (time-seeded like
+ * farthest_point_sampling.cpp:93-94); pts f32[pn,3], idxs i32[sn]. */
+void farthest_point_sampling(float* pts, int* idxs, int pn, int sn);
+/* core/csrc/fps/src/ext.h:9-14 — start = farthest from bbox centre
+ * (farthest_point_sampling.cpp:122-160). */
+void farthest_point_sampling_init_center(float* pts, int* idxs, int pn, int sn);
+
+/* core/csrc/uncertainty_pnp/src/ext.h:1-9 — covariance-weighted reprojection
+ * LM (uncertainty_pnp.cpp:61-92).  pts2d f64[pn,2], pts3d f64[pn,3],
+ * wgt2d f64[pn,3]=(wxx,wxy,wyy), K f64[9], init_rt/result_rt f64[6]
+ * = (angle-axis, t). */
+void uncertainty_pnp(double* pts2d, double* pts3d, double* wgt2d, double* K,
+                     double* init_rt, double* result_rt, int pn);
+
+/* ------------------------------------------------------------------------ */
+/* (2) device-pointer entry points                                           */
+/* ------------------------------------------------------------------------ */
+
+/* ---- farthest point sampling (a9) ---------------------------------------
+ * pts f32[b,pn,3]; idxs i32[b,sn]; start_idx i32[b] or NULL.
+ * mode 0: start from start_idx[b] (farthest_point_sampling.cpp:76-105 with the
+ *         random draw made explicit); mode 1: init-center (…:122-160).
+ * workspace: gdrnpp_fps_workspace_bytes(b,pn) bytes (may be 0). */
+size_t gdrnpp_fps_workspace_bytes(int b, int pn);
+int gdrnpp_fps(const float* pts, int* idxs, const int* start_idx, int b, int pn,
+               int sn, int mode, void* workspace, void* stream);
+
+/* ---- bidirectional NN distance / chamfer (a12) ---------------------------
+ * nnd_cuda.cpp:37-60 (forward), :63-84 (backward).
+ * xyz1 f32[b,n,3], xyz2 f32[b,m,3] -> dist1 f32[b,n], idx1 i32[b,n],
+ * dist2 f32[b,m], idx2 i32[b,m]; first minimum wins (nnd_cpu.cpp:3-25). */
+int gdrnpp_nnd_forward(const float* xyz1, const float* xyz2, float* dist1,
+                       float* dist2, int* idx1, int* idx2, int b, int n, int m,
+                       void* stream);
+/* grad buffers are overwritten (zeroed inside), like nnd_cuda_kernel.cu:185-222 */
+int gdrnpp_nnd_backward(const float* xyz1, const float* xyz2, float* gradxyz1,
+                        float* gradxyz2, const float* graddist1,
+                        const float* graddist2, const int* idx1, const int* idx2,
+                        int b, int n, int m, void* stream);
+
+/* ---- PVNet-style RANSAC voting (a10) -------------------------------------
+ * ransac_voting.cpp:30-41,51-65,74-85,95-109.
+ * direct f32[tn,vn,2], coords f32[tn,2], idxs i32[hn,vn,2],
+ * hypo_pts f32[hn,vn,2] (vanishing point: [hn,vn,3]); the kernels overwrite
+ * the whole of hypo_pts (degenerate pairs -> 0, like at::zeros + skip);
+ * inliers u8[hn,vn,tn] must be pre-zeroed by the caller exactly as in the
+ * reference (ransac_voting_gpu.py:58) — only 1s are written. */
+int gdrnpp_generate_hypothesis(const float* direct, const float* coords,
+                               const int* idxs, float* hypo_pts, int tn, int vn,
+                               int hn, void* stream);
+int gdrnpp_voting_for_hypothesis(const float* direct, const float* coords,
+                                 const float* hypo_pts, unsigned char* inliers,
+                                 int tn, int vn, int hn, float inlier_thresh,
+                                 void* stream);
+int gdrnpp_generate_hypothesis_vanishing_point(const float* direct,
+                                               const float* coords,
+                                               const int* idxs, float* hypo_pts,
+                                               int tn, int vn, int hn,
+                                               void* stream);
+int gdrnpp_voting_for_hypothesis_vanishing_point(
+    const float* direct, const float* coords, const float* hypo_pts,
+    unsigned char* inliers, int tn, int vn, int hn, float inlier_thresh,
+    void* stream);
+/* fused vote + count: counts i32[hn,vn] = sum_t inlier(hi,vi,ti) without
+ * materialising the [hn,vn,tn] tensor (replaces voting + torch.sum(...,2),
+ * ransac_voting_gpu.py:58-62).  homogeneous=1 -> vanishing-point variant. */
+int gdrnpp_vote_count(const float* direct, const float* coords,
+                      const float* hypo_pts, int* counts, int tn, int vn, int hn,
+                      float inlier_thresh, int homogeneous, void* stream);
+
+/* ---- uncertainty-PnP, batched (a11) --------------------------------------
+ * One problem per workgroup; same cost and LM schedule as the host symbol.
+ * pts2d f64[b,pn,2], pts3d f64[b,pn,3], wgt f64[b,pn,3], K f64[b,9],
+ * init f64[b,6] -> result f64[b,6]; info i32[b,2] = (iterations, status) or NULL. */
+int gdrnpp_uncertainty_pnp_batched(const double* pts2d, const double* pts3d,
+                                   const double* wgt2d, const double* K,
+                                   const double* init_rt, double* result_rt,
+                                   int* info, int b, int pn, void* stream);
+
+/* ---- map decoding + 2D-3D correspondences (a4 + a6) ----------------------
+ * engine_utils.py:295-333 (regression xyz, mask_type: 0=L1 min-max, 1=sigmoid)
+ * and gdrn_evaluator.py:115-153.  coor f32[b,3,64*64] (x,y,z planes, may be
+ * three separate [b,1,h,w] tensors laid out contiguously or passed via
+ * strides = plane stride in floats), mask_raw f32[b,hw], coord2d f32[b,2,hw],
+ * extent f32[b,3], imwh f32[b,2]=(im_W, im_H).
+ * outputs: out_mask f32[b,hw] (normalised mask, may be NULL), count i32[b],
+ * sel_idx i32[b,hw] (row-major pixel index of every selected pixel, in
+ * order), img_pts f32[b,hw,2], mdl_pts f32[b,hw,3]; rows >= count[b] are left
+ * untouched. */
+int gdrnpp_decode_correspondences(const float* coor_x, const float* coor_y,
+                                  const float* coor_z, const float* mask_raw,
+                                  const float* coord2d, const float* extent,
+                                  const float* imwh, float* out_mask, int* count,
+                                  int* sel_idx, float* img_pts, float* mdl_pts,
+                                  int b, int hw, int mask_type, float mask_thr,
+                                  void* stream);
+
+/* ---- allocentric->egocentric pose from Patch-PnP output (a3.4 + a3.5) -----
+ * rot_reps.py:34-55 + pose_from_pred_centroid_z.py:56-154 + utils.py:31-75.
+ * rot6d f32[b,6] (allo), t_ f32[b,3] = (dx,dy,z_rel), cams f32[b,9],
+ * centers f32[b,2], whs f32[b,2], resize_ratios f32[b] -> rot f32[b,9] (ego),
+ * trans f32[b,3].  z_type 0=REL 1=ABS; is_allo 0/1. */
+int gdrnpp_pose_from_pred_centroid_z(const float* rot6d, const float* t_,
+                                     const float* cams, const float* centers,
+                                     const float* whs, const float* resize_ratios,
+                                     float* rot, float* trans, int b, int z_type,
+                                     int is_allo, void* stream);
+
+/* ---- crop-resize intrinsics (a8.2) — camera_geometry.py:6-21 --------------
+ * K f32[b,9], centers f32[b,2], scales f32[b] -> K_crop f32[b,9],
+ * with crop_xy = center - scale/2 and ratio = out_res/scale
+ * (engine_utils.py:260-264). */
+int gdrnpp_zoom_K(const float* K, const float* centers, const float* scales,
+                  float* K_crop, int b, float out_res, void* stream);
+
+/* ---- mesh set for the depth rasteriser -----------------------------------
+ * A flat, caller-owned description of all object models resident in HBM:
+ * verts f32[sum V,3], faces i32[sum F,3] (indices local to the object),
+ * vert_off i32[n_obj+1], face_off i32[n_obj+1]. */
+typedef struct gdrnpp_meshes {
+  const float* verts;
+  const int* faces;
+  const int* vert_off;
+  const int* face_off;
+  int n_obj;
+} gdrnpp_meshes;
+
+/* ---- depth render (a8.1 / a14) — lib/render_vispy/renderer.py:126-130,
+ * 155-182,363-407,461-477 restated without GL: depth f32[b,res,res] in metres,
+ * 0 = background; optional xyz f32[b,res,res,3] = object-space surface point
+ * (the PCObject attachment of egl_renderer, egl_renderer_v3.py:1185-1225),
+ * NULL to skip.  K f32[b,9], R f32[b,9], t f32[b,3], obj i32[b]. */
+int gdrnpp_render_depth(const gdrnpp_meshes* meshes, const int* obj,
+                        const float* K, const float* R, const float* t,
+                        float* depth, float* xyz, int b, int res, float z_near,
+                        float z_far, void* stream);
+
+/* ---- fast depth refinement (a8) — gdrn_evaluator.py:461-573 ---------------
+ * One workgroup per ROI runs all iterations (render -> query map -> threshold
+ * -> median -> weighted centroid -> ray update) on chip.
+ * coor_{x,y,z} f32[b,hw] normalised xyz maps; mask_raw f32[b,hw];
+ * roi_depth f32[b,4*res,4*res] sensor depth crop (256x256 for res=64);
+ * K_crop f32[b,9]; R f32[b,9]; t_in f32[b,3]; obj i32[b] -> t_out f64[b,3].
+ * mask_type as in gdrnpp_decode_correspondences; use_coor_z: TEST.USE_COOR_Z_REFINE.
+ * debug_depth (f32[b,iters,hw]) receives each iteration's render or NULL. */
+int gdrnpp_depth_refine(const gdrnpp_meshes* meshes, const int* obj,
+                        const float* coor_x, const float* coor_y,
+                        const float* coor_z, const float* mask_raw,
+                        const float* roi_depth, const float* K_crop,
+                        const float* R, const float* t_in, double* t_out,
+                        float* debug_depth, int b, int res, int iters,
+                        float threshold, int mask_type, int use_coor_z,
+                        float z_near, float z_far, void* stream);
+
+/* ---- pose record packing for the RCCL all-gather (a13) -------------------
+ * rec f32[b,16] = R(9) | t(3) | score | obj_id | roi_id | valid(1) */
+int gdrnpp_pack_pose_records(const float* R, const double* t_refined,
+                             const float* t_net, const float* score,
+                             const int* obj_id, const int* roi_id, float* rec,
+                             int b, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDRNPP_HIP_H_ */

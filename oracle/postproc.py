@@ -1,0 +1,345 @@
+"""ORACLE — test infrastructure only (never imported by ``gdrnpp_bop2022_amd``).
+
+NumPy restatements of the per-ROI CPU post-processing of the reference, plus ctypes wrappers
+around the C restatements in this directory.  Each function cites the reference lines it
+follows (paths relative to /root/reference).  NumPy >= 2 (NEP 50) float32 scalar semantics are
+fixed here, as stated in SURVEY.md §8a ("Threshold scalars and NumPy promotion").
+
+PARITY STATUS: the reference has no golden vectors or tests for any of this and
+cannot be imported here (cv2 / vispy / transforms3d / detectron2 missing), so these
+restatements are pinned only by (a) the reference sources that do compile (FPS, nnd_cpu —
+see tests), (b) the vendored Ceres jet/rotation headers for the uncertainty-PnP cost, and
+(c) closed-form checks (analytic depth of planes/spheres, exact inverse problems).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import lib as _lib
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_i32p = ctypes.POINTER(ctypes.c_int)
+_u8p = ctypes.POINTER(ctypes.c_ubyte)
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(ty)
+
+
+# ------------------------------------------------------------------------------------------
+# C restatement wrappers
+# ------------------------------------------------------------------------------------------
+def fps(pts: np.ndarray, sn: int, init_center: bool = True, start: int = 0) -> np.ndarray:
+    """core/csrc/fps/src/farthest_point_sampling.cpp:76-160 -> indices i32[sn]."""
+    pts = np.ascontiguousarray(pts, np.float32)
+    idxs = np.zeros([sn], np.int32)
+    _lib().oracle_fps(_p(pts, _f32p), _p(idxs, _i32p), int(pts.shape[0]), int(sn), 1 if init_center else 0,
+                      int(start))
+    return idxs
+
+
+def nnd_forward(xyz1: np.ndarray, xyz2: np.ndarray):
+    """core/csrc/torch_nndistance/src/nnd_cpu.cpp:3-60."""
+    xyz1 = np.ascontiguousarray(xyz1, np.float32)
+    xyz2 = np.ascontiguousarray(xyz2, np.float32)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d1, d2 = np.zeros((b, n), np.float32), np.zeros((b, m), np.float32)
+    i1, i2 = np.zeros((b, n), np.int32), np.zeros((b, m), np.int32)
+    _lib().oracle_nnd_forward(b, n, m, _p(xyz1, _f32p), _p(xyz2, _f32p), _p(d1, _f32p), _p(d2, _f32p), _p(i1, _i32p),
+                              _p(i2, _i32p))
+    return d1, d2, i1, i2
+
+
+def nnd_backward(xyz1, xyz2, gd1, gd2, idx1, idx2):
+    """core/csrc/torch_nndistance/src/nnd_cpu.cpp:64-132."""
+    xyz1 = np.ascontiguousarray(xyz1, np.float32)
+    xyz2 = np.ascontiguousarray(xyz2, np.float32)
+    gd1 = np.ascontiguousarray(gd1, np.float32)
+    gd2 = np.ascontiguousarray(gd2, np.float32)
+    idx1 = np.ascontiguousarray(idx1, np.int32)
+    idx2 = np.ascontiguousarray(idx2, np.int32)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    g1, g2 = np.zeros_like(xyz1), np.zeros_like(xyz2)
+    _lib().oracle_nnd_backward(b, n, m, _p(xyz1, _f32p), _p(xyz2, _f32p), _p(g1, _f32p), _p(g2, _f32p),
+                               _p(gd1, _f32p), _p(gd2, _f32p), _p(idx1, _i32p), _p(idx2, _i32p))
+    return g1, g2
+
+
+def generate_hypothesis(direct, coords, idxs, vanishing_point=False):
+    """ransac_voting_kernel.cu:11-49 / :170-229."""
+    direct = np.ascontiguousarray(direct, np.float32)
+    coords = np.ascontiguousarray(coords, np.float32)
+    idxs = np.ascontiguousarray(idxs, np.int32)
+    tn, vn, _ = direct.shape
+    hn = idxs.shape[0]
+    out = np.zeros((hn, vn, 3 if vanishing_point else 2), np.float32)
+    fn = _lib().oracle_generate_hypothesis_vanishing_point if vanishing_point else _lib().oracle_generate_hypothesis
+    fn(_p(direct, _f32p), _p(coords, _f32p), _p(idxs, _i32p), _p(out, _f32p), tn, vn, hn)
+    return out
+
+
+def voting_for_hypothesis(direct, coords, hypo_pts, inlier_thresh, vanishing_point=False):
+    """ransac_voting_kernel.cu:88-126 / :268-310 -> inliers u8[hn,vn,tn] (pre-zeroed)."""
+    direct = np.ascontiguousarray(direct, np.float32)
+    coords = np.ascontiguousarray(coords, np.float32)
+    hypo_pts = np.ascontiguousarray(hypo_pts, np.float32)
+    tn, vn, _ = direct.shape
+    hn = hypo_pts.shape[0]
+    inl = np.zeros((hn, vn, tn), np.uint8)
+    fn = (_lib().oracle_voting_for_hypothesis_vanishing_point if vanishing_point
+          else _lib().oracle_voting_for_hypothesis)
+    fn(_p(direct, _f32p), _p(coords, _f32p), _p(hypo_pts, _f32p), _p(inl, _u8p), tn, vn, hn,
+       ctypes.c_float(inlier_thresh))
+    return inl
+
+
+def uncertainty_pnp(pts2d, pts3d, wgt2d, K, init_rt, return_info=False):
+    """uncertainty_pnp.cpp:61-92 with the Ceres LM schedule restated (oracle/upnp_oracle.c)."""
+    pts2d = np.ascontiguousarray(pts2d, np.float64)
+    pts3d = np.ascontiguousarray(pts3d, np.float64)
+    wgt2d = np.ascontiguousarray(wgt2d, np.float64)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    init_rt = np.ascontiguousarray(init_rt, np.float64).reshape(6)
+    out = np.zeros(6, np.float64)
+    info = np.zeros(2, np.int32)
+    _lib().oracle_uncertainty_pnp(_p(pts2d, _f64p), _p(pts3d, _f64p), _p(wgt2d, _f64p), _p(K, _f64p),
+                                  _p(init_rt, _f64p), _p(out, _f64p), int(pts2d.shape[0]), _p(info, _i32p))
+    return (out, info) if return_info else out
+
+
+def uncertainty_pnp_batched(pts2d, pts3d, wgt2d, K, init_rt):
+    pts2d = np.ascontiguousarray(pts2d, np.float64)
+    pts3d = np.ascontiguousarray(pts3d, np.float64)
+    wgt2d = np.ascontiguousarray(wgt2d, np.float64)
+    K = np.ascontiguousarray(K, np.float64)
+    init_rt = np.ascontiguousarray(init_rt, np.float64)
+    b, pn, _ = pts2d.shape
+    out = np.zeros((b, 6), np.float64)
+    info = np.zeros((b, 2), np.int32)
+    _lib().oracle_uncertainty_pnp_batched(_p(pts2d, _f64p), _p(pts3d, _f64p), _p(wgt2d, _f64p), _p(K, _f64p),
+                                          _p(init_rt, _f64p), _p(out, _f64p), _p(info, _i32p), b, pn)
+    return out, info
+
+
+def upnp_residual(pose, p2, p3, w, K):
+    pose, p2, p3, w = (np.ascontiguousarray(a, np.float64) for a in (pose, p2, p3, w))
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    r, J = np.zeros(2), np.zeros((2, 6))
+    _lib().oracle_upnp_residual(_p(pose, _f64p), _p(p2, _f64p), _p(p3, _f64p), _p(w, _f64p), _p(K, _f64p),
+                                _p(r, _f64p), _p(J, _f64p))
+    return r, J
+
+
+def render_depth(verts, faces, K, R, t, res_w=64, res_h=None, z_near=0.1, z_far=100.0, want_xyz=False):
+    """lib/render_vispy/renderer.py:126-130,155-182,363-407,461-477 restated (oracle/raster_oracle.c).
+    K, R float32 3x3; t float64[3] -> depth f32[res_h,res_w] (0 = background)."""
+    res_h = res_h or res_w
+    verts = np.ascontiguousarray(verts, np.float32)
+    faces = np.ascontiguousarray(faces, np.int32)
+    K = np.ascontiguousarray(K, np.float32).reshape(9)
+    R = np.ascontiguousarray(R, np.float32).reshape(9)
+    t = np.ascontiguousarray(t, np.float64).reshape(3)
+    depth = np.zeros((res_h, res_w), np.float32)
+    xyz = np.zeros((res_h, res_w, 3), np.float32) if want_xyz else None
+    _lib().oracle_render_depth(_p(verts, _f32p), _p(faces, _i32p), int(faces.shape[0]), _p(K, _f32p), _p(R, _f32p),
+                               _p(t, _f64p), res_w, res_h, ctypes.c_double(z_near), ctypes.c_double(z_far),
+                               _p(depth, _f32p), _p(xyz, _f32p) if want_xyz else None, None)
+    return (depth, xyz) if want_xyz else depth
+
+
+# ------------------------------------------------------------------------------------------
+# NumPy restatements
+# ------------------------------------------------------------------------------------------
+def get_out_coor(coor_x, coor_y, coor_z):
+    """engine_utils.py:295-312, regression branch (one channel per axis)."""
+    return np.concatenate([coor_x, coor_y, coor_z], axis=1)
+
+
+def get_out_mask(pred_mask: np.ndarray, mask_loss_type: str = "L1") -> np.ndarray:
+    """engine_utils.py:315-333: L1 -> per-ROI (m-min)/(max-min), no epsilon; BCE -> sigmoid."""
+    pred_mask = np.asarray(pred_mask, np.float32)
+    bs = pred_mask.shape[0]
+    if mask_loss_type == "L1":
+        flat = pred_mask.reshape(bs, -1)
+        mx = flat.max(-1).reshape(bs, 1, 1, 1)
+        mn = flat.min(-1).reshape(bs, 1, 1, 1)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return ((pred_mask - mn) / (mx - mn)).astype(np.float32)
+    if mask_loss_type in ("BCE", "RW_BCE", "dice"):
+        return (np.float32(1) / (np.float32(1) + np.exp(-pred_mask))).astype(np.float32)
+    raise NotImplementedError(mask_loss_type)
+
+
+def get_img_model_points_with_coords2d(mask_pred_crop, xyz_pred_crop, coord2d_crop, im_H, im_W, extent,
+                                       mask_thr=0.5):
+    """gdrn_evaluator.py:115-153 (max_num_points branch inactive by default).
+    mask HW, xyz HWC (normalised [0,1]), coord2d HW2, extent f32[3] -> (image_points [N,2], model_points [N,3],
+    sel_mask HW bool)."""
+    xyz = np.array(xyz_pred_crop, np.float32, copy=True)
+    extent = np.asarray(extent, np.float32)
+    for c in range(3):
+        xyz[:, :, c] = (xyz[:, :, c] - np.float32(0.5)) * extent[c]
+    c2 = np.array(coord2d_crop, np.float32, copy=True)
+    c2[:, :, 0] = c2[:, :, 0] * np.float32(im_W)
+    c2[:, :, 1] = c2[:, :, 1] * np.float32(im_H)
+    with np.errstate(invalid="ignore"):
+        sel = (
+            (np.asarray(mask_pred_crop, np.float32) > np.float32(mask_thr))
+            & (np.abs(xyz[:, :, 0]) > np.float32(0.0001) * extent[0])
+            & (np.abs(xyz[:, :, 1]) > np.float32(0.0001) * extent[1])
+            & (np.abs(xyz[:, :, 2]) > np.float32(0.0001) * extent[2])
+        )
+    return c2[sel].reshape(-1, 2), xyz[sel].reshape(-1, 3), sel
+
+
+def get_K_crop_resize(K, crop_xy, resize_ratio):
+    """core/utils/camera_geometry.py:6-21 (float32)."""
+    K = np.asarray(K, np.float32)
+    new_K = K.copy()
+    new_K[:, [0, 1], 2] = K[:, [0, 1], 2] - np.asarray(crop_xy, np.float32)
+    new_K[:, [0, 1]] = new_K[:, [0, 1]] * np.asarray(resize_ratio, np.float32).reshape(K.shape[0], -1, 1)
+    return new_K
+
+
+def zoom_K(K, centers, scales, out_res):
+    """engine_utils.py:260-264: crop_xy = center - scale/2, ratio = out_res/scale."""
+    centers = np.asarray(centers, np.float32)
+    scales = np.asarray(scales, np.float32).reshape(-1, 1)
+    crop_xy = centers - scales / np.float32(2)
+    ratio = np.float32(out_res) / scales
+    return get_K_crop_resize(K, crop_xy, ratio)
+
+
+def resize_depth_x4_linear(depth: np.ndarray) -> np.ndarray:
+    """cv2.resize(depth, (res,res)) with the default INTER_LINEAR at an exact 4:1 ratio
+    (gdrn_evaluator.py:515 / predictor_gdrn.py:238): source coordinate 4x+1.5, i.e. the float32
+    mean of the 2x2 centre of each 4x4 block, horizontal pass first (OpenCV HResize then VResize)."""
+    d = np.asarray(depth, np.float32)
+    h = np.float32(0.5)
+    r0 = d[1::4, 1::4] * h + d[1::4, 2::4] * h
+    r1 = d[2::4, 1::4] * h + d[2::4, 2::4] * h
+    return (r0 * h + r1 * h).astype(np.float32)
+
+
+def rot6d_to_mat_batch(d6: np.ndarray) -> np.ndarray:
+    """core/utils/rot_reps.py:34-55 (float32, F.normalize eps 1e-12)."""
+    d6 = np.asarray(d6, np.float32)
+    x_raw, y_raw = d6[..., 0:3], d6[..., 3:6]
+
+    def _norm(v):
+        n = np.sqrt((v * v).sum(-1, keepdims=True, dtype=np.float32))
+        return v / np.maximum(n, np.float32(1e-12))
+
+    x = _norm(x_raw)
+    z = _norm(np.cross(x, y_raw))
+    y = np.cross(z, x)
+    return np.stack((x, y, z), axis=-1).astype(np.float32)
+
+
+def axangle2mat(axis, angle):
+    """transforms3d.axangles.axangle2mat (third-party, not in tree; published algorithm), float64."""
+    x, y, z = (float(a) for a in axis)
+    n = np.sqrt(x * x + y * y + z * z)
+    x, y, z = x / n, y / n, z / n
+    c, s = np.cos(angle), np.sin(angle)
+    C = 1 - c
+    xs, ys, zs = x * s, y * s, z * s
+    xC, yC, zC = x * C, y * C, z * C
+    xyC, yzC, zxC = x * yC, y * zC, z * xC
+    return np.array([[x * xC + c, xyC - zs, zxC + ys], [xyC + zs, y * yC + c, yzC - xs],
+                     [zxC - ys, yzC + xs, z * zC + c]])
+
+
+def allocentric_to_egocentric_mat(allo_pose: np.ndarray) -> np.ndarray:
+    """core/utils/utils.py:31-62, src_type = dst_type = "mat", cam_ray (0,0,1)."""
+    cam_ray = np.asarray((0, 0, 1.0))
+    trans = allo_pose[:3, 3]
+    obj_ray = trans.copy() / np.linalg.norm(trans)
+    angle = np.arccos(cam_ray.dot(obj_ray))
+    if angle > 0:
+        ego_pose = np.zeros((3, 4), dtype=allo_pose.dtype)
+        ego_pose[:3, 3] = trans
+        rot_mat = axangle2mat(np.cross(cam_ray, obj_ray), angle)
+        ego_pose[:3, :3] = np.dot(rot_mat, allo_pose[:3, :3])
+        return ego_pose
+    return allo_pose.copy()
+
+
+def pose_from_predictions_test(pred_rots, pred_centroids, pred_z_vals, roi_cams, roi_centers, resize_ratios, roi_whs,
+                               is_allo=True, z_type="REL"):
+    """pose_from_pred_centroid_z.py:56-154 (rotation-matrix branch).  float32 like the torch ops."""
+    f32 = np.float32
+    pred_rots = np.asarray(pred_rots, f32)
+    pc, pz = np.asarray(pred_centroids, f32), np.asarray(pred_z_vals, f32).reshape(-1, 1)
+    K, ctr, whs = np.asarray(roi_cams, f32), np.asarray(roi_centers, f32), np.asarray(roi_whs, f32)
+    rr = np.asarray(resize_ratios, f32).reshape(-1, 1)
+    cx = (pc[:, 0:1] * whs[:, 0:1]) + ctr[:, 0:1]
+    cy = (pc[:, 1:2] * whs[:, 1:2]) + ctr[:, 1:2]
+    z = pz if z_type == "ABS" else pz * rr
+    trans = np.concatenate([z * (cx - K[:, 0:1, 2]) / K[:, 0:1, 0], z * (cy - K[:, 1:2, 2]) / K[:, 1:2, 1], z],
+                           axis=1).astype(f32)
+    ego = np.zeros_like(pred_rots)
+    for i in range(pred_rots.shape[0]):
+        if is_allo:
+            ego[i] = allocentric_to_egocentric_mat(np.hstack([pred_rots[i], trans[i].reshape(3, 1)]))[:3, :3]
+        else:
+            ego[i] = pred_rots[i]
+    return ego, trans
+
+
+def depth_refine_roi(xyz_i, mask_i, roi_depth_256, K_crop, rot_est, trans_est, verts, faces, iters=2, threshold=0.8,
+                     use_coor_z=False, crop_res=64, z_near=0.1, z_far=100.0, return_debug=False):
+    """gdrn_evaluator.py:485-561 for ONE ROI (demo/predictor_gdrn.py:228-284 is the runnable twin).
+
+    xyz_i f32[res,res,3] normalised maps (HWC), mask_i f32[res,res] normalised soft mask,
+    roi_depth_256 f32[4res,4res], K_crop f32[3,3], rot_est f32[3,3], trans_est f32[3].
+    Returns the refined translation (float64[3], or the float32 input values if no iteration applied).
+    """
+    f32 = np.float32
+    xyz_i = np.asarray(xyz_i, f32)
+    mask_i = np.asarray(mask_i, f32)
+    K_crop = np.asarray(K_crop, f32)
+    rot_est = np.asarray(rot_est, f32)
+    trans_est = np.asarray(trans_est, f32)
+    depth_sensor_crop = resize_depth_x4_linear(roi_depth_256)
+    depth_sensor_mask_crop = depth_sensor_crop > 0
+    renders = []
+    for _ in range(iters):
+        # GL receives the pose as float32 uniforms (renderer.py:382,405)
+        ren_dp = render_depth(verts, faces, K_crop, rot_est, np.asarray(trans_est, f32).astype(np.float64),
+                              res_w=crop_res, z_near=z_near, z_far=z_far)
+        renders.append(ren_dp)
+        ren_mask = ren_dp > 0
+        if use_coor_z:
+            coor_np_r = (rot_est @ xyz_i.reshape(-1, 3).T).T.reshape(crop_res, crop_res, 3)
+            query_img_norm = coor_np_r[:, :, -1] * mask_i
+            query_img_norm = query_img_norm * ren_mask * depth_sensor_mask_crop
+        else:
+            nrm = np.sqrt((xyz_i[..., 0] * xyz_i[..., 0] + xyz_i[..., 1] * xyz_i[..., 1])
+                          + xyz_i[..., 2] * xyz_i[..., 2]).astype(f32)  # torch.norm(query_img, dim=-1)
+            query_img_norm = nrm * mask_i
+            query_img_norm = query_img_norm * ren_mask * depth_sensor_mask_crop
+        query_img_norm = query_img_norm.astype(f32)
+        norm_sum = query_img_norm.sum()
+        if norm_sum == 0:
+            continue
+        query_img_norm = query_img_norm / norm_sum
+        norm_mask = query_img_norm > (query_img_norm.max() * f32(threshold))
+        yy, xx = np.argwhere(norm_mask).T
+        depth_diff = depth_sensor_crop[yy, xx] - ren_dp[yy, xx]
+        depth_adjustment = np.median(depth_diff)
+
+        yx_coords = np.meshgrid(np.arange(crop_res), np.arange(crop_res))
+        yx_coords = np.stack(yx_coords[::-1], axis=-1)
+        yx_ray_2d = (yx_coords * query_img_norm[..., None]).sum(axis=(0, 1))
+        ray_3d = np.linalg.inv(K_crop) @ (*yx_ray_2d[::-1], 1)
+        ray_3d /= ray_3d[2]
+        trans_delta = ray_3d[:, None] * depth_adjustment
+        trans_est = trans_est + trans_delta.reshape(3)
+    out = np.asarray(trans_est, np.float64)
+    return (out, renders) if return_debug else out

@@ -1,0 +1,91 @@
+"""Host-side / oracle logic that needs no GPU: synthetic generator, decode + correspondence
+restatement properties, depth-refine restatement recovering a known depth error."""
+import numpy as np
+
+from gdrnpp_bop2022_amd import synthetic as S
+from oracle import postproc as P
+
+
+def _render_fn(verts, faces):
+    def fn(obj, K, R, t, res):
+        ds, xs = [], []
+        for i in range(len(obj)):
+            d, x = P.render_depth(verts[obj[i]], faces[obj[i]], K[i], R[i], t[i].astype(np.float64), res,
+                                  want_xyz=True)
+            ds.append(d)
+            xs.append(x)
+        return np.stack(ds), np.stack(xs)
+    return fn
+
+
+def make_case(b=6, seed=0, subdiv=3, num_classes=4):
+    rng = np.random.default_rng(seed)
+    verts, faces, ext = S.make_models(num_classes, rng, subdiv)
+    det = S.make_detections(b, num_classes, ext, rng)
+    maps = S.make_map_inputs(det, verts, faces, _render_fn(verts, faces), rng)
+    return verts, faces, det, maps
+
+
+def test_icosphere_counts():
+    v, f = S.icosphere(4)
+    assert v.shape == (2562, 3) and f.shape == (5120, 3)
+    v, f = S.icosphere(3)
+    assert v.shape == (642, 3) and f.shape == (1280, 3)
+
+
+def test_get_out_mask_l1_range_and_constant_map():
+    m = np.random.default_rng(0).standard_normal((3, 1, 8, 8)).astype(np.float32)
+    o = P.get_out_mask(m)
+    assert o.min() == 0 and o.max() == 1
+    c = P.get_out_mask(np.ones((1, 1, 4, 4), np.float32))
+    assert np.isnan(c).all()  # no epsilon in engine_utils.py:325
+
+
+def test_correspondences_are_row_major_and_thresholded():
+    verts, faces, det, maps = make_case()
+    mask = P.get_out_mask(maps["mask"])
+    for i in range(len(det["scale"])):
+        xyz = np.concatenate([maps["coor_x"][i], maps["coor_y"][i], maps["coor_z"][i]], 0).transpose(1, 2, 0)
+        c2 = maps["roi_coord_2d"][i].transpose(1, 2, 0)
+        ip, mp, sel = P.get_img_model_points_with_coords2d(mask[i, 0], xyz, c2, 480, 640, det["roi_extent"][i])
+        idx = np.flatnonzero(sel.reshape(-1))
+        assert np.all(np.diff(idx) > 0) and len(idx) == len(ip) == len(mp)
+        assert np.all(np.abs(mp) > 1e-4 * det["roi_extent"][i] * 0.999)
+        assert len(idx) > 4
+
+
+def test_depth_refine_restatement_removes_depth_error():
+    verts, faces, det, maps = make_case(b=8, seed=5)
+    mask = P.get_out_mask(maps["mask"])
+    err0, err1 = [], []
+    for i in range(8):
+        o = int(det["roi_cls"][i])
+        xyz = np.concatenate([maps["coor_x"][i], maps["coor_y"][i], maps["coor_z"][i]], 0).transpose(1, 2, 0)
+        t = P.depth_refine_roi(xyz, mask[i, 0], maps["roi_depth"][i, 0], maps["K_crop"][i], det["R_gt"][i],
+                               maps["t_init"][i], verts[o], faces[o])
+        err0.append(abs(maps["t_init"][i][2] - det["t_gt"][i][2]))
+        err1.append(abs(t[2] - det["t_gt"][i][2]))
+    assert np.median(err1) < 0.25 * np.median(err0)
+    assert np.median(err1) < 3e-3
+
+
+def test_allocentric_to_egocentric_identity_on_axis():
+    R = S.random_rotation(np.random.default_rng(1)).astype(np.float32)
+    pose = np.hstack([R, np.array([[0], [0], [1.0]], np.float32)])
+    assert np.array_equal(P.allocentric_to_egocentric_mat(pose)[:3, :3], R)
+    pose[:, 3] = [0.2, -0.1, 0.9]
+    Re = P.allocentric_to_egocentric_mat(pose)[:3, :3].astype(np.float64)
+    np.testing.assert_allclose(Re @ Re.T, np.eye(3), atol=1e-6)
+
+
+def test_zoom_K_maps_roi_to_output_square():
+    det = S.make_detections(4, 3, np.full((3, 3), 0.1, np.float32), np.random.default_rng(2))
+    Kc = P.zoom_K(det["roi_cam"], det["roi_center"], det["scale"], 64)
+    # the ROI centre must land on (32, 32)
+    for i in range(4):
+        K = det["roi_cam"][i].astype(np.float64)
+        c = det["roi_center"][i]
+        ray = np.array([(c[0] - K[0, 2]) / K[0, 0], (c[1] - K[1, 2]) / K[1, 1], 1.0])
+        uv = Kc[i].astype(np.float64) @ ray
+        np.testing.assert_allclose(uv[:2] / uv[2], [32, 32], atol=1e-3)
+    np.testing.assert_array_equal(Kc, S.zoom_K_np(det["roi_cam"], det["roi_center"], det["scale"], 64))
