@@ -1,0 +1,243 @@
+#!/usr/bin/env python
+"""bench.py — ROIs/sec of the GDRNPP hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic ROIs already resident in HBM:
+    GDRN_Net forward (ConvNeXt-B + geometry head + Patch-PnP, fp32)  ->  K_crop  ->  fast depth refine
+    (render + compare, 2 iterations, HIP)  ->  pose records  ->  (N>1) one RCCL all-gather of the records.
+
+Workload (config.workload): BASELINE.json configs[2] — "YCB-V convnext_a6 + fast depth refine
+(render-compare), 1xMI355X, batch=128 ROIs": it is the configuration the metric
+"ROIs/sec (GDRNPP fwd + PnP + depth refine)" is quoted on and it fits one GPU.  --workload rgb selects
+configs[1] (batch 64, no refine) for reference.  Multi-GPU: ROIs are sharded, every rank gets its own
+batch (weak scaling), the only collective is the all-gather of the [n,16] pose records.
+
+Prints ONE JSON line on rank 0 (driver contract) with two extra objects:
+  roofline      dominant hand-written kernel (depth_refine_kernel), HBM-bound by assignment:
+                achieved = algorithmic bytes per launch / mean launch duration measured with HIP events on
+                the stream the kernel runs on, inside the timed region.
+  cpu_baseline  the CPU restatement of the reference's per-ROI refine path (oracle "port": NumPy +
+                C software rasteriser standing in for the GL render), one thread, bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from gdrnpp_bop2022_amd import hip_lib, synthetic as S  # noqa: E402
+from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg  # noqa: E402
+from gdrnpp_bop2022_amd.gdrn_modeling.engine import GdrnHipPost, gather_records  # noqa: E402
+from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--workload", default="refine", choices=["refine", "rgb"])
+    p.add_argument("--batch", type=int, default=0, help="ROIs per GPU per step (0 = the config's batch)")
+    p.add_argument("--subdiv", type=int, default=4, help="icosphere subdivision of the synthetic meshes (4 = 2562V/5120F)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample", type=int, default=32)
+    p.add_argument("--exact-reference-order", action="store_true",
+                   help="run the reference's full 1470-channel output layer + gather instead of the class-sliced one")
+    p.add_argument("--post-only", action="store_true", help="time only the post-processing (maps from a fixed forward)")
+    return p.parse_args()
+
+
+def algorithmic_bytes_refine(b, iters, n_verts, n_faces):
+    """SURVEY.md §8(d) row a8, per ROI: (3+1) maps x 64^2 x 4 B + the used quarter of the 256^2 depth crop
+    (64^2 x 4 x 4 B) + K,R,t (84 B) + iters x (12 V + 12 F) mesh bytes + 12 B written."""
+    per_roi = 65536 + 65536 + 84 + iters * (12 * n_verts + 12 * n_faces) + 12
+    return b * per_roi, per_roi
+
+
+def make_batch(cfg, b, rng, dev, verts, faces, ext, meshes, with_depth):
+    C = cfg.MODEL.POSE_NET.NUM_CLASSES
+    det = S.make_detections(b, C, ext, rng)
+
+    def T(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    batch = dict(
+        roi_img=torch.rand(b, 3, 256, 256, device=dev), roi_cls=T(det["roi_cls"]), roi_cam=T(det["roi_cam"]),
+        roi_wh=T(det["roi_wh"]), roi_center=T(det["roi_center"]), resize_ratio=T(det["resize_ratio"]),
+        roi_coord_2d=T(S.coord2d_roi(det["roi_center"], det["scale"])), roi_extent=T(det["roi_extent"]),
+        scale=T(det["scale"]), score=T(det["score"]), im_W=T(det["im_W"]), im_H=T(det["im_H"]))
+    K_crop = S.zoom_K_np(det["roi_cam"], det["roi_center"], det["scale"], 64)
+    if with_depth:
+        # sensor depth: HIP render of the GT pose at 64^2, nearest x4 to 256^2, + N(0, 2 mm), 5 % holes (§8d)
+        depth = hip_lib.render_depth(meshes, T(det["roi_cls"].astype(np.int32)), T(K_crop), T(det["R_gt"]),
+                                     T(det["t_gt"]), 64)
+        big = depth.repeat_interleave(4, 1).repeat_interleave(4, 2)
+        g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
+        noisy = torch.where(big > 0, big + 0.002 * torch.randn(big.shape, device=dev, generator=g), big)
+        drop = torch.rand(big.shape, device=dev, generator=g) < 0.05
+        batch["roi_depth"] = torch.where(drop, torch.zeros_like(noisy), noisy)[:, None].contiguous()
+    return batch, det, K_crop
+
+
+def cpu_baseline(det, K_crop, out_np, roi_depth_np, verts, faces, n, iters, thr):
+    """Reference CPU refine path (gdrn_evaluator.py:485-561 per ROI) restated: oracle port, 1 thread."""
+    from oracle import postproc as P  # the only place bench.py touches the oracle
+
+    n = min(n, len(det["scale"]))
+    mask = P.get_out_mask(out_np["mask"][:n])
+    t0 = time.perf_counter()
+    for i in range(n):
+        o = int(det["roi_cls"][i])
+        xyz = np.concatenate([out_np["coor_x"][i], out_np["coor_y"][i], out_np["coor_z"][i]], 0).transpose(1, 2, 0)
+        P.depth_refine_roi(xyz, mask[i, 0], roi_depth_np[i, 0], K_crop[i], out_np["rot"][i], out_np["trans"][i],
+                           verts[o], faces[o], iters=iters, threshold=thr)
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="ROIs/s", cores=1, kind="port",
+                sample=f"{n} ROIs of the same batch through oracle.postproc.depth_refine_roi (NumPy + C software "
+                       f"rasteriser in place of the vispy GL render), post-processing stage only; {dt:.2f} s")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+    hip_lib.load()
+
+    refine = args.workload == "refine"
+    opts = ["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"] if refine else []
+    cfg = get_cfg("ycbv_convnext_a6", opts)
+    b = args.batch or (128 if refine else 64)
+    torch.manual_seed(20220925 + rank)
+    rng = np.random.default_rng(20220925 + 3 + rank)
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode during warm-up
+
+    model, _ = build_model_optimizer(cfg, is_test=True)
+    model.exact_reference_order = bool(args.exact_reference_order)
+    C = cfg.MODEL.POSE_NET.NUM_CLASSES
+    verts, faces, ext = S.make_models(C, np.random.default_rng(20220925), subdiv=args.subdiv)
+    meshes = hip_lib.MeshSet(verts, faces, device=dev)
+    post = GdrnHipPost(cfg, meshes)
+    batch, det, K_crop = make_batch(cfg, b, rng, dev, verts, faces, ext, meshes, refine)
+    roi_ids = torch.arange(rank * b, (rank + 1) * b, dtype=torch.int32, device=dev)
+
+    ev_pairs = []
+
+    @torch.no_grad()
+    def forward_only():
+        return model(batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"],
+                     roi_whs=batch["roi_wh"], roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"],
+                     roi_coord_2d=batch["roi_coord_2d"], roi_extents=batch["roi_extent"])
+
+    fixed_out = forward_only() if args.post_only else None
+
+    @torch.no_grad()
+    def step(record_events=False):
+        out = fixed_out if args.post_only else forward_only()
+        if refine and record_events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            K_c = hip_lib.zoom_K(batch["roi_cam"].reshape(b, 9), batch["roi_center"], batch["scale"], 64)
+            e0.record()  # torch's current stream == the stream hip_lib launches on
+            t_ref = hip_lib.depth_refine(
+                meshes, batch["roi_cls"].to(torch.int32), out["coor_x"].contiguous(), out["coor_y"].contiguous(),
+                out["coor_z"].contiguous(), out["mask"].contiguous(), batch["roi_depth"], K_c,
+                out["rot"].reshape(b, 9).contiguous(), out["trans"].contiguous(), iters=cfg.TEST.DEPTH_REFINE_ITER,
+                threshold=cfg.TEST.DEPTH_REFINE_THRESHOLD)
+            e1.record()
+            ev_pairs.append((e0, e1))
+            rec = hip_lib.pack_pose_records(out["rot"].reshape(b, 9).contiguous(), t_ref, out["trans"].contiguous(),
+                                            batch["score"], batch["roi_cls"].to(torch.int32), roi_ids)
+        else:
+            rec = post.process(batch, out, roi_ids)
+        return gather_records(rec, b)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = step(record_events=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-stage split (outside the timed region)
+    def timed(fn, n=5):
+        torch.cuda.synchronize()
+        s = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - s) / n * 1e3
+
+    fwd_ms = timed(forward_only) if not args.post_only else None
+
+    roofline = None
+    if refine and ev_pairs:
+        ms = [a.elapsed_time(bb) for a, bb in ev_pairs]
+        mean_ms = float(np.mean(ms))
+        nv, nf = len(verts[0]), len(faces[0])
+        bytes_launch, per_roi = algorithmic_bytes_refine(b, cfg.TEST.DEPTH_REFINE_ITER, nv, nf)
+        achieved = bytes_launch / (mean_ms * 1e-3) / 1e9
+        roofline = dict(kernel="depth_refine_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, launch_ms=mean_ms, bytes_per_launch=bytes_launch,
+                        bytes_per_roi=per_roi, rois_per_launch=b)
+
+    if rank == 0:
+        cpu = None
+        if refine and not args.no_cpu_baseline:
+            out = forward_only()
+            torch.cuda.synchronize()
+            out_np = {k: out[k].detach().cpu().numpy() for k in ("mask", "coor_x", "coor_y", "coor_z", "rot", "trans")}
+            cpu = cpu_baseline(det, K_crop, out_np, batch["roi_depth"].cpu().numpy(), verts, faces, args.cpu_sample,
+                               cfg.TEST.DEPTH_REFINE_ITER, cfg.TEST.DEPTH_REFINE_THRESHOLD)
+            cpu["host_cores_available"] = os.cpu_count()
+        total_rois = world * b * args.steps
+        line = {
+            "metric": "ROIs/sec (GDRNPP fwd + PnP + depth refine), 256x256 crops" if refine
+            else "ROIs/sec (GDRNPP fwd + Patch-PnP, RGB only), 256x256 crops",
+            "value": total_rois / dt, "unit": "ROIs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (seeded ROIs, ellipsoid meshes 2562V/5120F, random-init weights)",
+            "config": {
+                "workload": ("YCB-V convnext_a6 + fast depth refine (render-compare), batch=%d ROIs/GPU"
+                             % b) if refine else ("YCB-V convnext_a6, RGB-only Patch-PnP, batch=%d ROIs/GPU" % b),
+                "baseline_config_index": 2 if refine else 1, "global_batch": world * b, "rois_per_gpu": b,
+                "num_classes": C, "input_res": 256, "output_res": 64, "refine_iters": cfg.TEST.DEPTH_REFINE_ITER if refine else 0,
+                "parallelism": f"roi-shard x{world}", "class_sliced_out_layer": not args.exact_reference_order,
+                "post_only": bool(args.post_only)},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "stages_ms": {"forward": fwd_ms, "depth_refine": roofline["launch_ms"] if roofline else None},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,238 @@
+"""``GDRN_Net`` for inference: the forward/API surface of the reference kept verbatim
+(core/gdrn_modeling/models/GDRN_double_mask.py:35-214,539-615 and models/GDRN.py:66-205),
+the schedule re-designed for MI355X:
+
+* backbone / geometry head / Patch-PnP run as PyTorch-ROCm modules (fp32, channels-last);
+* CLASS-SLICED OUTPUT LAYER: the reference computes all ``(2+3+65)*C`` output maps
+  (1470 channels = 24 MB/ROI for YCB-V) and then keeps the 70 of the ROI's class
+  (GDRN_double_mask.py:107-126).  Here the 70 rows of ``out_layer.weight`` belonging to each ROI's
+  class are gathered and applied with one batched GEMM ``[B,70,256] x [B,256,4096]`` — same
+  arithmetic per kept channel, 21x less MFMA work and none of the 24 MB/ROI of HBM traffic
+  (SURVEY.md §7 item 9.ii).  ``exact_reference_order=True`` runs the reference's own graph instead;
+* rot6d -> R, centroid/z -> t and allocentric -> egocentric run in one HIP kernel on the device
+  (``gdrnpp_pose_from_pred_centroid_z``) instead of the reference's D2H sync + per-ROI NumPy loop
+  (pose_from_pred_centroid_z.py:118-154), so ``forward`` never synchronises with the host.
+  Consequence: ``out["rot"]`` is a DEVICE tensor (the reference returns a CPU tensor).
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip_lib
+from .backbones import create_backbone
+from .heads import HEADS
+
+
+def get_xyz_mask_region_out_dim(cfg, double_mask=False):
+    """models/model_utils.py:40-65 (and the doublemask variant): (xyz, mask, region) output dims."""
+    net_cfg = cfg.MODEL.POSE_NET
+    loss_cfg = net_cfg.LOSS_CFG
+    if loss_cfg.XYZ_LOSS_TYPE in ("MSE", "L1", "L2", "SmoothL1"):
+        xyz_out_dim = 3
+    elif loss_cfg.XYZ_LOSS_TYPE in ("CE_coor", "CE"):
+        xyz_out_dim = 3 * (net_cfg.GEO_HEAD.XYZ_BIN + 1)
+    else:
+        raise NotImplementedError(loss_cfg.XYZ_LOSS_TYPE)
+    if loss_cfg.MASK_LOSS_TYPE in ("L1", "BCE", "RW_BCE", "dice"):
+        mask_out_dim = 2 if double_mask else 1
+    elif loss_cfg.MASK_LOSS_TYPE == "CE":
+        mask_out_dim = 4 if double_mask else 2
+    else:
+        raise NotImplementedError(loss_cfg.MASK_LOSS_TYPE)
+    region_out_dim = net_cfg.GEO_HEAD.NUM_REGIONS + 1
+    assert region_out_dim > 2
+    return xyz_out_dim, mask_out_dim, region_out_dim
+
+
+def get_mask_prob(pred_mask, mask_loss_type):
+    """models/model_utils.py:362-380."""
+    bs = pred_mask.shape[0]
+    if mask_loss_type == "L1":
+        mx = pred_mask.view(bs, -1).max(-1)[0].view(bs, 1, 1, 1)
+        mn = pred_mask.view(bs, -1).min(-1)[0].view(bs, 1, 1, 1)
+        return (pred_mask - mn) / (mx - mn)
+    if mask_loss_type in ("BCE", "RW_BCE", "dice"):
+        return torch.sigmoid(pred_mask)
+    raise NotImplementedError(mask_loss_type)
+
+
+class GDRN_DoubleMask(nn.Module):
+    def __init__(self, cfg, backbone, geo_head_net, neck=None, pnp_net=None):
+        super().__init__()
+        assert cfg.MODEL.POSE_NET.NAME in ("GDRN_double_mask", "GDRN"), cfg.MODEL.POSE_NET.NAME
+        self.backbone = backbone
+        self.neck = neck
+        self.geo_head_net = geo_head_net
+        self.pnp_net = pnp_net
+        self.cfg = cfg
+        self.double_mask = cfg.MODEL.POSE_NET.NAME == "GDRN_double_mask"
+        self.xyz_out_dim, self.mask_out_dim, self.region_out_dim = get_xyz_mask_region_out_dim(cfg, self.double_mask)
+        g = cfg.MODEL.POSE_NET.GEO_HEAD
+        self.class_aware = bool(g.XYZ_CLASS_AWARE and g.MASK_CLASS_AWARE and g.REGION_CLASS_AWARE)
+        self.exact_reference_order = False
+        if self.class_aware and self.xyz_out_dim == 3:
+            self.register_buffer("_cls_rows", geo_head_net.class_channel_index(cfg.MODEL.POSE_NET.NUM_CLASSES),
+                                 persistent=False)
+        self._sliced_w = None  # cache of (weight[C,70,256], bias[C,70]) for eval
+
+    # ------------------------------------------------------------------------------------------
+    def _sliced_out_layer(self, feat, roi_classes):
+        """Per-ROI 70-channel output layer = the class-aware gather folded into the weights."""
+        ol = self.geo_head_net.out_layer
+        if self._sliced_w is None or self.training or self._sliced_w[0].device != feat.device:
+            w = ol.weight.view(ol.out_channels, -1)[self._cls_rows]  # [C,70,256]
+            b = ol.bias[self._cls_rows]                               # [C,70]
+            self._sliced_w = (w.contiguous(), b.contiguous())
+        w, b = self._sliced_w
+        bs, ch, h, wd = feat.shape
+        x = feat.reshape(bs, ch, h * wd)  # NCHW-logical [B,256,4096]; one copy if feat is channels-last
+        out = torch.baddbmm(b[roi_classes].unsqueeze(-1), w[roi_classes], x)  # [B,70,4096]
+        out = out.view(bs, -1, h, wd)
+        k = self.mask_out_dim
+        vis = out[:, 0:1]
+        full = out[:, 1:2] if k == 2 else None
+        return vis, full, out[:, k:k + 1], out[:, k + 1:k + 2], out[:, k + 2:k + 3], out[:, k + 3:]
+
+    def forward_maps(self, x, roi_classes=None, roi_coord_2d=None, roi_coord_2d_rel=None, roi_extents=None):
+        """Everything of ``forward`` up to the Patch-PnP outputs: pure PyTorch (also runs on CPU)."""
+        cfg = self.cfg
+        net_cfg = cfg.MODEL.POSE_NET
+        g_head_cfg = net_cfg.GEO_HEAD
+        pnp_net_cfg = net_cfg.PNP_NET
+        bs = x.shape[0]
+        num_classes = net_cfg.NUM_CLASSES
+        out_res = net_cfg.OUTPUT_RES
+
+        conv_feat = self.backbone(x)  # [bs, c, 8, 8]
+        if self.neck is not None:
+            conv_feat = self.neck(conv_feat)
+
+        full_mask = None
+        if self.class_aware and self.xyz_out_dim == 3 and not self.exact_reference_order:
+            assert roi_classes is not None
+            feat = self.geo_head_net.trunk(conv_feat)
+            vis_mask, full_mask, coor_x, coor_y, coor_z, region = self._sliced_out_layer(feat, roi_classes)
+        else:
+            outs = self.geo_head_net(conv_feat)
+            if self.double_mask:
+                vis_mask, full_mask, coor_x, coor_y, coor_z, region = outs
+            else:
+                vis_mask, coor_x, coor_y, coor_z, region = outs
+            ar = torch.arange(bs, device=x.device)
+            if g_head_cfg.XYZ_CLASS_AWARE:
+                assert roi_classes is not None
+                coor_x = coor_x.reshape(bs, num_classes, self.xyz_out_dim // 3, out_res, out_res)[ar, roi_classes]
+                coor_y = coor_y.reshape(bs, num_classes, self.xyz_out_dim // 3, out_res, out_res)[ar, roi_classes]
+                coor_z = coor_z.reshape(bs, num_classes, self.xyz_out_dim // 3, out_res, out_res)[ar, roi_classes]
+            if g_head_cfg.MASK_CLASS_AWARE:
+                md = self.mask_out_dim // 2 if self.double_mask else self.mask_out_dim
+                vis_mask = vis_mask.reshape(bs, num_classes, md, out_res, out_res)[ar, roi_classes]
+                if full_mask is not None:
+                    full_mask = full_mask.reshape(bs, num_classes, md, out_res, out_res)[ar, roi_classes]
+            if g_head_cfg.REGION_CLASS_AWARE:
+                region = region.reshape(bs, num_classes, self.region_out_dim, out_res, out_res)[ar, roi_classes]
+
+        # ---- Patch-PnP inputs (GDRN_double_mask.py:128-160) -----------------------------------------
+        if coor_x.shape[1] > 1:
+            coor_feat = torch.cat([F.softmax(coor_x[:, :-1], dim=1), F.softmax(coor_y[:, :-1], dim=1),
+                                   F.softmax(coor_z[:, :-1], dim=1)], dim=1)
+        else:
+            coor_feat = torch.cat([coor_x, coor_y, coor_z], dim=1)
+        if pnp_net_cfg.WITH_2D_COORD:
+            if pnp_net_cfg.COORD_2D_TYPE == "rel":
+                coor_feat = torch.cat([coor_feat, roi_coord_2d_rel], dim=1)
+            else:
+                coor_feat = torch.cat([coor_feat, roi_coord_2d], dim=1)
+        region_softmax = F.softmax(region[:, 1:], dim=1)  # channel 0 is bg
+        mask_atten = None
+        if pnp_net_cfg.MASK_ATTENTION != "none":
+            mask_atten = get_mask_prob(vis_mask, net_cfg.LOSS_CFG.MASK_LOSS_TYPE)
+        region_atten = region_softmax if pnp_net_cfg.REGION_ATTENTION else None
+        pred_rot_, pred_t_ = self.pnp_net(coor_feat, region=region_atten, extents=roi_extents,
+                                          mask_attention=mask_atten)
+
+        maps = {"mask": vis_mask, "coor_x": coor_x, "coor_y": coor_y, "coor_z": coor_z, "region": region}
+        if full_mask is not None:
+            maps["full_mask"] = full_mask
+        return pred_rot_, pred_t_, maps
+
+    def forward(self, x, gt_xyz=None, gt_xyz_bin=None, gt_mask_trunc=None, gt_mask_visib=None, gt_mask_obj=None,
+                gt_mask_full=None, gt_region=None, gt_ego_rot=None, gt_points=None, sym_infos=None, gt_trans=None,
+                gt_trans_ratio=None, roi_classes=None, roi_coord_2d=None, roi_coord_2d_rel=None, roi_cams=None,
+                roi_centers=None, roi_whs=None, roi_extents=None, resize_ratios=None, do_loss=False):
+        if do_loss:
+            raise NotImplementedError("training losses are out of scope of this build (SURVEY.md §2.1)")
+        cfg = self.cfg
+        pnp_net_cfg = cfg.MODEL.POSE_NET.PNP_NET
+        bs = x.shape[0]
+        pred_rot_, pred_t_, maps = self.forward_maps(x, roi_classes, roi_coord_2d, roi_coord_2d_rel, roi_extents)
+
+        # ---- rot6d -> R, centroid/z -> t, allo -> ego: one HIP kernel, no host sync --------------------------
+        rot_type = pnp_net_cfg.ROT_TYPE
+        if rot_type not in ("allo_rot6d", "ego_rot6d") or pnp_net_cfg.TRANS_TYPE != "centroid_z":
+            raise NotImplementedError(f"ROT_TYPE={rot_type} TRANS_TYPE={pnp_net_cfg.TRANS_TYPE}")
+        if pnp_net_cfg.Z_TYPE not in ("REL", "ABS"):
+            raise NotImplementedError(f"Z_TYPE={pnp_net_cfg.Z_TYPE}")
+        pred_ego_rot, pred_trans = hip_lib.pose_from_pred_centroid_z(
+            pred_rot_.float().contiguous(), pred_t_.float().contiguous(), roi_cams.reshape(bs, 9).contiguous(),
+            roi_centers.contiguous(), roi_whs.contiguous(), resize_ratios.reshape(bs).contiguous(),
+            z_type=pnp_net_cfg.Z_TYPE, is_allo="allo" in rot_type)
+
+        out_dict = {"rot": pred_ego_rot, "trans": pred_trans}
+        if cfg.TEST.USE_PNP or cfg.TEST.SAVE_RESULTS_ONLY or cfg.TEST.USE_DEPTH_REFINE:
+            out_dict.update(maps)
+        return out_dict
+
+
+def build_model_optimizer(cfg, is_test=True):
+    """GDRN_double_mask.py:539-615 — returns (model, optimizer); the optimizer is None (inference build)."""
+    if not is_test:
+        raise NotImplementedError("training is out of scope of this build (SURVEY.md §2.1)")
+    net_cfg = cfg.MODEL.POSE_NET
+    init_backbone_args = copy.deepcopy(dict(net_cfg.BACKBONE.INIT_CFG))
+    backbone = create_backbone(**init_backbone_args)
+
+    double = net_cfg.NAME == "GDRN_double_mask"
+    g = net_cfg.GEO_HEAD
+    head_cfg = copy.deepcopy(dict(g.INIT_CFG))
+    head_type = head_cfg.pop("type")
+    xyz_dim, mask_dim, region_dim = get_xyz_mask_region_out_dim(cfg, double)
+    head_cfg.update(
+        xyz_num_classes=net_cfg.NUM_CLASSES if g.XYZ_CLASS_AWARE else 1,
+        mask_num_classes=net_cfg.NUM_CLASSES if g.MASK_CLASS_AWARE else 1,
+        region_num_classes=net_cfg.NUM_CLASSES if g.REGION_CLASS_AWARE else 1,
+        xyz_out_dim=xyz_dim, mask_out_dim=mask_dim, region_out_dim=region_dim)
+    geo_head = HEADS[head_type](**head_cfg)
+
+    # models/model_utils.py:198-274 (get_pnp_net)
+    p = net_cfg.PNP_NET
+    xyz_dim1, _, _ = get_xyz_mask_region_out_dim(cfg, False)
+    n_in = xyz_dim1 - 3 if net_cfg.LOSS_CFG.XYZ_LOSS_TYPE in ("CE_coor", "CE") else xyz_dim1
+    n_in += 2 if p.WITH_2D_COORD else 0
+    n_in += g.NUM_REGIONS if p.REGION_ATTENTION else 0
+    n_in += 1 if p.MASK_ATTENTION == "concat" else 0
+    rot_dim = {"allo_rot6d": 6, "ego_rot6d": 6, "allo_quat": 4, "ego_quat": 4}[p.ROT_TYPE]
+    pnp_cfg = copy.deepcopy(dict(p.INIT_CFG))
+    pnp_type = pnp_cfg.pop("type")
+    pnp_cfg.update(nIn=n_in, rot_dim=rot_dim, num_regions=g.NUM_REGIONS, mask_attention_type=p.MASK_ATTENTION)
+    pnp_net = HEADS[pnp_type](**pnp_cfg)
+
+    model = GDRN_DoubleMask(cfg, backbone, neck=None, geo_head_net=geo_head, pnp_net=pnp_net)
+    model.eval()
+    if cfg.MODEL.DEVICE != "cpu" and torch.cuda.is_available():
+        model.to(torch.device(cfg.MODEL.DEVICE))
+        model.to(memory_format=torch.channels_last)
+    return model, None
+
+
+def load_checkpoint(model, path, strict=False):
+    """core/utils/my_checkpoint.py:28-83: ``{"model": state_dict}``, keys may carry a ``_module.`` / ``module.`` prefix."""
+    sd = torch.load(path, map_location="cpu")
+    sd = sd.get("model", sd)
+    sd = {k.replace("_module.", "", 1).replace("module.", "", 1) if k.startswith(("_module.", "module.")) else k: v
+          for k, v in sd.items()}
+    return model.load_state_dict(sd, strict=strict)

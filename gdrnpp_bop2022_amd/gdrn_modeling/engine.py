@@ -1,0 +1,129 @@
+"""Inference engine: the reference's ``gdrn_inference_on_dataset`` + ``GDRN_Evaluator.process*`` hot loop
+(core/gdrn_modeling/engine/gdrn_evaluator.py:155-239,461-573,575-585,668-809) re-scheduled for MI355X.
+
+Reference schedule per image: forward -> D2H of all maps -> per-ROI Python loop (cv2.resize, vispy GL
+render x2, NumPy compare) -> pickle all-gather.  Here, per batch of ROIs resident in HBM:
+
+    forward (PyTorch-ROCm, no host sync)                                 a3
+      -> gdrnpp_zoom_K                         (K_crop for the 64x64 maps)   a8.2
+      -> gdrnpp_depth_refine                   (all iterations on chip)      a8 / a8.1
+      -> gdrnpp_pack_pose_records              ([n,16] f32 records)          a13
+      -> one RCCL all_gather of the fixed-shape records (multi-GPU only)
+
+Nothing is copied to the host until the caller asks for the records.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .. import hip_lib
+
+
+def shard_range(n: int, rank: int, world: int):
+    """Contiguous ROI shard of rank ``rank`` — InferenceSampler's rule (core/utils/my_distributed_sampler.py:
+    181-194) at ROI granularity: ceil(n/world)-sized blocks, the last ranks may get fewer (or none)."""
+    shard = (n - 1) // world + 1 if n > 0 else 0
+    begin = min(shard * rank, n)
+    end = min(shard * (rank + 1), n)
+    return begin, end
+
+
+class GdrnHipPost:
+    """Batched, device-resident replacement of ``GDRN_Evaluator.process / process_depth_refine``."""
+
+    def __init__(self, cfg, meshes: "hip_lib.MeshSet | None" = None, z_near: float = 0.1, z_far: float = 100.0):
+        self.cfg = cfg
+        self.meshes = meshes
+        self.z_near, self.z_far = z_near, z_far  # Renderer.set_cam defaults (render_vispy/renderer.py:126)
+        net_cfg = cfg.MODEL.POSE_NET
+        self.out_res = net_cfg.OUTPUT_RES
+        mlt = net_cfg.LOSS_CFG.MASK_LOSS_TYPE
+        if mlt == "L1":
+            self.mask_type = 0
+        elif mlt in ("BCE", "RW_BCE", "dice"):
+            self.mask_type = 1
+        else:
+            raise NotImplementedError(f"MASK_LOSS_TYPE={mlt}")
+        if cfg.TEST.USE_DEPTH_REFINE and meshes is None:
+            raise ValueError("TEST.USE_DEPTH_REFINE needs the object meshes (gdrn_evaluator.py:64-84)")
+
+    def process_depth_refine(self, batch: dict, out_dict: dict) -> torch.Tensor:
+        """-> refined translation f64[b,3]; rotation is unchanged (gdrn_evaluator.py:559-561)."""
+        cfg = self.cfg
+        b = out_dict["trans"].shape[0]
+        K_crop = hip_lib.zoom_K(batch["roi_cam"].reshape(b, 9).contiguous(), batch["roi_center"].contiguous(),
+                                batch["scale"].reshape(b).contiguous(), self.out_res)
+        return hip_lib.depth_refine(
+            self.meshes, batch["roi_cls"].to(torch.int32), out_dict["coor_x"].contiguous(),
+            out_dict["coor_y"].contiguous(), out_dict["coor_z"].contiguous(), out_dict["mask"].contiguous(),
+            batch["roi_depth"].contiguous(), K_crop, out_dict["rot"].reshape(b, 9).contiguous(),
+            out_dict["trans"].contiguous(), res=self.out_res, iters=cfg.TEST.DEPTH_REFINE_ITER,
+            threshold=cfg.TEST.DEPTH_REFINE_THRESHOLD, mask_type=self.mask_type,
+            use_coor_z=bool(cfg.TEST.USE_COOR_Z_REFINE), z_near=self.z_near, z_far=self.z_far)
+
+    def process_correspondences(self, batch: dict, out_dict: dict):
+        """2D-3D correspondences for the PnP variants (gdrn_evaluator.py:115-153,255-311), all ROIs at once."""
+        imwh = torch.stack([batch["im_W"], batch["im_H"]], 1).float().contiguous()
+        return hip_lib.decode_correspondences(
+            out_dict["coor_x"].contiguous(), out_dict["coor_y"].contiguous(), out_dict["coor_z"].contiguous(),
+            out_dict["mask"].contiguous(), batch["roi_coord_2d"].contiguous(), batch["roi_extent"].contiguous(), imwh,
+            mask_type=self.mask_type, mask_thr=self.cfg.MODEL.POSE_NET.GEO_HEAD.MASK_THR_TEST)
+
+    def process(self, batch: dict, out_dict: dict, roi_ids: torch.Tensor | None = None) -> torch.Tensor:
+        """-> pose records f32[b,16] = R(9) | t(3, metres) | score | obj | roi_id | valid."""
+        t_ref = self.process_depth_refine(batch, out_dict) if self.cfg.TEST.USE_DEPTH_REFINE else None
+        b = out_dict["trans"].shape[0]
+        return hip_lib.pack_pose_records(
+            out_dict["rot"].reshape(b, 9).contiguous(), t_ref, out_dict["trans"].contiguous(),
+            batch["score"].float().contiguous() if "score" in batch else None,
+            batch["roi_cls"].to(torch.int32).contiguous(), roi_ids)
+
+
+@torch.no_grad()
+def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor | None = None) -> torch.Tensor:
+    """One pass of the hot path over one batch of ROIs (the unit ``bench.py`` times)."""
+    out_dict = model(
+        batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"], roi_whs=batch["roi_wh"],
+        roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"],
+        roi_coord_2d=batch.get("roi_coord_2d"), roi_coord_2d_rel=batch.get("roi_coord_2d_rel"),
+        roi_extents=batch.get("roi_extent"))
+    return post.process(batch, out_dict, roi_ids)
+
+
+def gather_records(rec: torch.Tensor, n_local_max: int, group=None) -> torch.Tensor:
+    """The one collective of the inference path (gdrn_evaluator.py:575-585 / my_comm.py:70-171): instead of
+    pickling Python dicts into byte tensors (size all-gather + padded byte all-gather), every rank contributes a
+    fixed-shape f32[n_local_max,16] block (``valid`` = 0 on padding rows) to ONE all_gather — 64 B per ROI,
+    latency-bound on xGMI.  Returns f32[world*n_local_max,16] on every rank."""
+    if rec.shape[0] < n_local_max:
+        pad = torch.zeros((n_local_max - rec.shape[0], 16), dtype=rec.dtype, device=rec.device)
+        rec = torch.cat([rec, pad], 0)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return rec
+    world = dist.get_world_size(group)
+    rec = rec.contiguous()
+    if dist.get_backend(group) == "gloo":  # CPU tests: list form
+        parts = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(parts, rec, group=group)
+        return torch.cat(parts, 0)
+    out = torch.empty((world * n_local_max, 16), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, rec, group=group)  # RCCL ncclAllGather over xGMI
+    return out
+
+
+def records_to_bop(rec: torch.Tensor, scene_im_ids, obj_ids, times=None):
+    """BOP result dicts as ``pose_prediction_to_json`` writes them (gdrn_evaluator.py:636-665): t in mm."""
+    rec = rec.detach().cpu()
+    results = []
+    for r in rec:
+        if r[15] < 0.5:
+            continue
+        i = int(r[14])
+        scene_id, im_id = scene_im_ids[i].split("/")
+        results.append({
+            "scene_id": scene_id, "im_id": int(im_id), "obj_id": int(obj_ids[int(r[13])]), "score": float(r[12]),
+            "R": r[:9].reshape(3, 3).tolist(), "t": (1000.0 * r[9:12]).tolist(),
+            "time": float(times[i]) if times is not None else -1.0,
+        })
+    return results

@@ -1,0 +1,227 @@
+"""Geometry head and Patch-PnP head of GDRNPP, mirroring the reference modules by name:
+
+* ``TopDownDoubleMaskXyzRegionHead`` / ``TopDownMaskXyzRegionHead``
+  (models/heads/top_down_doublemask_xyz_region_head.py:9-211, top_down_mask_xyz_region_head.py)
+* ``ConvPnPNet`` (models/heads/conv_pnp_net.py:10-183)
+* ``ConvModule`` (lib/torch_utils/layers/conv_module.py:103-236): sub-modules ``conv``, ``gn``, ``activate``.
+
+Parameter names equal the reference's so that ``geo_head_net.*`` / ``pnp_net.*`` checkpoint keys load
+by name.  Inference only: initialisers follow the reference, losses/dropblock are not carried.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+
+def get_nn_act_func(act: str):
+    """lib/torch_utils/layers/layer_utils.py:63-100 (subset used by the GDRNPP configs)."""
+    a = act.lower()
+    if a == "relu":
+        return nn.ReLU(inplace=True)
+    if a in ("lrelu", "leaky_relu", "leakyrelu"):
+        return nn.LeakyReLU(negative_slope=0.1, inplace=True)
+    if a == "gelu":
+        return nn.GELU()
+    if a in ("silu", "swish"):
+        return nn.SiLU(inplace=True)
+    if a == "mish":
+        return nn.Mish(inplace=True)
+    raise ValueError(f"Unknown activation: {act}")
+
+
+def get_norm(norm: str, ch: int, num_gn_groups: int = 32):
+    """layer_utils.py:32-60."""
+    if norm is None or norm == "" or norm.lower() == "none":
+        return nn.Identity()
+    if norm == "GN":
+        return nn.GroupNorm(num_gn_groups, ch)
+    if norm == "BN":
+        return nn.BatchNorm2d(ch)
+    raise ValueError(f"Unknown norm: {norm}")
+
+
+class ConvModule(nn.Module):
+    """conv (bias only without norm) -> norm (registered as ``gn``/``bn``) -> act (``activate``)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, stride=1, padding=0, norm=None, num_gn_groups=32, act=None):
+        super().__init__()
+        with_norm = norm is not None and norm != "" and norm.lower() != "none"
+        self.conv = nn.Conv2d(in_ch, out_ch, kernel_size, stride, padding, bias=not with_norm)
+        self.norm_name = None
+        if with_norm:
+            self.norm_name = {"GN": "gn", "BN": "bn"}[norm]
+            self.add_module(self.norm_name, get_norm(norm, out_ch, num_gn_groups))
+        self.activate = get_nn_act_func(act) if act else None
+        nn.init.kaiming_normal_(self.conv.weight, a=0, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.norm_name is not None:
+            x = getattr(self, self.norm_name)(x)
+        if self.activate is not None:
+            x = self.activate(x)
+        return x
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # the reference registers the norm twice (`self.norm = …` and add_module("gn", …),
+        # conv_module.py:175-182), so its checkpoints carry duplicate `norm.*` keys: drop them.
+        for k in [k for k in state_dict if k.startswith(prefix + "norm.")]:
+            state_dict.pop(k)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+def _normal_init(m, std):
+    nn.init.normal_(m.weight, 0.0, std)
+    if getattr(m, "bias", None) is not None:
+        nn.init.constant_(m.bias, 0.0)
+
+
+class TopDownMaskXyzRegionHead(nn.Module):
+    """Shared trunk 8x8 -> 64x64 and a shared 1x1 output layer.  ``double_mask`` selects the
+    [vis C | full C | xyz 3C | region 65C] split of the DoubleMask variant
+    (top_down_doublemask_xyz_region_head.py:184-197), else [mask | xyz | region]."""
+
+    double_mask = False
+
+    def __init__(self, in_dim, up_types=("deconv", "bilinear", "bilinear"), deconv_kernel_size=3,
+                 num_conv_per_block=2, feat_dim=256, feat_kernel_size=3, norm="GN", num_gn_groups=32, act="GELU",
+                 out_kernel_size=1, out_layer_shared=True, mask_num_classes=1, xyz_num_classes=1,
+                 region_num_classes=1, mask_out_dim=1, xyz_out_dim=3, region_out_dim=65, **_unused):
+        super().__init__()
+        assert out_layer_shared and out_kernel_size == 1, "GDRNPP configs use the shared 1x1 output layer"
+        self.features = nn.ModuleList()
+        for i, up_type in enumerate(up_types):
+            _in = in_dim if i == 0 else feat_dim
+            if up_type == "deconv":
+                pad, out_pad = {4: (1, 0), 3: (1, 1), 2: (0, 0)}[deconv_kernel_size]
+                self.features.append(nn.ConvTranspose2d(_in, feat_dim, deconv_kernel_size, stride=2, padding=pad,
+                                                        output_padding=out_pad, bias=False))
+                self.features.append(get_norm(norm, feat_dim, num_gn_groups))
+                self.features.append(get_nn_act_func(act))
+            elif up_type == "bilinear":
+                self.features.append(nn.UpsamplingBilinear2d(scale_factor=2))
+            elif up_type == "nearest":
+                self.features.append(nn.UpsamplingNearest2d(scale_factor=2))
+            else:
+                raise ValueError(f"Unknown up_type: {up_type}")
+            for i_conv in range(num_conv_per_block):
+                cin = in_dim if (i == 0 and i_conv == 0 and up_type in ("bilinear", "nearest")) else feat_dim
+                self.features.append(ConvModule(cin, feat_dim, feat_kernel_size, padding=(feat_kernel_size - 1) // 2,
+                                                norm=norm, num_gn_groups=num_gn_groups, act=act))
+        self.mask_num_classes, self.xyz_num_classes = mask_num_classes, xyz_num_classes
+        self.region_num_classes = region_num_classes
+        self.mask_out_dim, self.xyz_out_dim, self.region_out_dim = mask_out_dim, xyz_out_dim, region_out_dim
+        out_dim = mask_out_dim * mask_num_classes + xyz_out_dim * xyz_num_classes + region_out_dim * region_num_classes
+        self.out_layer = nn.Conv2d(feat_dim, out_dim, kernel_size=1, bias=True)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                _normal_init(m, 0.001)
+            elif isinstance(m, nn.GroupNorm):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0.0)
+        _normal_init(self.out_layer, 0.01)
+
+    def trunk(self, x):
+        if isinstance(x, (tuple, list)) and len(x) == 1:
+            x = x[0]
+        for layer in self.features:
+            x = layer(x)
+        return x
+
+    def split(self, out):
+        """Channel split of the full output (reference forward tail)."""
+        mask_dim = self.mask_out_dim * self.mask_num_classes
+        xyz_dim = self.xyz_out_dim * self.xyz_num_classes
+        xyz = out[:, mask_dim:mask_dim + xyz_dim]
+        region = out[:, mask_dim + xyz_dim:]
+        bs, c, h, w = xyz.shape
+        xyz = xyz.view(bs, 3, xyz_dim // 3, h, w)
+        coor = (xyz[:, 0], xyz[:, 1], xyz[:, 2])
+        if self.double_mask:
+            return (out[:, :mask_dim // 2], out[:, mask_dim // 2:mask_dim]) + coor + (region,)
+        return (out[:, :mask_dim],) + coor + (region,)
+
+    def forward(self, x):
+        return self.split(self.out_layer(self.trunk(x)))
+
+    # ---- class-sliced output layer ------------------------------------
+    def class_channel_index(self, num_classes: int) -> torch.Tensor:
+        """Rows of ``out_layer.weight`` that the class-aware gather of GDRN_double_mask.py:107-126
+        keeps for class c, in the order [vis, full, x, y, z, region(65)] -> i64[C, 70]."""
+        C = num_classes
+        assert self.xyz_out_dim == 3 and self.mask_num_classes == self.xyz_num_classes == self.region_num_classes == C
+        rows = []
+        md = self.mask_out_dim  # 2 (double mask) or 1
+        for c in range(C):
+            r = [k * C + c for k in range(md)]                       # vis (, full)
+            r += [md * C + k * C + c for k in range(3)]               # x, y, z
+            r += [md * C + 3 * C + c * self.region_out_dim + j for j in range(self.region_out_dim)]
+            rows.append(r)
+        return torch.tensor(rows, dtype=torch.long)
+
+
+class TopDownDoubleMaskXyzRegionHead(TopDownMaskXyzRegionHead):
+    double_mask = True
+
+    def __init__(self, in_dim, mask_out_dim=2, **kw):
+        super().__init__(in_dim, mask_out_dim=mask_out_dim, **kw)
+
+
+class ConvPnPNet(nn.Module):
+    """Patch-PnP: 3 x [conv3x3 s2 -> GN -> act] -> flatten -> fc1 -> fc2 -> (fc_r, fc_t)."""
+
+    def __init__(self, nIn, num_regions=8, mask_attention_type="none", featdim=128, rot_dim=6, num_stride2_layers=3,
+                 num_extra_layers=0, norm="GN", num_gn_groups=32, act="relu", drop_prob=0.0, flat_op="flatten",
+                 final_spatial_size=(8, 8), denormalize_by_extent=True, **_unused):
+        super().__init__()
+        assert flat_op == "flatten" and drop_prob == 0.0
+        self.mask_attention_type = mask_attention_type
+        self.denormalize_by_extent = denormalize_by_extent
+        # legacy quirk kept: cfg act "relu" means ReLU in the convs but LeakyReLU(0.1) in the fcs (conv_pnp_net.py:43-48)
+        self.act = get_nn_act_func("lrelu") if act == "relu" else get_nn_act_func(act)
+        self.features = nn.ModuleList()
+        for i in range(num_stride2_layers):
+            self.features.append(nn.Conv2d(nIn if i == 0 else featdim, featdim, 3, stride=2, padding=1, bias=False))
+            self.features.append(get_norm(norm, featdim, num_gn_groups))
+            self.features.append(get_nn_act_func(act))
+        for _ in range(num_extra_layers):
+            self.features.append(nn.Conv2d(featdim, featdim, 3, stride=1, padding=1, bias=False))
+            self.features.append(get_norm(norm, featdim, num_gn_groups))
+            self.features.append(get_nn_act_func(act))
+        fh, fw = final_spatial_size
+        self.fc1 = nn.Linear(featdim * fh * fw, 1024)
+        self.fc2 = nn.Linear(1024, 256)
+        self.fc_r = nn.Linear(256, rot_dim)
+        self.fc_t = nn.Linear(256, 3)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                _normal_init(m, 0.001)
+            elif isinstance(m, nn.GroupNorm):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0.0)
+        _normal_init(self.fc_r, 0.01)
+        _normal_init(self.fc_t, 0.01)
+
+    def forward(self, coor_feat, region=None, extents=None, mask_attention=None):
+        bs, in_c, fh, fw = coor_feat.shape
+        if in_c in (3, 5) and self.denormalize_by_extent and extents is not None:
+            coor_feat[:, :3] = (coor_feat[:, :3] - 0.5) * extents.view(bs, 3, 1, 1)  # in place, like :130-131
+        x = torch.cat([coor_feat, region], dim=1) if region is not None else coor_feat
+        if self.mask_attention_type == "mul":
+            x = x * mask_attention
+        elif self.mask_attention_type == "concat":
+            x = torch.cat([x, mask_attention], dim=1)
+        for layer in self.features:
+            x = layer(x)
+        x = x.flatten(2).flatten(1)  # NCHW order, like the reference (weights of fc1 depend on it)
+        x = self.act(self.fc1(x))
+        x = self.act(self.fc2(x))
+        return self.fc_r(x), self.fc_t(x)
+
+
+HEADS = {
+    "TopDownMaskXyzRegionHead": TopDownMaskXyzRegionHead,
+    "TopDownDoubleMaskXyzRegionHead": TopDownDoubleMaskXyzRegionHead,
+    "ConvPnPNet": ConvPnPNet,
+}

@@ -1,0 +1,114 @@
+"""Host logic of the engine without a GPU: ROI sharding rule, the record all-gather over gloo with
+world_size 2, the class-sliced output layer against the reference-order graph, config surface."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gdrnpp_bop2022_amd.gdrn_modeling import engine
+from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+
+
+def test_shard_range_matches_inference_sampler_rule():
+    # core/utils/my_distributed_sampler.py:191-194: shard = (n-1)//world+1; [shard*rank, min(shard*(rank+1), n))
+    for n in (0, 1, 7, 128, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                b, e = engine.shard_range(n, r, world)
+                assert 0 <= b <= e <= n
+                seen += list(range(b, e))
+            assert seen == list(range(n))
+    assert engine.shard_range(1024, 3, 8) == (384, 512)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, n_total, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = engine.shard_range(n_total, rank, world)
+    n_max = engine.shard_range(n_total, 0, world)[1]
+    rec = torch.zeros((e - b, 16))
+    rec[:, 14] = torch.arange(b, e)  # roi id
+    rec[:, 15] = 1.0                 # valid
+    rec[:, 9] = rank
+    out = engine.gather_records(rec, n_max)
+    ret[rank] = out.numpy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [10, 7])
+def test_gather_records_gloo_world2(n_total):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gather_worker, args=(world, port, n_total, ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    assert np.array_equal(a, b)                 # every rank holds the same gathered block
+    valid = a[a[:, 15] > 0.5]
+    assert sorted(valid[:, 14].astype(int).tolist()) == list(range(n_total))   # every ROI exactly once
+    assert a.shape[0] == world * engine.shard_range(n_total, 0, world)[1]      # fixed shape incl. padding rows
+
+
+def test_config_surface_and_opts():
+    cfg = get_cfg("ycbv_convnext_a6", ["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"])
+    net = cfg.MODEL.POSE_NET
+    assert net.NAME == "GDRN_double_mask" and net.NUM_CLASSES == 21 and net.OUTPUT_RES == 64
+    assert net.GEO_HEAD.INIT_CFG.type == "TopDownDoubleMaskXyzRegionHead" and net.GEO_HEAD.INIT_CFG.in_dim == 1024
+    assert net.GEO_HEAD.INIT_CFG.feat_dim == 256          # inherited from configs/_base_/gdrn_base.py
+    assert net.PNP_NET.INIT_CFG.act == "gelu" and net.PNP_NET.INIT_CFG.type == "ConvPnPNet"
+    assert cfg.TEST.USE_DEPTH_REFINE is True and cfg.TEST.DEPTH_REFINE_ITER == 2
+    assert get_cfg("tless_convnext_a6").MODEL.POSE_NET.NUM_CLASSES == 30
+
+
+def test_class_sliced_out_layer_equals_reference_graph():
+    """The [B,70,256]x[B,256,4096] batched GEMM must reproduce conv1x1(1470 ch) + class gather."""
+    from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+
+    cfg = get_cfg("tless_convnext_a6", ["MODEL.DEVICE=cpu", "TEST.USE_DEPTH_REFINE=True",
+                                        "MODEL.POSE_NET.BACKBONE.INIT_CFG.type=timm/convnext_tiny",
+                                        "MODEL.POSE_NET.GEO_HEAD.INIT_CFG.in_dim=768"])
+    torch.manual_seed(0)
+    model, _ = build_model_optimizer(cfg)
+    torch.nn.init.normal_(model.geo_head_net.out_layer.weight, 0, 0.05)
+    torch.nn.init.normal_(model.geo_head_net.out_layer.bias, 0, 0.5)
+    b = 3
+    x = torch.rand(b, 3, 256, 256)
+    cls = torch.tensor([0, 29, 13])
+    c2 = torch.rand(b, 2, 64, 64)
+    ext = torch.rand(b, 3) * 0.2 + 0.05
+    with torch.no_grad():
+        r1, t1, m1 = model.forward_maps(x, cls, c2, None, ext)
+        model.exact_reference_order = True
+        r2, t2, m2 = model.forward_maps(x, cls, c2, None, ext)
+    assert set(m1) == set(m2) == {"mask", "full_mask", "coor_x", "coor_y", "coor_z", "region"}
+    for k in m1:
+        assert m1[k].shape == m2[k].shape
+        torch.testing.assert_close(m1[k], m2[k], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(r1, r2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(t1, t2, rtol=1e-5, atol=1e-6)
+    # checkpoint key names the reference fixes (GDRN_double_mask.py:39-43, conv_module.py:175-182)
+    keys = set(model.state_dict())
+    for k in ["backbone.stem_0.weight", "backbone.stages_3.blocks.0.conv_dw.weight",
+              "backbone.stages_1.downsample.1.weight", "geo_head_net.features.0.weight",
+              "geo_head_net.features.3.conv.weight", "geo_head_net.features.3.gn.weight",
+              "geo_head_net.out_layer.bias", "pnp_net.features.0.weight", "pnp_net.fc1.weight", "pnp_net.fc_r.bias"]:
+        assert k in keys, k
+    # duplicate `norm.*` keys of reference checkpoints are tolerated
+    sd = model.state_dict()
+    sd["geo_head_net.features.3.norm.weight"] = sd["geo_head_net.features.3.gn.weight"].clone()
+    sd["geo_head_net.features.3.norm.bias"] = sd["geo_head_net.features.3.gn.bias"].clone()
+    model.load_state_dict(sd, strict=True)
