@@ -130,6 +130,12 @@ def main():
 
     model, _ = build_model_optimizer(cfg, is_test=True)
     model.exact_reference_order = bool(args.exact_reference_order)
+    # Random-init weights predict t ~ 0 (object at the camera centre), which no trained model does and which
+    # would make every triangle straddle the camera plane.  Set the translation head's bias to the dataset
+    # prior of the scale-invariant depth z_rel = t_z / resize_ratio (SITE parametrisation,
+    # pose_from_pred_centroid_z.py:84-90) so that predicted poses land in the view frustum.
+    with torch.no_grad():
+        model.pnp_net.fc_t.bias.copy_(torch.tensor([0.0, 0.0, 1.5 * float(S.YCBV_K[0, 0]) * 0.19 / 64.0]))
     C = cfg.MODEL.POSE_NET.NUM_CLASSES
     verts, faces, ext = S.make_models(C, np.random.default_rng(20220925), subdiv=args.subdiv)
     meshes = hip_lib.MeshSet(verts, faces, device=dev)
@@ -223,7 +229,7 @@ def main():
             else "ROIs/sec (GDRNPP fwd + Patch-PnP, RGB only), 256x256 crops",
             "value": total_rois / dt, "unit": "ROIs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded ROIs, ellipsoid meshes 2562V/5120F, random-init weights)",
+            "dtype": "f32", "data": "synthetic (seeded ROIs, ellipsoid meshes 2562V/5120F, random-init weights, t-head bias = z_rel prior)",
             "config": {
                 "workload": ("YCB-V convnext_a6 + fast depth refine (render-compare), batch=%d ROIs/GPU"
                              % b) if refine else ("YCB-V convnext_a6, RGB-only Patch-PnP, batch=%d ROIs/GPU" % b),

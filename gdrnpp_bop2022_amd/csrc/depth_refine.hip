@@ -54,13 +54,13 @@ __device__ __forceinline__ MeshView mesh_of(const float* verts, const int* faces
 }
 
 __device__ __forceinline__ void face_setup(const MeshView& m, int f, const double* K, const double* R,
-                                           const double* t, int res, TriSetup& s) {
+                                           const double* t, int res, double z_near, double z_far, TriSetup& s) {
   const int i0 = m.faces[3 * f], i1 = m.faces[3 * f + 1], i2 = m.faces[3 * f + 2];
   double h0[3], h1[3], h2[3];
   project_vertex(m.verts + 3 * (size_t)i0, K, R, t, h0);
   project_vertex(m.verts + 3 * (size_t)i1, K, R, t, h1);
   project_vertex(m.verts + 3 * (size_t)i2, K, R, t, h2);
-  setup_triangle(h0, h1, h2, res, res, s);
+  setup_triangle(h0, h1, h2, res, res, z_near, z_far, s);
 }
 
 // rasterise the whole mesh into an LDS z-buffer of float-Z bits (must be pre-filled with kInfBits)
@@ -70,7 +70,7 @@ __device__ void raster_mesh_u32(const MeshView& m, const double* K, const double
   __syncthreads();
   for (int f = threadIdx.x; f < m.nfaces; f += kT) {
     TriSetup s;
-    face_setup(m, f, K, R, t, res, s);
+    face_setup(m, f, K, R, t, res, z_near, z_far, s);
     if (s.i_lo > s.i_hi || s.j_lo > s.j_hi) continue;
     const int area = (s.i_hi - s.i_lo + 1) * (s.j_hi - s.j_lo + 1);
     if (area > kLargeArea) {
@@ -88,7 +88,7 @@ __device__ void raster_mesh_u32(const MeshView& m, const double* K, const double
   const int nl = min(*s_nlarge, kMaxLarge);
   for (int q = 0; q < nl; ++q) {
     TriSetup s;
-    face_setup(m, s_large[q], K, R, t, res, s);
+    face_setup(m, s_large[q], K, R, t, res, z_near, z_far, s);
     const int bw = s.i_hi - s.i_lo + 1, bh = s.j_hi - s.j_lo + 1;
     for (int p = threadIdx.x; p < bw * bh; p += kT) {
       const int j = s.j_lo + p / bw, i = s.i_lo + p % bw;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kT) void render_depth_kernel(const float* __restric
     bool large = false;
     TriSetup s;
     if (f < mesh.nfaces) {
-      face_setup(mesh, f, K, R, t, res, s);
+      face_setup(mesh, f, K, R, t, res, z_near, z_far, s);
       if (s.i_lo <= s.i_hi && s.j_lo <= s.j_hi) {
         const int area = (s.i_hi - s.i_lo + 1) * (s.j_hi - s.j_lo + 1);
         if (area > kLargeArea) large = true;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kT) void render_depth_kernel(const float* __restric
       bal &= bal - 1;
       const int ff = __shfl(f, src, 64);
       TriSetup s2;
-      face_setup(mesh, ff, K, R, t, res, s2);
+      face_setup(mesh, ff, K, R, t, res, z_near, z_far, s2);
       const int bw = s2.i_hi - s2.i_lo + 1, bh = s2.j_hi - s2.j_lo + 1;
       for (int p = lane; p < bw * bh; p += 64) {
         const int j = s2.j_lo + p / bw, i = s2.i_lo + p % bw;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kT) void render_depth_kernel(const float* __restric
       if (hit) {
         const int f = (int)(key & 0xffffffffu);
         TriSetup s;
-        face_setup(mesh, f, K, R, t, res, s);
+        face_setup(mesh, f, K, R, t, res, z_near, z_far, s);
         double Z, lam[3];
         const int j = p / res, i = p - j * res;
         if (sample_triangle(s, i, j, z_near, z_far, Z, lam)) {

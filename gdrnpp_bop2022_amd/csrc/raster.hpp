@@ -50,26 +50,49 @@ __device__ __forceinline__ int clampi(double v, int lo, int hi) {
   return (int)v;
 }
 
+// Conservative pixel bbox of the part of the triangle with Z >= z_near (h[2] is the camera-space Z:
+// the last row of K is (0,0,1)).  Triangles entirely nearer than z_near or farther than z_far cannot
+// produce a fragment and are dropped; triangles crossing the near plane are clipped against it
+// (Sutherland-Hodgman on the 3 edges, in homogeneous pixel space where interpolation is linear) so that
+// objects straddling the camera plane do not degrade to a full-image bbox.  The bbox only bounds the
+// search: coverage and depth are decided by sample_triangle alone, so results do not depend on it.
 __device__ __forceinline__ void setup_triangle(const double* h0, const double* h1, const double* h2, int res_w,
-                                               int res_h, TriSetup& s) {
+                                               int res_h, double z_near, double z_far, TriSetup& s) {
   cross3(h1, h2, s.e0);
   cross3(h2, h0, s.e1);
   cross3(h0, h1, s.e2);
   s.D = (h0[0] * s.e0[0] + h0[1] * s.e0[1]) + h0[2] * s.e0[2];
-  if (h0[2] > 0.0 && h1[2] > 0.0 && h2[2] > 0.0) {
+  const double zmin = fmin(h0[2], fmin(h1[2], h2[2])), zmax = fmax(h0[2], fmax(h1[2], h2[2]));
+  double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+  if (zmin >= z_near) {
     const double u0 = h0[0] / h0[2], u1 = h1[0] / h1[2], u2 = h2[0] / h2[2];
     const double v0 = h0[1] / h0[2], v1 = h1[1] / h1[2], v2 = h2[1] / h2[2];
-    const double umin = fmin(u0, fmin(u1, u2)), umax = fmax(u0, fmax(u1, u2));
-    const double vmin = fmin(v0, fmin(v1, v2)), vmax = fmax(v0, fmax(v1, v2));
-    // pixel centre i+0.5 in [umin,umax]  =>  i in [umin-0.5, umax-0.5]; widened by floor/ceil
-    s.i_lo = clampi(floor(umin - 0.5), 0, res_w);       // res_w => empty after the hi clamp
-    s.i_hi = clampi(ceil(umax - 0.5), -1, res_w - 1);
-    s.j_lo = clampi(floor(vmin - 0.5), 0, res_h);
-    s.j_hi = clampi(ceil(vmax - 0.5), -1, res_h - 1);
+    umin = fmin(u0, fmin(u1, u2)); umax = fmax(u0, fmax(u1, u2));
+    vmin = fmin(v0, fmin(v1, v2)); vmax = fmax(v0, fmax(v1, v2));
   } else {
-    s.i_lo = 0; s.i_hi = res_w - 1; s.j_lo = 0; s.j_hi = res_h - 1;
+    const double* hv[3] = {h0, h1, h2};
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const double* a = hv[e];
+      const double* b = hv[(e + 1) % 3];
+      const bool ain = a[2] >= z_near, bin = b[2] >= z_near;
+      if (ain) {
+        const double u = a[0] / a[2], v = a[1] / a[2];
+        umin = fmin(umin, u); umax = fmax(umax, u); vmin = fmin(vmin, v); vmax = fmax(vmax, v);
+      }
+      if (ain != bin) {
+        const double t = (z_near - a[2]) / (b[2] - a[2]);
+        const double u = (a[0] + t * (b[0] - a[0])) / z_near, v = (a[1] + t * (b[1] - a[1])) / z_near;
+        umin = fmin(umin, u); umax = fmax(umax, u); vmin = fmin(vmin, v); vmax = fmax(vmax, v);
+      }
+    }
   }
-  if (!(s.D != 0.0)) { s.i_lo = 1; s.i_hi = 0; }  // degenerate (or NaN) triangle
+  // pixel centre i+0.5 in [umin,umax]  =>  i in [umin-0.5, umax-0.5]; widened by a whole pixel each side
+  s.i_lo = clampi(floor(umin - 0.5) - 1.0, 0, res_w);  // res_w => empty after the hi clamp
+  s.i_hi = clampi(ceil(umax - 0.5) + 1.0, -1, res_w - 1);
+  s.j_lo = clampi(floor(vmin - 0.5) - 1.0, 0, res_h);
+  s.j_hi = clampi(ceil(vmax - 0.5) + 1.0, -1, res_h - 1);
+  if (!(s.D != 0.0) || zmax < z_near || zmin > z_far || !(umin <= umax)) { s.i_lo = 1; s.i_hi = 0; }
 }
 
 // depth of the triangle at pixel (i,j); returns false when the pixel centre is not covered

@@ -343,3 +343,48 @@ def depth_refine_roi(xyz_i, mask_i, roi_depth_256, K_crop, rot_est, trans_est, v
         trans_est = trans_est + trans_delta.reshape(3)
     out = np.asarray(trans_est, np.float64)
     return (out, renders) if return_debug else out
+
+
+def ransac_voting_layer(mask, vertex, idxs_rounds, inlier_thresh=0.999, confidence=0.99, max_iter=20, min_num=5):
+    """ransac_voting_gpu.py:123-218 for ONE image given the random index draws (list of i32[hn,vn,2], one per
+    RANSAC round): hypothesis generation, voting, winner selection (first maximum), confidence test, final
+    inlier least squares.  mask [h,w], vertex [h,w,vn,2] -> mean f32[vn,2]."""
+    f32 = np.float32
+    mask = np.asarray(mask) > 0
+    vn = vertex.shape[2]
+    if mask.sum() < min_num:
+        return np.zeros((vn, 2), f32)
+    ys, xs = np.nonzero(mask)
+    coords = np.stack([xs, ys], 1).astype(f32)
+    direct = np.ascontiguousarray(vertex[ys, xs], f32)            # [tn,vn,2]
+    tn = coords.shape[0]
+    all_win_ratio = np.zeros(vn, f32)
+    all_win_pts = np.zeros((vn, 2), f32)
+    hyp_num, cur_iter = 0, 0
+    while True:
+        idxs = idxs_rounds[cur_iter]
+        hyp = generate_hypothesis(direct, coords, idxs)
+        counts = voting_for_hypothesis(direct, coords, hyp, inlier_thresh).sum(2).astype(np.int32)  # [hn,vn]
+        win_idx = counts.argmax(0)
+        win_counts = counts[win_idx, np.arange(vn)]
+        win_pts = hyp[win_idx, np.arange(vn)]
+        ratio = win_counts.astype(f32) / f32(tn)
+        larger = all_win_ratio < ratio
+        all_win_pts[larger] = win_pts[larger]
+        all_win_ratio[larger] = ratio[larger]
+        hyp_num += idxs.shape[0]
+        cur_iter += 1
+        if (1 - (1 - all_win_ratio.min() ** 2) ** hyp_num) > confidence or cur_iter > max_iter:
+            break
+    inl = voting_for_hypothesis(direct, coords, all_win_pts[None], inlier_thresh)[0].astype(np.float64)  # [vn,tn]
+    normal = np.stack([direct[:, :, 1], -direct[:, :, 0]], -1).transpose(1, 0, 2).astype(np.float64) * inl[:, :, None]
+    b = (normal * coords[None].astype(np.float64)).sum(2)
+    ATA = normal.transpose(0, 2, 1) @ normal
+    ATb = (normal * b[:, :, None]).sum(1)
+    out = np.zeros((vn, 2))
+    for v in range(vn):
+        try:
+            out[v] = np.linalg.solve(ATA[v], ATb[v])
+        except np.linalg.LinAlgError:
+            out[v] = ATb[v]
+    return out.astype(f32), cur_iter

@@ -1,0 +1,108 @@
+"""The reference-named Python surface (core.csrc.* shims) on the GPU against the oracle (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import postproc as P
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_fps_utils_like_reference_call_site():
+    """core/utils/data_utils.py:255-264 / gdrn_evaluator.py:105-113 style use."""
+    from gdrnpp_bop2022_amd.core.csrc.fps.fps_utils import farthest_point_sampling
+
+    rng = np.random.default_rng(0)
+    pts = (rng.standard_normal((4000, 3)) * 0.05).astype(np.float32)
+    out = farthest_point_sampling(pts, 8, init_center=True)
+    assert out.shape == (8, 3) and np.array_equal(out, pts[P.fps(pts, 8, True)])
+    out = farthest_point_sampling(pts, 8, init_center=False)
+    idx0 = int(np.flatnonzero((pts == out[0]).all(1))[0])
+    assert np.array_equal(out, pts[P.fps(pts, 8, False, idx0)])
+
+
+def test_un_pnp_utils_like_pose_from_upnp():
+    """gdrn_evaluator.py:612-628 (pose_from_upnp) with the EPnP initialiser supplied by the caller."""
+    from gdrnpp_bop2022_amd.core.csrc.uncertainty_pnp.un_pnp_utils import uncertainty_pnp, uncertainty_pnp_v2
+
+    rng = np.random.default_rng(1)
+    K = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1.0]])
+    rt = np.array([0.4, -0.3, 0.2, 0.03, -0.02, 0.9])
+    p3 = rng.uniform(-0.05, 0.05, (9, 3))
+    th = np.linalg.norm(rt[:3]); k = rt[:3] / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    X = p3 @ R.T + rt[3:]
+    p2 = np.stack([K[0, 0] * X[:, 0] / X[:, 2] + K[0, 2], K[1, 1] * X[:, 1] / X[:, 2] + K[1, 2]], 1)
+    p2 = p2 + rng.normal(0, 0.5, p2.shape)
+    cov = np.stack([np.diag(rng.uniform(0.5, 4, 2)) for _ in range(9)])
+    w = np.stack([[1 / np.sqrt(c[0, 0]), 0.0, 1 / np.sqrt(c[1, 1])] for c in cov])
+    init = rt + rng.uniform(0, 0.05, 6)
+    Rt = uncertainty_pnp(p2, w, p3, K, init_rt=init)
+    o = P.uncertainty_pnp(p2, p3, w, K, init)
+    assert Rt.shape == (3, 4)
+    np.testing.assert_allclose(Rt[:, 3], o[3:], atol=1e-9)
+    th2 = np.linalg.norm(o[:3]); k2 = o[:3] / th2
+    K2 = np.array([[0, -k2[2], k2[1]], [k2[2], 0, -k2[0]], [-k2[1], k2[0], 0]])
+    np.testing.assert_allclose(Rt[:, :3], np.eye(3) + np.sin(th2) * K2 + (1 - np.cos(th2)) * K2 @ K2, atol=1e-9)
+    np.testing.assert_allclose(Rt[:, :3], R, atol=5e-2)
+    Rt2 = uncertainty_pnp_v2(p2, cov, p3, K, init_rt=init)
+    assert np.isfinite(Rt2).all()
+    with pytest.raises(RuntimeError, match="init_rt"):
+        uncertainty_pnp(p2, w, p3, K)  # cv2 absent: must not silently invent an initialiser
+
+
+def test_ransac_voting_layer_matches_oracle():
+    from gdrnpp_bop2022_amd.core.csrc.ransac_voting.ransac_voting_gpu import (
+        estimate_voting_distribution_with_mean, ransac_voting_layer_v3)
+
+    rng = np.random.default_rng(2)
+    b, h, w, vn, hn = 2, 64, 64, 9, 128
+    mask = np.zeros((b, h, w), np.float32)
+    mask[:, 16:48, 12:52] = 1
+    mask[1, :, :] = 0
+    mask[1, 10, 10:13] = 1  # < min_num foreground -> zeros
+    kp = rng.uniform(5, 60, (b, vn, 2)).astype(np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    pix = np.stack([xx, yy], -1).astype(np.float32)
+    vertex = kp[:, None, None] - pix[None, :, :, None]
+    vertex = vertex / np.maximum(np.linalg.norm(vertex, axis=-1, keepdims=True), 1e-6)
+    vertex = (vertex + rng.normal(0, 0.02, vertex.shape)).astype(np.float32)
+    tn0 = int(mask[0].sum())
+    rounds = [rng.integers(0, tn0, (hn, vn, 2)).astype(np.int32) for _ in range(25)]
+
+    def idxs_fn(bi, it, hn_, vn_, tn_):
+        return torch.from_numpy(rounds[it]).to(DEV)
+
+    out = ransac_voting_layer_v3(torch.from_numpy(mask).to(DEV), torch.from_numpy(vertex).to(DEV), hn, idxs_fn=idxs_fn)
+    out = out.cpu().numpy()
+    ref, iters = P.ransac_voting_layer(mask[0], vertex[0], rounds)
+    np.testing.assert_allclose(out[0], ref, atol=2e-3)      # fp32 torch LSQ vs fp64 NumPy
+    assert np.abs(out[0] - kp[0]).max() < 1.0                # the keypoints are recovered
+    assert np.array_equal(out[1], np.zeros((vn, 2), np.float32))
+    mean, cov = estimate_voting_distribution_with_mean(torch.from_numpy(mask).to(DEV), torch.from_numpy(vertex).to(DEV),
+                                                       torch.from_numpy(out).to(DEV), round_hyp_num=hn, min_hyp_num=512)
+    cov = cov.cpu().numpy()
+    assert cov.shape == (b, vn, 2, 2) and np.isfinite(cov).all()
+    assert (np.linalg.eigvalsh(cov[0]) > -1e-4).all()
+
+
+def test_nnd_autograd_wrapper():
+    from gdrnpp_bop2022_amd.core.csrc.torch_nndistance.torch_nndistance import nnd
+
+    torch.manual_seed(0)
+    x1 = torch.rand(4, 300, 3, device=DEV, requires_grad=True)
+    x2 = torch.rand(4, 500, 3, device=DEV, requires_grad=True)
+    d1, d2 = nnd(x1, x2)
+    (d1.mean() + d2.mean()).backward()
+    # plain PyTorch fp32 reference of the same op
+    y1 = x1.detach().clone().requires_grad_(True)
+    y2 = x2.detach().clone().requires_grad_(True)
+    D = ((y1[:, :, None] - y2[:, None]) ** 2).sum(-1)
+    r1, r2 = D.min(2)[0], D.min(1)[0]
+    (r1.mean() + r2.mean()).backward()
+    torch.testing.assert_close(d1, r1, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(d2, r2, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(x1.grad, y1.grad, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(x2.grad, y2.grad, rtol=1e-4, atol=1e-7)
