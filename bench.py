@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from gdrnpp_bop2022_amd import hip_lib, synthetic as S  # noqa: E402
+from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers  # noqa: E402
 from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg  # noqa: E402
 from gdrnpp_bop2022_amd.gdrn_modeling.engine import GdrnHipPost, gather_records  # noqa: E402
 from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer  # noqa: E402
@@ -53,6 +54,7 @@ def parse():
     p.add_argument("--cpu-sample", type=int, default=32)
     p.add_argument("--exact-reference-order", action="store_true",
                    help="run the reference's full 1470-channel output layer + gather instead of the class-sliced one")
+    p.add_argument("--no-hip-layers", action="store_true", help="A/B: run the memory-bound network layers with PyTorch ops")
     p.add_argument("--post-only", action="store_true", help="time only the post-processing (maps from a fixed forward)")
     return p.parse_args()
 
@@ -129,6 +131,7 @@ def main():
     torch.backends.cudnn.benchmark = True  # MIOpen find mode during warm-up
 
     model, _ = build_model_optimizer(cfg, is_test=True)
+    hip_layers.set_enabled(not args.no_hip_layers)
     model.exact_reference_order = bool(args.exact_reference_order)
     # Random-init weights predict t ~ 0 (object at the camera centre), which no trained model does and which
     # would make every triangle straddle the camera plane.  Set the translation head's bias to the dataset
@@ -235,7 +238,7 @@ def main():
                              % b) if refine else ("YCB-V convnext_a6, RGB-only Patch-PnP, batch=%d ROIs/GPU" % b),
                 "baseline_config_index": 2 if refine else 1, "global_batch": world * b, "rois_per_gpu": b,
                 "num_classes": C, "input_res": 256, "output_res": 64, "refine_iters": cfg.TEST.DEPTH_REFINE_ITER if refine else 0,
-                "parallelism": f"roi-shard x{world}", "class_sliced_out_layer": not args.exact_reference_order,
+                "parallelism": f"roi-shard x{world}", "class_sliced_out_layer": not args.exact_reference_order, "hip_network_layers": not args.no_hip_layers,
                 "post_only": bool(args.post_only)},
             "roofline": roofline, "cpu_baseline": cpu,
             "stages_ms": {"forward": fwd_ms, "depth_refine": roofline["launch_ms"] if roofline else None},

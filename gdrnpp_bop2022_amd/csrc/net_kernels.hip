@@ -1,0 +1,337 @@
+// Network-side HIP kernels for the GDRN_Net forward on gfx950.
+//
+// The dense layers of ConvNeXt-B + head stay on MIOpen / hipBLASLt (already ~140 TFLOP/s fp32).  rocprofv3
+// (profiles/r01_steady_state_step_breakdown.md) showed that three memory-bound layer types were far off
+// their HBM roofline in PyTorch-ROCm at B=128, fp32, channels-last:
+//   * depthwise 7x7 conv (timm ConvNeXtBlock.conv_dw) ran as a CK grouped implicit-GEMM: 32 ms / step,
+//     HBM floor ≈ 1 ms;  + the LayerNorm that always follows it (4.4 ms)
+//   * nn.UpsamplingBilinear2d in the head (top_down_doublemask_xyz_region_head.py:80): 24.6 ms, floor 0.15 ms
+//   * GroupNorm(32) + GELU of lib/torch_utils ConvModule (conv_module.py:222-236): NHWC->NCHW copy, moments,
+//     apply, copy back, separate GELU: ≈ 3 ms per 64x64 layer, floor 0.3 ms
+// They are re-written here for NHWC fp32 with 16-byte lanes (one float4 of channels per lane, so a wave
+// touches 1 KiB contiguous per pixel), fused where the reference graph allows it.  Arithmetic is the same
+// fp32 math as the PyTorch operators (exact erf GELU, biased variance, eps inside the sqrt); summation
+// order differs, so parity is a tolerance (1e-5 rel, tests/test_gpu_net_kernels.py), not bit equality.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+// --------------------------------------------------------------------------------------------------
+// depthwise 7x7 (pad 3, stride 1) + bias [+ LayerNorm over C], NHWC.
+// One thread: one channel quad x (TH x TW) output pixels; the lanes of a workgroup cover the C/4 quads of
+// NP pixel tiles, so every global access is a contiguous 16 B x (C/4) run.  Input rows stream through
+// registers (10 float4 per row), weights are read tap-major [49][C] (L1/L2 resident, 49*C*4 B).
+// --------------------------------------------------------------------------------------------------
+constexpr int TH = 2, TW = 4;
+
+template <bool FUSE_LN>
+__global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w49c,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ ln_w,
+                                                         const float* __restrict__ ln_b, float* __restrict__ y, int N,
+                                                         int H, int W, int C, float eps) {
+  __shared__ float red[TH * TW * 4];  // FUSE_LN: per-wave partials when a pixel spans several waves
+  const int Q = C >> 2;                       // channel quads per pixel
+  const int tiles_per_block = blockDim.x / Q; // >= 1 (host guarantees Q <= 256 and blockDim % Q == 0)
+  const int q = threadIdx.x % Q;
+  const int tl = threadIdx.x / Q;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const long tile = (long)blockIdx.x * tiles_per_block + tl;
+  const long n_tiles = (long)N * tiles_y * tiles_x;
+  const bool active = tile < n_tiles;
+  int n = 0, ty0 = 0, tx0 = 0;
+  if (active) {
+    n = (int)(tile / (tiles_y * tiles_x));
+    const int r = (int)(tile - (long)n * tiles_y * tiles_x);
+    ty0 = (r / tiles_x) * TH;
+    tx0 = (r % tiles_x) * TW;
+  }
+  float4 acc[TH][TW];
+  const float4 b4 = ld4(bias + 4 * q);
+#pragma unroll
+  for (int i = 0; i < TH; ++i)
+#pragma unroll
+    for (int j = 0; j < TW; ++j) acc[i][j] = b4;
+
+  if (active) {
+    const float* xn = x + (size_t)n * H * W * C + 4 * q;
+#pragma unroll 1
+    for (int r = 0; r < TH + 6; ++r) {
+      const int iy = ty0 + r - 3;
+      if (iy < 0 || iy >= H) continue;
+      float4 row[TW + 6];
+#pragma unroll
+      for (int c = 0; c < TW + 6; ++c) {
+        const int ix = tx0 + c - 3;
+        row[c] = (ix >= 0 && ix < W) ? ld4(xn + ((size_t)iy * W + ix) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < TH; ++i) {
+        const int ky = r - i;
+        if (ky < 0 || ky > 6) continue;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const float4 wv = ld4(w49c + (size_t)(ky * 7 + kx) * C + 4 * q);
+#pragma unroll
+          for (int j = 0; j < TW; ++j) acc[i][j] = fma4(row[j + kx], wv, acc[i][j]);
+        }
+      }
+    }
+  }
+
+  if (FUSE_LN) {
+    // LayerNorm over the C channels of each pixel.  The Q = C/4 lanes holding one pixel are Q consecutive lanes:
+    // xor-shuffle tree inside the wave (width min(Q,64)), then <= 4 per-wave partials through LDS when Q > 64.
+    // Two rounds — mean, then centred variance (biased), as ATen's layer norm defines them.
+    constexpr int P = TH * TW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int width = Q < 64 ? Q : 64;
+    const int wpt = Q > 64 ? Q / 64 : 1;  // waves per pixel tile
+    const int w0 = (wave / wpt) * wpt;
+    float mean[P], var[P];
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      float part[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const float4 v = acc[p / TW][p % TW];
+        float s;
+        if (round == 0) {
+          s = (v.x + v.y) + (v.z + v.w);
+        } else {
+          const float dx = v.x - mean[p], dy = v.y - mean[p], dz = v.z - mean[p], dw = v.w - mean[p];
+          s = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        for (int off = width >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        part[p] = s;
+      }
+      if (wpt > 1) {
+        if (round == 1) __syncthreads();  // red[] of round 0 has been consumed by every wave
+        if (lane == 0) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) red[p * 4 + wave] = part[p];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          float s = 0.f;
+          for (int k = 0; k < wpt; ++k) s += red[p * 4 + w0 + k];
+          part[p] = s;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (round == 0) mean[p] = part[p] / (float)C;
+        else var[p] = part[p] / (float)C;
+      }
+    }
+    const float4 g4 = ld4(ln_w + 4 * q), be4 = ld4(ln_b + 4 * q);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float rstd = rsqrtf(var[p] + eps);
+      const float m = mean[p];
+      float4 v = acc[p / TW][p % TW];
+      v.x = (v.x - m) * rstd * g4.x + be4.x;
+      v.y = (v.y - m) * rstd * g4.y + be4.y;
+      v.z = (v.z - m) * rstd * g4.z + be4.z;
+      v.w = (v.w - m) * rstd * g4.w + be4.w;
+      acc[p / TW][p % TW] = v;
+    }
+  }
+  if (active) {
+    float* yn = y + (size_t)n * H * W * C + 4 * q;
+#pragma unroll
+    for (int i = 0; i < TH; ++i)
+#pragma unroll
+      for (int j = 0; j < TW; ++j) {
+        const int oy = ty0 + i, ox = tx0 + j;
+        if (oy < H && ox < W) st4(yn + ((size_t)oy * W + ox) * C, acc[i][j]);
+      }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// bilinear x2 upsample, align_corners=True (nn.UpsamplingBilinear2d), NHWC.  Index/lambda arithmetic follows
+// ATen's area_pixel_compute_source_index (scale = (in-1)/(out-1) in fp32, src = scale*dst).
+// --------------------------------------------------------------------------------------------------
+__global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+  const int Q = C >> 2;
+  const int OH = 2 * H, OW = 2 * W;
+  const long total = (long)N * OH * OW * Q;
+  const float sh = (OH > 1) ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float sw = (OW > 1) ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    long p = i / Q;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int n = (int)(p / OH);
+    const float fy = sh * (float)oy, fx = sw * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int yp = (y0 < H - 1) ? 1 : 0, xp = (x0 < W - 1) ? 1 : 0;
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+    const float* b = x + ((size_t)n * H * W) * C + 4 * q;
+    const float4 v00 = ld4(b + ((size_t)y0 * W + x0) * C), v01 = ld4(b + ((size_t)y0 * W + x0 + xp) * C);
+    const float4 v10 = ld4(b + ((size_t)(y0 + yp) * W + x0) * C), v11 = ld4(b + ((size_t)(y0 + yp) * W + x0 + xp) * C);
+    float4 o;
+    o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+    o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+    o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+    o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+    st4(y + (((size_t)n * OH + oy) * OW + ox) * C + 4 * q, o);
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// GroupNorm (+ optional exact GELU), NHWC.  Pass A: per (sample, pixel chunk) fp64 partial sums per group,
+// written to a workspace [N, P, G, 2] (no atomics -> deterministic).  Pass B: every thread rebuilds mean/rstd of
+// its quad's group from the P partials and applies (x-mean)*rstd*gamma+beta, then GELU.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ part, int HW,
+                                                       int C, int G, int P) {
+  extern __shared__ double sred[];  // [2][256]
+  const int Q = C >> 2, cpg = C / G;
+  const int n = blockIdx.y, pc = blockIdx.x;
+  const int q = threadIdx.x % Q, row = threadIdx.x / Q, rows = blockDim.x / Q;
+  const int per = (HW + P - 1) / P;
+  const int p0 = pc * per, p1 = min(HW, p0 + per);
+  double s = 0.0, ss = 0.0;
+  const float* b = x + (size_t)n * HW * C + 4 * q;
+  for (int p = p0 + row; p < p1; p += rows) {
+    const float4 v = ld4(b + (size_t)p * C);
+    s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    ss += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+  }
+  sred[threadIdx.x] = s;
+  sred[256 + threadIdx.x] = ss;
+  __syncthreads();
+  // one thread per group sums the (rows x quads-per-group) partials in a fixed order
+  if ((int)threadIdx.x < G) {
+    const int g = threadIdx.x, qpg = cpg >> 2;
+    double a = 0.0, c2 = 0.0;
+    for (int r = 0; r < rows; ++r)
+      for (int k = 0; k < qpg; ++k) {
+        const int t = r * Q + g * qpg + k;
+        a += sred[t];
+        c2 += sred[256 + t];
+      }
+    double* o = part + (((size_t)n * P + pc) * G + g) * 2;
+    o[0] = a;
+    o[1] = c2;
+  }
+}
+
+template <bool GELU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, int HW, int C, int G, int P, float eps) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int Q = C >> 2, cpg = C / G;
+  const int n = blockIdx.y;
+  if ((int)threadIdx.x < G) {
+    double a = 0.0, c2 = 0.0;
+    for (int p = 0; p < P; ++p) {
+      const double* o = part + (((size_t)n * P + p) * G + threadIdx.x) * 2;
+      a += o[0];
+      c2 += o[1];
+    }
+    const double cnt = (double)HW * cpg;
+    const double m = a / cnt;
+    double var = c2 / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    s_mean[threadIdx.x] = (float)m;
+    s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const long total = (long)HW * Q;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    const long p = i / Q;
+    const int g = (4 * q) / cpg;
+    const float m = s_mean[g], r = s_rstd[g];
+    const float4 ga = ld4(gamma + 4 * q), be = ld4(beta + 4 * q);
+    const size_t off = ((size_t)n * HW + p) * C + 4 * q;
+    float4 v = ld4(x + off);
+    v.x = (v.x - m) * r * ga.x + be.x;
+    v.y = (v.y - m) * r * ga.y + be.y;
+    v.z = (v.z - m) * r * ga.z + be.z;
+    v.w = (v.w - m) * r * ga.w + be.w;
+    if (GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+    st4(y + off, v);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bias, const float* ln_w,
+                             const float* ln_b, float* y, int N, int H, int W, int C, float eps, void* stream) {
+  GDRNPP_REQUIRE(x && w49c && bias && y, GDRNPP_EINVAL, "gdrnpp_dwconv7x7_ln_nhwc: null pointer");
+  GDRNPP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, GDRNPP_EINVAL, "gdrnpp_dwconv7x7_ln_nhwc: N=%d H=%d W=%d C=%d", N,
+                 H, W, C);
+  GDRNPP_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_dwconv7x7_ln_nhwc: C=%d must give a power-of-two quad count <= 256", C);
+  const int Q = C / 4, tiles_per_block = 256 / Q;
+  const long n_tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  const long blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+  GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "gdrnpp_dwconv7x7_ln_nhwc: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (ln_w && ln_b) {
+    hipLaunchKernelGGL(dwconv7_ln_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias, ln_w, ln_b,
+                       y, N, H, W, C, eps);
+  } else {
+    hipLaunchKernelGGL(dwconv7_ln_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias, nullptr,
+                       nullptr, y, N, H, W, C, eps);
+  }
+  return gdrnpp::check_launch("gdrnpp_dwconv7x7_ln_nhwc");
+}
+
+int gdrnpp_upsample_bilinear2x_nhwc(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  GDRNPP_REQUIRE(x && y, GDRNPP_EINVAL, "gdrnpp_upsample_bilinear2x_nhwc: null pointer");
+  GDRNPP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, GDRNPP_EINVAL,
+                 "gdrnpp_upsample_bilinear2x_nhwc: N=%d H=%d W=%d C=%d (C %% 4 == 0 required)", N, H, W, C);
+  const long total = (long)N * 4 * H * W * (C / 4);
+  const long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)(blocks < 65536 * 8 ? blocks : 65536 * 8)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, N, H, W, C);
+  return gdrnpp::check_launch("gdrnpp_upsample_bilinear2x_nhwc");
+}
+
+size_t gdrnpp_groupnorm_workspace_bytes(int N, int HW, int G) {
+  const int P = HW >= 1024 ? 64 : (HW >= 64 ? 8 : 1);
+  return sizeof(double) * 2 * (size_t)N * P * G;
+}
+
+int gdrnpp_groupnorm_act_nhwc(const float* x, const float* gamma, const float* beta, float* y, void* workspace,
+                              int N, int HW, int C, int G, float eps, int act_gelu, void* stream) {
+  GDRNPP_REQUIRE(x && gamma && beta && y && workspace, GDRNPP_EINVAL, "gdrnpp_groupnorm_act_nhwc: null pointer");
+  GDRNPP_REQUIRE(N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, GDRNPP_EINVAL,
+                 "gdrnpp_groupnorm_act_nhwc: N=%d HW=%d C=%d G=%d", N, HW, C, G);
+  const int cpg = C / G, Q = C / 4;
+  GDRNPP_REQUIRE(C % 4 == 0 && cpg % 4 == 0 && Q <= 256 && 256 % Q == 0 && G <= 64 && N <= 65535, GDRNPP_ELIMIT,
+                 "gdrnpp_groupnorm_act_nhwc: unsupported shape C=%d G=%d N=%d", C, G, N);
+  const int P = HW >= 1024 ? 64 : (HW >= 64 ? 8 : 1);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(P, N), dim3(256), sizeof(double) * 512, st, x, (double*)workspace, HW, C, G,
+                     P);
+  const long total = (long)HW * Q;
+  long bx = (total + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  if (act_gelu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)bx, N), dim3(256), 0, st, x, (const double*)workspace,
+                       gamma, beta, y, HW, C, G, P, eps);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)bx, N), dim3(256), 0, st, x, (const double*)workspace,
+                       gamma, beta, y, HW, C, G, P, eps);
+  return gdrnpp::check_launch("gdrnpp_groupnorm_act_nhwc");
+}
+
+}  // extern "C"

@@ -20,6 +20,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import hip_layers
+
 
 class LayerNorm2d(nn.LayerNorm):
     """LayerNorm over the channel dim of an NCHW tensor (timm.models.layers.LayerNorm2d)."""
@@ -50,16 +52,15 @@ class ConvNeXtBlock(nn.Module):
         self.norm = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = Mlp(dim, 4 * dim)
         self.gamma = nn.Parameter(ls_init_value * torch.ones(dim))
+        self._cache = {}  # tap-major depthwise weights for the HIP kernel (inference only)
 
     def forward(self, x):
         shortcut = x
-        x = self.conv_dw(x)
-        x = x.permute(0, 2, 3, 1)
-        x = self.norm(x)
+        x = hip_layers.dwconv_ln(self.conv_dw, self.norm, x, self._cache)  # NHWC view, LayerNorm applied
         x = self.mlp(x)
-        x = x * self.gamma  # == x.permute(0,3,1,2).mul(gamma.reshape(1,-1,1,1))
-        x = x.permute(0, 3, 1, 2)
-        return x + shortcut
+        # layer scale + residual in one pass: shortcut + gamma * x  (timm: x.mul(gamma) then drop_path(x) + shortcut)
+        x = torch.addcmul(shortcut.permute(0, 2, 3, 1), x, self.gamma)
+        return x.permute(0, 3, 1, 2)
 
 
 class ConvNeXtStage(nn.Module):

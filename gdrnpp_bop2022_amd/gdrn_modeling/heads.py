@@ -13,6 +13,8 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import hip_layers
+
 
 def get_nn_act_func(act: str):
     """lib/torch_utils/layers/layer_utils.py:63-100 (subset used by the GDRNPP configs)."""
@@ -57,6 +59,8 @@ class ConvModule(nn.Module):
 
     def forward(self, x):
         x = self.conv(x)
+        if self.norm_name == "gn":
+            return hip_layers.groupnorm_act(getattr(self, "gn"), self.activate, x)  # fused GN(+GELU) on the GPU
         if self.norm_name is not None:
             x = getattr(self, self.norm_name)(x)
         if self.activate is not None:
@@ -69,6 +73,31 @@ class ConvModule(nn.Module):
         for k in [k for k in state_dict if k.startswith(prefix + "norm.")]:
             state_dict.pop(k)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+
+def run_features(features, x):
+    """Run a ``features`` ModuleList, fusing [GroupNorm, act] pairs and routing bilinear x2 upsampling to the
+    NHWC HIP kernels when on the GPU (module structure and parameter names are untouched)."""
+    i, n = 0, len(features)
+    while i < n:
+        layer = features[i]
+        if isinstance(layer, nn.GroupNorm):
+            nxt = features[i + 1] if i + 1 < n else None
+            if isinstance(nxt, (nn.GELU, nn.ReLU, nn.LeakyReLU, nn.SiLU, nn.Mish)):
+                if isinstance(nxt, nn.GELU):
+                    x = hip_layers.groupnorm_act(layer, nxt, x)
+                else:
+                    x = nxt(hip_layers.groupnorm_act(layer, None, x))
+                i += 2
+                continue
+            x = hip_layers.groupnorm_act(layer, None, x)
+        elif isinstance(layer, nn.UpsamplingBilinear2d) and layer.scale_factor in (2, 2.0):
+            x = hip_layers.upsample2x(layer, x)
+        else:
+            x = layer(x)
+        i += 1
+    return x
 
 
 def _normal_init(m, std):
@@ -125,9 +154,7 @@ class TopDownMaskXyzRegionHead(nn.Module):
     def trunk(self, x):
         if isinstance(x, (tuple, list)) and len(x) == 1:
             x = x[0]
-        for layer in self.features:
-            x = layer(x)
-        return x
+        return run_features(self.features, x)
 
     def split(self, out):
         """Channel split of the full output (reference forward tail)."""
@@ -212,8 +239,7 @@ class ConvPnPNet(nn.Module):
             x = x * mask_attention
         elif self.mask_attention_type == "concat":
             x = torch.cat([x, mask_attention], dim=1)
-        for layer in self.features:
-            x = layer(x)
+        x = run_features(self.features, x)
         x = x.flatten(2).flatten(1)  # NCHW order, like the reference (weights of fc1 depend on it)
         x = self.act(self.fc1(x))
         x = self.act(self.fc2(x))

@@ -1,0 +1,62 @@
+"""Dispatch of the memory-bound network layers to the hand-written NHWC HIP kernels
+(csrc/net_kernels.hip) when the tensors live on the GPU; plain PyTorch otherwise (CPU unit tests,
+or ``set_enabled(False)`` for A/B measurements).  Same math as the PyTorch operators, different summation order."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip_lib
+
+_ENABLED = True
+
+
+def set_enabled(flag: bool) -> None:
+    global _ENABLED
+    _ENABLED = bool(flag)
+
+
+def enabled_for(x: torch.Tensor) -> bool:
+    return _ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+
+
+def _cl(x):
+    return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+
+
+def upsample2x(layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    if enabled_for(x) and x.shape[1] % 4 == 0:
+        return hip_lib.upsample_bilinear2x(_cl(x))
+    return layer(x)
+
+
+def _gn_ok(gn: nn.GroupNorm, x) -> bool:
+    c, g = gn.num_channels, gn.num_groups
+    q = c // 4
+    return (enabled_for(x) and c % 4 == 0 and (c // g) % 4 == 0 and q <= 256 and 256 % q == 0 and g <= 64
+            and x.shape[0] <= 65535 and gn.affine)
+
+
+def groupnorm_act(gn: nn.GroupNorm, act: nn.Module | None, x: torch.Tensor) -> torch.Tensor:
+    """GroupNorm followed by ``act`` (fused when act is the exact GELU or None)."""
+    fusable_act = act is None or (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none")
+    if isinstance(gn, nn.GroupNorm) and _gn_ok(gn, x) and fusable_act:
+        return hip_lib.groupnorm_act(_cl(x), gn.weight, gn.bias, gn.num_groups, gn.eps, gelu=act is not None)
+    x = gn(x)
+    return act(x) if act is not None else x
+
+
+def dwconv_ln(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor, cache: dict) -> torch.Tensor:
+    """ConvNeXt block head: depthwise 7x7 then LayerNorm over C.  Returns the NHWC *view* [N,H,W,C]."""
+    c = conv.in_channels
+    q = c // 4
+    if enabled_for(x) and conv.kernel_size == (7, 7) and conv.groups == c and c % 4 == 0 and q <= 256 and 256 % q == 0:
+        w = cache.get("w49c")
+        if w is None or w.device != x.device:
+            w = conv.weight.detach().reshape(c, 49).t().contiguous()  # tap-major [49, C]
+            cache["w49c"] = w
+        y = hip_lib.dwconv7x7_ln(_cl(x), w, conv.bias, ln.weight, ln.bias, ln.eps)
+        return y.permute(0, 2, 3, 1)
+    y = conv(x).permute(0, 2, 3, 1)
+    return F.layer_norm(y, ln.normalized_shape, ln.weight, ln.bias, ln.eps)

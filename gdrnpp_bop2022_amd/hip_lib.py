@@ -58,6 +58,10 @@ SIGNATURES = {
         c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
                 c_int, c_int, c_float, c_float, _P]),
     "gdrnpp_pack_pose_records": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "gdrnpp_dwconv7x7_ln_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "gdrnpp_upsample_bilinear2x_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_groupnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gdrnpp_groupnorm_act_nhwc": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
 }
 
 
@@ -274,3 +278,44 @@ def pack_pose_records(R, t_refined, t_net, score, obj_id, roi_id):
         _dev(roi_id, torch.int32, "roi_id") if roi_id is not None else None, rec.data_ptr(), b, _stream()),
         "gdrnpp_pack_pose_records")
     return rec
+
+
+# ------------------------------------------------------------------------------------------
+# network-side NHWC layers (tensors are logically NCHW with channels_last strides)
+# ------------------------------------------------------------------------------------------
+def _nhwc(t: torch.Tensor, name: str) -> int:
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
+        raise RuntimeError(f"{name} must be a 4-D float32 CUDA(HIP) tensor")
+    if not t.is_contiguous(memory_format=torch.channels_last):
+        raise RuntimeError(f"{name} must be channels_last contiguous")
+    return t.data_ptr()
+
+
+def dwconv7x7_ln(x, w49c, bias, ln_w=None, ln_b=None, eps: float = 1e-6):
+    """x (N,C,H,W) channels_last -> depthwise 7x7 (+ LayerNorm over C), same shape/format."""
+    n, c, h, w = x.shape
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    _check(load().gdrnpp_dwconv7x7_ln_nhwc(
+        _nhwc(x, "x"), _dev(w49c, torch.float32, "w49c"), _dev(bias, torch.float32, "bias"),
+        _dev(ln_w, torch.float32, "ln_w") if ln_w is not None else None,
+        _dev(ln_b, torch.float32, "ln_b") if ln_b is not None else None, y.data_ptr(), n, h, w, c, float(eps),
+        _stream()), "gdrnpp_dwconv7x7_ln_nhwc")
+    return y
+
+
+def upsample_bilinear2x(x):
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _check(load().gdrnpp_upsample_bilinear2x_nhwc(_nhwc(x, "x"), y.data_ptr(), n, h, w, c, _stream()),
+           "gdrnpp_upsample_bilinear2x_nhwc")
+    return y
+
+
+def groupnorm_act(x, gamma, beta, groups: int, eps: float = 1e-5, gelu: bool = False):
+    n, c, h, w = x.shape
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    ws = torch.empty((load().gdrnpp_groupnorm_workspace_bytes(n, h * w, groups),), dtype=torch.uint8, device=x.device)
+    _check(load().gdrnpp_groupnorm_act_nhwc(
+        _nhwc(x, "x"), _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"), y.data_ptr(),
+        ws.data_ptr(), n, h * w, c, groups, float(eps), 1 if gelu else 0, _stream()), "gdrnpp_groupnorm_act_nhwc")
+    return y

@@ -197,6 +197,26 @@ int gdrnpp_depth_refine(const gdrnpp_meshes* meshes, const int* obj,
                         float threshold, int mask_type, int use_coor_z,
                         float z_near, float z_far, void* stream);
 
+/* ---- network-side layers of GDRN_Net (a3), NHWC fp32 ----------------------------------------
+ * Memory-bound layers that PyTorch-ROCm runs far from the HBM roofline: all tensors are
+ * channels-last (N,H,W,C contiguous), C % 4 == 0.
+ *  dwconv7x7_ln : timm ConvNeXtBlock.conv_dw (depthwise 7x7, pad 3) + bias, fused with the LayerNorm(C, eps)
+ *                 that follows it when ln_w/ln_b are non-NULL.  w49c f32[49,C] = weight[C,1,7,7] tap-major.
+ *  upsample_bilinear2x : nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True) of the geometry head
+ *                 (top_down_doublemask_xyz_region_head.py:80).
+ *  groupnorm_act : nn.GroupNorm(G, C, eps) [+ exact-erf GELU] of ConvModule / ConvPnPNet
+ *                 (lib/torch_utils/layers/conv_module.py:222-236, conv_pnp_net.py:59-72); workspace sized by
+ *                 gdrnpp_groupnorm_workspace_bytes. */
+int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bias,
+                             const float* ln_w, const float* ln_b, float* y, int N,
+                             int H, int W, int C, float eps, void* stream);
+int gdrnpp_upsample_bilinear2x_nhwc(const float* x, float* y, int N, int H, int W,
+                                    int C, void* stream);
+size_t gdrnpp_groupnorm_workspace_bytes(int N, int HW, int G);
+int gdrnpp_groupnorm_act_nhwc(const float* x, const float* gamma, const float* beta,
+                              float* y, void* workspace, int N, int HW, int C, int G,
+                              float eps, int act_gelu, void* stream);
+
 /* ---- pose record packing for the RCCL all-gather (a13) -------------------
  * rec f32[b,16] = R(9) | t(3) | score | obj_id | roi_id | valid(1) */
 int gdrnpp_pack_pose_records(const float* R, const double* t_refined,

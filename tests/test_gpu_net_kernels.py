@@ -1,0 +1,95 @@
+"""Network-side NHWC HIP kernels against the plain PyTorch fp32 operators they replace (-m gpu).
+Floating-point kernels with a different summation order: tolerance 1e-5 (rel) / 1e-5 (abs) stated per test."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _cl(x):
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(3, 128, 64, 64), (2, 256, 32, 32), (2, 512, 16, 16), (2, 1024, 8, 8),
+                                      (1, 128, 5, 7)])
+@pytest.mark.parametrize("fuse_ln", [True, False])
+def test_dwconv7x7_ln(hip, n, c, h, w, fuse_ln):
+    torch.manual_seed(c + h)
+    conv = nn.Conv2d(c, c, 7, padding=3, groups=c).to(DEV)
+    ln = nn.LayerNorm(c, eps=1e-6).to(DEV)
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.2)
+        ln.bias.normal_(0.0, 0.2)
+        x = _cl(torch.randn(n, c, h, w, device=DEV))
+        w49c = conv.weight.reshape(c, 49).t().contiguous()
+        y = hip.dwconv7x7_ln(x, w49c, conv.bias, ln.weight if fuse_ln else None, ln.bias if fuse_ln else None, 1e-6)
+        ref = conv(x)
+        if fuse_ln:
+            ref = F.layer_norm(ref.permute(0, 2, 3, 1), (c,), ln.weight, ln.bias, 1e-6).permute(0, 3, 1, 2)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(4, 256, 16, 16), (2, 256, 32, 32), (1, 8, 3, 5)])
+def test_upsample_bilinear2x(hip, n, c, h, w):
+    torch.manual_seed(0)
+    x = _cl(torch.randn(n, c, h, w, device=DEV))
+    y = hip.upsample_bilinear2x(x)
+    ref = nn.UpsamplingBilinear2d(scale_factor=2)(x)
+    assert y.shape == ref.shape
+    torch.testing.assert_close(y, ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,c,g,h,w", [(4, 256, 32, 64, 64), (3, 256, 32, 16, 16), (5, 128, 32, 32, 32),
+                                        (2, 128, 32, 8, 8)])
+@pytest.mark.parametrize("gelu", [True, False])
+def test_groupnorm_act(hip, n, c, g, h, w, gelu):
+    torch.manual_seed(h)
+    gn = nn.GroupNorm(g, c).to(DEV)
+    with torch.no_grad():
+        gn.weight.normal_(1.0, 0.3)
+        gn.bias.normal_(0.0, 0.3)
+        x = _cl(torch.randn(n, c, h, w, device=DEV) * 2.0 + 0.7)
+        y = hip.groupnorm_act(x, gn.weight, gn.bias, g, gn.eps, gelu=gelu)
+        ref = gn(x)
+        if gelu:
+            ref = F.gelu(ref)
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_model_forward_hip_layers_vs_torch_ops(hip):
+    """Whole GDRN_Net forward with the HIP layers on vs off (same weights): maps within 1e-4, pose within 1e-4."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+    from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+
+    cfg = get_cfg("ycbv_convnext_a6", ["TEST.USE_DEPTH_REFINE=True"])
+    torch.manual_seed(0)
+    model, _ = build_model_optimizer(cfg)
+    with torch.no_grad():
+        model.pnp_net.fc_t.bias.copy_(torch.tensor([0.0, 0.0, 4.0]))
+        for m in model.modules():  # make layer-scale / out layer non-trivial so differences would show
+            if hasattr(m, "gamma") and isinstance(m.gamma, nn.Parameter):
+                m.gamma.fill_(0.3)
+        nn.init.normal_(model.geo_head_net.out_layer.weight, 0, 0.05)
+    b = 6
+    x = torch.rand(b, 3, 256, 256, device=DEV)
+    cls = torch.randint(0, 21, (b,), device=DEV)
+    K = torch.tensor([[1066.778, 0, 312.9869], [0, 1067.487, 241.3109], [0, 0, 1]], device=DEV).repeat(b, 1, 1)
+    args = dict(roi_classes=cls, roi_cams=K, roi_whs=torch.full((b, 2), 120.0, device=DEV),
+                roi_centers=torch.full((b, 2), 250.0, device=DEV), resize_ratios=torch.full((b,), 64 / 180.0, device=DEV),
+                roi_coord_2d=torch.rand(b, 2, 64, 64, device=DEV), roi_extents=torch.full((b, 3), 0.1, device=DEV))
+    with torch.no_grad():
+        hip_layers.set_enabled(True)
+        o1 = model(x, **args)
+        hip_layers.set_enabled(False)
+        o2 = model(x, **args)
+        hip_layers.set_enabled(True)
+    for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
+        scale = o2[k].abs().max().item()
+        assert (o1[k] - o2[k]).abs().max().item() <= 1e-4 * max(scale, 1.0), k
+    torch.testing.assert_close(o1["rot"], o2["rot"], rtol=0, atol=1e-4)
+    torch.testing.assert_close(o1["trans"], o2["trans"], rtol=0, atol=1e-4)
