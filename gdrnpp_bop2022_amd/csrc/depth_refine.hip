@@ -34,7 +34,7 @@ constexpr int kT = 512;           // threads per ROI workgroup (8 waves; 1024 sp
 constexpr int kWaves = kT / 64;
 constexpr int kMaxPix = 4096;     // res*res limit for the refine kernel (res <= 64)
 constexpr int kPPT = kMaxPix / kT;
-constexpr int kLargeArea = 48;    // bbox pixels above which a triangle goes to the cooperative queue
+constexpr int kLargeArea = 32;    // bbox pixel centres above which a triangle is rasterised by its whole wave
 constexpr int kMaxLarge = 512;
 constexpr unsigned kInfBits = 0x7f800000u;
 
@@ -66,35 +66,38 @@ __device__ __forceinline__ void face_setup(const MeshView& m, int f, const doubl
 // rasterise the whole mesh into an LDS z-buffer of float-Z bits (must be pre-filled with kInfBits)
 __device__ void raster_mesh_u32(const MeshView& m, const double* K, const double* R, const double* t, int res,
                                 double z_near, double z_far, unsigned* zbuf, int* s_large, int* s_nlarge) {
-  if (threadIdx.x == 0) *s_nlarge = 0;
   __syncthreads();
-  for (int f = threadIdx.x; f < m.nfaces; f += kT) {
+  for (int f0 = 0; f0 < m.nfaces; f0 += kT) {
+    const int f = f0 + (int)threadIdx.x;
     TriSetup s;
-    face_setup(m, f, K, R, t, res, z_near, z_far, s);
-    if (s.i_lo > s.i_hi || s.j_lo > s.j_hi) continue;
-    const int area = (s.i_hi - s.i_lo + 1) * (s.j_hi - s.j_lo + 1);
-    if (area > kLargeArea) {
-      const int slot = atomicAdd(s_nlarge, 1);
-      if (slot < kMaxLarge) { s_large[slot] = f; continue; }
+    s.i_lo = 1; s.i_hi = 0; s.j_lo = 1; s.j_hi = 0;
+    bool large = false;
+    if (f < m.nfaces) {
+      face_setup(m, f, K, R, t, res, z_near, z_far, s);
+      if (s.i_lo <= s.i_hi && s.j_lo <= s.j_hi) {
+        large = (s.i_hi - s.i_lo + 1) * (s.j_hi - s.j_lo + 1) > kLargeArea;
+        if (!large)
+          for (int j = s.j_lo; j <= s.j_hi; ++j)
+            for (int i = s.i_lo; i <= s.i_hi; ++i) {
+              double Z;
+              if (sample_triangle(s, i, j, z_near, z_far, Z, nullptr))
+                atomicMin(&zbuf[j * res + i], __float_as_uint((float)Z));
+            }
+      }
     }
-    for (int j = s.j_lo; j <= s.j_hi; ++j)
-      for (int i = s.i_lo; i <= s.i_hi; ++i) {
+    unsigned long long bal = __ballot(large);
+    const int lane = threadIdx.x & 63;
+    while (bal) {
+      const int src = __ffsll((long long)bal) - 1;
+      bal &= bal - 1;
+      const TriSetup s2 = shfl_setup(s, src);
+      const int bw = s2.i_hi - s2.i_lo + 1, bh = s2.j_hi - s2.j_lo + 1;
+      for (int p = lane; p < bw * bh; p += 64) {
+        const int j = s2.j_lo + p / bw, i = s2.i_lo + p % bw;
         double Z;
-        if (sample_triangle(s, i, j, z_near, z_far, Z, nullptr))
+        if (sample_triangle(s2, i, j, z_near, z_far, Z, nullptr))
           atomicMin(&zbuf[j * res + i], __float_as_uint((float)Z));
       }
-  }
-  __syncthreads();
-  const int nl = min(*s_nlarge, kMaxLarge);
-  for (int q = 0; q < nl; ++q) {
-    TriSetup s;
-    face_setup(m, s_large[q], K, R, t, res, z_near, z_far, s);
-    const int bw = s.i_hi - s.i_lo + 1, bh = s.j_hi - s.j_lo + 1;
-    for (int p = threadIdx.x; p < bw * bh; p += kT) {
-      const int j = s.j_lo + p / bw, i = s.i_lo + p % bw;
-      double Z;
-      if (sample_triangle(s, i, j, z_near, z_far, Z, nullptr))
-        atomicMin(&zbuf[j * res + i], __float_as_uint((float)Z));
     }
   }
   __syncthreads();
@@ -291,6 +294,327 @@ __global__ __launch_bounds__(kT) void depth_refine_kernel(
     for (int r = 0; r < 3; ++r) t_out[3 * (size_t)bi + r] = t[r];
 }
 
+
+// ==================================================================================================
+// Staged variant (default whenever every mesh of the set has <= kMaxStagedVerts vertices):
+//   * 1024 threads per ROI; K, R, t live in LDS (wave-uniform doubles would otherwise cost 42 VGPRs/lane),
+//   * per iteration the V model points are transformed ONCE into homogeneous pixel space and staged in LDS
+//     (24 B/vertex, coalesced 12 B/vertex global reads) — triangles then gather their corners from LDS instead
+//     of re-transforming each vertex ~6x from dependent global loads,
+//   * np.median by a two-rank radix select over the selected differences kept in registers (4 x 8-bit passes,
+//     two 256-bin LDS histograms, 12 barriers) instead of a bitonic sort (up to 78 barrier stages).
+// Arithmetic (and therefore every rendered depth bit and the refined t) is identical to depth_refine_kernel.
+// ==================================================================================================
+// phase stamps of workgroup 0 (s_memtime cycles): [0] start [1] prologue done, then per iteration
+// [2+5i] staged [3+5i] rastered [4+5i] reduced [5+5i] median [6+5i] updated; read by gdrnpp_debug_refine_profile
+__device__ long long g_refine_prof[16];
+#define PROF_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (k) < 16) g_refine_prof[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
+
+constexpr int kTS = 1024;
+constexpr int kWavesS = kTS / 64;
+constexpr int kPPTS = kMaxPix / kTS;
+constexpr int kMaxStagedVerts = 4096;  // 96 KiB of LDS
+
+__device__ __forceinline__ double block_sum_s(double v, double* s_red) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int w = 0; w < kWavesS; ++w) r += s_red[w];
+  return r;
+}
+__device__ __forceinline__ float block_max_s(float v, float* s_red) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  float r = -FLT_MAX;
+  for (int w = 0; w < kWavesS; ++w) r = fmaxf(r, s_red[w]);
+  return r;
+}
+
+__device__ __forceinline__ unsigned f2key(float f) {  // order-preserving float -> uint
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// keys[k] valid where sel[k]; returns the elements of 0-based ranks r0 and r1 (r0 <= r1) among the selected keys.
+__device__ void radix_select2(const unsigned* keys, const bool* sel, int nkeys, int r0, int r1, unsigned (*hist)[256],
+                              unsigned* s_pref, unsigned& out0, unsigned& out1) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned pref0 = 0, pref1 = 0;
+  int rank0 = r0, rank1 = r1;
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = 8 * pass;
+    const unsigned himask = (pass == 3) ? 0u : (0xffffffffu << (shift + 8));
+    if (threadIdx.x < 512) hist[threadIdx.x >> 8][threadIdx.x & 255] = 0;
+    __syncthreads();
+    for (int k = 0; k < nkeys; ++k)
+      if (sel[k]) {
+        const unsigned key = keys[k], byte = (key >> shift) & 255u;
+        if ((key & himask) == (pref0 & himask)) atomicAdd(&hist[0][byte], 1u);
+        if ((key & himask) == (pref1 & himask)) atomicAdd(&hist[1][byte], 1u);
+      }
+    __syncthreads();
+    if (wave < 2) {  // wave 0 resolves rank0, wave 1 resolves rank1: 4 bins per lane, shuffle prefix scan
+      const unsigned* h = hist[wave];
+      const int want = wave == 0 ? rank0 : rank1;
+      const unsigned c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
+      const unsigned tot = c0 + c1 + c2 + c3;
+      unsigned incl = tot;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+      }
+      const unsigned excl = incl - tot;
+      const bool mine = (unsigned)want >= excl && (unsigned)want < incl;
+      if (mine) {
+        unsigned r = (unsigned)want - excl, b;
+        if (r < c0) b = 0;
+        else if (r < c0 + c1) { b = 1; r -= c0; }
+        else if (r < c0 + c1 + c2) { b = 2; r -= c0 + c1; }
+        else { b = 3; r -= c0 + c1 + c2; }
+        s_pref[2 * wave] = (unsigned)(4 * lane) + b;  // winning byte
+        s_pref[2 * wave + 1] = r;                     // rank inside that bin
+      }
+    }
+    __syncthreads();
+    pref0 |= s_pref[0] << shift; rank0 = (int)s_pref[1];
+    pref1 |= s_pref[2] << shift; rank1 = (int)s_pref[3];
+    __syncthreads();
+  }
+  out0 = pref0;
+  out1 = pref1;
+}
+
+__global__ __launch_bounds__(kTS) void depth_refine_staged_kernel(
+    const float* __restrict__ verts, const int* __restrict__ faces, const int* __restrict__ vert_off,
+    const int* __restrict__ face_off, const int* __restrict__ obj, const float* __restrict__ coor_x,
+    const float* __restrict__ coor_y, const float* __restrict__ coor_z, const float* __restrict__ mask_raw,
+    const float* __restrict__ roi_depth, const float* __restrict__ K_crop, const float* __restrict__ Rin,
+    const float* __restrict__ t_in, double* __restrict__ t_out, float* __restrict__ debug_depth, int res, int iters,
+    float threshold, int mask_type, int use_coor_z, float z_near, float z_far) {
+  extern __shared__ double hv[];  // [V][3] homogeneous pixel-space vertices of the current iteration
+  __shared__ unsigned zbuf[kMaxPix];
+  __shared__ unsigned hist[2][256];
+  __shared__ unsigned s_pref[4];
+  __shared__ int s_nsel;
+  __shared__ double s_redd[kWavesS];
+  __shared__ float s_redf[kWavesS];
+  __shared__ double s_K[9], s_R[9], s_t[3];
+  __shared__ float s_Rf[3];
+
+  const int bi = blockIdx.x, tid = threadIdx.x;
+  const int hw = res * res;
+  const int ob = obj[bi];
+  const float* mverts = verts + 3 * (size_t)vert_off[ob];
+  const int nverts = vert_off[ob + 1] - vert_off[ob];
+  const int* mfaces = faces + 3 * (size_t)face_off[ob];
+  const int nfaces = face_off[ob + 1] - face_off[ob];
+  const double zn = (double)z_near, zf = (double)z_far;
+
+  PROF_STAMP(0);
+  if (tid < 9) { s_K[tid] = (double)K_crop[9 * (size_t)bi + tid]; s_R[tid] = (double)Rin[9 * (size_t)bi + tid]; }
+  if (tid < 3) { s_t[tid] = (double)t_in[3 * (size_t)bi + tid]; s_Rf[tid] = Rin[9 * (size_t)bi + 6 + tid]; }
+
+  // ---- prologue (identical arithmetic to depth_refine_kernel) -----------------------------------------------
+  const float* mk = mask_raw + (size_t)bi * hw;
+  float mraw[kPPTS];
+  float lo = FLT_MAX, hi = -FLT_MAX;
+#pragma unroll
+  for (int k = 0; k < kPPTS; ++k) {
+    const int p = k * kTS + tid;
+    mraw[k] = (p < hw) ? mk[p] : 0.f;
+    if (p < hw) { lo = fminf(lo, mraw[k]); hi = fmaxf(hi, mraw[k]); }
+  }
+  float mmin = 0.f, mden = 1.f;
+  if (mask_type == 0) {
+    mmin = -block_max_s(-lo, s_redf);
+    const float mmax = block_max_s(hi, s_redf);
+    mden = mmax - mmin;
+  } else {
+    __syncthreads();
+  }
+  float qbase[kPPTS], ds[kPPTS];
+  const int in_w = 4 * res;
+  const float* dep = roi_depth + (size_t)bi * in_w * in_w;
+  const float r20 = s_Rf[0], r21 = s_Rf[1], r22 = s_Rf[2];
+#pragma unroll
+  for (int k = 0; k < kPPTS; ++k) {
+    const int p = k * kTS + tid;
+    qbase[k] = 0.f; ds[k] = 0.f;
+    if (p < hw) {
+      float m = mraw[k];
+      if (mask_type == 0) m = (m - mmin) / mden;
+      else m = 1.f / (1.f + expf(-m));
+      const float x = coor_x[(size_t)bi * hw + p], y = coor_y[(size_t)bi * hw + p], z = coor_z[(size_t)bi * hw + p];
+      float qv;
+      if (use_coor_z) qv = (r20 * x + r21 * y) + r22 * z;
+      else qv = sqrtf((x * x + y * y) + z * z);
+      qbase[k] = qv * m;
+      const int yy = p / res, xx = p - yy * res;
+      const float* r0 = dep + (size_t)(4 * yy + 1) * in_w + 4 * xx + 1;
+      const float* r1 = r0 + in_w;
+      const float h0 = r0[0] * 0.5f + r0[1] * 0.5f;
+      const float h1 = r1[0] * 0.5f + r1[1] * 0.5f;
+      ds[k] = h0 * 0.5f + h1 * 0.5f;
+    }
+  }
+
+  PROF_STAMP(1);
+  for (int it = 0; it < iters; ++it) {
+    // ---- stage the transformed model points, clear the z-buffer ------------------------------------------------
+    {
+      double K[9], R[9], tr[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { K[k] = s_K[k]; R[k] = s_R[k]; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tr[k] = (double)(float)s_t[k];  // GL receives float32 uniforms
+      for (int v = tid; v < nverts; v += kTS) {
+        double h[3];
+        project_vertex(mverts + 3 * (size_t)v, K, R, tr, h);
+        hv[3 * v] = h[0]; hv[3 * v + 1] = h[1]; hv[3 * v + 2] = h[2];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kPPTS; ++k) {
+      const int p = k * kTS + tid;
+      if (p < hw) zbuf[p] = kInfBits;
+    }
+    if (tid == 0) s_nsel = 0;
+    __syncthreads();
+    PROF_STAMP(2 + 5 * it);
+
+    // ---- rasterise: triangles -> threads, corners gathered from LDS; a triangle whose bbox holds more than
+    //      kLargeArea pixel centres is rasterised by all 64 lanes of its wave (set-up broadcast by shuffles) ----
+    for (int f0 = 0; f0 < nfaces; f0 += kTS) {
+      const int f = f0 + tid;
+      TriSetup s;
+      s.i_lo = 1; s.i_hi = 0; s.j_lo = 1; s.j_hi = 0;
+      bool large = false;
+      if (f < nfaces) {
+        const int i0 = mfaces[3 * f], i1 = mfaces[3 * f + 1], i2 = mfaces[3 * f + 2];
+        const double h0[3] = {hv[3 * i0], hv[3 * i0 + 1], hv[3 * i0 + 2]};
+        const double h1[3] = {hv[3 * i1], hv[3 * i1 + 1], hv[3 * i1 + 2]};
+        const double h2[3] = {hv[3 * i2], hv[3 * i2 + 1], hv[3 * i2 + 2]};
+        setup_triangle(h0, h1, h2, res, res, zn, zf, s);
+        if (s.i_lo <= s.i_hi && s.j_lo <= s.j_hi) {
+          large = (s.i_hi - s.i_lo + 1) * (s.j_hi - s.j_lo + 1) > kLargeArea;
+          if (!large)
+            for (int j = s.j_lo; j <= s.j_hi; ++j)
+              for (int i = s.i_lo; i <= s.i_hi; ++i) {
+                double Z;
+                if (sample_triangle(s, i, j, zn, zf, Z, nullptr))
+                  atomicMin(&zbuf[j * res + i], __float_as_uint((float)Z));
+              }
+        }
+      }
+      unsigned long long bal = __ballot(large);
+      const int lane = tid & 63;
+      while (bal) {
+        const int src = __ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        const TriSetup s2 = shfl_setup(s, src);
+        const int bw = s2.i_hi - s2.i_lo + 1, bh = s2.j_hi - s2.j_lo + 1;
+        for (int p = lane; p < bw * bh; p += 64) {
+          const int j = s2.j_lo + p / bw, i = s2.i_lo + p % bw;
+          double Z;
+          if (sample_triangle(s2, i, j, zn, zf, Z, nullptr)) atomicMin(&zbuf[j * res + i], __float_as_uint((float)Z));
+        }
+      }
+    }
+    __syncthreads();
+    PROF_STAMP(3 + 5 * it);
+
+    // ---- query map -----------------------------------------------------------------------------------------------
+    float ren[kPPTS], q[kPPTS];
+    double part = 0.0;
+#pragma unroll
+    for (int k = 0; k < kPPTS; ++k) {
+      const int p = k * kTS + tid;
+      ren[k] = 0.f; q[k] = 0.f;
+      if (p < hw) {
+        const unsigned zb = zbuf[p];
+        ren[k] = (zb == kInfBits) ? 0.f : __uint_as_float(zb);
+        if (debug_depth) debug_depth[((size_t)bi * iters + it) * hw + p] = ren[k];
+        const float rm = ren[k] > 0.f ? 1.f : 0.f, dm = ds[k] > 0.f ? 1.f : 0.f;
+        q[k] = (qbase[k] * rm) * dm;
+        part += (double)q[k];
+      }
+    }
+    const float norm_sum = (float)block_sum_s(part, s_redd);
+    if (norm_sum == 0.f) continue;
+
+    float qm = -FLT_MAX;
+    double sy = 0.0, sx = 0.0;
+#pragma unroll
+    for (int k = 0; k < kPPTS; ++k) {
+      const int p = k * kTS + tid;
+      if (p < hw) {
+        q[k] = q[k] / norm_sum;
+        qm = fmaxf(qm, q[k]);
+        const int yy = p / res, xx = p - yy * res;
+        sy += (double)yy * (double)q[k];
+        sx += (double)xx * (double)q[k];
+      }
+    }
+    const float qmax = block_max_s(qm, s_redf);
+    const float thr = qmax * threshold;
+    sy = block_sum_s(sy, s_redd);
+    sx = block_sum_s(sx, s_redd);
+
+    PROF_STAMP(4 + 5 * it);
+    // ---- median of the selected depth differences: two-rank radix select --------------------------------------------
+    unsigned keys[kPPTS];
+    bool sel[kPPTS];
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < kPPTS; ++k) {
+      const int p = k * kTS + tid;
+      sel[k] = (p < hw) && (q[k] > thr);
+      keys[k] = f2key(ds[k] - ren[k]);
+      mine += sel[k] ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((tid & 63) == 0 && mine) atomicAdd(&s_nsel, mine);
+    __syncthreads();
+    const int nsel = s_nsel;
+    if (nsel == 0) continue;
+    unsigned k0, k1;
+    radix_select2(keys, sel, kPPTS, (nsel - 1) >> 1, nsel >> 1, hist, s_pref, k0, k1);
+    PROF_STAMP(5 + 5 * it);
+    if (tid == 0) {
+      const float a0 = key2f(k0), a1 = key2f(k1);
+      const float med = (nsel & 1) ? a1 : (a0 + a1) / 2.f;  // np.median
+      const double a = s_K[0], b = s_K[1], c = s_K[2], d = s_K[3], e = s_K[4], f = s_K[5], g = s_K[6], h = s_K[7],
+                   i9 = s_K[8];
+      const double det = a * (e * i9 - f * h) - b * (d * i9 - f * g) + c * (d * h - e * g);
+      double Ki[9] = {(e * i9 - f * h) / det, (c * h - b * i9) / det, (b * f - c * e) / det,
+                      (f * g - d * i9) / det, (a * i9 - c * g) / det, (c * d - a * f) / det,
+                      (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+      for (int k = 0; k < 9; ++k) Ki[k] = (double)(float)Ki[k];
+      double ray[3];
+      for (int r = 0; r < 3; ++r) ray[r] = (Ki[3 * r] * sx + Ki[3 * r + 1] * sy) + Ki[3 * r + 2] * 1.0;
+      const double rz = ray[2];
+      for (int r = 0; r < 3; ++r) s_t[r] = s_t[r] + (ray[r] / rz) * (double)med;
+    }
+    __syncthreads();
+    PROF_STAMP(6 + 5 * it);
+  }
+  if (tid == 0)
+    for (int r = 0; r < 3; ++r) t_out[3 * (size_t)bi + r] = s_t[r];
+}
+
 // ---- stand-alone render: depth (+ optional object-space xyz) -------------------------------
 __global__ __launch_bounds__(kT) void render_depth_kernel(const float* __restrict__ verts,
                                                           const int* __restrict__ faces,
@@ -335,8 +659,7 @@ __global__ __launch_bounds__(kT) void render_depth_kernel(const float* __restric
       const int src = __ffsll((long long)bal) - 1;
       bal &= bal - 1;
       const int ff = __shfl(f, src, 64);
-      TriSetup s2;
-      face_setup(mesh, ff, K, R, t, res, z_near, z_far, s2);
+      const TriSetup s2 = shfl_setup(s, src);
       const int bw = s2.i_hi - s2.i_lo + 1, bh = s2.j_hi - s2.j_lo + 1;
       for (int p = lane; p < bw * bh; p += 64) {
         const int j = s2.j_lo + p / bw, i = s2.i_lo + p % bw;
@@ -412,10 +735,31 @@ int gdrnpp_depth_refine(const gdrnpp_meshes* meshes, const int* obj, const float
                  iters);
   GDRNPP_REQUIRE(res * res <= kMaxPix, GDRNPP_ELIMIT, "gdrnpp_depth_refine: res=%d > 64", res);
   GDRNPP_REQUIRE(mask_type == 0 || mask_type == 1, GDRNPP_EINVAL, "gdrnpp_depth_refine: mask_type=%d", mask_type);
-  hipLaunchKernelGGL(depth_refine_kernel, dim3(b), dim3(kT), 0, (hipStream_t)stream, meshes->verts, meshes->faces,
-                     meshes->vert_off, meshes->face_off, obj, coor_x, coor_y, coor_z, mask_raw, roi_depth, K_crop, R,
-                     t_in, t_out, debug_depth, res, iters, threshold, mask_type, use_coor_z, z_near, z_far);
+  hipStream_t st = (hipStream_t)stream;
+  if (meshes->max_verts > 0 && meshes->max_verts <= kMaxStagedVerts) {
+    const int lds = 3 * (int)sizeof(double) * meshes->max_verts;
+    static int attr_lds = 0;
+    if (lds > attr_lds) {
+      GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)depth_refine_staged_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)sizeof(double) * kMaxStagedVerts));
+      attr_lds = 3 * (int)sizeof(double) * kMaxStagedVerts;
+    }
+    hipLaunchKernelGGL(depth_refine_staged_kernel, dim3(b), dim3(kTS), lds, st, meshes->verts, meshes->faces,
+                       meshes->vert_off, meshes->face_off, obj, coor_x, coor_y, coor_z, mask_raw, roi_depth, K_crop, R,
+                       t_in, t_out, debug_depth, res, iters, threshold, mask_type, use_coor_z, z_near, z_far);
+  } else {
+    hipLaunchKernelGGL(depth_refine_kernel, dim3(b), dim3(kT), 0, st, meshes->verts, meshes->faces, meshes->vert_off,
+                       meshes->face_off, obj, coor_x, coor_y, coor_z, mask_raw, roi_depth, K_crop, R, t_in, t_out,
+                       debug_depth, res, iters, threshold, mask_type, use_coor_z, z_near, z_far);
+  }
   return gdrnpp::check_launch("gdrnpp_depth_refine");
+}
+
+/* debug: s_memtime stamps of workgroup 0 of the last staged refine launch (see g_refine_prof) */
+int gdrnpp_debug_refine_profile(long long* h_out16) {
+  GDRNPP_REQUIRE(h_out16, GDRNPP_EINVAL, "gdrnpp_debug_refine_profile: null pointer");
+  GDRNPP_HIP_TRY(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_refine_prof), sizeof(long long) * 16));
+  return 0;
 }
 
 }  // extern "C"

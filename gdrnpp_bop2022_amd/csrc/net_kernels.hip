@@ -323,8 +323,10 @@ int gdrnpp_groupnorm_act_nhwc(const float* x, const float* gamma, const float* b
   hipLaunchKernelGGL(gn_stats_kernel, dim3(P, N), dim3(256), sizeof(double) * 512, st, x, (double*)workspace, HW, C, G,
                      P);
   const long total = (long)HW * Q;
-  long bx = (total + 255) / 256;
-  if (bx > 1024) bx = 1024;
+  // every block first rebuilds mean/rstd from the P partials (a ~2 us prologue): give it >= 16 float4 per thread
+  long bx = (total + 256 * 16 - 1) / (256 * 16);
+  if (bx > 64) bx = 64;
+  if (bx < 1) bx = 1;
   if (act_gelu)
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)bx, N), dim3(256), 0, st, x, (const double*)workspace,
                        gamma, beta, y, HW, C, G, P, eps);

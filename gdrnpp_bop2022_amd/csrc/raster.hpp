@@ -54,8 +54,8 @@ __device__ __forceinline__ int clampi(double v, int lo, int hi) {
 // the last row of K is (0,0,1)).  Triangles entirely nearer than z_near or farther than z_far cannot
 // produce a fragment and are dropped; triangles crossing the near plane are clipped against it
 // (Sutherland-Hodgman on the 3 edges, in homogeneous pixel space where interpolation is linear) so that
-// objects straddling the camera plane do not degrade to a full-image bbox.  The bbox only bounds the
-// search: coverage and depth are decided by sample_triangle alone, so results do not depend on it.
+// objects straddling the camera plane do not degrade to a full-image bbox.  oracle/raster_oracle.c computes
+// the same bbox with the same expressions, so even degenerate slivers resolve identically on both sides.
 __device__ __forceinline__ void setup_triangle(const double* h0, const double* h1, const double* h2, int res_w,
                                                int res_h, double z_near, double z_far, TriSetup& s) {
   cross3(h1, h2, s.e0);
@@ -87,11 +87,11 @@ __device__ __forceinline__ void setup_triangle(const double* h0, const double* h
       }
     }
   }
-  // pixel centre i+0.5 in [umin,umax]  =>  i in [umin-0.5, umax-0.5]; widened by a whole pixel each side
-  s.i_lo = clampi(floor(umin - 0.5) - 1.0, 0, res_w);  // res_w => empty after the hi clamp
-  s.i_hi = clampi(ceil(umax - 0.5) + 1.0, -1, res_w - 1);
-  s.j_lo = clampi(floor(vmin - 0.5) - 1.0, 0, res_h);
-  s.j_hi = clampi(ceil(vmax - 0.5) + 1.0, -1, res_h - 1);
+  // pixel centre i+0.5 in [umin,umax]  =>  i in [umin-0.5, umax-0.5]; floor/ceil round outwards
+  s.i_lo = clampi(floor(umin - 0.5), 0, res_w);  // res_w => empty after the hi clamp
+  s.i_hi = clampi(ceil(umax - 0.5), -1, res_w - 1);
+  s.j_lo = clampi(floor(vmin - 0.5), 0, res_h);
+  s.j_hi = clampi(ceil(vmax - 0.5), -1, res_h - 1);
   if (!(s.D != 0.0) || zmax < z_near || zmin > z_far || !(umin <= umax)) { s.i_lo = 1; s.i_hi = 0; }
 }
 
@@ -111,6 +111,23 @@ __device__ __forceinline__ bool sample_triangle(const TriSetup& s, int i, int j,
   if (!(Z >= z_near && Z <= z_far)) return false;
   if (lam) { lam[0] = w0 / sum; lam[1] = w1 / sum; lam[2] = w2 / sum; }
   return true;
+}
+
+// wave-wide broadcast of a triangle set-up from lane `src` (used to rasterise a large triangle with all 64 lanes)
+__device__ __forceinline__ TriSetup shfl_setup(const TriSetup& s, int src) {
+  TriSetup o;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    o.e0[k] = __shfl(s.e0[k], src, 64);
+    o.e1[k] = __shfl(s.e1[k], src, 64);
+    o.e2[k] = __shfl(s.e2[k], src, 64);
+  }
+  o.D = __shfl(s.D, src, 64);
+  o.i_lo = __shfl(s.i_lo, src, 64);
+  o.i_hi = __shfl(s.i_hi, src, 64);
+  o.j_lo = __shfl(s.j_lo, src, 64);
+  o.j_hi = __shfl(s.j_hi, src, 64);
+  return o;
 }
 
 }  // namespace gdrnpp

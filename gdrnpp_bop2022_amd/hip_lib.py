@@ -27,6 +27,8 @@ class gdrnpp_meshes(ctypes.Structure):
         ("vert_off", c_void_p),
         ("face_off", c_void_p),
         ("n_obj", c_int),
+        ("max_verts", c_int),
+        ("max_faces", c_int),
     ]
 
 
@@ -57,6 +59,7 @@ SIGNATURES = {
     "gdrnpp_depth_refine": (
         c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
                 c_int, c_int, c_float, c_float, _P]),
+    "gdrnpp_debug_refine_profile": (c_int, [_P]),
     "gdrnpp_pack_pose_records": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "gdrnpp_dwconv7x7_ln_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "gdrnpp_upsample_bilinear2x_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -126,7 +129,8 @@ class MeshSet:
         self.n_verts = v_off[1:]
         self.n_faces = f_off[1:]
         self._c = gdrnpp_meshes(self.verts.data_ptr(), self.faces.data_ptr(), self.vert_off.data_ptr(),
-                                self.face_off.data_ptr(), self.n_obj)
+                                self.face_off.data_ptr(), self.n_obj, max(len(v) for v in vertices),
+                                max(len(f) for f in faces))
 
     @property
     def c(self):

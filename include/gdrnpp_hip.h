@@ -168,6 +168,8 @@ typedef struct gdrnpp_meshes {
   const int* vert_off;
   const int* face_off;
   int n_obj;
+  int max_verts; /* host-side hint: max vertices of any object (0 = unknown -> no LDS staging) */
+  int max_faces; /* host-side hint: max faces of any object (0 = unknown) */
 } gdrnpp_meshes;
 
 /* ---- depth render (a8.1 / a14) — lib/render_vispy/renderer.py:126-130,
@@ -196,6 +198,10 @@ int gdrnpp_depth_refine(const gdrnpp_meshes* meshes, const int* obj,
                         float* debug_depth, int b, int res, int iters,
                         float threshold, int mask_type, int use_coor_z,
                         float z_near, float z_far, void* stream);
+
+/* debug aid: 16 s_memtime stamps written by workgroup 0 of the last gdrnpp_depth_refine launch (LDS-staged
+ * kernel): [0] start, [1] prologue, then per iteration staged/rastered/reduced/median/updated. Host pointer. */
+int gdrnpp_debug_refine_profile(long long* h_out16);
 
 /* ---- network-side layers of GDRN_Net (a3), NHWC fp32 ----------------------------------------
  * Memory-bound layers that PyTorch-ROCm runs far from the HBM roofline: all tensors are

@@ -67,17 +67,38 @@ void oracle_render_depth(const float* verts, const int* faces, int nfaces, const
     cross3(h0, h1, e2);
     double D = (h0[0] * e0[0] + h0[1] * e0[1]) + h0[2] * e0[2];
     if (!(D != 0.0)) continue;
-    int i_lo = 0, i_hi = res_w - 1, j_lo = 0, j_hi = res_h - 1;
-    if (h0[2] > 0.0 && h1[2] > 0.0 && h2[2] > 0.0) {
+    /* conservative pixel bbox of the part with Z >= z_near (same expressions as csrc/raster.hpp:setup_triangle):
+     * whole triangle in front -> bbox of the projected corners; crossing the near plane -> corners in front plus the
+     * edge/near-plane intersections; entirely nearer than z_near or beyond z_far -> no fragment possible */
+    double zmin = fmin(h0[2], fmin(h1[2], h2[2])), zmax = fmax(h0[2], fmax(h1[2], h2[2]));
+    double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+    if (zmin >= z_near) {
       double u0 = h0[0] / h0[2], u1 = h1[0] / h1[2], u2 = h2[0] / h2[2];
       double w0 = h0[1] / h0[2], w1 = h1[1] / h1[2], w2 = h2[1] / h2[2];
-      double umin = fmin(u0, fmin(u1, u2)), umax = fmax(u0, fmax(u1, u2));
-      double vmin = fmin(w0, fmin(w1, w2)), vmax = fmax(w0, fmax(w1, w2));
-      i_lo = clampi(floor(umin - 0.5), 0, res_w);
-      i_hi = clampi(ceil(umax - 0.5), -1, res_w - 1);
-      j_lo = clampi(floor(vmin - 0.5), 0, res_h);
-      j_hi = clampi(ceil(vmax - 0.5), -1, res_h - 1);
+      umin = fmin(u0, fmin(u1, u2)); umax = fmax(u0, fmax(u1, u2));
+      vmin = fmin(w0, fmin(w1, w2)); vmax = fmax(w0, fmax(w1, w2));
+    } else {
+      const double* hvv[3] = {h0, h1, h2};
+      for (int e = 0; e < 3; ++e) {
+        const double* a = hvv[e];
+        const double* b = hvv[(e + 1) % 3];
+        int ain = a[2] >= z_near, bin = b[2] >= z_near;
+        if (ain) {
+          double u = a[0] / a[2], v = a[1] / a[2];
+          umin = fmin(umin, u); umax = fmax(umax, u); vmin = fmin(vmin, v); vmax = fmax(vmax, v);
+        }
+        if (ain != bin) {
+          double tt = (z_near - a[2]) / (b[2] - a[2]);
+          double u = (a[0] + tt * (b[0] - a[0])) / z_near, v = (a[1] + tt * (b[1] - a[1])) / z_near;
+          umin = fmin(umin, u); umax = fmax(umax, u); vmin = fmin(vmin, v); vmax = fmax(vmax, v);
+        }
+      }
     }
+    if (zmax < z_near || zmin > z_far || !(umin <= umax)) continue;
+    int i_lo = clampi(floor(umin - 0.5), 0, res_w);
+    int i_hi = clampi(ceil(umax - 0.5), -1, res_w - 1);
+    int j_lo = clampi(floor(vmin - 0.5), 0, res_h);
+    int j_hi = clampi(ceil(vmax - 0.5), -1, res_h - 1);
     for (int j = j_lo; j <= j_hi; ++j)
       for (int i = i_lo; i <= i_hi; ++i) {
         double u = (double)i + 0.5, v = (double)j + 0.5;
