@@ -60,6 +60,8 @@ SIGNATURES = {
         c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
                 c_int, c_int, c_float, c_float, _P]),
     "gdrnpp_debug_refine_profile": (c_int, [_P]),
+    "gdrnpp_crop_resize_roi": (
+        c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "gdrnpp_pack_pose_records": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "gdrnpp_dwconv7x7_ln_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "gdrnpp_upsample_bilinear2x_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -323,3 +325,28 @@ def groupnorm_act(x, gamma, beta, groups: int, eps: float = 1e-5, gelu: bool = F
         _nhwc(x, "x"), _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"), y.data_ptr(),
         ws.data_ptr(), n, h * w, c, groups, float(eps), 1 if gelu else 0, _stream()), "gdrnpp_groupnorm_act_nhwc")
     return y
+
+
+def crop_resize_roi(images, depths, im_idx, centers, scales, out_res: int = 256, out_res_small: int = 64,
+                    pixel_mean=(0.0, 0.0, 0.0), pixel_std=(255.0, 255.0, 255.0), want_img=True, want_coord2d=True):
+    """GPU ROI preparation (read_data_test, data_loader.py:754-797).  images u8[n_im,H,W,3] BGR, depths f32[n_im,H,W]
+    or None, im_idx i32[b] or None, centers f64[b,2], scales f64[b] ->
+    (roi_img f32[b,3,out,out] | None, roi_depth f32[b,1,out,out] | None, roi_coord_2d f32[b,2,os,os] | None)."""
+    lib = load()
+    n_im, H, W, _ = images.shape
+    b = centers.shape[0]
+    dev = images.device
+    roi_img = torch.empty((b, 3, out_res, out_res), dtype=torch.float32, device=dev) if want_img else None
+    roi_depth = torch.empty((b, 1, out_res, out_res), dtype=torch.float32, device=dev) if depths is not None else None
+    roi_c2d = (torch.empty((b, 2, out_res_small, out_res_small), dtype=torch.float32, device=dev)
+               if want_coord2d else None)
+    mean = (ctypes.c_double * 3)(*[float(v) for v in pixel_mean])
+    std = (ctypes.c_double * 3)(*[float(v) for v in pixel_std])
+    _check(lib.gdrnpp_crop_resize_roi(
+        _dev(images, torch.uint8, "images"), _dev(depths, torch.float32, "depths") if depths is not None else None,
+        n_im, H, W, _dev(im_idx, torch.int32, "im_idx") if im_idx is not None else None,
+        _dev(centers, torch.float64, "centers"), _dev(scales, torch.float64, "scales"),
+        roi_img.data_ptr() if want_img else None, roi_depth.data_ptr() if roi_depth is not None else None,
+        roi_c2d.data_ptr() if want_coord2d else None, b, out_res, out_res_small,
+        ctypes.cast(mean, c_void_p), ctypes.cast(std, c_void_p), _stream()), "gdrnpp_crop_resize_roi")
+    return roi_img, roi_depth, roi_c2d

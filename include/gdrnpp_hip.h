@@ -223,6 +223,19 @@ int gdrnpp_groupnorm_act_nhwc(const float* x, const float* gamma, const float* b
                               float* y, void* workspace, int N, int HW, int C, int G,
                               float eps, int act_gelu, void* stream);
 
+/* ---- ROI crop-resize (a1) — read_data_test, data_loader.py:754-797 ---------------------------------
+ * cv2.warpAffine restated (data_utils.py:115-184): images u8[n_im,H,W,3] (BGR), depths f32[n_im,H,W] or NULL,
+ * im_idx i32[b] (NULL = image 0), centers f64[b,2] = bbox centre, scales f64[b] (float64 like the reference's
+ * call site) -> roi_img f32[b,3,out,out] = (bilinear u8 - mean[c]) / std[c] (float64 math, float32 store);
+ * roi_depth f32[b,1,out,out] (nearest); roi_coord2d f32[b,2,out_small,out_small] = bilinear crop of the
+ * analytic coord_2d map.  Any output pointer may be NULL.  h_mean3/h_std3 are HOST pointers to 3 doubles
+ * (MODEL.PIXEL_MEAN / PIXEL_STD). */
+int gdrnpp_crop_resize_roi(const unsigned char* images, const float* depths, int n_im,
+                           int H, int W, const int* im_idx, const double* centers,
+                           const double* scales, float* roi_img, float* roi_depth,
+                           float* roi_coord2d, int b, int out_res, int out_res_small,
+                           const double* h_mean3, const double* h_std3, void* stream);
+
 /* ---- pose record packing for the RCCL all-gather (a13) -------------------
  * rec f32[b,16] = R(9) | t(3) | score | obj_id | roi_id | valid(1) */
 int gdrnpp_pack_pose_records(const float* R, const double* t_refined,

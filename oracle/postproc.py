@@ -388,3 +388,57 @@ def ransac_voting_layer(mask, vertex, idxs_rounds, inlier_thresh=0.999, confiden
         except np.linalg.LinAlgError:
             out[v] = ATb[v]
     return out.astype(f32), cur_iter
+
+
+# ------------------------------------------------------------------------------------------
+# ROI crop (read_data_test) — cv2.warpAffine restated in oracle/warp_oracle.c
+# ------------------------------------------------------------------------------------------
+def get_affine_transform(center, scale, output_size):
+    """core/utils/data_utils.py:136-184 (rot=0) + cv2.getAffineTransform -> float64[2,3]."""
+    M = np.zeros(6, np.float64)
+    _lib().oracle_get_affine_transform(ctypes.c_double(float(center[0])), ctypes.c_double(float(center[1])),
+                                       ctypes.c_double(float(scale)), int(output_size), int(output_size), _p(M, _f64p))
+    return M.reshape(2, 3)
+
+
+def warp_affine(img, M, out_size, nearest=False):
+    """cv2.warpAffine(img, M, (out,out), flags=INTER_LINEAR|INTER_NEAREST), border constant 0.  img HW or HWC."""
+    M = np.ascontiguousarray(M, np.float64).reshape(6)
+    img = np.ascontiguousarray(img)
+    H, W = img.shape[:2]
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    if img.dtype == np.uint8:
+        assert not nearest
+        dst = np.zeros((out_size, out_size, cn), np.uint8)
+        _lib().oracle_warp_affine_u8(_p(img, _u8p), H, W, cn, _p(M, _f64p), _p(dst, _u8p), out_size, out_size)
+    else:
+        img = np.ascontiguousarray(img, np.float32)
+        dst = np.zeros((out_size, out_size, cn), np.float32)
+        _lib().oracle_warp_affine_f32(_p(img, _f32p), H, W, cn, _p(M, _f64p), _p(dst, _f32p), out_size, out_size,
+                                      1 if nearest else 0)
+    return dst[..., 0] if img.ndim == 2 else dst
+
+
+def get_2d_coord_np(width, height):
+    """core/utils/data_utils.py:304-323 (low=0, high=1, endpoint=False) -> HWC float32."""
+    x = np.linspace(0, 1, width, dtype=np.float32, endpoint=False)
+    y = np.linspace(0, 1, height, dtype=np.float32, endpoint=False)
+    return np.asarray(np.meshgrid(x, y)).transpose(1, 2, 0)
+
+
+def crop_resize_roi(image, depth, center, scale, input_res=256, out_res=64, pixel_mean=(0, 0, 0),
+                    pixel_std=(255.0, 255.0, 255.0)):
+    """data_loader.py:773-797 for one detection: (roi_img f32[3,256,256], roi_depth f32[1,256,256] | None,
+    roi_coord_2d f32[2,64,64])."""
+    H, W = image.shape[:2]
+    M = get_affine_transform(center, scale, input_res)
+    roi_img = warp_affine(image, M, input_res).transpose(2, 0, 1)
+    mean = np.array(pixel_mean).reshape(-1, 1, 1)
+    std = np.array(pixel_std).reshape(-1, 1, 1)
+    roi_img = ((roi_img - mean) / std).astype("float32")  # base_data_loader.py:128-135
+    roi_depth = None
+    if depth is not None:
+        roi_depth = warp_affine(depth, M, input_res, nearest=True).reshape(1, input_res, input_res).astype("float32")
+    M64 = get_affine_transform(center, scale, out_res)
+    roi_c2d = warp_affine(get_2d_coord_np(W, H), M64, out_res).transpose(2, 0, 1).astype("float32")
+    return roi_img, roi_depth, roi_c2d

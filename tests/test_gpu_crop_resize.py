@@ -1,0 +1,43 @@
+"""ROI crop-resize (row a1) on the GPU against the cv2.warpAffine restatement (-m gpu): all three outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import postproc as P
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_crop_resize_roi_bit_exact(hip):
+    rng = np.random.default_rng(0)
+    n_im, H, W = 2, 480, 640
+    images = rng.integers(0, 256, (n_im, H, W, 3), dtype=np.uint8)
+    depths = rng.uniform(0.3, 2.0, (n_im, H, W)).astype(np.float32)
+    depths[rng.uniform(size=depths.shape) < 0.1] = 0
+    b = 24
+    centers = np.stack([rng.uniform(-20, 660, b), rng.uniform(-20, 500, b)], 1)     # some ROIs leave the image
+    scales = rng.uniform(40, 640, b)
+    centers[0], scales[0] = (320.0, 240.0), 256.0                                    # pure integer translation
+    centers[1], scales[1] = (100.5, 77.25), 64.0                                     # 4x up-sampling
+    im_idx = rng.integers(0, n_im, b).astype(np.int32)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    img, dep, c2d = hip.crop_resize_roi(T(images), T(depths), T(im_idx), T(centers), T(scales))
+    img, dep, c2d = img.cpu().numpy(), dep.cpu().numpy(), c2d.cpu().numpy()
+    for i in range(b):
+        o_img, o_dep, o_c2d = P.crop_resize_roi(images[im_idx[i]], depths[im_idx[i]], centers[i], scales[i])
+        assert np.array_equal(img[i].view(np.uint32), o_img.view(np.uint32)), i
+        assert np.array_equal(dep[i].view(np.uint32), o_dep.view(np.uint32)), i
+        assert np.array_equal(c2d[i].view(np.uint32), o_c2d.view(np.uint32)), i
+    assert np.array_equal((img[0] * 255).round().astype(np.uint8).transpose(1, 2, 0),
+                          images[im_idx[0], 112:368, 192:448])
+
+
+def test_crop_resize_feeds_the_network_inputs(hip):
+    """Output shapes/dtypes are what batch_data_test hands to GDRN_Net.forward (engine_utils.py:213-241)."""
+    images = torch.randint(0, 256, (1, 480, 640, 3), dtype=torch.uint8, device=DEV)
+    centers = torch.tensor([[320.0, 240.0], [100.0, 90.0]], dtype=torch.float64, device=DEV)
+    scales = torch.tensor([200.0, 120.0], dtype=torch.float64, device=DEV)
+    img, dep, c2d = hip.crop_resize_roi(images, None, None, centers, scales)
+    assert img.shape == (2, 3, 256, 256) and img.dtype == torch.float32 and dep is None and c2d.shape == (2, 2, 64, 64)
+    assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0

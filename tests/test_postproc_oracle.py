@@ -89,3 +89,25 @@ def test_zoom_K_maps_roi_to_output_square():
         uv = Kc[i].astype(np.float64) @ ray
         np.testing.assert_allclose(uv[:2] / uv[2], [32, 32], atol=1e-3)
     np.testing.assert_array_equal(Kc, S.zoom_K_np(det["roi_cam"], det["roi_center"], det["scale"], 64))
+
+
+def test_warp_affine_restatement_properties():
+    """Self-consistency of the cv2.warpAffine restatement (cv2 itself is unavailable: parity unpinned)."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)
+    dep = rng.uniform(0.3, 2, (120, 160)).astype(np.float32)
+    # scale == out size -> pure integer translation: bilinear == nearest == a slice
+    a, b, c = P.crop_resize_roi(img, dep, (80.0, 60.0), 64.0, input_res=64, out_res=16)
+    assert np.array_equal((a * 255).round().astype(np.uint8).transpose(1, 2, 0), img[28:92, 48:112])
+    assert np.array_equal(b[0], dep[28:92, 48:112])
+    # interior bilinear of the linear ramp coord_2d reproduces the ramp (to float32 rounding)
+    ys, xs = np.mgrid[0:16, 0:16]
+    np.testing.assert_allclose(c[0], (80 + (xs - 8) * 4.0) / 160.0, atol=2e-7)
+    np.testing.assert_allclose(c[1], (60 + (ys - 8) * 4.0) / 120.0, atol=2e-7)
+    # constant image stays constant inside, border value 0 outside
+    const = np.full((120, 160, 3), 200, np.uint8)
+    a, _, _ = P.crop_resize_roi(const, None, (0.0, 0.0), 100.0, input_res=64, out_res=16)
+    v = (a * 255).round().astype(np.uint8)
+    assert set(np.unique(v[:, 40:, 40:])) == {200} and set(np.unique(v[:, :30, :30])) == {0}
+    M = P.get_affine_transform((80.0, 60.0), 64.0, 64)
+    np.testing.assert_allclose(M, [[1, 0, -48], [0, 1, -28]], atol=1e-12)
