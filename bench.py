@@ -214,8 +214,12 @@ def main():
         nv, nf = len(verts[0]), len(faces[0])
         bytes_launch, per_roi = algorithmic_bytes_refine(b, cfg.TEST.DEPTH_REFINE_ITER, nv, nf)
         achieved = bytes_launch / (mean_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same workload only
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc) and b == 128 and args.subdiv == 4:
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
         roofline = dict(kernel="depth_refine_staged_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, launch_ms=mean_ms, bytes_per_launch=bytes_launch,
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, launch_ms=mean_ms, bytes_per_launch=bytes_launch,
                         bytes_per_roi=per_roi, rois_per_launch=b)
 
     if rank == 0:

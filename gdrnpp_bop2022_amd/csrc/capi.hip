@@ -12,7 +12,37 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace gdrnpp
 
+namespace {
+// PMC calibration streams (tools/pmc_traffic.py): read n floats with 4-byte or 16-byte lanes, fold, write one
+// float per workgroup — a known byte count in the two access widths the path's kernels use.
+template <int WIDTH>
+__global__ void stream_read_kernel(const float* __restrict__ p, size_t n, float* __restrict__ out) {
+  float acc = 0.f;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  if (WIDTH == 4) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += stride) {
+      const float4 v = q[i];
+      acc += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += p[i];
+  }
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out + blockIdx.x, acc);
+}
+}  // namespace
+
 extern "C" {
+int gdrnpp_debug_stream_read(const float* p, size_t n, int lane_bytes, float* out_blocks, int blocks, void* stream) {
+  GDRNPP_REQUIRE(p && out_blocks && n > 0 && blocks > 0 && (lane_bytes == 4 || lane_bytes == 16), GDRNPP_EINVAL,
+                 "gdrnpp_debug_stream_read: bad arguments");
+  if (lane_bytes == 16)
+    hipLaunchKernelGGL(stream_read_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, out_blocks);
+  else
+    hipLaunchKernelGGL(stream_read_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, out_blocks);
+  return gdrnpp::check_launch("gdrnpp_debug_stream_read");
+}
 int gdrnpp_version(void) { return 100; /* 0.1.0 */ }
 const char* gdrnpp_last_error(void) { return gdrnpp::g_err; }
 }

@@ -310,10 +310,11 @@ __global__ __launch_bounds__(kT) void depth_refine_kernel(
 __device__ long long g_refine_prof[16];
 #define PROF_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (k) < 16) g_refine_prof[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
 
-constexpr int kTS = 1024;
+constexpr int kTS = 512;
 constexpr int kWavesS = kTS / 64;
 constexpr int kPPTS = kMaxPix / kTS;
 constexpr int kMaxStagedVerts = 4096;  // 96 KiB of LDS
+constexpr int kMaxLargeS = 2048;       // queue of wave-rasterised triangles (overflow falls back to per-lane)
 
 __device__ __forceinline__ double block_sum_s(double v, double* s_red) {
 #pragma unroll
@@ -405,9 +406,11 @@ __global__ __launch_bounds__(kTS) void depth_refine_staged_kernel(
     float threshold, int mask_type, int use_coor_z, float z_near, float z_far) {
   extern __shared__ double hv[];  // [V][3] homogeneous pixel-space vertices of the current iteration
   __shared__ unsigned zbuf[kMaxPix];
+  __shared__ float s_qbase[kMaxPix], s_ds[kMaxPix];  // iteration-invariant per-pixel terms (kept out of the VGPRs)
   __shared__ unsigned hist[2][256];
   __shared__ unsigned s_pref[4];
-  __shared__ int s_nsel;
+  __shared__ int s_large[kMaxLargeS];
+  __shared__ int s_nsel, s_nlarge;
   __shared__ double s_redd[kWavesS];
   __shared__ float s_redf[kWavesS];
   __shared__ double s_K[9], s_R[9], s_t[3];
@@ -444,14 +447,12 @@ __global__ __launch_bounds__(kTS) void depth_refine_staged_kernel(
   } else {
     __syncthreads();
   }
-  float qbase[kPPTS], ds[kPPTS];
   const int in_w = 4 * res;
   const float* dep = roi_depth + (size_t)bi * in_w * in_w;
   const float r20 = s_Rf[0], r21 = s_Rf[1], r22 = s_Rf[2];
 #pragma unroll
   for (int k = 0; k < kPPTS; ++k) {
     const int p = k * kTS + tid;
-    qbase[k] = 0.f; ds[k] = 0.f;
     if (p < hw) {
       float m = mraw[k];
       if (mask_type == 0) m = (m - mmin) / mden;
@@ -460,13 +461,13 @@ __global__ __launch_bounds__(kTS) void depth_refine_staged_kernel(
       float qv;
       if (use_coor_z) qv = (r20 * x + r21 * y) + r22 * z;
       else qv = sqrtf((x * x + y * y) + z * z);
-      qbase[k] = qv * m;
+      s_qbase[p] = qv * m;
       const int yy = p / res, xx = p - yy * res;
       const float* r0 = dep + (size_t)(4 * yy + 1) * in_w + 4 * xx + 1;
       const float* r1 = r0 + in_w;
       const float h0 = r0[0] * 0.5f + r0[1] * 0.5f;
       const float h1 = r1[0] * 0.5f + r1[1] * 0.5f;
-      ds[k] = h0 * 0.5f + h1 * 0.5f;
+      s_ds[p] = h0 * 0.5f + h1 * 0.5f;
     }
   }
 
@@ -490,64 +491,67 @@ __global__ __launch_bounds__(kTS) void depth_refine_staged_kernel(
       const int p = k * kTS + tid;
       if (p < hw) zbuf[p] = kInfBits;
     }
-    if (tid == 0) s_nsel = 0;
+    if (tid == 0) { s_nsel = 0; s_nlarge = 0; }
     __syncthreads();
     PROF_STAMP(2 + 5 * it);
 
-    // ---- rasterise: triangles -> threads, corners gathered from LDS; a triangle whose bbox holds more than
-    //      kLargeArea pixel centres is rasterised by all 64 lanes of its wave (set-up broadcast by shuffles) ----
-    for (int f0 = 0; f0 < nfaces; f0 += kTS) {
-      const int f = f0 + tid;
+    // ---- rasterise: triangles -> threads, corners gathered from LDS.  A triangle whose bbox holds more than
+    //      kLargeArea pixel centres is queued in LDS and rasterised by a whole wave (16 waves drain the queue in
+    //      parallel), so one lane never serialises a big triangle --------------------------------------------------
+    for (int f = tid; f < nfaces; f += kTS) {
+      const int i0 = mfaces[3 * f], i1 = mfaces[3 * f + 1], i2 = mfaces[3 * f + 2];
+      const double h0[3] = {hv[3 * i0], hv[3 * i0 + 1], hv[3 * i0 + 2]};
+      const double h1[3] = {hv[3 * i1], hv[3 * i1 + 1], hv[3 * i1 + 2]};
+      const double h2[3] = {hv[3 * i2], hv[3 * i2 + 1], hv[3 * i2 + 2]};
       TriSetup s;
-      s.i_lo = 1; s.i_hi = 0; s.j_lo = 1; s.j_hi = 0;
-      bool large = false;
-      if (f < nfaces) {
+      setup_triangle(h0, h1, h2, res, res, zn, zf, s);
+      if (s.i_lo > s.i_hi || s.j_lo > s.j_hi) continue;
+      if ((s.i_hi - s.i_lo + 1) * (s.j_hi - s.j_lo + 1) > kLargeArea) {
+        const int slot = atomicAdd(&s_nlarge, 1);
+        if (slot < kMaxLargeS) { s_large[slot] = f; continue; }
+      }
+      for (int j = s.j_lo; j <= s.j_hi; ++j)
+        for (int i = s.i_lo; i <= s.i_hi; ++i) {
+          double Z;
+          if (sample_triangle(s, i, j, zn, zf, Z, nullptr)) atomicMin(&zbuf[j * res + i], __float_as_uint((float)Z));
+        }
+    }
+    __syncthreads();
+    {
+      const int nl = min(s_nlarge, kMaxLargeS);
+      const int lane = tid & 63;
+      for (int qd = tid >> 6; qd < nl; qd += kWavesS) {
+        const int f = s_large[qd];
         const int i0 = mfaces[3 * f], i1 = mfaces[3 * f + 1], i2 = mfaces[3 * f + 2];
         const double h0[3] = {hv[3 * i0], hv[3 * i0 + 1], hv[3 * i0 + 2]};
         const double h1[3] = {hv[3 * i1], hv[3 * i1 + 1], hv[3 * i1 + 2]};
         const double h2[3] = {hv[3 * i2], hv[3 * i2 + 1], hv[3 * i2 + 2]};
+        TriSetup s;
         setup_triangle(h0, h1, h2, res, res, zn, zf, s);
-        if (s.i_lo <= s.i_hi && s.j_lo <= s.j_hi) {
-          large = (s.i_hi - s.i_lo + 1) * (s.j_hi - s.j_lo + 1) > kLargeArea;
-          if (!large)
-            for (int j = s.j_lo; j <= s.j_hi; ++j)
-              for (int i = s.i_lo; i <= s.i_hi; ++i) {
-                double Z;
-                if (sample_triangle(s, i, j, zn, zf, Z, nullptr))
-                  atomicMin(&zbuf[j * res + i], __float_as_uint((float)Z));
-              }
-        }
-      }
-      unsigned long long bal = __ballot(large);
-      const int lane = tid & 63;
-      while (bal) {
-        const int src = __ffsll((long long)bal) - 1;
-        bal &= bal - 1;
-        const TriSetup s2 = shfl_setup(s, src);
-        const int bw = s2.i_hi - s2.i_lo + 1, bh = s2.j_hi - s2.j_lo + 1;
+        const int bw = s.i_hi - s.i_lo + 1, bh = s.j_hi - s.j_lo + 1;
         for (int p = lane; p < bw * bh; p += 64) {
-          const int j = s2.j_lo + p / bw, i = s2.i_lo + p % bw;
+          const int j = s.j_lo + p / bw, i = s.i_lo + p % bw;
           double Z;
-          if (sample_triangle(s2, i, j, zn, zf, Z, nullptr)) atomicMin(&zbuf[j * res + i], __float_as_uint((float)Z));
+          if (sample_triangle(s, i, j, zn, zf, Z, nullptr)) atomicMin(&zbuf[j * res + i], __float_as_uint((float)Z));
         }
       }
     }
     __syncthreads();
-    PROF_STAMP(3 + 5 * it);
 
     // ---- query map -----------------------------------------------------------------------------------------------
-    float ren[kPPTS], q[kPPTS];
+    float ren[kPPTS], q[kPPTS], ds[kPPTS];
     double part = 0.0;
 #pragma unroll
     for (int k = 0; k < kPPTS; ++k) {
       const int p = k * kTS + tid;
-      ren[k] = 0.f; q[k] = 0.f;
+      ren[k] = 0.f; q[k] = 0.f; ds[k] = 0.f;
       if (p < hw) {
+        ds[k] = s_ds[p];
         const unsigned zb = zbuf[p];
         ren[k] = (zb == kInfBits) ? 0.f : __uint_as_float(zb);
         if (debug_depth) debug_depth[((size_t)bi * iters + it) * hw + p] = ren[k];
         const float rm = ren[k] > 0.f ? 1.f : 0.f, dm = ds[k] > 0.f ? 1.f : 0.f;
-        q[k] = (qbase[k] * rm) * dm;
+        q[k] = (s_qbase[p] * rm) * dm;
         part += (double)q[k];
       }
     }

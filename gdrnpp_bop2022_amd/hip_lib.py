@@ -60,6 +60,7 @@ SIGNATURES = {
         c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
                 c_int, c_int, c_float, c_float, _P]),
     "gdrnpp_debug_refine_profile": (c_int, [_P]),
+    "gdrnpp_debug_stream_read": (c_int, [_P, c_size_t, c_int, _P, c_int, _P]),
     "gdrnpp_crop_resize_roi": (
         c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "gdrnpp_pack_pose_records": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),

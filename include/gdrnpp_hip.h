@@ -199,6 +199,10 @@ int gdrnpp_depth_refine(const gdrnpp_meshes* meshes, const int* obj,
                         float threshold, int mask_type, int use_coor_z,
                         float z_near, float z_far, void* stream);
 
+/* debug aid: PMC calibration stream — reads n floats with 4- or 16-byte lanes (a known byte count) */
+int gdrnpp_debug_stream_read(const float* p, size_t n, int lane_bytes, float* out_blocks,
+                             int blocks, void* stream);
+
 /* debug aid: 16 s_memtime stamps written by workgroup 0 of the last gdrnpp_depth_refine launch (LDS-staged
  * kernel): [0] start, [1] prologue, then per iteration staged/rastered/reduced/median/updated. Host pointer. */
 int gdrnpp_debug_refine_profile(long long* h_out16);
