@@ -60,6 +60,7 @@ SIGNATURES = {
         c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
                 c_int, c_int, c_float, c_float, _P]),
     "gdrnpp_debug_refine_profile": (c_int, [_P]),
+    "gdrnpp_roi_align": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     "gdrnpp_debug_stream_read": (c_int, [_P, c_size_t, c_int, _P, c_int, _P]),
     "gdrnpp_crop_resize_roi": (
         c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
@@ -351,3 +352,16 @@ def crop_resize_roi(images, depths, im_idx, centers, scales, out_res: int = 256,
         roi_c2d.data_ptr() if want_coord2d else None, b, out_res, out_res_small,
         ctypes.cast(mean, c_void_p), ctypes.cast(std, c_void_p), _stream()), "gdrnpp_crop_resize_roi")
     return roi_img, roi_depth, roi_c2d
+
+
+def roi_align(x, rois, output_size, spatial_scale: float = 1.0, sampling_ratio: int = 0, aligned: bool = True):
+    """detectron2.layers.ROIAlign(output_size, spatial_scale, sampling_ratio, aligned)(x, rois): x f32[B,C,H,W] (NCHW
+    contiguous), rois f32[N,5] -> f32[N,C,oh,ow]."""
+    oh, ow = (output_size, output_size) if isinstance(output_size, int) else output_size
+    bsz, c, h, w = x.shape
+    n = rois.shape[0]
+    out = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
+    _check(load().gdrnpp_roi_align(_dev(x, torch.float32, "x"), _dev(rois, torch.float32, "rois"), out.data_ptr(), n, c,
+                                   h, w, oh, ow, float(spatial_scale), int(sampling_ratio), 1 if aligned else 0,
+                                   _stream()), "gdrnpp_roi_align")
+    return out

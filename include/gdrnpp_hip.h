@@ -240,6 +240,13 @@ int gdrnpp_crop_resize_roi(const unsigned char* images, const float* depths, int
                            float* roi_coord2d, int b, int out_res, int out_res_small,
                            const double* h_mean3, const double* h_std3, void* stream);
 
+/* ---- ROIAlign crop-resize (a1b) — detectron2 ROIAlign(output_size, spatial_scale, sampling_ratio, aligned)
+ * as called at core/utils/data_utils.py:65-112 and core/utils/zoom_utils.py:80-96.
+ * x f32[B,C,H,W] (NCHW), rois f32[N,5] = (batch idx, x1, y1, x2, y2) -> out f32[N,C,pooled_h,pooled_w]. */
+int gdrnpp_roi_align(const float* x, const float* rois, float* out, int n_rois, int C,
+                     int H, int W, int pooled_h, int pooled_w, float spatial_scale,
+                     int sampling_ratio, int aligned, void* stream);
+
 /* ---- pose record packing for the RCCL all-gather (a13) -------------------
  * rec f32[b,16] = R(9) | t(3) | score | obj_id | roi_id | valid(1) */
 int gdrnpp_pack_pose_records(const float* R, const double* t_refined,

@@ -442,3 +442,15 @@ def crop_resize_roi(image, depth, center, scale, input_res=256, out_res=64, pixe
     M64 = get_affine_transform(center, scale, out_res)
     roi_c2d = warp_affine(get_2d_coord_np(W, H), M64, out_res).transpose(2, 0, 1).astype("float32")
     return roi_img, roi_depth, roi_c2d
+
+
+def roi_align(x, rois, output_size, spatial_scale=1.0, sampling_ratio=0, aligned=True):
+    """detectron2 ROIAlign forward (oracle/roi_align_oracle.c): x f32[B,C,H,W], rois f32[N,5] -> f32[N,C,oh,ow]."""
+    oh, ow = (output_size, output_size) if isinstance(output_size, int) else output_size
+    x = np.ascontiguousarray(x, np.float32)
+    rois = np.ascontiguousarray(rois, np.float32)
+    b, c, h, w = x.shape
+    out = np.zeros((rois.shape[0], c, oh, ow), np.float32)
+    _lib().oracle_roi_align(_p(x, _f32p), _p(rois, _f32p), _p(out, _f32p), rois.shape[0], c, h, w, oh, ow,
+                            ctypes.c_float(spatial_scale), int(sampling_ratio), 1 if aligned else 0)
+    return out
