@@ -126,7 +126,7 @@ def main():
     opts = ["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"] if refine else []
     cfg = get_cfg("ycbv_convnext_a6", opts)
     b = args.batch or (128 if refine else 64)
-    torch.manual_seed(20220925 + rank)
+    torch.manual_seed(20220925)  # identical weights on every rank; the data below is per-rank
     rng = np.random.default_rng(20220925 + 3 + rank)
     torch.backends.cudnn.benchmark = True  # MIOpen find mode during warm-up
 
