@@ -19,6 +19,7 @@
 
 namespace {
 
+constexpr int kPixPerThread = 16;  // 4096 pixels per workgroup: the per-ROI LU prologue is amortised over 16 rows
 constexpr int AB_BITS = 10, AB_SCALE = 1 << AB_BITS, INTER_BITS = 5, INTER_TAB_SIZE = 1 << INTER_BITS;
 
 __device__ __forceinline__ int cv_round(double v) { return __double2int_rn(v); }
@@ -124,10 +125,11 @@ __global__ __launch_bounds__(256) void crop_img_depth_kernel(const unsigned char
   double M[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) M[k] = sM[k];
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= out * out) return;
-  const int y = p / out, x = p - y * out;
   const size_t im = (size_t)(im_idx ? im_idx[bi] : 0);
+  for (int it = 0; it < kPixPerThread; ++it) {
+  const int p = (blockIdx.x * kPixPerThread + it) * blockDim.x + threadIdx.x;
+  if (p >= out * out) break;
+  const int y = p / out, x = p - y * out;
   if (roi_img) {
     const unsigned char* src = images + im * H * W * 3;
     int sx, sy, alpha;
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(256) void crop_img_depth_kernel(const unsigned char
     int sx, sy, alpha;
     src_coord(M, x, y, true, sx, sy, alpha);
     roi_depth[((size_t)bi * out + y) * out + x] = (sx >= 0 && sx < W && sy >= 0 && sy < H) ? src[(size_t)sy * W + sx] : 0.f;
+  }
   }
 }
 
@@ -208,7 +211,7 @@ int gdrnpp_crop_resize_roi(const unsigned char* images, const float* depths, int
   if ((roi_img || (roi_depth && depths)) && out_res > 0) {
     Norm3 nrm;
     for (int k = 0; k < 3; ++k) { nrm.mean[k] = h_mean3 ? h_mean3[k] : 0.0; nrm.stdv[k] = h_std3 ? h_std3[k] : 1.0; }
-    dim3 grid((out_res * out_res + 255) / 256, b);
+    dim3 grid((out_res * out_res + 256 * kPixPerThread - 1) / (256 * kPixPerThread), b);
     hipLaunchKernelGGL(crop_img_depth_kernel, grid, dim3(256), 0, st, images, depths, H, W, im_idx, centers, scales,
                        roi_img, roi_depth, out_res, nrm);
   }

@@ -124,9 +124,9 @@ __global__ void voting_kernel(const float* __restrict__ direct, const float* __r
 }
 
 constexpr int kPixTile = 4096;  // pixels per LDS tile: 64 KiB as float4 -> 2 workgroups / CU
-constexpr int kHypPerWG = 16;   // hypotheses per workgroup (4 per wave)
+constexpr int kHypPerWG = 4;    // hypotheses per workgroup (1 per wave): hn*vn/4 workgroups fill the chip
 
-// grid: (vn, ceil(hn/16)); counts[hi,vi] = number of inlier pixels
+// grid: (vn, ceil(hn/4)); counts[hi,vi] = number of inlier pixels
 template <bool HOMO>
 __global__ __launch_bounds__(256) void vote_count_kernel(const float* __restrict__ direct,
                                                          const float* __restrict__ coords,
