@@ -47,7 +47,11 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="refine", choices=["refine", "rgb"])
+    p.add_argument("--workload", default="refine", choices=["refine", "rgb", "bop7"],
+                   help="refine = BASELINE configs[2] (default); rgb = configs[1]; bop7 = configs[4]-style mixed stream "
+                        "(lmo/ycbv/tless/icbin/hb/itodd/tudl models cycled step by step, with depth refine)")
+    p.add_argument("--with-crop", action="store_true",
+                   help="start each step from full images: GPU ROI crop-resize (row a1) feeds the forward")
     p.add_argument("--batch", type=int, default=0, help="ROIs per GPU per step (0 = the config's batch)")
     p.add_argument("--subdiv", type=int, default=4, help="icosphere subdivision of the synthetic meshes (4 = 2562V/5120F)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,63 +126,87 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
     hip_lib.load()
 
-    refine = args.workload == "refine"
+    refine = args.workload in ("refine", "bop7")
     opts = ["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"] if refine else []
-    cfg = get_cfg("ycbv_convnext_a6", opts)
+    datasets = ["lmo", "ycbv", "tless", "icbin", "hb", "itodd", "tudl"] if args.workload == "bop7" else ["ycbv"]
     b = args.batch or (128 if refine else 64)
-    torch.manual_seed(20220925)  # identical weights on every rank; the data below is per-rank
-    rng = np.random.default_rng(20220925 + 3 + rank)
     torch.backends.cudnn.benchmark = True  # MIOpen find mode during warm-up
-
-    model, _ = build_model_optimizer(cfg, is_test=True)
     hip_layers.set_enabled(not args.no_hip_layers)
-    model.exact_reference_order = bool(args.exact_reference_order)
-    # Random-init weights predict t ~ 0 (object at the camera centre), which no trained model does and which
-    # would make every triangle straddle the camera plane.  Set the translation head's bias to the dataset
-    # prior of the scale-invariant depth z_rel = t_z / resize_ratio (SITE parametrisation,
-    # pose_from_pred_centroid_z.py:84-90) so that predicted poses land in the view frustum.
-    with torch.no_grad():
-        model.pnp_net.fc_t.bias.copy_(torch.tensor([0.0, 0.0, 1.5 * float(S.YCBV_K[0, 0]) * 0.19 / 64.0]))
-    C = cfg.MODEL.POSE_NET.NUM_CLASSES
-    verts, faces, ext = S.make_models(C, np.random.default_rng(20220925), subdiv=args.subdiv)
-    meshes = hip_lib.MeshSet(verts, faces, device=dev)
-    post = GdrnHipPost(cfg, meshes)
-    batch, det, K_crop = make_batch(cfg, b, rng, dev, verts, faces, ext, meshes, refine)
+
+    streams = []  # one (cfg, model, post, batch, det, K_crop, meshes, verts, faces) per dataset of the stream
+    for di, ds in enumerate(datasets):
+        cfg = get_cfg(f"{ds}_convnext_a6", opts)
+        torch.manual_seed(20220925)  # identical weights on every rank; the data below is per-rank
+        rng = np.random.default_rng(20220925 + 3 + rank + 100 * di)
+        model, _ = build_model_optimizer(cfg, is_test=True)
+        model.exact_reference_order = bool(args.exact_reference_order)
+        # Random-init weights predict t ~ 0 (object at the camera centre), which no trained model does and which
+        # would make every triangle straddle the camera plane.  Set the translation head's bias to the dataset
+        # prior of the scale-invariant depth z_rel = t_z / resize_ratio (SITE parametrisation,
+        # pose_from_pred_centroid_z.py:84-90) so that predicted poses land in the view frustum.
+        with torch.no_grad():
+            model.pnp_net.fc_t.bias.copy_(torch.tensor([0.0, 0.0, 1.5 * float(S.YCBV_K[0, 0]) * 0.19 / 64.0]))
+        C = cfg.MODEL.POSE_NET.NUM_CLASSES
+        verts, faces, ext = S.make_models(C, np.random.default_rng(20220925 + di), subdiv=args.subdiv)
+        meshes = hip_lib.MeshSet(verts, faces, device=dev)
+        post = GdrnHipPost(cfg, meshes if refine else None)
+        batch, det, K_crop = make_batch(cfg, b, rng, dev, verts, faces, ext, meshes, refine)
+        if args.with_crop:
+            g = torch.Generator(device=dev).manual_seed(7 + di)
+            batch["images"] = torch.randint(0, 256, (16, S.IM_H, S.IM_W, 3), dtype=torch.uint8, device=dev, generator=g)
+            batch["depths"] = torch.rand((16, S.IM_H, S.IM_W), device=dev, generator=g) + 0.3
+            batch["im_idx"] = torch.from_numpy(rng.integers(0, 16, b).astype(np.int32)).to(dev)
+            batch["center64"] = torch.from_numpy(det["roi_center"].astype(np.float64)).to(dev)
+            batch["scale64"] = torch.from_numpy(det["scale"].astype(np.float64)).to(dev)
+        streams.append(dict(cfg=cfg, model=model, post=post, batch=batch, det=det, K_crop=K_crop, meshes=meshes,
+                            verts=verts, faces=faces, C=C, cls_i32=batch["roi_cls"].to(torch.int32)))
+    cfg, model, post, batch, det, K_crop, meshes, verts, faces, C = (streams[0][k] for k in (
+        "cfg", "model", "post", "batch", "det", "K_crop", "meshes", "verts", "faces", "C"))
     roi_ids = torch.arange(rank * b, (rank + 1) * b, dtype=torch.int32, device=dev)
+    step_counter = [0]
 
     ev_pairs = []
-    cls_i32 = batch["roi_cls"].to(torch.int32)
     t_ref_buf = torch.empty((b, 3), dtype=torch.float64, device=dev)
 
     @torch.no_grad()
-    def forward_only():
-        return model(batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"],
-                     roi_whs=batch["roi_wh"], roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"],
-                     roi_coord_2d=batch["roi_coord_2d"], roi_extents=batch["roi_extent"])
+    def forward_only(st=None):
+        st = st or streams[0]
+        bt, mdl = st["batch"], st["model"]
+        roi_img, roi_c2d = bt["roi_img"], bt["roi_coord_2d"]
+        if args.with_crop:  # ROI preparation on the GPU (data_loader.py:754-797): full images -> ROI tensors
+            roi_img, _roi_depth_from_image, roi_c2d = hip_lib.crop_resize_roi(
+                bt["images"], bt["depths"], bt["im_idx"], bt["center64"], bt["scale64"])
+        return mdl(roi_img, roi_classes=bt["roi_cls"], roi_cams=bt["roi_cam"], roi_whs=bt["roi_wh"],
+                   roi_centers=bt["roi_center"], resize_ratios=bt["resize_ratio"], roi_coord_2d=roi_c2d,
+                   roi_extents=bt["roi_extent"])
 
     fixed_out = forward_only() if args.post_only else None
 
     @torch.no_grad()
     def step(record_events=False):
-        out = fixed_out if args.post_only else forward_only()
+        st = streams[step_counter[0] % len(streams)]
+        step_counter[0] += 1
+        bt, cfg_s = st["batch"], st["cfg"]
+        out = fixed_out if args.post_only else forward_only(st)
         if refine and record_events:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            K_c = hip_lib.zoom_K(batch["roi_cam"].reshape(b, 9), batch["roi_center"], batch["scale"], 64)
+            K_c = hip_lib.zoom_K(bt["roi_cam"].reshape(b, 9), bt["roi_center"], bt["scale"], 64)
             maps = [out[k].contiguous() for k in ("coor_x", "coor_y", "coor_z", "mask")]
             rot9, trans = out["rot"].reshape(b, 9).contiguous(), out["trans"].contiguous()
             e0.record()  # torch's current stream == the stream hip_lib launches on; brackets ONLY the refine launch
-            t_ref = hip_lib.depth_refine(meshes, cls_i32, maps[0], maps[1], maps[2], maps[3], batch["roi_depth"], K_c,
-                                         rot9, trans, iters=cfg.TEST.DEPTH_REFINE_ITER,
-                                         threshold=cfg.TEST.DEPTH_REFINE_THRESHOLD, out=t_ref_buf)
+            t_ref = hip_lib.depth_refine(st["meshes"], st["cls_i32"], maps[0], maps[1], maps[2], maps[3], bt["roi_depth"],
+                                         K_c, rot9, trans, iters=cfg_s.TEST.DEPTH_REFINE_ITER,
+                                         threshold=cfg_s.TEST.DEPTH_REFINE_THRESHOLD, out=t_ref_buf)
             e1.record()
             ev_pairs.append((e0, e1))
-            rec = hip_lib.pack_pose_records(rot9, t_ref, trans, batch["score"], cls_i32, roi_ids)
+            rec = hip_lib.pack_pose_records(rot9, t_ref, trans, bt["score"], st["cls_i32"], roi_ids)
         else:
-            rec = post.process(batch, out, roi_ids)
+            rec = st["post"].process(bt, out, roi_ids)
         return gather_records(rec, b)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1) * len(streams) if len(streams) > 1 else args.warmup):
         step()
+    step_counter[0] = 0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -216,7 +244,7 @@ def main():
         achieved = bytes_launch / (mean_ms * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same workload only
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and b == 128 and args.subdiv == 4:
+        if os.path.exists(pmc) and b == 128 and args.subdiv == 4 and args.workload == "refine":
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
         roofline = dict(kernel="depth_refine_staged_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic, launch_ms=mean_ms, bytes_per_launch=bytes_launch,
@@ -239,9 +267,12 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (seeded ROIs, ellipsoid meshes 2562V/5120F, random-init weights, t-head bias = z_rel prior)",
             "config": {
-                "workload": ("YCB-V convnext_a6 + fast depth refine (render-compare), batch=%d ROIs/GPU"
-                             % b) if refine else ("YCB-V convnext_a6, RGB-only Patch-PnP, batch=%d ROIs/GPU" % b),
-                "baseline_config_index": 2 if refine else 1, "global_batch": world * b, "rois_per_gpu": b,
+                "workload": ("BOP-7 mixed stream (lmo/ycbv/tless/icbin/hb/itodd/tudl convnext_a6 models cycled per step) "
+                             "+ fast depth refine, batch=%d ROIs/GPU" % b) if args.workload == "bop7" else
+                            (("YCB-V convnext_a6 + fast depth refine (render-compare), batch=%d ROIs/GPU"
+                              % b) if refine else ("YCB-V convnext_a6, RGB-only Patch-PnP, batch=%d ROIs/GPU" % b)),
+                "baseline_config_index": 4 if args.workload == "bop7" else (2 if refine else 1),
+                "roi_prep_on_gpu": bool(args.with_crop), "global_batch": world * b, "rois_per_gpu": b,
                 "num_classes": C, "input_res": 256, "output_res": 64, "refine_iters": cfg.TEST.DEPTH_REFINE_ITER if refine else 0,
                 "parallelism": f"roi-shard x{world}", "class_sliced_out_layer": not args.exact_reference_order, "hip_network_layers": not args.no_hip_layers,
                 "post_only": bool(args.post_only)},
