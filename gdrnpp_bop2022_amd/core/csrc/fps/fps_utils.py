@@ -1,30 +1,24 @@
-"""core/csrc/fps/fps_utils.py:6-21, verbatim interface: ``farthest_point_sampling(pts, sn, init_center=False)``
--> the sampled points ``pts[idxs]`` (f32[sn,3])."""
+"""Call surface of the reference's ``core/csrc/fps/fps_utils.py`` (``farthest_point_sampling(pts, sn, init_center)``
+returning the sampled points), routed through the host-pointer symbols of ``libgdrnpp_hip.so`` that keep the
+reference's C prototypes (core/csrc/fps/src/ext.h:1-14).  ``farthest_point_sampling_idx`` additionally exposes the
+index list, which is what the offline tools persist (tools/ycbv/ycbv_1_compute_fps.py:29-37)."""
 import numpy as np
 
 from ._ext import ffi, lib
 
 
-def farthest_point_sampling(pts, sn, init_center=False):
-    pn, _ = pts.shape
-    assert pts.shape[1] == 3
-    pts = np.ascontiguousarray(pts, np.float32)
-    idxs = np.ascontiguousarray(np.zeros([sn], np.int32))
-    pts_ptr = ffi.cast("float*", pts.ctypes.data)
-    idxs_ptr = ffi.cast("int*", idxs.ctypes.data)
-    if init_center:
-        lib.farthest_point_sampling_init_center(pts_ptr, idxs_ptr, pn, sn)
-    else:
-        lib.farthest_point_sampling(pts_ptr, idxs_ptr, pn, sn)
-    if (idxs < 0).any():
-        raise RuntimeError("farthest_point_sampling failed on the device (see stderr)")
-    return pts[idxs]
-
-
 def farthest_point_sampling_idx(pts, sn, init_center=False):
-    """Same call, returning the indices (what tools/ycbv/ycbv_1_compute_fps.py effectively stores)."""
-    pts = np.ascontiguousarray(pts, np.float32)
-    idxs = np.zeros([sn], np.int32)
-    fn = lib.farthest_point_sampling_init_center if init_center else lib.farthest_point_sampling
-    fn(ffi.cast("float*", pts.ctypes.data), ffi.cast("int*", idxs.ctypes.data), pts.shape[0], sn)
-    return idxs
+    """Indices i32[sn] of the farthest-point sample of ``pts`` f32[pn,3]."""
+    cloud = np.ascontiguousarray(pts, dtype=np.float32)
+    if cloud.ndim != 2 or cloud.shape[1] != 3:
+        raise ValueError(f"pts must be [pn, 3], got {cloud.shape}")
+    picked = np.full((int(sn),), -1, dtype=np.int32)
+    entry = lib.farthest_point_sampling_init_center if init_center else lib.farthest_point_sampling
+    entry(ffi.cast("float*", cloud.ctypes.data), ffi.cast("int*", picked.ctypes.data), cloud.shape[0], int(sn))
+    if picked.min() < 0:  # the C symbol has no status channel: -1 marks a device failure
+        raise RuntimeError("farthest_point_sampling failed on the device (see stderr)")
+    return picked
+
+
+def farthest_point_sampling(pts, sn, init_center=False):
+    return np.ascontiguousarray(pts, dtype=np.float32)[farthest_point_sampling_idx(pts, sn, init_center)]
