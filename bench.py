@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 from gdrnpp_bop2022_amd import hip_lib, synthetic as S  # noqa: E402
 from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers  # noqa: E402
 from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg  # noqa: E402
-from gdrnpp_bop2022_amd.gdrn_modeling.engine import GdrnHipPost, gather_records  # noqa: E402
+from gdrnpp_bop2022_amd.gdrn_modeling.engine import GdrnHipPost, GraphedInference, gather_records  # noqa: E402
 from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--workload", default="refine", choices=["refine", "rgb", "bop7"],
                    help="refine = BASELINE configs[2] (default); rgb = configs[1]; bop7 = configs[4]-style mixed stream "
                         "(lmo/ycbv/tless/icbin/hb/itodd/tudl models cycled step by step, with depth refine)")
+    p.add_argument("--graph", action="store_true", help="replay the whole step from a captured hipGraph (small batches)")
     p.add_argument("--with-crop", action="store_true",
                    help="start each step from full images: GPU ROI crop-resize (row a1) feeds the forward")
     p.add_argument("--batch", type=int, default=0, help="ROIs per GPU per step (0 = the config's batch)")
@@ -182,10 +183,18 @@ def main():
 
     fixed_out = forward_only() if args.post_only else None
 
+    graphed = {}
+
     @torch.no_grad()
     def step(record_events=False):
         st = streams[step_counter[0] % len(streams)]
         step_counter[0] += 1
+        if args.graph and not args.with_crop and not args.post_only:
+            key = id(st)
+            if key not in graphed:
+                graphed[key] = GraphedInference(st["model"], st["post"], st["batch"], roi_ids)
+            graphed[key].graph.replay()  # inputs already live in the graph's static buffers (resident in HBM)
+            return gather_records(graphed[key].records, b)
         bt, cfg_s = st["batch"], st["cfg"]
         out = fixed_out if args.post_only else forward_only(st)
         if refine and record_events:
@@ -272,7 +281,7 @@ def main():
                             (("YCB-V convnext_a6 + fast depth refine (render-compare), batch=%d ROIs/GPU"
                               % b) if refine else ("YCB-V convnext_a6, RGB-only Patch-PnP, batch=%d ROIs/GPU" % b)),
                 "baseline_config_index": 4 if args.workload == "bop7" else (2 if refine else 1),
-                "roi_prep_on_gpu": bool(args.with_crop), "global_batch": world * b, "rois_per_gpu": b,
+                "roi_prep_on_gpu": bool(args.with_crop), "hipgraph": bool(args.graph), "global_batch": world * b, "rois_per_gpu": b,
                 "num_classes": C, "input_res": 256, "output_res": 64, "refine_iters": cfg.TEST.DEPTH_REFINE_ITER if refine else 0,
                 "parallelism": f"roi-shard x{world}", "class_sliced_out_layer": not args.exact_reference_order, "hip_network_layers": not args.no_hip_layers,
                 "post_only": bool(args.post_only)},

@@ -127,3 +127,35 @@ def records_to_bop(rec: torch.Tensor, scene_im_ids, obj_ids, times=None):
             "time": float(times[i]) if times is not None else -1.0,
         })
     return results
+
+
+class GraphedInference:
+    """The whole hot path (forward + HIP post-processing + record packing) captured once into a hipGraph and
+    replayed per batch.  At the reference's own batch sizes (one image = a few to ~30 ROIs, gdrn_evaluator.py:702)
+    the ≈260 launches of a step are launch-bound; a graph replay removes the per-launch host cost.  Shapes are
+    fixed at capture time: batches are copied into static device buffers (pad the ROI dimension to the captured
+    size; padded rows are ordinary ROIs whose records the caller ignores)."""
+
+    def __init__(self, model, post: GdrnHipPost, example_batch: dict, roi_ids: torch.Tensor | None = None,
+                 warmup: int = 3):
+        self.model, self.post = model, post
+        self.static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in example_batch.items()}
+        self.roi_ids = roi_ids.clone() if roi_ids is not None else None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # MIOpen find, hipFuncSetAttribute, allocator warm-up happen outside capture
+            for _ in range(max(warmup, 1)):
+                inference_step(model, post, self.static, self.roi_ids)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.records = inference_step(model, post, self.static, self.roi_ids)
+
+    @torch.no_grad()
+    def __call__(self, batch: dict) -> torch.Tensor:
+        for k, v in batch.items():
+            if isinstance(v, torch.Tensor) and k in self.static:
+                self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        return self.records

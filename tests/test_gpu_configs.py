@@ -117,3 +117,38 @@ def test_config2_and_config4_shard_end_to_end(hip, name, b, refine):
                                    out["rot"][i].cpu().numpy(), out["trans"][i].cpu().numpy(), verts[o], faces[o])
             np.testing.assert_allclose(rec[i, 9:12], t, atol=1e-5)   # R/t bar: 1e-4
         assert shard_range(1024, 3, 8) == (384, 512)
+
+
+def test_hipgraph_replay_equals_eager(hip):
+    """Small-batch serving path: the captured hipGraph of the whole step reproduces the eager records (R/t within
+    1e-4; MIOpen/hipBLASLt may pick other kernels under capture), also after the static inputs are overwritten."""
+    from gdrnpp_bop2022_amd.gdrn_modeling.engine import GraphedInference
+
+    cfg = get_cfg("ycbv_convnext_a6", ["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"])
+    rng = np.random.default_rng(11)
+    torch.manual_seed(3)
+    model, _ = build_model_optimizer(cfg)
+    with torch.no_grad():
+        model.pnp_net.fc_t.bias.copy_(torch.tensor([0.0, 0.0, 4.7]))
+    verts, faces, ext = S.make_models(21, rng, subdiv=3)
+    meshes = hip.MeshSet(verts, faces)
+    post = GdrnHipPost(cfg, meshes)
+    b = 8
+
+    def new_batch():
+        det = S.make_detections(b, 21, ext, rng)
+        bt = _batch(det, b)
+        K_crop = S.zoom_K_np(det["roi_cam"], det["roi_center"], det["scale"], 64)
+        depth = hip.render_depth(meshes, T(det["roi_cls"].astype(np.int32)), T(K_crop), T(det["R_gt"]), T(det["t_gt"]), 64)
+        bt["roi_depth"] = depth.repeat_interleave(4, 1).repeat_interleave(4, 2)[:, None].contiguous()
+        return bt
+
+    b1, b2 = new_batch(), new_batch()
+    ids = torch.arange(b, dtype=torch.int32, device=DEV)
+    g = GraphedInference(model, post, b1, ids)
+    for bt in (b1, b2, b1):
+        r_graph = g(bt).clone()
+        r_eager = inference_step(model, post, bt, ids)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(r_graph, r_eager, rtol=0, atol=1e-4)
+        assert torch.equal(r_graph[:, 12:], r_eager[:, 12:])  # score / obj / roi id / valid are exact
