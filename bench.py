@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--workload", default="refine", choices=["refine", "rgb", "bop7"],
                    help="refine = BASELINE configs[2] (default); rgb = configs[1]; bop7 = configs[4]-style mixed stream "
                         "(lmo/ycbv/tless/icbin/hb/itodd/tudl models cycled step by step, with depth refine)")
+    p.add_argument("--streams", type=int, default=1,
+                   help="split each step's batch over this many HIP streams so that memory-bound layers of one part "
+                        "overlap MFMA-bound layers of another")
     p.add_argument("--graph", action="store_true", help="replay the whole step from a captured hipGraph (small batches)")
     p.add_argument("--with-crop", action="store_true",
                    help="start each step from full images: GPU ROI crop-resize (row a1) feeds the forward")
@@ -184,11 +187,37 @@ def main():
     fixed_out = forward_only() if args.post_only else None
 
     graphed = {}
+    record_events_only_path = False
+    side_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else []
+    if args.streams > 1:
+        for st_ in streams:
+            parts = []
+            for ci in range(args.streams):
+                lo, hi = ci * b // args.streams, (ci + 1) * b // args.streams
+                sub = {k: (v[lo:hi].contiguous() if isinstance(v, torch.Tensor) and v.shape[:1] == (b,) else v)
+                       for k, v in st_["batch"].items()}
+                sub["roi_ids"] = roi_ids[lo:hi].contiguous()
+                parts.append(sub)
+            st_["parts"] = parts
 
     @torch.no_grad()
     def step(record_events=False):
         st = streams[step_counter[0] % len(streams)]
         step_counter[0] += 1
+        if args.streams > 1 and not record_events_only_path:
+            outs = []
+            cur = torch.cuda.current_stream()
+            for si, (sub, ss) in enumerate(zip(st["parts"], side_streams)):
+                ss.wait_stream(cur)
+                with torch.cuda.stream(ss):
+                    o = st["model"](sub["roi_img"], roi_classes=sub["roi_cls"], roi_cams=sub["roi_cam"],
+                                    roi_whs=sub["roi_wh"], roi_centers=sub["roi_center"],
+                                    resize_ratios=sub["resize_ratio"], roi_coord_2d=sub["roi_coord_2d"],
+                                    roi_extents=sub["roi_extent"])
+                    outs.append(st["post"].process(sub, o, sub["roi_ids"]))
+            for ss in side_streams:
+                cur.wait_stream(ss)
+            return gather_records(torch.cat(outs, 0), b)
         if args.graph and not args.with_crop and not args.post_only:
             key = id(st)
             if key not in graphed:
@@ -281,7 +310,7 @@ def main():
                             (("YCB-V convnext_a6 + fast depth refine (render-compare), batch=%d ROIs/GPU"
                               % b) if refine else ("YCB-V convnext_a6, RGB-only Patch-PnP, batch=%d ROIs/GPU" % b)),
                 "baseline_config_index": 4 if args.workload == "bop7" else (2 if refine else 1),
-                "roi_prep_on_gpu": bool(args.with_crop), "hipgraph": bool(args.graph), "global_batch": world * b, "rois_per_gpu": b,
+                "roi_prep_on_gpu": bool(args.with_crop), "hipgraph": bool(args.graph), "streams": args.streams, "global_batch": world * b, "rois_per_gpu": b,
                 "num_classes": C, "input_res": 256, "output_res": 64, "refine_iters": cfg.TEST.DEPTH_REFINE_ITER if refine else 0,
                 "parallelism": f"roi-shard x{world}", "class_sliced_out_layer": not args.exact_reference_order, "hip_network_layers": not args.no_hip_layers,
                 "post_only": bool(args.post_only)},

@@ -306,3 +306,52 @@ def test_depth_refine_full_size_properties(hip):
     err0 = np.abs(maps["t_init"][:, 2] - det["t_gt"][:, 2])
     err1 = np.abs(t1[:, 2] - det["t_gt"][:, 2])
     assert np.median(err1) < 0.3 * np.median(err0)
+
+
+def test_decode_and_refine_sigmoid_mask_type(hip):
+    """MASK_LOSS_TYPE = BCE: get_out_mask is a sigmoid (engine_utils.py:326-328).  exp() differs in the last ulps
+    between libm and the device, so the mask is compared to 1e-6 and the selection on pixels away from the 0.5 tie."""
+    verts, faces, det, maps = make_case(b=6, seed=12, subdiv=3)
+    logits = ((maps["mask"] - maps["mask"].mean()) * 4).astype(np.float32)
+    cnt, sel, ip, mp, om = hip.decode_correspondences(
+        T(maps["coor_x"]), T(maps["coor_y"]), T(maps["coor_z"]), T(logits), T(maps["roi_coord_2d"]),
+        T(det["roi_extent"]), T(np.stack([det["im_W"], det["im_H"]], 1)), mask_type=1)
+    omask = P.get_out_mask(logits, "BCE")
+    np.testing.assert_allclose(om.cpu().numpy(), omask, atol=1e-6)
+    for i in range(6):
+        xyz = np.concatenate([maps["coor_x"][i], maps["coor_y"][i], maps["coor_z"][i]], 0).transpose(1, 2, 0)
+        _, _, osel = P.get_img_model_points_with_coords2d(omask[i, 0], xyz, maps["roi_coord_2d"][i].transpose(1, 2, 0),
+                                                          480, 640, det["roi_extent"][i])
+        mine = np.zeros(4096, bool)
+        mine[sel[i, :int(cnt[i])].cpu().numpy()] = True
+        safe = np.abs(logits[i, 0].reshape(-1)) > 1e-4
+        assert np.array_equal(mine[safe], osel.reshape(-1)[safe])
+    meshes = hip.MeshSet(verts, faces)
+    t = hip.depth_refine(meshes, T(det["roi_cls"].astype(np.int32)), T(maps["coor_x"]), T(maps["coor_y"]),
+                         T(maps["coor_z"]), T(logits), T(maps["roi_depth"]), T(maps["K_crop"]), T(det["R_gt"]),
+                         T(maps["t_init"]), mask_type=1).cpu().numpy()
+    for i in range(6):
+        o = int(det["roi_cls"][i])
+        xyz = np.concatenate([maps["coor_x"][i], maps["coor_y"][i], maps["coor_z"][i]], 0).transpose(1, 2, 0)
+        ot = P.depth_refine_roi(xyz, omask[i, 0], maps["roi_depth"][i, 0], maps["K_crop"][i], det["R_gt"][i],
+                                maps["t_init"][i], verts[o], faces[o])
+        np.testing.assert_allclose(t[i], ot, atol=1e-5)
+
+
+def test_fallback_refine_kernel_for_large_meshes(hip):
+    """Meshes above the LDS staging limit (4096 vertices) take the non-staged kernel: same results."""
+    b = 4
+    verts, faces, det, maps = make_case(b=b, seed=13, subdiv=5, num_classes=2)   # 10242 V / 20480 F
+    assert len(verts[0]) > 4096
+    meshes = hip.MeshSet(verts, faces)
+    t_out, dbg = hip.depth_refine(meshes, T(det["roi_cls"].astype(np.int32)), T(maps["coor_x"]), T(maps["coor_y"]),
+                                  T(maps["coor_z"]), T(maps["mask"]), T(maps["roi_depth"]), T(maps["K_crop"]),
+                                  T(det["R_gt"]), T(maps["t_init"]), debug=True)
+    omask = P.get_out_mask(maps["mask"])
+    for i in range(b):
+        o = int(det["roi_cls"][i])
+        xyz = np.concatenate([maps["coor_x"][i], maps["coor_y"][i], maps["coor_z"][i]], 0).transpose(1, 2, 0)
+        ot, rend = P.depth_refine_roi(xyz, omask[i, 0], maps["roi_depth"][i, 0], maps["K_crop"][i], det["R_gt"][i],
+                                      maps["t_init"][i], verts[o], faces[o], return_debug=True)
+        assert np.array_equal(dbg[i, 0].cpu().numpy().view(np.uint32), rend[0].view(np.uint32))
+        np.testing.assert_allclose(t_out[i].cpu().numpy(), ot, atol=1e-6, rtol=0)

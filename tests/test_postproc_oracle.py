@@ -111,3 +111,40 @@ def test_warp_affine_restatement_properties():
     assert set(np.unique(v[:, 40:, 40:])) == {200} and set(np.unique(v[:, :30, :30])) == {0}
     M = P.get_affine_transform((80.0, 60.0), 64.0, 64)
     np.testing.assert_allclose(M, [[1, 0, -48], [0, 1, -28]], atol=1e-12)
+
+
+def test_axangle2mat_restatement_against_scipy():
+    """transforms3d.axangles.axangle2mat is restated from its published algorithm; scipy's Rotation is an
+    independent implementation of the same map."""
+    from scipy.spatial.transform import Rotation
+
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        axis = rng.standard_normal(3)
+        ang = rng.uniform(0, np.pi)
+        ref = Rotation.from_rotvec(axis / np.linalg.norm(axis) * ang).as_matrix()
+        np.testing.assert_allclose(P.axangle2mat(axis, ang), ref, atol=1e-12)
+
+
+def test_upnp_oracle_against_scipy_least_squares():
+    """Independent check of the restated LM: MINPACK (scipy) minimises the same residuals to the same optimum."""
+    from scipy.optimize import least_squares
+
+    rng = np.random.default_rng(8)
+    K = np.array([572.4114, 0, 325.2611, 0, 573.57043, 242.04899, 0, 0, 1.0])
+    pn = 40
+    rt = np.array([0.5, -0.4, 0.3, 0.02, 0.01, 0.8])
+    p3 = rng.uniform(-0.08, 0.08, (pn, 3))
+    th = np.linalg.norm(rt[:3]); k = rt[:3] / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    X = p3 @ (np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx).T + rt[3:]
+    p2 = np.stack([K[0] * X[:, 0] / X[:, 2] + K[2], K[4] * X[:, 1] / X[:, 2] + K[5]], 1) + rng.normal(0, 0.7, (pn, 2))
+    w = np.stack([rng.uniform(0.5, 2, pn), rng.uniform(-0.3, 0.3, pn), rng.uniform(0.5, 2, pn)], 1)
+    init = rt + rng.uniform(-0.05, 0.05, 6)
+
+    def res(x):
+        return np.concatenate([P.upnp_residual(x, p2[i], p3[i], w[i], K)[0] for i in range(pn)])
+
+    sol = least_squares(res, init, method="lm", xtol=1e-14, ftol=1e-14, gtol=1e-14).x
+    out = P.uncertainty_pnp(p2, p3, w, K, init)
+    np.testing.assert_allclose(out, sol, atol=1e-4)
