@@ -106,3 +106,34 @@ def test_nnd_autograd_wrapper():
     torch.testing.assert_close(d2, r2, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(x1.grad, y1.grad, rtol=1e-4, atol=1e-7)
     torch.testing.assert_close(x2.grad, y2.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_egl_renderer_shim_pc_obj_and_pc_cam():
+    """EGLRenderer.render(obj_ids, poses, K, pc_obj_tensor=…, pc_cam_tensor=…) as engine_utils.py:131-172 calls it:
+    object-space xyz / camera-space xyz + depth, two objects composited by nearest depth."""
+    from gdrnpp_bop2022_amd import synthetic as S
+    from gdrnpp_bop2022_amd.lib.egl_renderer.egl_renderer_v3 import EGLRenderer
+
+    rng = np.random.default_rng(5)
+    verts, faces, ext = S.make_models(2, rng, subdiv=3)
+    ren = EGLRenderer(models=[{"pts": verts[i], "faces": faces[i]} for i in range(2)], height=64, width=64,
+                      znear=0.1, zfar=10.0)
+    K = np.array([[300.0, 0, 32], [0, 300.0, 32], [0, 0, 1]], np.float32)
+    poses = [np.hstack([S.random_rotation(rng), [[0.01], [0.0], [0.7]]]).astype(np.float32),
+             np.hstack([S.random_rotation(rng), [[-0.03], [0.02], [0.9]]]).astype(np.float32)]
+    pc_obj = torch.zeros(64, 64, 4, device=DEV)
+    pc_cam = torch.zeros(64, 64, 4, device=DEV)
+    ren.render([0, 1], poses, K=K, pc_obj_tensor=pc_obj, pc_cam_tensor=pc_cam)
+    d = [P.render_depth(verts[i], faces[i], K, poses[i][:, :3], poses[i][:, 3].astype(np.float64), 64, z_near=0.1,
+                        z_far=10.0, want_xyz=True) for i in range(2)]
+    d0 = np.where(d[0][0] > 0, d[0][0], np.inf); d1 = np.where(d[1][0] > 0, d[1][0], np.inf)
+    z = np.minimum(d0, d1); z = np.where(np.isfinite(z), z, 0).astype(np.float32)
+    assert np.array_equal(pc_cam[:, :, 2].cpu().numpy(), z)
+    xyz = np.where((d0 <= d1)[..., None], d[0][1], d[1][1]) * (z > 0)[..., None]
+    np.testing.assert_allclose(pc_obj[:, :, :3].cpu().numpy(), xyz, atol=1e-6)
+    assert np.array_equal(pc_obj[:, :, 3].cpu().numpy(), (z > 0).astype(np.float32))
+    # camera-space points back-project to the pixel centres
+    m = z > 0
+    u = pc_cam[:, :, 0].cpu().numpy()[m] / z[m] * 300 + 32
+    jj, ii = np.mgrid[0:64, 0:64]
+    np.testing.assert_allclose(u, ii[m] + 0.5, atol=1e-3)

@@ -148,3 +148,35 @@ def test_upnp_oracle_against_scipy_least_squares():
     sol = least_squares(res, init, method="lm", xtol=1e-14, ftol=1e-14, gtol=1e-14).x
     out = P.uncertainty_pnp(p2, p3, w, K, init)
     np.testing.assert_allclose(out, sol, atol=1e-4)
+
+
+def test_load_ply_ascii_and_binary(tmp_path):
+    from gdrnpp_bop2022_amd.lib.pysixd.inout import load_ply
+
+    v, f = S.icosphere(1)
+    v = (v * 37.5).astype(np.float32)
+    a = tmp_path / "a.ply"
+    with open(a, "w") as fh:
+        fh.write("ply\nformat ascii 1.0\ncomment test\nelement vertex %d\nproperty float x\nproperty float y\n"
+                 "property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nelement face %d\n"
+                 "property list uchar int vertex_indices\nend_header\n" % (len(v), len(f)))
+        for p in v:
+            fh.write("%r %r %r 10 20 30\n" % (float(p[0]), float(p[1]), float(p[2])))
+        for t in f:
+            fh.write("3 %d %d %d\n" % tuple(t))
+    b = tmp_path / "b.ply"
+    with open(b, "wb") as fh:
+        fh.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\n"
+                  "property float z\nelement face %d\nproperty list uchar uint vertex_index\nend_header\n"
+                  % (len(v), len(f) // 2 + 1)).encode())
+        fh.write(v.astype("<f4").tobytes())
+        quads = 0
+        for t in f[: len(f) // 2]:
+            fh.write(b"\x03" + np.asarray(t, "<u4").tobytes())
+        fh.write(b"\x04" + np.asarray([0, 1, 2, 3], "<u4").tobytes())  # one quad -> 2 triangles
+    ma = load_ply(str(a), vertex_scale=0.001)
+    mb = load_ply(str(b), vertex_scale=0.001)
+    np.testing.assert_allclose(ma["pts"], v.astype(np.float64) * 0.001, rtol=1e-7)
+    np.testing.assert_allclose(mb["pts"], v.astype(np.float64) * 0.001, rtol=1e-7)
+    assert np.array_equal(ma["faces"], f) and ma["colors"].shape == (len(v), 3)
+    assert len(mb["faces"]) == len(f) // 2 + 2 and np.array_equal(mb["faces"][-2:], [[0, 1, 2], [0, 2, 3]])
