@@ -159,3 +159,58 @@ class GraphedInference:
                 self.static[k].copy_(v, non_blocking=True)
         self.graph.replay()
         return self.records
+
+
+# --------------------------------------------------------------------------------------------------
+# ROI preparation on the device (rows a1 + a2): detections -> ROI tensors, no CPU crop, no H2D of crops
+# --------------------------------------------------------------------------------------------------
+def rois_from_detections(bboxes_xyxy, im_H: int, im_W: int, dzi_pad_scale: float = 1.5, out_res: int = 64):
+    """Per-detection ROI parameters exactly as read_data_test derives them (data_loader.py:754-769), float64 like
+    the reference's NumPy/Python scalars: centre, (bw, bh) clamped to >= 1, scale = min(max(bw,bh)*DZI_PAD_SCALE,
+    max(im_H, im_W)), resize_ratio = out_res / scale."""
+    import numpy as np
+
+    bb = np.asarray(bboxes_xyxy, np.float64).reshape(-1, 4)
+    x1, y1, x2, y2 = bb[:, 0], bb[:, 1], bb[:, 2], bb[:, 3]
+    center = np.stack([0.5 * (x1 + x2), 0.5 * (y1 + y2)], 1)
+    bw = np.maximum(x2 - x1, 1)
+    bh = np.maximum(y2 - y1, 1)
+    scale = np.minimum(np.maximum(bh, bw) * dzi_pad_scale, max(im_H, im_W)) * 1.0
+    return dict(bbox_center=center, scale=scale, roi_wh=np.stack([bw, bh], 1).astype(np.float32),
+                resize_ratio=(out_res / scale))
+
+
+def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, device=None) -> dict:
+    """``read_data_test`` + ``batch_data_test`` (data_loader.py:647-818, engine_utils.py:213-241) with the crops made
+    on the GPU.  images u8[n_im,H,W,3] (BGR, device), depths f32[n_im,H,W] or None, detections:
+    {"bbox": [n,4] xyxy, "im_idx": [n], "roi_cls": [n], "score": [n], "cam": [n,3,3] or [3,3], "extents": [C,3]}.
+    Returns the batch dict ``GDRN_Net.forward`` / ``GdrnHipPost`` consume (all tensors on the device)."""
+    import numpy as np
+
+    dev = device or images.device
+    net_cfg = cfg.MODEL.POSE_NET
+    n_im, H, W, _ = images.shape
+    r = rois_from_detections(detections["bbox"], H, W, cfg.INPUT.DZI_PAD_SCALE, net_cfg.OUTPUT_RES)
+    n = len(r["scale"])
+    cls = np.asarray(detections["roi_cls"], np.int64)
+    cam = np.asarray(detections["cam"], np.float32)
+    cam = np.repeat(cam[None], n, 0) if cam.ndim == 2 else cam
+
+    def T(a, dt=None):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return (t.to(dt) if dt is not None else t).to(dev)
+
+    centers64, scales64 = T(r["bbox_center"]), T(r["scale"])
+    roi_img, roi_depth, roi_c2d = hip_lib.crop_resize_roi(
+        images, depths, T(np.asarray(detections["im_idx"], np.int32)), centers64, scales64,
+        out_res=net_cfg.INPUT_RES, out_res_small=net_cfg.OUTPUT_RES, pixel_mean=cfg.MODEL.PIXEL_MEAN,
+        pixel_std=cfg.MODEL.PIXEL_STD)
+    batch = dict(
+        roi_img=roi_img, roi_coord_2d=roi_c2d, roi_cls=T(cls), roi_cam=T(cam), roi_center=T(r["bbox_center"], torch.float32),
+        roi_wh=T(r["roi_wh"]), scale=T(r["scale"], torch.float32), resize_ratio=T(r["resize_ratio"], torch.float32),
+        roi_extent=T(np.asarray(detections["extents"], np.float32)[cls]),
+        score=T(np.asarray(detections.get("score", np.ones(n)), np.float32)),
+        im_H=torch.full((n,), float(H), device=dev), im_W=torch.full((n,), float(W), device=dev))
+    if roi_depth is not None:
+        batch["roi_depth"] = roi_depth
+    return batch

@@ -112,3 +112,12 @@ def test_class_sliced_out_layer_equals_reference_graph():
     sd["geo_head_net.features.3.norm.weight"] = sd["geo_head_net.features.3.gn.weight"].clone()
     sd["geo_head_net.features.3.norm.bias"] = sd["geo_head_net.features.3.gn.bias"].clone()
     model.load_state_dict(sd, strict=True)
+
+
+def test_rois_from_detections_rules():
+    """data_loader.py:754-769: centre, clamped box size, padded + clipped scale, resize ratio."""
+    r = engine.rois_from_detections([[100, 50, 180, 250], [0, 0, 639.5, 479], [10, 10, 10.2, 10.4]], 480, 640)
+    np.testing.assert_allclose(r["bbox_center"], [[140, 150], [319.75, 239.5], [10.1, 10.2]])
+    np.testing.assert_allclose(r["scale"], [300.0, 640.0, 1.5])          # 200*1.5, clipped to max(H,W), bw/bh >= 1
+    np.testing.assert_allclose(r["roi_wh"], [[80, 200], [639.5, 479], [1, 1]])
+    np.testing.assert_allclose(r["resize_ratio"], 64 / r["scale"])
