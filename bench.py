@@ -242,7 +242,8 @@ def main():
             rec = st["post"].process(bt, out, roi_ids)
         return gather_records(rec, b)
 
-    for _ in range(max(args.warmup, 1) * len(streams) if len(streams) > 1 else args.warmup):
+    # at least one untimed step: MIOpen's find mode and hipFuncSetAttribute run on first use
+    for _ in range(max(args.warmup, 1) * len(streams)):
         step()
     step_counter[0] = 0
     torch.cuda.synchronize()
