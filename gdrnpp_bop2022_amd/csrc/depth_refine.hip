@@ -742,12 +742,9 @@ int gdrnpp_depth_refine(const gdrnpp_meshes* meshes, const int* obj, const float
   hipStream_t st = (hipStream_t)stream;
   if (meshes->max_verts > 0 && meshes->max_verts <= kMaxStagedVerts) {
     const int lds = 3 * (int)sizeof(double) * meshes->max_verts;
-    static int attr_lds = 0;
-    if (lds > attr_lds) {
-      GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)depth_refine_staged_kernel,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (int)sizeof(double) * kMaxStagedVerts));
-      attr_lds = 3 * (int)sizeof(double) * kMaxStagedVerts;
-    }
+    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)depth_refine_staged_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       3 * (int)sizeof(double) * kMaxStagedVerts));  // per device, so per call
     hipLaunchKernelGGL(depth_refine_staged_kernel, dim3(b), dim3(kTS), lds, st, meshes->verts, meshes->faces,
                        meshes->vert_off, meshes->face_off, obj, coor_x, coor_y, coor_z, mask_raw, roi_depth, K_crop, R,
                        t_in, t_out, debug_depth, res, iters, threshold, mask_type, use_coor_z, z_near, z_far);

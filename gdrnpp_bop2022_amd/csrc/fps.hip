@@ -303,13 +303,9 @@ int gdrnpp_fps(const float* pts, int* idxs, const int* start_idx, int b, int pn,
   GDRNPP_REQUIRE(mode == 0 || mode == 1, GDRNPP_EINVAL, "gdrnpp_fps: mode=%d", mode);
   hipStream_t st = (hipStream_t)stream;
   if (pn <= kLdsPts) {
-    static bool attr_set = false;
     const int lds_bytes = 3 * kLdsPts * (int)sizeof(float);
-    if (!attr_set) {
-      GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)fps_lds_kernel,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      attr_set = true;
-    }
+    // per call: the attribute is per device, and a process may drive several devices
+    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)fps_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipLaunchKernelGGL(fps_lds_kernel, dim3(b), dim3(kThreads), lds_bytes, st, pts, idxs, start_idx, pn, sn, mode);
   } else {
     GDRNPP_REQUIRE(workspace, GDRNPP_EINVAL, "gdrnpp_fps: pn=%d needs a workspace of %zu bytes", pn,

@@ -78,8 +78,9 @@ __device__ __forceinline__ double wave_sum(double x) {
 }
 
 // One pass over the correspondences: cost, g = J^T r, H = J^T J (full 6x6, symmetric)
-__device__ double evaluate(const double* x, const double* __restrict__ p2, const double* __restrict__ p3,
-                           const double* __restrict__ wg, double fx, double fy, double px, double py, int pn,
+template <typename T>
+__device__ double evaluate(const double* x, const T* __restrict__ p2, const T* __restrict__ p3,
+                           const T* __restrict__ wg, double fx, double fy, double px, double py, int pn,
                            double* H, double* g) {
   double R[9], dR[3][9];
   rotation_and_derivs(x, R, dR);
@@ -88,7 +89,7 @@ __device__ double evaluate(const double* x, const double* __restrict__ p2, const
   for (int i = 0; i < 28; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
   for (int i = lane; i < pn; i += 64) {
-    const double X = p3[3 * i], Y = p3[3 * i + 1], Z = p3[3 * i + 2];
+    const double X = (double)p3[3 * i], Y = (double)p3[3 * i + 1], Z = (double)p3[3 * i + 2];
     const double tx = R[0] * X + R[1] * Y + R[2] * Z + x[3];
     const double ty = R[3] * X + R[4] * Y + R[5] * Z + x[4];
     const double tz = R[6] * X + R[7] * Y + R[8] * Z + x[5];
@@ -104,8 +105,9 @@ __device__ double evaluate(const double* x, const double* __restrict__ p2, const
     dZ[3] = 0; dZ[4] = 0; dZ[5] = 1;
     const double inv = 1.0 / tz;
     const double qx = fx * tx * inv, qy = fy * ty * inv;  // jet division: f*h, (f' - f*h*g')*h
-    const double ex = (qx + px) - p2[2 * i], ey = (qy + py) - p2[2 * i + 1];
-    const double wxx = wg[3 * i], wxy = wg[3 * i + 1], wyy = wg[3 * i + 2];
+    const double ex = (qx + px) - (double)p2[2 * i], ey = (qy + py) - (double)p2[2 * i + 1];
+    // wg == nullptr: identity weights = plain reprojection error (cv2.solvePnP ITERATIVE's cost)
+    const double wxx = wg ? (double)wg[3 * i] : 1.0, wxy = wg ? (double)wg[3 * i + 1] : 0.0, wyy = wg ? (double)wg[3 * i + 2] : 1.0;
     const double r0 = wxx * ex + wxy * ey, r1 = wxy * ex + wyy * ey;
     double J0[6], J1[6];
 #pragma unroll
@@ -165,23 +167,17 @@ __device__ bool chol_solve6(const double* A, const double* b, double* y) {
   return true;
 }
 
-__global__ __launch_bounds__(64) void upnp_kernel(const double* __restrict__ pts2d, const double* __restrict__ pts3d,
-                                                  const double* __restrict__ wgt2d, const double* __restrict__ Kb,
-                                                  const double* __restrict__ init_rt, double* __restrict__ result_rt,
-                                                  int* __restrict__ info, int pn) {
-  const int bi = blockIdx.x;
-  const double* p2 = pts2d + (size_t)bi * pn * 2;
-  const double* p3 = pts3d + (size_t)bi * pn * 3;
-  const double* wg = wgt2d + (size_t)bi * pn * 3;
-  const double* K = Kb + 9 * (size_t)bi;
-  const double fx = K[0], fy = K[4], px = K[2], py = K[5];
-
+// Levenberg-Marquardt with Ceres' trust-region schedule (see oracle/upnp_oracle.c); x0 -> x, wave-uniform
+template <typename T>
+__device__ void lm_minimise(const double* x0, double* x, const T* __restrict__ p2, const T* __restrict__ p3,
+                            const T* __restrict__ wg, double fx, double fy, double px, double py, int pn, int& iter_out,
+                            int& term_out) {
   const int max_it = 50;
   const double min_rel_dec = 1e-3, ftol = 1e-6, gtol = 1e-10, ptol = 1e-8;
   const double min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
 
-  double x[6], H[36], g[6], scale[6], diag[6];
-  for (int k = 0; k < 6; ++k) { x[k] = init_rt[6 * (size_t)bi + k]; diag[k] = 0.0; }
+  double H[36], g[6], scale[6], diag[6];
+  for (int k = 0; k < 6; ++k) { x[k] = x0[k]; diag[k] = 0.0; }
   double radius = 1e4, decrease_factor = 2.0;
   int invalid = 0, iter = 0, term = 3;
   bool reuse_diag = false;
@@ -256,8 +252,87 @@ __global__ __launch_bounds__(64) void upnp_kernel(const double* __restrict__ pts
       reuse_diag = true;
     }
   }
+  iter_out = iter;
+  term_out = term;
+}
+
+__global__ __launch_bounds__(64) void upnp_kernel(const double* __restrict__ pts2d, const double* __restrict__ pts3d,
+                                                  const double* __restrict__ wgt2d, const double* __restrict__ Kb,
+                                                  const double* __restrict__ init_rt, double* __restrict__ result_rt,
+                                                  int* __restrict__ info, int pn) {
+  const int bi = blockIdx.x;
+  const double* p2 = pts2d + (size_t)bi * pn * 2;
+  const double* p3 = pts3d + (size_t)bi * pn * 3;
+  const double* wg = wgt2d + (size_t)bi * pn * 3;
+  const double* K = Kb + 9 * (size_t)bi;
+  double x0[6], x[6];
+  for (int k = 0; k < 6; ++k) x0[k] = init_rt[6 * (size_t)bi + k];
+  int iter, term;
+  lm_minimise<double>(x0, x, p2, p3, wg, K[0], K[4], K[2], K[5], pn, iter, term);
   if ((threadIdx.x & 63) == 0) {
     for (int k = 0; k < 6; ++k) result_rt[6 * (size_t)bi + k] = x[k];
+    if (info) { info[2 * bi] = iter; info[2 * bi + 1] = term; }
+  }
+}
+
+// ---- net-initialised iterative PnP on the decoded correspondences (gdrn_evaluator.py:241-371, pnp_type "iter") ----
+// cv2.Rodrigues restated (matrix -> rotation vector) in fp64
+__device__ void rodrigues_log(const double* R, double* r) {
+  double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+  const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+  double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+  c = c > 1. ? 1. : (c < -1. ? -1. : c);
+  const double theta = acos(c);
+  if (s < 1e-5) {
+    if (c > 0) { r[0] = r[1] = r[2] = 0.0; return; }
+    double t = (R[0] + 1) * 0.5;
+    rx = sqrt(fmax(t, 0.));
+    t = (R[4] + 1) * 0.5;
+    ry = sqrt(fmax(t, 0.)) * (R[1] < 0 ? -1. : 1.);
+    t = (R[8] + 1) * 0.5;
+    rz = sqrt(fmax(t, 0.)) * (R[2] < 0 ? -1. : 1.);
+    if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+    const double sc = theta / sqrt(rx * rx + ry * ry + rz * rz);
+    r[0] = rx * sc; r[1] = ry * sc; r[2] = rz * sc;
+    return;
+  }
+  const double vth = 1 / (2 * s) * theta;
+  r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
+}
+
+__global__ __launch_bounds__(64) void pnp_iter_kernel(const float* __restrict__ img_pts, const float* __restrict__ mdl_pts,
+                                                      const int* __restrict__ count, int stride,
+                                                      const float* __restrict__ Kb, const float* __restrict__ R_net,
+                                                      const float* __restrict__ t_net, float* __restrict__ R_out,
+                                                      float* __restrict__ t_out, int* __restrict__ info) {
+  const int bi = blockIdx.x;
+  const int pn = count[bi];
+  const float* p2 = img_pts + (size_t)bi * stride * 2;
+  const float* p3 = mdl_pts + (size_t)bi * stride * 3;
+  const float* K = Kb + 9 * (size_t)bi;
+  double Rn[9], x0[6], x[6];
+  for (int k = 0; k < 9; ++k) Rn[k] = (double)R_net[9 * (size_t)bi + k];
+  for (int k = 0; k < 3; ++k) x0[3 + k] = (double)t_net[3 * (size_t)bi + k];
+  rodrigues_log(Rn, x0);
+  int iter = 0, term = -1;
+  bool use_pnp = pn >= 4;  // fewer than 4 correspondences: keep the network pose (gdrn_evaluator.py:355-358)
+  if (use_pnp) lm_minimise<float>(x0, x, p2, p3, (const float*)nullptr, (double)K[0], (double)K[4], (double)K[2], (double)K[5], pn, iter, term);
+  if ((threadIdx.x & 63) == 0) {
+    float* Ro = R_out + 9 * (size_t)bi;
+    float* to = t_out + 3 * (size_t)bi;
+    if (!use_pnp) {
+      for (int k = 0; k < 9; ++k) Ro[k] = R_net[9 * (size_t)bi + k];
+      for (int k = 0; k < 3; ++k) to[k] = t_net[3 * (size_t)bi + k];
+    } else {
+      double R[9], dR[3][9];
+      rotation_and_derivs(x, R, dR);
+      for (int k = 0; k < 9; ++k) Ro[k] = (float)R[k];
+      // te(t_est, t_net) > 1 m -> fall back to the network translation (gdrn_evaluator.py:347-351)
+      const double dx = x[3] - x0[3], dy = x[4] - x0[4], dz = x[5] - x0[5];
+      const bool far = sqrt(dx * dx + dy * dy + dz * dz) > 1.0;
+      for (int k = 0; k < 3; ++k) to[k] = far ? t_net[3 * (size_t)bi + k] : (float)x[3 + k];
+      if (far) term = 100 + term;
+    }
     if (info) { info[2 * bi] = iter; info[2 * bi + 1] = term; }
   }
 }
@@ -275,6 +350,17 @@ int gdrnpp_uncertainty_pnp_batched(const double* pts2d, const double* pts3d, con
   hipLaunchKernelGGL(upnp_kernel, dim3(b), dim3(64), 0, (hipStream_t)stream, pts2d, pts3d, wgt2d, K, init_rt,
                      result_rt, info, pn);
   return gdrnpp::check_launch("gdrnpp_uncertainty_pnp_batched");
+}
+
+int gdrnpp_pnp_iter_from_correspondences(const float* img_pts, const float* mdl_pts, const int* count, int stride,
+                                         const float* K, const float* R_net, const float* t_net, float* R_out,
+                                         float* t_out, int* info, int b, void* stream) {
+  GDRNPP_REQUIRE(img_pts && mdl_pts && count && K && R_net && t_net && R_out && t_out, GDRNPP_EINVAL,
+                 "gdrnpp_pnp_iter_from_correspondences: null pointer");
+  GDRNPP_REQUIRE(b > 0 && stride > 0, GDRNPP_EINVAL, "gdrnpp_pnp_iter_from_correspondences: b=%d stride=%d", b, stride);
+  hipLaunchKernelGGL(pnp_iter_kernel, dim3(b), dim3(64), 0, (hipStream_t)stream, img_pts, mdl_pts, count, stride, K,
+                     R_net, t_net, R_out, t_out, info);
+  return gdrnpp::check_launch("gdrnpp_pnp_iter_from_correspondences");
 }
 
 void uncertainty_pnp(double* pts2d, double* pts3d, double* wgt2d, double* K, double* init_rt, double* result_rt,

@@ -70,8 +70,24 @@ class GdrnHipPost:
             out_dict["mask"].contiguous(), batch["roi_coord_2d"].contiguous(), batch["roi_extent"].contiguous(), imwh,
             mask_type=self.mask_type, mask_thr=self.cfg.MODEL.POSE_NET.GEO_HEAD.MASK_THR_TEST)
 
+    def process_net_and_pnp(self, batch: dict, out_dict: dict):
+        """``TEST.USE_PNP`` with ``PNP_TYPE="net_iter_pnp"`` (gdrn_evaluator.py:241-371, pnp_type="iter"): decode the
+        maps, compact the 2D-3D correspondences and run the net-initialised LM for every ROI on the device."""
+        b = out_dict["trans"].shape[0]
+        count, _, img_pts, mdl_pts, _ = self.process_correspondences(batch, out_dict)
+        return hip_lib.pnp_iter_from_correspondences(
+            img_pts, mdl_pts, count, batch["roi_cam"].reshape(b, 9).contiguous(),
+            out_dict["rot"].reshape(b, 9).contiguous(), out_dict["trans"].contiguous())
+
     def process(self, batch: dict, out_dict: dict, roi_ids: torch.Tensor | None = None) -> torch.Tensor:
         """-> pose records f32[b,16] = R(9) | t(3, metres) | score | obj | roi_id | valid."""
+        if self.cfg.TEST.USE_PNP:
+            if self.cfg.TEST.PNP_TYPE != "net_iter_pnp":
+                raise NotImplementedError(
+                    f"TEST.PNP_TYPE={self.cfg.TEST.PNP_TYPE}: the OpenCV RANSAC/EPnP variants stay host-side "
+                    "(DESIGN.md §7); use process_correspondences() to feed them")
+            R, t = self.process_net_and_pnp(batch, out_dict)
+            out_dict = dict(out_dict, rot=R, trans=t)
         t_ref = self.process_depth_refine(batch, out_dict) if self.cfg.TEST.USE_DEPTH_REFINE else None
         b = out_dict["trans"].shape[0]
         return hip_lib.pack_pose_records(

@@ -50,6 +50,7 @@ SIGNATURES = {
     "gdrnpp_voting_for_hypothesis_vanishing_point": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "gdrnpp_vote_count": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
     "gdrnpp_uncertainty_pnp_batched": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "gdrnpp_pnp_iter_from_correspondences": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "gdrnpp_decode_correspondences": (
         c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "gdrnpp_pose_from_pred_centroid_z": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
@@ -365,3 +366,16 @@ def roi_align(x, rois, output_size, spatial_scale: float = 1.0, sampling_ratio: 
                                    h, w, oh, ow, float(spatial_scale), int(sampling_ratio), 1 if aligned else 0,
                                    _stream()), "gdrnpp_roi_align")
     return out
+
+
+def pnp_iter_from_correspondences(img_pts, mdl_pts, count, K, R_net, t_net, return_info: bool = False):
+    """Net-initialised iterative PnP (gdrn_evaluator.py:241-371, pnp_type="iter") for all ROIs at once."""
+    b, stride, _ = img_pts.shape
+    R_out = torch.empty((b, 3, 3), dtype=torch.float32, device=img_pts.device)
+    t_out = torch.empty((b, 3), dtype=torch.float32, device=img_pts.device)
+    info = torch.zeros((b, 2), dtype=torch.int32, device=img_pts.device)
+    _check(load().gdrnpp_pnp_iter_from_correspondences(
+        _dev(img_pts, torch.float32, "img_pts"), _dev(mdl_pts, torch.float32, "mdl_pts"), _dev(count, torch.int32, "count"),
+        stride, _dev(K, torch.float32, "K"), _dev(R_net, torch.float32, "R_net"), _dev(t_net, torch.float32, "t_net"),
+        R_out.data_ptr(), t_out.data_ptr(), info.data_ptr(), b, _stream()), "gdrnpp_pnp_iter_from_correspondences")
+    return (R_out, t_out, info) if return_info else (R_out, t_out)

@@ -122,6 +122,20 @@ int gdrnpp_uncertainty_pnp_batched(const double* pts2d, const double* pts3d,
                                    const double* init_rt, double* result_rt,
                                    int* info, int b, int pn, void* stream);
 
+/* ---- net-initialised iterative PnP on the decoded correspondences (a7, "net_iter_pnp") ------------------------
+ * gdrn_evaluator.py:241-371 with pnp_type="iter": cv2.solvePnP(SOLVEPNP_ITERATIVE, useExtrinsicGuess=True) seeded
+ * with the network pose = Levenberg-Marquardt on the plain reprojection error.  OpenCV's own LM is third-party and
+ * not in the tree; the same restated LM as gdrnpp_uncertainty_pnp_batched is used with identity weights (both
+ * converge to the minimiser of the same cost).  img_pts f32[b,stride,2], mdl_pts f32[b,stride,3] and count i32[b]
+ * are the outputs of gdrnpp_decode_correspondences (stride = hw).  Reference fallbacks kept: count < 4 -> network
+ * pose (:355-358); |t_est - t_net| > 1 m -> network translation (:347-351, info status += 100).
+ * K f32[b,9], R_net f32[b,9], t_net f32[b,3] -> R_out f32[b,9], t_out f32[b,3], info i32[b,2] or NULL. */
+int gdrnpp_pnp_iter_from_correspondences(const float* img_pts, const float* mdl_pts,
+                                         const int* count, int stride, const float* K,
+                                         const float* R_net, const float* t_net,
+                                         float* R_out, float* t_out, int* info, int b,
+                                         void* stream);
+
 /* ---- map decoding + 2D-3D correspondences (a4 + a6) ----------------------
  * engine_utils.py:295-333 (regression xyz, mask_type: 0=L1 min-max, 1=sigmoid)
  * and gdrn_evaluator.py:115-153.  coor f32[b,3,64*64] (x,y,z planes, may be

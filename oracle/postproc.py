@@ -454,3 +454,54 @@ def roi_align(x, rois, output_size, spatial_scale=1.0, sampling_ratio=0, aligned
     _lib().oracle_roi_align(_p(x, _f32p), _p(rois, _f32p), _p(out, _f32p), rois.shape[0], c, h, w, oh, ow,
                             ctypes.c_float(spatial_scale), int(sampling_ratio), 1 if aligned else 0)
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# net-initialised iterative PnP (gdrn_evaluator.py:241-371, pnp_type="iter")
+# ------------------------------------------------------------------------------------------
+def rodrigues_log(R):
+    """cv2.Rodrigues(R)[0] restated (matrix -> rotation vector, OpenCV calib3d cvRodrigues2, without its SVD clean-up)."""
+    R = np.asarray(R, np.float64).reshape(9)
+    rx, ry, rz = R[7] - R[5], R[2] - R[6], R[3] - R[1]
+    s = np.sqrt((rx * rx + ry * ry + rz * rz) * 0.25)
+    c = min(max((R[0] + R[4] + R[8] - 1) * 0.5, -1.0), 1.0)
+    theta = np.arccos(c)
+    if s < 1e-5:
+        if c > 0:
+            return np.zeros(3)
+        rx = np.sqrt(max((R[0] + 1) * 0.5, 0.0))
+        ry = np.sqrt(max((R[4] + 1) * 0.5, 0.0)) * (-1.0 if R[1] < 0 else 1.0)
+        rz = np.sqrt(max((R[8] + 1) * 0.5, 0.0)) * (-1.0 if R[2] < 0 else 1.0)
+        if abs(rx) < abs(ry) and abs(rx) < abs(rz) and (R[5] > 0) != (ry * rz > 0):
+            rz = -rz
+        return np.array([rx, ry, rz]) * (theta / np.sqrt(rx * rx + ry * ry + rz * rz))
+    return np.array([rx, ry, rz]) * (theta / (2 * s))
+
+
+def rodrigues_exp(r):
+    """cv2.Rodrigues(rvec)[0] (rotation vector -> matrix)."""
+    r = np.asarray(r, np.float64)
+    th = np.linalg.norm(r)
+    if th * th <= np.finfo(np.float64).eps:
+        K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+        return np.eye(3) + K
+    k = r / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * K
+
+
+def net_iter_pnp(img_points, model_points, K, rot_est_net, trans_est_net):
+    """process_net_and_pnp, pnp_type="iter" for ONE ROI (gdrn_evaluator.py:311-358): LM on the reprojection error
+    seeded with the network pose (cv2.solvePnP ITERATIVE restated by the same LM as the uncertainty-PnP oracle with
+    identity weights), |dt| > 1 m -> network translation, < 4 points -> network pose.  -> (R f32[3,3], t f32[3])."""
+    n = len(img_points)
+    if n < 4:
+        return np.asarray(rot_est_net, np.float32), np.asarray(trans_est_net, np.float32)
+    init = np.concatenate([rodrigues_log(rot_est_net), np.asarray(trans_est_net, np.float64)])
+    w = np.tile([1.0, 0.0, 1.0], (n, 1))
+    rt = uncertainty_pnp(np.asarray(img_points, np.float64), np.asarray(model_points, np.float64), w,
+                         np.asarray(K, np.float64), init)
+    t = rt[3:]
+    if np.linalg.norm(t - np.asarray(trans_est_net, np.float64)) > 1:
+        t = np.asarray(trans_est_net, np.float64)
+    return rodrigues_exp(rt[:3]).astype(np.float32), t.astype(np.float32)
