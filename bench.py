@@ -63,6 +63,7 @@ def parse():
     p.add_argument("--exact-reference-order", action="store_true",
                    help="run the reference's full 1470-channel output layer + gather instead of the class-sliced one")
     p.add_argument("--no-hip-layers", action="store_true", help="A/B: run the memory-bound network layers with PyTorch ops")
+    p.add_argument("--no-fused-mlp", action="store_true", help="A/B: hipBLASLt GEMMs + separate GELU / addcmul")
     p.add_argument("--post-only", action="store_true", help="time only the post-processing (maps from a fixed forward)")
     return p.parse_args()
 
@@ -136,6 +137,7 @@ def main():
     b = args.batch or (128 if refine else 64)
     torch.backends.cudnn.benchmark = True  # MIOpen find mode during warm-up
     hip_layers.set_enabled(not args.no_hip_layers)
+    hip_layers.set_fused_mlp(not args.no_fused_mlp)
 
     streams = []  # one (cfg, model, post, batch, det, K_crop, meshes, verts, faces) per dataset of the stream
     for di, ds in enumerate(datasets):
@@ -289,6 +291,41 @@ def main():
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic, launch_ms=mean_ms, bytes_per_launch=bytes_launch,
                         bytes_per_roi=per_roi, rois_per_launch=b)
 
+    # secondary hand-written kernels at the same batch, timed live with HIP events after the timed region
+    def ev_time(fn, n=10):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+
+    others = []
+    if rank == 0 and refine and not args.post_only:
+        out = forward_only()
+        maps = [out[k].contiguous() for k in ("coor_x", "coor_y", "coor_z", "mask")]
+        imwh = torch.stack([batch["im_W"], batch["im_H"]], 1).contiguous()
+        t = ev_time(lambda: hip_lib.decode_correspondences(maps[0], maps[1], maps[2], maps[3], batch["roi_coord_2d"],
+                                                           batch["roi_extent"], imwh))
+        nsel = int(hip_lib.decode_correspondences(maps[0], maps[1], maps[2], maps[3], batch["roi_coord_2d"],
+                                                  batch["roi_extent"], imwh)[0].sum())
+        by = b * (98304 + 48 + 16384 + 4) + nsel * 24
+        others.append(dict(kernel="decode_corr_kernel", bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                           frac=by / t / 1e9 / HBM_PEAK_GBS, launch_ms=t * 1e3, bytes_per_launch=by))
+        imgs = torch.randint(0, 256, (16, S.IM_H, S.IM_W, 3), dtype=torch.uint8, device=dev)
+        deps = torch.rand((16, S.IM_H, S.IM_W), device=dev)
+        imi = torch.from_numpy(np.random.default_rng(1).integers(0, 16, b).astype(np.int32)).to(dev)
+        c64 = torch.from_numpy(det["roi_center"].astype(np.float64)).to(dev)
+        s64 = torch.from_numpy(det["scale"].astype(np.float64)).to(dev)
+        t = ev_time(lambda: hip_lib.crop_resize_roi(imgs, deps, imi, c64, s64))
+        by = b * (3 * 256 * 256 * 4 + 256 * 256 * 4 + 2 * 64 * 64 * 4) + int(sum(7 * float(v) ** 2 for v in det["scale"]))
+        others.append(dict(kernel="crop_img_depth_kernel+crop_coord2d_kernel", bound="hbm", achieved=by / t / 1e9,
+                           peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS, launch_ms=t * 1e3,
+                           bytes_per_launch=by))
+
     if rank == 0:
         cpu = None
         if refine and not args.no_cpu_baseline:
@@ -313,9 +350,9 @@ def main():
                 "baseline_config_index": 4 if args.workload == "bop7" else (2 if refine else 1),
                 "roi_prep_on_gpu": bool(args.with_crop), "hipgraph": bool(args.graph), "streams": args.streams, "global_batch": world * b, "rois_per_gpu": b,
                 "num_classes": C, "input_res": 256, "output_res": 64, "refine_iters": cfg.TEST.DEPTH_REFINE_ITER if refine else 0,
-                "parallelism": f"roi-shard x{world}", "class_sliced_out_layer": not args.exact_reference_order, "hip_network_layers": not args.no_hip_layers,
+                "parallelism": f"roi-shard x{world}", "class_sliced_out_layer": not args.exact_reference_order, "hip_network_layers": not args.no_hip_layers, "fused_mlp_gemm": not args.no_fused_mlp,
                 "post_only": bool(args.post_only)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_other_kernels": others, "cpu_baseline": cpu,
             "stages_ms": {"forward": fwd_ms, "depth_refine": roofline["launch_ms"] if roofline else None},
         }
         print(json.dumps(line))

@@ -57,9 +57,8 @@ class ConvNeXtBlock(nn.Module):
     def forward(self, x):
         shortcut = x
         x = hip_layers.dwconv_ln(self.conv_dw, self.norm, x, self._cache)  # NHWC view, LayerNorm applied
-        x = self.mlp(x)
-        # layer scale + residual in one pass: shortcut + gamma * x  (timm: x.mul(gamma) then drop_path(x) + shortcut)
-        x = torch.addcmul(shortcut.permute(0, 2, 3, 1), x, self.gamma)
+        # Mlp + layer scale + residual: shortcut + gamma * fc2(gelu(fc1(x)))  (timm: x.mul(gamma); drop_path(x) + shortcut)
+        x = hip_layers.convnext_mlp(self.mlp, self.gamma, x, shortcut.permute(0, 2, 3, 1))
         return x.permute(0, 3, 1, 2)
 
 

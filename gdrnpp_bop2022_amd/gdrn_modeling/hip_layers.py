@@ -60,3 +60,29 @@ def dwconv_ln(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor, cache: dict) -
         return y.permute(0, 2, 3, 1)
     y = conv(x).permute(0, 2, 3, 1)
     return F.layer_norm(y, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+
+
+_FUSED_MLP = True
+_FUSED_MLP_MAX_C = 256
+
+
+def set_fused_mlp(flag: bool) -> None:
+    global _FUSED_MLP
+    _FUSED_MLP = bool(flag)
+
+
+def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: torch.Tensor) -> torch.Tensor:
+    """timm ConvNeXtBlock tail on NHWC tensors: shortcut + gamma * fc2(gelu(fc1(x))).  On the GPU both Linear layers
+    run in ``gdrnpp_linear_f32`` with the exact-erf GELU and the layer-scale/residual fused into the epilogues
+    (two HBM passes over the hidden tensor saved); otherwise plain PyTorch."""
+    c = x_nhwc.shape[-1]
+    m = x_nhwc.numel() // c
+    # measured on MI355X (tools/microbench_gemm.py, 128 ROIs): the fused kernel wins where the epilogue passes are
+    # large relative to the GEMM (C <= 256: 1.41 vs 1.67 ms at C=128, 1.21 vs 1.25 ms at C=256) and loses ~2-5 %
+    # to hipBLASLt's 256x256 macro-tile at C >= 512, so the wide stages keep hipBLASLt + separate GELU / addcmul.
+    if (_FUSED_MLP and enabled_for(x_nhwc) and x_nhwc.is_contiguous() and shortcut_nhwc.is_contiguous()
+            and m % 128 == 0 and c % 128 == 0 and c <= _FUSED_MLP_MAX_C):
+        h = hip_lib.linear_f32(x_nhwc.view(m, c), mlp.fc1.weight, mlp.fc1.bias, "gelu")
+        y = hip_lib.linear_f32(h, mlp.fc2.weight, mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
+        return y.view(x_nhwc.shape)
+    return torch.addcmul(shortcut_nhwc, mlp(x_nhwc), gamma)

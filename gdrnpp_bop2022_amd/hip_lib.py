@@ -15,7 +15,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libgdrnpp_hip.so")
+LIB_PATH = os.environ.get("GDRNPP_HIP_LIB", os.path.join(_PKG_DIR, "libgdrnpp_hip.so"))
 
 _lib = None
 
@@ -61,6 +61,7 @@ SIGNATURES = {
         c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
                 c_int, c_int, c_float, c_float, _P]),
     "gdrnpp_debug_refine_profile": (c_int, [_P]),
+    "gdrnpp_linear_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_roi_align": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     "gdrnpp_debug_stream_read": (c_int, [_P, c_size_t, c_int, _P, c_int, _P]),
     "gdrnpp_crop_resize_roi": (
@@ -379,3 +380,18 @@ def pnp_iter_from_correspondences(img_pts, mdl_pts, count, K, R_net, t_net, retu
         stride, _dev(K, torch.float32, "K"), _dev(R_net, torch.float32, "R_net"), _dev(t_net, torch.float32, "t_net"),
         R_out.data_ptr(), t_out.data_ptr(), info.data_ptr(), b, _stream()), "gdrnpp_pnp_iter_from_correspondences")
     return (R_out, t_out, info) if return_info else (R_out, t_out)
+
+
+def linear_f32(x2d, weight, bias, epilogue: str = "none", gamma=None, resid=None):
+    """x2d f32[M,K] (contiguous rows), weight f32[N,K] -> f32[M,N] with the fused epilogue
+    ("none" | "gelu" | "scale_res": resid + gamma * (x W^T + b))."""
+    m, k = x2d.shape
+    n = weight.shape[0]
+    out = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
+    _check(load().gdrnpp_linear_f32(
+        _dev(x2d, torch.float32, "x"), _dev(weight, torch.float32, "weight"),
+        _dev(bias, torch.float32, "bias") if bias is not None else None,
+        _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
+        _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
+        {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream()), "gdrnpp_linear_f32")
+    return out

@@ -261,6 +261,14 @@ int gdrnpp_roi_align(const float* x, const float* rois, float* out, int n_rois, 
                      int H, int W, int pooled_h, int pooled_w, float spatial_scale,
                      int sampling_ratio, int aligned, void* stream);
 
+/* ---- fp32 linear layer with fused epilogue (ConvNeXt Mlp of GDRN_Net, a3) --------------------------------------
+ * C[M,N] = A[M,K] * W[N,K]^T + bias[N]; epilogue 0 = none, 1 = exact-erf GELU (timm Mlp.fc1 + act),
+ * 2 = resid[M,N] + gamma[N] * C (Mlp.fc2 + layer scale + residual).  fp32 MFMA (exact fp32 fma chain).
+ * M, N multiples of 128, K multiple of 32. */
+int gdrnpp_linear_f32(const float* A, const float* W, const float* bias, const float* gamma,
+                      const float* resid, float* C, int M, int N, int K, int epilogue,
+                      void* stream);
+
 /* ---- pose record packing for the RCCL all-gather (a13) -------------------
  * rec f32[b,16] = R(9) | t(3) | score | obj_id | roi_id | valid(1) */
 int gdrnpp_pack_pose_records(const float* R, const double* t_refined,

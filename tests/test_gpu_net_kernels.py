@@ -93,3 +93,21 @@ def test_model_forward_hip_layers_vs_torch_ops(hip):
         assert (o1[k] - o2[k]).abs().max().item() <= 1e-4 * max(scale, 1.0), k
     torch.testing.assert_close(o1["rot"], o2["rot"], rtol=0, atol=1e-4)
     torch.testing.assert_close(o1["trans"], o2["trans"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("m,k,n", [(128 * 64, 128, 512), (128 * 16, 512, 128), (256, 1024, 4096), (128, 32, 128)])
+def test_linear_f32_fused_epilogues(hip, m, k, n):
+    """fp32 MFMA GEMM with fused epilogues vs F.linear (+ exact GELU / layer-scale + residual): 2e-6 relative to the
+    output scale (both are fp32 fma chains over K, in different orders)."""
+    torch.manual_seed(m + k)
+    x = torch.randn(m, k, device=DEV)
+    w = torch.randn(n, k, device=DEV) * (k ** -0.5)
+    b = torch.randn(n, device=DEV)
+    gamma = torch.randn(n, device=DEV)
+    res = torch.randn(m, n, device=DEV)
+    ref = F.linear(x, w, b)
+    for epi, want in (("none", ref), ("gelu", F.gelu(ref)), ("scale_res", torch.addcmul(res, ref, gamma))):
+        out = hip.linear_f32(x, w, b, epi, gamma if epi == "scale_res" else None, res if epi == "scale_res" else None)
+        assert ((out - want).abs().max() / want.abs().max()).item() < 2e-6, epi
+    with pytest.raises(RuntimeError, match="multiples"):
+        hip.linear_f32(torch.randn(100, k, device=DEV), w, b)
