@@ -58,7 +58,7 @@ class ConvNeXtBlock(nn.Module):
         shortcut = x
         x = hip_layers.dwconv_ln(self.conv_dw, self.norm, x, self._cache)  # NHWC view, LayerNorm applied
         # Mlp + layer scale + residual: shortcut + gamma * fc2(gelu(fc1(x)))  (timm: x.mul(gamma); drop_path(x) + shortcut)
-        x = hip_layers.convnext_mlp(self.mlp, self.gamma, x, shortcut.permute(0, 2, 3, 1))
+        x = hip_layers.convnext_mlp(self.mlp, self.gamma, x, shortcut.permute(0, 2, 3, 1), self._cache)
         return x.permute(0, 3, 1, 2)
 
 

@@ -62,26 +62,53 @@ def dwconv_ln(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor, cache: dict) -
     return F.layer_norm(y, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
 
 
-_FUSED_MLP = True
-_FUSED_MLP_MAX_C = 256
+# GEMM engine of the ConvNeXt MLP:
+#   "split" (default) gdrnpp_linear_f32_split: bf16 matrix cores, exact 3-way operand split, six partial products,
+#                     fp32 accumulate — error vs fp64 at or below the fp32 fma chain, ~1.4x the fp32-MFMA rate;
+#   "f32"             fp32 MFMA: gdrnpp_linear_f32 (fused epilogues) for C <= 256, hipBLASLt + GELU/addcmul above
+#                     (the fused fp32 kernel wins only where the epilogue passes dominate: 1.41 vs 1.67 ms at C=128,
+#                     1.21 vs 1.25 ms at C=256, and loses 2-5 % to hipBLASLt's 256x256 macro-tile at C >= 512);
+#   "torch"           hipBLASLt + separate elementwise kernels everywhere.
+_MLP_GEMM = "split"
+_F32_FUSED_MAX_C = 256
+
+
+def set_mlp_gemm(mode: str) -> None:
+    global _MLP_GEMM
+    if mode not in ("split", "f32", "torch"):
+        raise ValueError(f"unknown MLP GEMM mode {mode!r}")
+    _MLP_GEMM = mode
 
 
 def set_fused_mlp(flag: bool) -> None:
-    global _FUSED_MLP
-    _FUSED_MLP = bool(flag)
+    """Backward-compatible switch: False = hipBLASLt + separate elementwise kernels."""
+    set_mlp_gemm("split" if flag else "torch")
 
 
-def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: torch.Tensor) -> torch.Tensor:
+def _packed(linear: nn.Linear, cache: dict, key: str) -> torch.Tensor:
+    w = linear.weight
+    tag = (w.data_ptr(), w._version, w.device)
+    hit = cache.get(key)
+    if hit is None or hit[0] != tag:
+        hit = (tag, hip_lib.pack_weight_bf16x3(w.detach()))
+        cache[key] = hit
+    return hit[1]
+
+
+def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: torch.Tensor, cache: dict) -> torch.Tensor:
     """timm ConvNeXtBlock tail on NHWC tensors: shortcut + gamma * fc2(gelu(fc1(x))).  On the GPU both Linear layers
-    run in ``gdrnpp_linear_f32`` with the exact-erf GELU and the layer-scale/residual fused into the epilogues
+    run in the library's own GEMM with the exact-erf GELU and the layer-scale/residual fused into the epilogues
     (two HBM passes over the hidden tensor saved); otherwise plain PyTorch."""
     c = x_nhwc.shape[-1]
     m = x_nhwc.numel() // c
-    # measured on MI355X (tools/microbench_gemm.py, 128 ROIs): the fused kernel wins where the epilogue passes are
-    # large relative to the GEMM (C <= 256: 1.41 vs 1.67 ms at C=128, 1.21 vs 1.25 ms at C=256) and loses ~2-5 %
-    # to hipBLASLt's 256x256 macro-tile at C >= 512, so the wide stages keep hipBLASLt + separate GELU / addcmul.
-    if (_FUSED_MLP and enabled_for(x_nhwc) and x_nhwc.is_contiguous() and shortcut_nhwc.is_contiguous()
-            and m % 128 == 0 and c % 128 == 0 and c <= _FUSED_MLP_MAX_C):
+    ok = (_MLP_GEMM != "torch" and enabled_for(x_nhwc) and x_nhwc.is_contiguous() and shortcut_nhwc.is_contiguous()
+          and m % 128 == 0 and c % 128 == 0)
+    if ok and _MLP_GEMM == "split":
+        h = hip_lib.linear_f32_split(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk"), mlp.fc1.bias, "gelu")
+        y = hip_lib.linear_f32_split(h, _packed(mlp.fc2, cache, "fc2_pk"), mlp.fc2.bias, "scale_res", gamma,
+                                     shortcut_nhwc.view(m, c))
+        return y.view(x_nhwc.shape)
+    if ok and c <= _F32_FUSED_MAX_C:
         h = hip_lib.linear_f32(x_nhwc.view(m, c), mlp.fc1.weight, mlp.fc1.bias, "gelu")
         y = hip_lib.linear_f32(h, mlp.fc2.weight, mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
         return y.view(x_nhwc.shape)

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 import torch
 
@@ -62,6 +62,8 @@ SIGNATURES = {
                 c_int, c_int, c_float, c_float, _P]),
     "gdrnpp_debug_refine_profile": (c_int, [_P]),
     "gdrnpp_linear_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_pack_weight_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
+    "gdrnpp_linear_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_roi_align": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     "gdrnpp_debug_stream_read": (c_int, [_P, c_size_t, c_int, _P, c_int, _P]),
     "gdrnpp_crop_resize_roi": (
@@ -380,6 +382,40 @@ def pnp_iter_from_correspondences(img_pts, mdl_pts, count, K, R_net, t_net, retu
         stride, _dev(K, torch.float32, "K"), _dev(R_net, torch.float32, "R_net"), _dev(t_net, torch.float32, "t_net"),
         R_out.data_ptr(), t_out.data_ptr(), info.data_ptr(), b, _stream()), "gdrnpp_pnp_iter_from_correspondences")
     return (R_out, t_out, info) if return_info else (R_out, t_out)
+
+
+def pack_weight_bf16x3(weight):
+    """nn.Linear weight f32[N,K] -> bf16[N/128, K/32, 3, 4, 128, 8]: exact 3-way bf16 split (w == h + m + l) of every
+    128x32 tile, laid out as gdrnpp_linear_f32_split stages it (split, k-block, row, 8 k)."""
+    n, k = weight.shape
+    packed = torch.empty((n // 128, k // 32, 3, 4, 128, 8), dtype=torch.bfloat16, device=weight.device)
+    _check(load().gdrnpp_pack_weight_bf16x3(_dev(weight, torch.float32, "weight"), packed.data_ptr(), n, k, _stream()),
+           "gdrnpp_pack_weight_bf16x3")
+    return packed
+
+
+def unpack_weight_bf16x3(packed):
+    """Inverse view of pack_weight_bf16x3 for tests: bf16[3, N, K] planes."""
+    tn, tk = packed.shape[:2]
+    return packed.permute(2, 0, 4, 1, 3, 5).reshape(3, tn * 128, tk * 32)
+
+
+def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None):
+    """Same contract as linear_f32 with the weight given as pack_weight_bf16x3(weight); runs on the bf16 matrix cores
+    with six partial products per fp32 product (fp32-accurate, see csrc/gemm_split.hip)."""
+    m, k = x2d.shape
+    if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or not weight_packed.is_contiguous() \
+            or weight_packed.shape[1] * 32 != k:
+        raise ValueError("weight_packed must be the contiguous bf16 tensor from pack_weight_bf16x3 with matching K")
+    n = weight_packed.shape[0] * 128
+    out = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
+    _check(load().gdrnpp_linear_f32_split(
+        _dev(x2d, torch.float32, "x"), weight_packed.data_ptr(),
+        _dev(bias, torch.float32, "bias") if bias is not None else None,
+        _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
+        _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
+        {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream()), "gdrnpp_linear_f32_split")
+    return out
 
 
 def linear_f32(x2d, weight, bias, epilogue: str = "none", gamma=None, resid=None):

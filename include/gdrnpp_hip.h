@@ -269,6 +269,19 @@ int gdrnpp_linear_f32(const float* A, const float* W, const float* bias, const f
                       const float* resid, float* C, int M, int N, int K, int epilogue,
                       void* stream);
 
+/* ---- fp32-accurate linear layer on the bf16 matrix cores (a3) -------------------------------------------------
+ * Same contract as gdrnpp_linear_f32.  Every fp32 operand is split EXACTLY into three bf16 values (x = h + m + l);
+ * six of the nine partial products (all terms above 2^-26 relative) are accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16.  Error against an fp64 product is below that of the fp32 fma chain.
+ * gdrnpp_pack_weight_bf16x3: W f32[N][K] (nn.Linear weight) -> bf16[N/128][K/32][3][4][128][8]: the three splits
+ * (h | m | l) of every 128x32 tile in the order the kernel stages them (split, k-block of 8, row); 6*N*K bytes,
+ * done once per weight.  gdrnpp_linear_f32_split: A stays fp32 and is split on the way into LDS.
+ * M, N multiples of 128, K multiple of 32. */
+int gdrnpp_pack_weight_bf16x3(const float* W, void* packed, int N, int K, void* stream);
+int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* bias, const float* gamma,
+                            const float* resid, float* C, int M, int N, int K, int epilogue,
+                            void* stream);
+
 /* ---- pose record packing for the RCCL all-gather (a13) -------------------
  * rec f32[b,16] = R(9) | t(3) | score | obj_id | roi_id | valid(1) */
 int gdrnpp_pack_pose_records(const float* R, const double* t_refined,

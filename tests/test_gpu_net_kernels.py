@@ -60,8 +60,10 @@ def test_groupnorm_act(hip, n, c, g, h, w, gelu):
     torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
 
 
-def test_model_forward_hip_layers_vs_torch_ops(hip):
-    """Whole GDRN_Net forward with the HIP layers on vs off (same weights): maps within 1e-4, pose within 1e-4."""
+@pytest.mark.parametrize("mlp_gemm", ["split", "f32"])
+def test_model_forward_hip_layers_vs_torch_ops(hip, mlp_gemm):
+    """Whole GDRN_Net forward with the HIP layers on vs off (same weights): maps within 1e-4, pose within 1e-4.
+    Both MLP GEMM engines (bf16x6 split on the bf16 matrix cores, fp32 MFMA) against hipBLASLt + PyTorch ops."""
     from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
     from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
     from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
@@ -84,7 +86,11 @@ def test_model_forward_hip_layers_vs_torch_ops(hip):
                 roi_coord_2d=torch.rand(b, 2, 64, 64, device=DEV), roi_extents=torch.full((b, 3), 0.1, device=DEV))
     with torch.no_grad():
         hip_layers.set_enabled(True)
-        o1 = model(x, **args)
+        hip_layers.set_mlp_gemm(mlp_gemm)
+        try:
+            o1 = model(x, **args)
+        finally:
+            hip_layers.set_mlp_gemm("split")
         hip_layers.set_enabled(False)
         o2 = model(x, **args)
         hip_layers.set_enabled(True)
@@ -111,3 +117,42 @@ def test_linear_f32_fused_epilogues(hip, m, k, n):
         assert ((out - want).abs().max() / want.abs().max()).item() < 2e-6, epi
     with pytest.raises(RuntimeError, match="multiples"):
         hip.linear_f32(torch.randn(100, k, device=DEV), w, b)
+
+
+def test_pack_weight_bf16x3_is_exact(hip):
+    """w == h + m + l exactly for every element (incl. tiny / huge magnitudes), and the tile layout round-trips."""
+    torch.manual_seed(3)
+    w = torch.randn(256, 96, device=DEV) * torch.logspace(-20, 20, 96, device=DEV)
+    w[0, :4] = torch.tensor([0.0, -0.0, 1.0, -1.5], device=DEV)
+    planes = hip.unpack_weight_bf16x3(hip.pack_weight_bf16x3(w)).float()
+    assert torch.equal((planes[0] + planes[1]) + planes[2], w)
+    assert (planes[1].abs() <= planes[0].abs() * 2.0 ** -8 + 1e-45).all()
+    assert (planes[2].abs() <= planes[0].abs() * 2.0 ** -16 + 1e-45).all()
+
+
+@pytest.mark.parametrize("m,k,n", [(128 * 64, 128, 512), (128 * 16, 512, 128), (256, 2048, 512), (128, 32, 128), (128 * 9, 64, 384)])
+def test_linear_f32_split_is_fp32_accurate(hip, m, k, n):
+    """bf16x6 split GEMM vs an fp64 product: its error must not exceed that of an fp32 GEMM — the k-ordered fp32 fma
+    chain of gdrnpp_linear_f32 or hipBLASLt, whichever accumulates worse at this shape (hipBLASLt splits K at small
+    M) — by more than rounding noise, for all three epilogues; and it agrees with fp32 to 4e-6 of the output scale."""
+    torch.manual_seed(m + k + n)
+    x = torch.randn(m, k, device=DEV)
+    w = torch.randn(n, k, device=DEV) * (k ** -0.5)
+    b = torch.randn(n, device=DEV)
+    gamma = torch.randn(n, device=DEV)
+    res = torch.randn(m, n, device=DEV)
+    pk = hip.pack_weight_bf16x3(w)
+    ref64 = x.double() @ w.double().t() + b.double()
+    ref32 = F.linear(x, w, b)
+    cases = (("none", ref64, ref32), ("gelu", F.gelu(ref64), F.gelu(ref32)),
+             ("scale_res", res.double() + gamma.double() * ref64, torch.addcmul(res, ref32, gamma)))
+    for epi, want64, got32 in cases:
+        out = hip.linear_f32_split(x, pk, b, epi, gamma if epi == "scale_res" else None, res if epi == "scale_res" else None)
+        scale = want64.abs().max().item()
+        e_split = (out.double() - want64).abs().max().item() / scale
+        chain = hip.linear_f32(x, w, b, epi, gamma if epi == "scale_res" else None, res if epi == "scale_res" else None)
+        e_f32 = max((got32.double() - want64).abs().max().item(), (chain.double() - want64).abs().max().item()) / scale
+        assert e_split <= 1.25 * e_f32 + 1.2e-7, (epi, e_split, e_f32)
+        assert ((out - got32).abs().max() / scale).item() < 4e-6, epi
+    with pytest.raises(RuntimeError, match="multiples"):
+        hip.linear_f32_split(torch.randn(100, k, device=DEV), pk, b)

@@ -23,7 +23,7 @@ def t(fn, n=20, warm=3):
     return e0.elapsed_time(e1) / n
 
 
-tot_t, tot_h = 0.0, 0.0
+tot_t, tot_h, tot_s = 0.0, 0.0, 0.0
 for (hw, c, nblk) in [(4096, 128, 3), (1024, 256, 3), (256, 512, 27), (64, 1024, 3)]:
     M = B * hw
     x = torch.randn(M, c, device=dev)
@@ -39,7 +39,20 @@ for (hw, c, nblk) in [(4096, 128, 3), (1024, 256, 3), (256, 512, 27), (64, 1024,
     tt1 = t(lambda: F.gelu(F.linear(x, w1, b1))); th1 = t(lambda: hip_lib.linear_f32(x, w1, b1, "gelu"))
     tt2 = t(lambda: torch.addcmul(sc, F.linear(ref1, w2, b2), gamma)); th2 = t(lambda: hip_lib.linear_f32(ref1, w2, b2, "scale_res", gamma, sc))
     fl = 2.0 * M * c * 4 * c
+    p1, p2 = hip_lib.pack_weight_bf16x3(w1), hip_lib.pack_weight_bf16x3(w2)
+    assert torch.equal(hip_lib.unpack_weight_bf16x3(p1).float().sum(0), w1), "split is not exact"
+    s1 = hip_lib.linear_f32_split(x, p1, b1, "gelu")
+    s2 = hip_lib.linear_f32_split(ref1, p2, b2, "scale_res", gamma, sc)
+    sub = slice(0, 2048)
+    r1 = F.gelu(x[sub].double() @ w1.double().t() + b1.double())
+    r2 = sc[sub].double() + gamma.double() * (ref1[sub].double() @ w2.double().t() + b2.double())
+    d = lambda y, r: ((y[sub].double() - r).abs().max() / r.abs().max()).item()
+    print(f"   vs fp64: fc1 torch {d(ref1, r1):.1e} hip-f32 {d(out1, r1):.1e} split {d(s1, r1):.1e} | "
+          f"fc2 torch {d(ref2, r2):.1e} hip-f32 {d(out2, r2):.1e} split {d(s2, r2):.1e}")
+    ts1 = t(lambda: hip_lib.linear_f32_split(x, p1, b1, "gelu")); ts2 = t(lambda: hip_lib.linear_f32_split(ref1, p2, b2, "scale_res", gamma, sc))
+    print(f"   split: fc1 {ts1:.3f} ms ({fl / ts1 / 1e9:.0f} TF eff) fc2 {ts2:.3f} ms ({fl / ts2 / 1e9:.0f} TF eff)")
+    tot_s += nblk * (ts1 + ts2)
     print(f"hw={hw} C={c}: fc1+gelu torch {tt1:.3f} ms / hip {th1:.3f} ms ({fl / th1 / 1e9:.0f} TF) err {e1:.1e} | "
           f"fc2+scale+res torch {tt2:.3f} / hip {th2:.3f} ms ({fl / th2 / 1e9:.0f} TF) err {e2:.1e}")
     tot_t += nblk * (tt1 + tt2); tot_h += nblk * (th1 + th2)
-print(f"MLP total per forward: torch {tot_t:.2f} ms, hip {tot_h:.2f} ms")
+print(f"MLP total per forward: torch {tot_t:.2f} ms, hip-f32 {tot_h:.2f} ms, hip-split {tot_s:.2f} ms")
