@@ -64,6 +64,7 @@ def parse():
                    help="run the reference's full 1470-channel output layer + gather instead of the class-sliced one")
     p.add_argument("--no-hip-layers", action="store_true", help="A/B: run the memory-bound network layers with PyTorch ops")
     p.add_argument("--no-fused-mlp", action="store_true", help="A/B: hipBLASLt GEMMs + separate GELU / addcmul")
+    p.add_argument("--no-conv-split", action="store_true", help="A/B: 3x3 head convolutions in MIOpen (fp32 MFMA)")
     p.add_argument("--mlp-gemm", choices=["split", "f32", "torch"], default="split",
                    help="ConvNeXt MLP GEMM engine: split = exact 3-way bf16 split on the bf16 matrix cores (six partial "
                         "products, fp32 accumulate, fp32-accurate); f32 = fp32 MFMA; torch = hipBLASLt + elementwise")
@@ -141,6 +142,7 @@ def main():
     torch.backends.cudnn.benchmark = True  # MIOpen find mode during warm-up
     hip_layers.set_enabled(not args.no_hip_layers)
     hip_layers.set_mlp_gemm("torch" if args.no_fused_mlp else args.mlp_gemm)
+    hip_layers.set_conv_split(not args.no_conv_split)
 
     streams = []  # one (cfg, model, post, batch, det, K_crop, meshes, verts, faces) per dataset of the stream
     for di, ds in enumerate(datasets):
@@ -353,7 +355,7 @@ def main():
                 "baseline_config_index": 4 if args.workload == "bop7" else (2 if refine else 1),
                 "roi_prep_on_gpu": bool(args.with_crop), "hipgraph": bool(args.graph), "streams": args.streams, "global_batch": world * b, "rois_per_gpu": b,
                 "num_classes": C, "input_res": 256, "output_res": 64, "refine_iters": cfg.TEST.DEPTH_REFINE_ITER if refine else 0,
-                "parallelism": f"roi-shard x{world}", "class_sliced_out_layer": not args.exact_reference_order, "hip_network_layers": not args.no_hip_layers, "mlp_gemm": "torch" if args.no_fused_mlp else args.mlp_gemm,
+                "parallelism": f"roi-shard x{world}", "class_sliced_out_layer": not args.exact_reference_order, "hip_network_layers": not args.no_hip_layers, "mlp_gemm": "torch" if args.no_fused_mlp else args.mlp_gemm, "conv3x3_split": not args.no_conv_split and not args.no_fused_mlp and args.mlp_gemm == "split",
                 "post_only": bool(args.post_only)},
             "roofline": roofline, "roofline_other_kernels": others, "cpu_baseline": cpu,
             "stages_ms": {"forward": fwd_ms, "depth_refine": roofline["launch_ms"] if roofline else None},

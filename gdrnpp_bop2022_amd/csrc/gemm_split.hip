@@ -11,17 +11,19 @@
 // fp32-MFMA fmaf chain (max error 1.4e-7 vs 6.1e-7 at K=128), because the individual products carry no rounding.
 // Six bf16 MFMAs replace sixteen fp32-MFMA-equivalents of matrix-pipe time: a 2.67x higher roofline (417 TFLOP/s).
 //
-// Data flow per 128x128x32 block tile (256 threads = 4 waves, each a 64x64 sub-tile = 2x2 MFMA 32x32x16 tiles):
-//   A  fp32 [M,K] in HBM -> registers (4 x float4 per thread; 8 lanes cover one 128-byte row segment, so a wave
-//      instruction touches 8 full cache lines) -> split in registers with v_cvt_pk_bf16_f32 -> three bf16 planes in
-//      LDS (ds_write_b64, conflict-free);
-//   W  split AND tiled once per weight (gdrnpp_pack_weight_bf16x3) into the exact LDS image of every 128x32 tile,
-//      [N/128][K/32][split][k-block][row][8] bf16, so the B stage is six lane-linear 16-byte loads and stores;
+// Data flow per 128x128x16 block tile (256 threads = 4 waves, each a 64x64 sub-tile = 2x2 MFMA 32x32x16 tiles):
+//   A  fp32 [M,K] in HBM -> registers (2 x float4 per thread; 4 lanes cover one 64-byte row segment) -> split in
+//      registers with v_cvt_pk_bf16_f32 -> three bf16 planes in LDS (ds_write_b64);
+//   W  split AND tiled once per weight (gdrnpp_pack_weight_bf16x3) into the exact LDS image of every 128x16 tile,
+//      [N/128][K/16][split][k-block][row][8] bf16, so the B stage is three lane-linear 16-byte loads and stores;
+//   pipeline: two LDS stages and two register stages.  While the matrix pipe works on tile t (24 MFMAs = 768 cycles
+//      per wave), the same wave splits tile t+1 (in registers since the previous iteration) into the other LDS stage
+//      in the shadow of its own MFMAs, and the loads of tile t+2 are in flight; one barrier per k-tile;
 //   workgroup -> tile map is XCD-aware: each XCD walks a contiguous range of tiles (n fastest), so the n-tiles that
 //      share A rows hit the same L2;
 //   LDS image per operand: [split][k-block of 8][row] 16-byte slots, plane pitch 132 slots: the 32 lanes of a
 //      ds_read_b128 lane group read 32 consecutive slots (conflict-free), a fragment is one ds_read_b128;
-//   per k-step of 16: 12 fragment reads feed 24 MFMAs (768 matrix-pipe cycles).
+//   per k-tile: 12 fragment reads (ds_read_b128) feed 24 MFMAs.
 #include "common.hpp"
 
 namespace {
@@ -31,14 +33,12 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
-#ifndef SPLIT_NBUF
-#define SPLIT_NBUF 1
-#endif
 #ifndef SPLIT_OCC
 #define SPLIT_OCC 2
 #endif
-constexpr int BM = 128, BN = 128, BK = 32, KB = BK / 8, PLANE = BM + 4, NBUF = SPLIT_NBUF;
+constexpr int BM = 128, BN = 128, BK = 16, KB = BK / 8, PLANE = BM + 4;
 constexpr int OPER_SLOTS = 3 * KB * PLANE;  // uint4 slots per operand image
+constexpr int W_TILE_SLOTS = 3 * KB * BN;   // uint4 slots of one packed 128x16 weight tile
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_SCALE_RES = 2 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
@@ -56,7 +56,7 @@ __device__ __forceinline__ Split3 split_pair(float x0, float x1) {
   return o;
 }
 
-// W f32[N][K] -> packed bf16 [N/128][K/32][3][4][128][8]; one thread per (row, k-block) = 8 consecutive k
+// W f32[N][K] -> packed bf16 [N/128][K/16][3][2][128][8]; one thread per (row, k-block) = 8 consecutive k
 __global__ void pack_weight_kernel(const float* __restrict__ W, uint4* __restrict__ packed, int N, int K) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int kbs = K / 8;
@@ -66,19 +66,24 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, uint4* __restric
   const float4 v1 = *reinterpret_cast<const float4*>(W + (size_t)n * K + kb_g * 8 + 4);
   const Split3 p0 = split_pair(v0.x, v0.y), p1 = split_pair(v0.z, v0.w), p2 = split_pair(v1.x, v1.y), p3 = split_pair(v1.z, v1.w);
   const int tn = n / BN, row = n % BN, tk = kb_g / KB, kb = kb_g % KB;
-  uint4* img = packed + ((size_t)tn * (K / BK) + tk) * (3 * KB * BN);
+  uint4* img = packed + ((size_t)tn * (K / BK) + tk) * W_TILE_SLOTS;
   img[(0 * KB + kb) * BN + row] = make_uint4(p0.h, p1.h, p2.h, p3.h);
   img[(1 * KB + kb) * BN + row] = make_uint4(p0.m, p1.m, p2.m, p3.m);
   img[(2 * KB + kb) * BN + row] = make_uint4(p0.l, p1.l, p2.l, p3.l);
 }
 
-template <int EPI>
+// CONV: A is an NHWC image [.,H,W,Cin] and the GEMM row m = output pixel, k = (tap, channel) of a 3x3 / stride 1 /
+// zero-pad 1 convolution (implicit im2col: the k-tile's 16 channels of one tap are 64 contiguous bytes per pixel).
+struct ConvGeom { int H, W, C; };
+
+template <int EPI, bool CONV>
 __global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float* __restrict__ A,
                                                                     const uint4* __restrict__ Wp,
                                                                     const float* __restrict__ bias,
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ resid,
-                                                                    float* __restrict__ C, int M, int N, int K) {
+                                                                    float* __restrict__ C, int M, int N, int K,
+                                                                    ConvGeom cg) {
   extern __shared__ uint4 lds4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -91,33 +96,60 @@ __global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float*
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int nk = K / BK;
 
-  // A staging: pass p covers rows p*32 + tid/8, lane%8 picks 4 consecutive k (half a k-block)
-  const int lrow = tid >> 3, lkq = tid & 7;
-  const float* Ag = A + (size_t)(m0 + lrow) * K + lkq * 4;
-  const uint4* Wg = Wp + (size_t)tile_n * nk * (3 * KB * BN) + tid;
-  float4 ra[4];
-  uint4 rb0, rb1, rb2, rb3, rb4, rb5;  // scalars: an indexed array lands in scratch
+  // A staging: rows tid/4 and 64 + tid/4, lane%4 picks 4 consecutive k (half a k-block)
+  const int lrow = tid >> 2, lkq = tid & 3;
+  const float* Ag = CONV ? A + (size_t)(m0 + lrow) * cg.C + lkq * 4 : A + (size_t)(m0 + lrow) * K + lkq * 4;
+  const uint4* Wg = Wp + (size_t)tile_n * nk * W_TILE_SLOTS + tid;
+  int py0 = 0, px0 = 0, py1 = 0, px1 = 0, cpt = 1;  // CONV: (y, x) of this thread's two pixels, k-tiles per tap
+  if (CONV) {
+    const int p0 = (m0 + lrow) % (cg.H * cg.W), p1 = (m0 + lrow + 64) % (cg.H * cg.W);
+    py0 = p0 / cg.W; px0 = p0 % cg.W; py1 = p1 / cg.W; px1 = p1 % cg.W;
+    cpt = cg.C / BK;
+  }
+  struct Stage { float4 a0, a1; uint4 b0, b1, b2; };
   auto gload = [&](int kt) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const float4*>(Ag + (size_t)(p * 32) * K + kt * BK);
-    const uint4* w = Wg + (size_t)kt * (3 * KB * BN);
-    rb0 = w[0]; rb1 = w[256]; rb2 = w[512]; rb3 = w[768]; rb4 = w[1024]; rb5 = w[1280];
+    Stage r;
+    if (CONV) {
+      // the loads are unconditional (address clamped to the centre pixel, value zeroed afterwards): a predicated load
+      // would make the outstanding-load count unknown to the compiler and collapse the software pipeline
+      const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const bool ok0 = (unsigned)(py0 + dy) < (unsigned)cg.H && (unsigned)(px0 + dx) < (unsigned)cg.W;
+      const bool ok1 = (unsigned)(py1 + dy) < (unsigned)cg.H && (unsigned)(px1 + dx) < (unsigned)cg.W;
+      const int off = (dy * cg.W + dx) * cg.C;
+      const float4 v0 = *reinterpret_cast<const float4*>(Ag + (ok0 ? off : 0) + c0);
+      const float4 v1 = *reinterpret_cast<const float4*>(Ag + (size_t)64 * cg.C + (ok1 ? off : 0) + c0);
+      r.a0 = ok0 ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
+      r.a1 = ok1 ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      r.a0 = *reinterpret_cast<const float4*>(Ag + kt * BK);
+      r.a1 = *reinterpret_cast<const float4*>(Ag + (size_t)64 * K + kt * BK);
+    }
+    const uint4* w = Wg + (size_t)kt * W_TILE_SLOTS;
+    r.b0 = w[0]; r.b1 = w[256]; r.b2 = w[512];
+    return r;
   };
-  auto lstore = [&](int buf) {
+  const int skb = lkq >> 1, shalf = lkq & 1;
+  auto lstore = [&](const Stage r, int buf) {
     uint4* a = lds4 + buf * 2 * OPER_SLOTS;
     uint4* b = a + OPER_SLOTS;
-    const int kb = lkq >> 1, half = lkq & 1;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const Split3 p0 = split_pair(ra[p].x, ra[p].y), p1 = split_pair(ra[p].z, ra[p].w);
-      uint2* dst = reinterpret_cast<uint2*>(a + kb * PLANE + p * 32 + lrow) + half;
+    {
+      const Split3 p0 = split_pair(r.a0.x, r.a0.y), p1 = split_pair(r.a0.z, r.a0.w);
+      uint2* dst = reinterpret_cast<uint2*>(a + skb * PLANE + lrow) + shalf;
+      dst[0] = make_uint2(p0.h, p1.h);
+      dst[2 * KB * PLANE] = make_uint2(p0.m, p1.m);
+      dst[4 * KB * PLANE] = make_uint2(p0.l, p1.l);
+    }
+    {
+      const Split3 p0 = split_pair(r.a1.x, r.a1.y), p1 = split_pair(r.a1.z, r.a1.w);
+      uint2* dst = reinterpret_cast<uint2*>(a + skb * PLANE + 64 + lrow) + shalf;
       dst[0] = make_uint2(p0.h, p1.h);
       dst[2 * KB * PLANE] = make_uint2(p0.m, p1.m);
       dst[4 * KB * PLANE] = make_uint2(p0.l, p1.l);
     }
     // image slot i*256 + tid = plane (i*2 + tid/128), row tid%128
     uint4* bd = b + (tid >> 7) * PLANE + (tid & 127);
-    bd[0] = rb0; bd[2 * PLANE] = rb1; bd[4 * PLANE] = rb2; bd[6 * PLANE] = rb3; bd[8 * PLANE] = rb4; bd[10 * PLANE] = rb5;
+    bd[0] = r.b0; bd[2 * PLANE] = r.b1; bd[4 * PLANE] = r.b2;
   };
 
   f32x16 acc[2][2];
@@ -128,47 +160,51 @@ __global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float*
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gload(0);
-  lstore(0);
-  __syncthreads();
   const int frow = lane & 31, fk = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = (NBUF == 2) ? (kt & 1) : 0;
-    if (kt + 1 < nk) gload(kt + 1);
-    const uint4* a = lds4 + buf * 2 * OPER_SLOTS + wm * 64 + frow;
-    const uint4* b = lds4 + buf * 2 * OPER_SLOTS + OPER_SLOTS + wn * 64 + frow;
+  // one k-tile: 12 fragment reads, 24 MFMAs; `mid` runs after the first 8 MFMAs are queued (the split + LDS stores of
+  // the next tile, hidden behind the matrix pipe)
+  auto compute = [&](int buf, auto&& mid) {
+    const uint4* a = lds4 + buf * 2 * OPER_SLOTS + fk * PLANE + wm * 64 + frow;
+    const uint4* b = lds4 + buf * 2 * OPER_SLOTS + OPER_SLOTS + fk * PLANE + wn * 64 + frow;
+    bf16x8 fa[3][2], fb[3][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kb = ks * 2 + fk;
-      bf16x8 fa[3][2], fb[3][2];
+    for (int s = 0; s < 3; ++s)
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          fa[s][i] = __builtin_bit_cast(bf16x8, a[(s * KB + kb) * PLANE + i * 32]);
-          fb[s][i] = __builtin_bit_cast(bf16x8, b[(s * KB + kb) * PLANE + i * 32]);
-        }
-      // smallest partial products first; the four accumulators rotate so no MFMA waits on its predecessor
-      constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
-      constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][0], fb[TB[t]][0], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][0], fb[TB[t]][1], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][1], fb[TB[t]][0], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][1], fb[TB[t]][1], acc[1][1], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) {
+        fa[s][i] = __builtin_bit_cast(bf16x8, a[s * KB * PLANE + i * 32]);
+        fb[s][i] = __builtin_bit_cast(bf16x8, b[s * KB * PLANE + i * 32]);
       }
-      if (NBUF == 2 && ks == 0 && kt + 1 < nk) lstore(buf ^ 1);
+    // smallest partial products first; the four accumulators rotate so no MFMA waits on its predecessor
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][0], fb[TB[t]][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][0], fb[TB[t]][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][1], fb[TB[t]][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][1], fb[TB[t]][1], acc[1][1], 0, 0, 0);
+      if (t == 1) mid();
     }
-    if (kt + 1 < nk) {
-      __syncthreads();
-      if (NBUF == 1) { lstore(0); __syncthreads(); }
-    }
+  };
+
+  // nk is even (K % 32 == 0): the loop is unrolled by two so the register stages r0 / r1 stay in fixed registers.
+  // Loads and stores are UNCONDITIONAL (the tile index is clamped, the tail re-stages the last tile into the idle
+  // buffer): a conditional load would force the compiler to drain vmcnt to 0 in the middle of every iteration.
+  Stage r0 = gload(0);
+  lstore(r0, 0);
+  Stage r1 = gload(1);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    r0 = gload(min(kt + 2, nk - 1));
+    compute(0, [&] { lstore(r1, 1); });
+    __syncthreads();
+    r1 = gload(min(kt + 3, nk - 1));
+    compute(1, [&] { lstore(r0, 0); });
+    __syncthreads();
   }
 
   // epilogue: lane holds column (lane & 31) of rows (r&3) + 8*(r>>2) + 4*(lane>>5).  Each wave parks one 32x64 half
-  // of its tile in LDS (the operand images are dead) and writes it back row-wise as float4.
-  __syncthreads();
+  // of its tile in LDS (the operand images are dead: the loop ends on a barrier) and writes it back row-wise as float4.
   float* T = reinterpret_cast<float*>(lds4) + wave * 32 * 65;  // [32][65] per wave
   const int c4 = (lane & 15) * 4;
   const int nb = n0 + wn * 64 + c4;
@@ -204,38 +240,59 @@ __global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float*
 
 extern "C" int gdrnpp_pack_weight_bf16x3(const float* W, void* packed, int N, int K, void* stream) {
   GDRNPP_REQUIRE(W && packed, GDRNPP_EINVAL, "gdrnpp_pack_weight_bf16x3: null pointer");
-  GDRNPP_REQUIRE(N > 0 && K > 0 && N % BN == 0 && K % BK == 0, GDRNPP_ELIMIT,
-                 "gdrnpp_pack_weight_bf16x3: N=%d K=%d must be multiples of %d/%d", N, K, BN, BK);
+  GDRNPP_REQUIRE(N > 0 && K > 0 && N % BN == 0 && K % 32 == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_pack_weight_bf16x3: N=%d K=%d must be multiples of %d/32", N, K, BN);
   const long threads = (long)N * (K / 8);
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
                      (uint4*)packed, N, K);
   return gdrnpp::check_launch("gdrnpp_pack_weight_bf16x3");
 }
 
+namespace {
+
+template <bool CONV>
+int launch_split(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
+                 int M, int N, int K, int epilogue, ConvGeom cg, hipStream_t st, const char* what) {
+  const long blocks = (long)(M / BM) * (N / BN);
+  GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "%s: grid too large", what);
+  int lds = 2 * 2 * OPER_SLOTS * (int)sizeof(uint4);
+  if (lds < 4 * 32 * 65 * (int)sizeof(float)) lds = 4 * 32 * 65 * (int)sizeof(float);
+  if (epilogue == EPI_BIAS) {
+    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI_BIAS, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((gemm_split_kernel<EPI_BIAS, CONV>), dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+  } else if (epilogue == EPI_GELU) {
+    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI_GELU, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((gemm_split_kernel<EPI_GELU, CONV>), dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+  } else {
+    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI_SCALE_RES, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((gemm_split_kernel<EPI_SCALE_RES, CONV>), dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+  }
+  return gdrnpp::check_launch(what);
+}
+
+}  // namespace
+
 extern "C" int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* bias, const float* gamma,
                                        const float* resid, float* C, int M, int N, int K, int epilogue,
                                        void* stream) {
   GDRNPP_REQUIRE(A && W_packed && C, GDRNPP_EINVAL, "gdrnpp_linear_f32_split: null pointer");
-  GDRNPP_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK == 0, GDRNPP_ELIMIT,
-                 "gdrnpp_linear_f32_split: M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, BM, BN, BK);
+  GDRNPP_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % 32 == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_linear_f32_split: M=%d N=%d K=%d must be multiples of %d/%d/32", M, N, K, BM, BN);
   GDRNPP_REQUIRE(epilogue >= 0 && epilogue <= 2, GDRNPP_EINVAL, "gdrnpp_linear_f32_split: epilogue=%d", epilogue);
   GDRNPP_REQUIRE(epilogue != EPI_SCALE_RES || (gamma && resid), GDRNPP_EINVAL,
                  "gdrnpp_linear_f32_split: scale+residual epilogue needs gamma and resid");
-  const long blocks = (long)(M / BM) * (N / BN);
-  GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "gdrnpp_linear_f32_split: grid too large");
-  int lds = NBUF * 2 * OPER_SLOTS * (int)sizeof(uint4);
-  if (lds < 4 * 32 * 65 * (int)sizeof(float)) lds = 4 * 32 * 65 * (int)sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
-  const uint4* Wp = (const uint4*)W_packed;
-  if (epilogue == EPI_BIAS) {
-    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(gemm_split_kernel<EPI_BIAS>, dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K);
-  } else if (epilogue == EPI_GELU) {
-    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(gemm_split_kernel<EPI_GELU>, dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K);
-  } else {
-    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI_SCALE_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(gemm_split_kernel<EPI_SCALE_RES>, dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K);
-  }
-  return gdrnpp::check_launch("gdrnpp_linear_f32_split");
+  return launch_split<false>(A, (const uint4*)W_packed, bias, gamma, resid, C, M, N, K, epilogue, ConvGeom{0, 0, 0},
+                             (hipStream_t)stream, "gdrnpp_linear_f32_split");
+}
+
+extern "C" int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
+                                        int n_img, int H, int W, int Cin, int Cout, int epilogue, void* stream) {
+  GDRNPP_REQUIRE(x_nhwc && W_packed && y_nhwc, GDRNPP_EINVAL, "gdrnpp_conv3x3_f32_split: null pointer");
+  GDRNPP_REQUIRE(n_img > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GDRNPP_EINVAL, "gdrnpp_conv3x3_f32_split: bad shape");
+  const long M = (long)n_img * H * W;
+  GDRNPP_REQUIRE(M % BM == 0 && M < (1l << 31) && Cout % BN == 0 && Cin % 32 == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_conv3x3_f32_split: pixels=%ld Cout=%d Cin=%d must be multiples of %d/%d/32", M, Cout, Cin, BM, BN);
+  GDRNPP_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_GELU, GDRNPP_EINVAL, "gdrnpp_conv3x3_f32_split: epilogue=%d", epilogue);
+  return launch_split<true>(x_nhwc, (const uint4*)W_packed, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, epilogue,
+                            ConvGeom{H, W, Cin}, (hipStream_t)stream, "gdrnpp_conv3x3_f32_split");
 }

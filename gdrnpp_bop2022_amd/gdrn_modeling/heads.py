@@ -58,7 +58,7 @@ class ConvModule(nn.Module):
         nn.init.kaiming_normal_(self.conv.weight, a=0, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x):
-        x = self.conv(x)
+        x = hip_layers.conv2d(self.conv, x)
         if self.norm_name == "gn":
             return hip_layers.groupnorm_act(getattr(self, "gn"), self.activate, x)  # fused GN(+GELU) on the GPU
         if self.norm_name is not None:
@@ -94,6 +94,8 @@ def run_features(features, x):
             x = hip_layers.groupnorm_act(layer, None, x)
         elif isinstance(layer, nn.UpsamplingBilinear2d) and layer.scale_factor in (2, 2.0):
             x = hip_layers.upsample2x(layer, x)
+        elif isinstance(layer, nn.Conv2d):
+            x = hip_layers.conv2d(layer, x)
         else:
             x = layer(x)
         i += 1

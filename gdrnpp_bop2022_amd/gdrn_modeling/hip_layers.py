@@ -113,3 +113,30 @@ def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: 
         y = hip_lib.linear_f32(h, mlp.fc2.weight, mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
         return y.view(x_nhwc.shape)
     return torch.addcmul(shortcut_nhwc, mlp(x_nhwc), gamma)
+
+
+_CONV_SPLIT = True
+
+
+def set_conv_split(flag: bool) -> None:
+    """3x3 convolutions of the geometry head: True = implicit-GEMM split kernel, False = MIOpen."""
+    global _CONV_SPLIT
+    _CONV_SPLIT = bool(flag)
+
+
+def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d forward; 3x3 / stride 1 / pad 1 / dense convolutions with 128-aligned shapes run as an implicit GEMM
+    in ``gdrnpp_conv3x3_f32_split`` (bf16 matrix cores, fp32-accurate), everything else in MIOpen."""
+    if (_CONV_SPLIT and _MLP_GEMM == "split" and isinstance(conv, nn.Conv2d) and enabled_for(x)
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0
+            and conv.out_channels % 128 == 0 and (x.shape[0] * x.shape[2] * x.shape[3]) % 128 == 0):
+        cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
+        w = conv.weight
+        tag = (w.data_ptr(), w._version, w.device)
+        hit = cache.get("w_pk")
+        if hit is None or hit[0] != tag:
+            hit = (tag, hip_lib.pack_conv3x3_weight_bf16x3(w.detach()))
+            cache["w_pk"] = hit
+        return hip_lib.conv3x3_f32_split(_cl(x), hit[1], conv.bias)
+    return conv(x)

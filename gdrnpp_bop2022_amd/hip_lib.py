@@ -64,6 +64,7 @@ SIGNATURES = {
     "gdrnpp_linear_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_pack_weight_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_conv3x3_f32_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_roi_align": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     "gdrnpp_debug_stream_read": (c_int, [_P, c_size_t, c_int, _P, c_int, _P]),
     "gdrnpp_crop_resize_roi": (
@@ -385,10 +386,10 @@ def pnp_iter_from_correspondences(img_pts, mdl_pts, count, K, R_net, t_net, retu
 
 
 def pack_weight_bf16x3(weight):
-    """nn.Linear weight f32[N,K] -> bf16[N/128, K/32, 3, 4, 128, 8]: exact 3-way bf16 split (w == h + m + l) of every
-    128x32 tile, laid out as gdrnpp_linear_f32_split stages it (split, k-block, row, 8 k)."""
+    """nn.Linear weight f32[N,K] -> bf16[N/128, K/16, 3, 2, 128, 8]: exact 3-way bf16 split (w == h + m + l) of every
+    128x16 tile, laid out as gdrnpp_linear_f32_split stages it (split, k-block, row, 8 k)."""
     n, k = weight.shape
-    packed = torch.empty((n // 128, k // 32, 3, 4, 128, 8), dtype=torch.bfloat16, device=weight.device)
+    packed = torch.empty((n // 128, k // 16, 3, 2, 128, 8), dtype=torch.bfloat16, device=weight.device)
     _check(load().gdrnpp_pack_weight_bf16x3(_dev(weight, torch.float32, "weight"), packed.data_ptr(), n, k, _stream()),
            "gdrnpp_pack_weight_bf16x3")
     return packed
@@ -397,7 +398,7 @@ def pack_weight_bf16x3(weight):
 def unpack_weight_bf16x3(packed):
     """Inverse view of pack_weight_bf16x3 for tests: bf16[3, N, K] planes."""
     tn, tk = packed.shape[:2]
-    return packed.permute(2, 0, 4, 1, 3, 5).reshape(3, tn * 128, tk * 32)
+    return packed.permute(2, 0, 4, 1, 3, 5).reshape(3, tn * 128, tk * 16)
 
 
 def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None):
@@ -405,7 +406,7 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
     with six partial products per fp32 product (fp32-accurate, see csrc/gemm_split.hip)."""
     m, k = x2d.shape
     if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or not weight_packed.is_contiguous() \
-            or weight_packed.shape[1] * 32 != k:
+            or weight_packed.shape[1] * 16 != k:
         raise ValueError("weight_packed must be the contiguous bf16 tensor from pack_weight_bf16x3 with matching K")
     n = weight_packed.shape[0] * 128
     out = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
@@ -415,6 +416,28 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
         _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
         _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
         {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream()), "gdrnpp_linear_f32_split")
+    return out
+
+
+def pack_conv3x3_weight_bf16x3(weight):
+    """nn.Conv2d weight f32[Cout,Cin,3,3] -> packed split image of the [Cout, (ky,kx,Cin)] GEMM weight."""
+    cout, cin = weight.shape[:2]
+    return pack_weight_bf16x3(weight.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous())
+
+
+def conv3x3_f32_split(x_cl, weight_packed, bias, gelu: bool = False):
+    """3x3 / stride 1 / pad 1 convolution of a channels_last tensor [N,Cin,H,W] on the bf16 matrix cores (fp32-accurate
+    split GEMM, implicit im2col) -> channels_last [N,Cout,H,W]."""
+    n, cin, h, w = x_cl.shape
+    if not x_cl.is_contiguous(memory_format=torch.channels_last) or x_cl.dtype != torch.float32 or not x_cl.is_cuda:
+        raise ValueError("conv3x3_f32_split expects a float32 channels_last device tensor")
+    if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or weight_packed.shape[1] * 16 != 9 * cin:
+        raise ValueError("weight_packed must come from pack_conv3x3_weight_bf16x3 with matching Cin")
+    cout = weight_packed.shape[0] * 128
+    out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
+    _check(load().gdrnpp_conv3x3_f32_split(
+        x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
+        out.data_ptr(), n, h, w, cin, cout, 1 if gelu else 0, _stream()), "gdrnpp_conv3x3_f32_split")
     return out
 
 

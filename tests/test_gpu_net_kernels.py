@@ -156,3 +156,27 @@ def test_linear_f32_split_is_fp32_accurate(hip, m, k, n):
         assert ((out - got32).abs().max() / scale).item() < 4e-6, epi
     with pytest.raises(RuntimeError, match="multiples"):
         hip.linear_f32_split(torch.randn(100, k, device=DEV), pk, b)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 256, 256, 32, 32), (8, 64, 128, 16, 16), (1, 32, 128, 8, 16), (4, 96, 256, 64, 64)])
+def test_conv3x3_f32_split_vs_fp64(hip, n, cin, cout, h, w):
+    """Implicit-GEMM 3x3 convolution (zero pad 1) on the split kernel vs an fp64 convolution: error at the level of
+    MIOpen's fp32 convolution; borders (zero padding) included; bias and GELU epilogue."""
+    torch.manual_seed(n * cin + h)
+    x = torch.randn(n, cin, h, w, device=DEV).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(cout, cin, 3, 3, device=DEV) * (9 * cin) ** -0.5
+    b = torch.randn(cout, device=DEV)
+    pk = hip.pack_conv3x3_weight_bf16x3(wt)
+    ref64 = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    ref32 = F.conv2d(x, wt, b, padding=1)
+    out = hip.conv3x3_f32_split(x, pk, b)
+    assert out.is_contiguous(memory_format=torch.channels_last) and out.shape == ref32.shape
+    scale = ref64.abs().max().item()
+    e_split = (out.double() - ref64).abs().max().item() / scale
+    e_f32 = (ref32.double() - ref64).abs().max().item() / scale
+    bound = lambda e: max(1.5 * e + 1.5e-7, 4e-8 * (9 * cin) ** 0.5)  # k-ordered fp32 accumulation: ~sqrt(K) ulp
+    assert e_split <= bound(e_f32), (e_split, e_f32)
+    out_nb = hip.conv3x3_f32_split(x, pk, None, gelu=True)
+    want = F.gelu(F.conv2d(x.double(), wt.double(), None, padding=1))
+    e_f32 = ((F.gelu(F.conv2d(x, wt, None, padding=1)).double() - want).abs().max() / want.abs().max()).item()
+    assert ((out_nb.double() - want).abs().max() / want.abs().max()).item() <= bound(e_f32)
