@@ -12,9 +12,12 @@ configs[1] (batch 64, no refine) for reference.  Multi-GPU: ROIs are sharded, ev
 batch (weak scaling), the only collective is the all-gather of the [n,16] pose records.
 
 Prints ONE JSON line on rank 0 (driver contract) with two extra objects:
-  roofline      dominant hand-written kernel (depth_refine_kernel), HBM-bound by assignment:
-                achieved = algorithmic bytes per launch / mean launch duration measured with HIP events on
-                the stream the kernel runs on, inside the timed region.
+  roofline      dominant kernel of the step: gemm_split_kernel (ConvNeXt MLP + head 3x3 convolutions, ~77 % of the
+                step), MFMA-bound: achieved = bf16 MFMA flops actually executed (6 partial products per fp32
+                product) / summed launch durations, measured with HIP events on the launch stream inside the timed
+                region; peak = dense bf16 MFMA.  roofline_other_kernels: depth_refine_staged_kernel (HBM-bound by
+                assignment; algorithmic bytes / launch duration, PMC traffic) and the other
+                hand-written kernels.
   cpu_baseline  the CPU restatement of the reference's per-ROI refine path (oracle "port": NumPy +
                 C software rasteriser standing in for the GL render), one thread, bounded sample.
 """
@@ -40,6 +43,8 @@ from gdrnpp_bop2022_amd.gdrn_modeling.engine import GdrnHipPost, GraphedInferenc
 from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: ~2.5 PF dense bf16 MFMA
+F32_MFMA_PEAK_TFLOPS = 157.3  # same guide: fp32-input MFMA (1/16 of bf16)
 
 
 def parse():
@@ -258,8 +263,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    gemm_timer = hip_lib.LaunchTimer() if (not args.graph and args.streams == 1) else None
+    hip_lib.set_launch_timer(gemm_timer)
     for _ in range(args.steps):
         rec = step(record_events=True)
+    hip_lib.set_launch_timer(None)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -282,6 +290,27 @@ def main():
     fwd_ms = timed(forward_only) if not args.post_only else None
 
     roofline = None
+    refine_roofline = None
+    if gemm_timer is not None and gemm_timer.records:
+        # every gemm_split_kernel launch of the timed region: fp32-equivalent flops and event-measured duration
+        fl = sum(r[1] for r in gemm_timer.records)
+        ms_all = sum(r[2].elapsed_time(r[3]) for r in gemm_timer.records)
+        n_l = len(gemm_timer.records)
+        bf16_tflops = 6.0 * fl / (ms_all * 1e-3) / 1e12
+        by_kind = {}
+        for kind in ("linear", "conv3x3"):
+            rs = [r for r in gemm_timer.records if r[0] == kind]
+            if rs:
+                t_k = sum(r[2].elapsed_time(r[3]) for r in rs)
+                by_kind[kind] = dict(launches_per_step=len(rs) // args.steps, ms_per_step=t_k / args.steps,
+                                     fp32_equiv_tflops=sum(r[1] for r in rs) / (t_k * 1e-3) / 1e12)
+        roofline = dict(kernel="gemm_split_kernel", bound="mfma", achieved=bf16_tflops, peak=BF16_MFMA_PEAK_TFLOPS,
+                        unit="TFLOP/s", frac=bf16_tflops / BF16_MFMA_PEAK_TFLOPS, traffic=None,
+                        launch_ms=ms_all / n_l, launches_per_step=n_l // args.steps, ms_per_step=ms_all / args.steps,
+                        flops_per_launch=6.0 * fl / n_l, fp32_equiv_tflops=fl / (ms_all * 1e-3) / 1e12,
+                        fp32_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS, by_kind=by_kind,
+                        note="bf16 MFMA flops executed = 6 x fp32-equivalent flops (exact 3-way operand split, six "
+                             "partial products, fp32 accumulate)")
     if refine and ev_pairs:
         ms = [a.elapsed_time(bb) for a, bb in ev_pairs]
         mean_ms = float(np.mean(ms))
@@ -292,9 +321,11 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and b == 128 and args.subdiv == 4 and args.workload == "refine":
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-        roofline = dict(kernel="depth_refine_staged_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, launch_ms=mean_ms, bytes_per_launch=bytes_launch,
-                        bytes_per_roi=per_roi, rois_per_launch=b)
+        refine_roofline = dict(kernel="depth_refine_staged_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
+                               unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic, launch_ms=mean_ms,
+                               bytes_per_launch=bytes_launch, bytes_per_roi=per_roi, rois_per_launch=b)
+        if roofline is None:
+            roofline = refine_roofline
 
     # secondary hand-written kernels at the same batch, timed live with HIP events after the timed region
     def ev_time(fn, n=10):
@@ -357,8 +388,10 @@ def main():
                 "num_classes": C, "input_res": 256, "output_res": 64, "refine_iters": cfg.TEST.DEPTH_REFINE_ITER if refine else 0,
                 "parallelism": f"roi-shard x{world}", "class_sliced_out_layer": not args.exact_reference_order, "hip_network_layers": not args.no_hip_layers, "mlp_gemm": "torch" if args.no_fused_mlp else args.mlp_gemm, "conv3x3_split": not args.no_conv_split and not args.no_fused_mlp and args.mlp_gemm == "split",
                 "post_only": bool(args.post_only)},
-            "roofline": roofline, "roofline_other_kernels": others, "cpu_baseline": cpu,
-            "stages_ms": {"forward": fwd_ms, "depth_refine": roofline["launch_ms"] if roofline else None},
+            "roofline": roofline,
+            "roofline_other_kernels": ([refine_roofline] if refine_roofline and refine_roofline is not roofline else []) + others,
+            "cpu_baseline": cpu,
+            "stages_ms": {"forward": fwd_ms, "depth_refine": refine_roofline["launch_ms"] if refine_roofline else None},
         }
         print(json.dumps(line))
     if world > 1:

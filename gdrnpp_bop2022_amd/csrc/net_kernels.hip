@@ -16,7 +16,9 @@
 
 namespace {
 
+using f4 = __attribute__((ext_vector_type(4))) float;
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ f4 ld4v(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
@@ -29,22 +31,84 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 // NP pixel tiles, so every global access is a contiguous 16 B x (C/4) run.  Input rows stream through
 // registers (10 float4 per row), weights are read tap-major [49][C] (L1/L2 resident, 49*C*4 B).
 // --------------------------------------------------------------------------------------------------
-constexpr int TH = 2, TW = 4;
+#ifndef DW_TH
+#define DW_TH 2
+#endif
+#ifndef DW_TW
+#define DW_TW 8
+#endif
+constexpr int TH = DW_TH, TW = DW_TW;
 
-template <bool FUSE_LN>
-__global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w49c,
+// LDS_W: the [49][C] weights live in LDS (loaded once per workgroup) and the workgroup is persistent, walking tile
+// groups with a grid stride.  Without it every thread re-reads its 49 weight quads per output row from L1/L2 — at
+// C >= 256 the weight set (49*C*4 B) exceeds the 32 KB L1, and rocprof showed the kernel bound by L2->L1 traffic
+// (~16 TB/s of requests, 98 of the 178 loads per thread were weights), not by HBM (1.5 TB/s) or VALU (18 TFLOP/s).
+// Sum over each aligned group of `width` lanes (16, 32 or 64), returned in every lane of the group.  DPP row shifts
+// and row broadcasts run in the VALU; the ds_bpermute tree that __shfl_xor expands to went through the LDS crossbar
+// six times per value and was 36 % of the dwconv+LN kernel (tools/microbench_dwconv.py, LN on/off).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float group_sum_dpp(float s, int width, int lane) {
+  s = dpp_add<0x111, 0xf>(s);  // row_shr:1
+  s = dpp_add<0x112, 0xf>(s);  // row_shr:2
+  s = dpp_add<0x114, 0xf>(s);  // row_shr:4
+  s = dpp_add<0x118, 0xf>(s);  // row_shr:8   -> lane 15 of every 16-lane row holds the row total
+  if (width >= 32) s = dpp_add<0x142, 0xa>(s);  // row_bcast:15 into rows 1 and 3
+  if (width == 64) {
+    s = dpp_add<0x143, 0xc>(s);                 // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 63));
+  }
+  return __shfl(s, lane | (width - 1), 64);
+}
+
+#ifndef DW_WPE
+#define DW_WPE 2
+#endif
+#ifndef DW_PK
+#define DW_PK 1
+#endif
+__device__ __forceinline__ f4 fma4s(f4 a, f4 b, f4 c) {
+  return f4{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
+}
+#if DW_PK
+#define DW_FMA(a, b, c) __builtin_elementwise_fma(a, b, c)
+#else
+#define DW_FMA(a, b, c) fma4s(a, b, c)
+#endif
+template <bool FUSE_LN, bool LDS_W>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DW_WPE))) void dwconv7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w49c,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ ln_w,
                                                          const float* __restrict__ ln_b, float* __restrict__ y, int N,
                                                          int H, int W, int C, float eps) {
-  __shared__ float red[TH * TW * 4];  // FUSE_LN: per-wave partials when a pixel spans several waves
+  __shared__ float red[TH * TW * 8];  // FUSE_LN: per-wave partials when a pixel spans several waves
+  extern __shared__ float4 wlds[];    // LDS_W: [49][C/4]
+  const f4* wldsv = reinterpret_cast<const f4*>(wlds);
   const int Q = C >> 2;                       // channel quads per pixel
   const int tiles_per_block = blockDim.x / Q; // >= 1 (host guarantees Q <= 256 and blockDim % Q == 0)
   const int q = threadIdx.x % Q;
   const int tl = threadIdx.x / Q;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-  const long tile = (long)blockIdx.x * tiles_per_block + tl;
   const long n_tiles = (long)N * tiles_y * tiles_x;
+  const long n_groups = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+  if (LDS_W) {
+    for (int i = threadIdx.x; i < 49 * Q; i += blockDim.x) wlds[i] = ld4(w49c + 4 * (size_t)i);
+    __syncthreads();
+  }
+  const f4 b4 = ld4v(bias + 4 * q);
+  // XCD-aware walk: consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  A tile needs
+  // a (TH+6)x(TW+6) input halo, 7x its own size, shared with its neighbours — so neighbouring tiles must run on the
+  // SAME XCD or every L2 fetches its own copy of the halo from HBM/MALL.  XCD k gets the contiguous group range
+  // [k*n/8, (k+1)*n/8) and its workgroups stride through it.
+  const bool by_xcd = gridDim.x >= 8;  // every XCD owns at least one workgroup
+  const int xcd = blockIdx.x & 7;
+  const long g_lo = by_xcd ? n_groups * xcd / 8 : 0, g_hi = by_xcd ? n_groups * (xcd + 1) / 8 : n_groups;
+  const int wg_stride = by_xcd ? (int)((gridDim.x - xcd + 7) >> 3) : (int)gridDim.x;
+  for (long group = g_lo + (by_xcd ? blockIdx.x >> 3 : blockIdx.x); group < g_hi; group += wg_stride) {
+  const long tile = group * tiles_per_block + tl;
   const bool active = tile < n_tiles;
   int n = 0, ty0 = 0, tx0 = 0;
   if (active) {
@@ -53,8 +117,9 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     ty0 = (r / tiles_x) * TH;
     tx0 = (r % tiles_x) * TW;
   }
-  float4 acc[TH][TW];
-  const float4 b4 = ld4(bias + 4 * q);
+  // accumulators as 4-wide vectors: __builtin_elementwise_fma lowers to two v_pk_fma_f32 (the plain v_fma_f32 rate is
+  // half the fp32 vector peak on CDNA4; same IEEE fma per channel)
+  f4 acc[TH][TW];
 #pragma unroll
   for (int i = 0; i < TH; ++i)
 #pragma unroll
@@ -66,11 +131,11 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     for (int r = 0; r < TH + 6; ++r) {
       const int iy = ty0 + r - 3;
       if (iy < 0 || iy >= H) continue;
-      float4 row[TW + 6];
+      f4 row[TW + 6];
 #pragma unroll
       for (int c = 0; c < TW + 6; ++c) {
         const int ix = tx0 + c - 3;
-        row[c] = (ix >= 0 && ix < W) ? ld4(xn + ((size_t)iy * W + ix) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        row[c] = (ix >= 0 && ix < W) ? ld4v(xn + ((size_t)iy * W + ix) * C) : f4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int i = 0; i < TH; ++i) {
@@ -78,9 +143,9 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
         if (ky < 0 || ky > 6) continue;
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx) {
-          const float4 wv = ld4(w49c + (size_t)(ky * 7 + kx) * C + 4 * q);
+          const f4 wv = LDS_W ? wldsv[(ky * 7 + kx) * Q + q] : ld4v(w49c + (size_t)(ky * 7 + kx) * C + 4 * q);
 #pragma unroll
-          for (int j = 0; j < TW; ++j) acc[i][j] = fma4(row[j + kx], wv, acc[i][j]);
+          for (int j = 0; j < TW; ++j) acc[i][j] = DW_FMA(row[j + kx], wv, acc[i][j]);
         }
       }
     }
@@ -101,7 +166,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
       float part[P];
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        const float4 v = acc[p / TW][p % TW];
+        const f4 v = acc[p / TW][p % TW];
         float s;
         if (round == 0) {
           s = (v.x + v.y) + (v.z + v.w);
@@ -109,20 +174,24 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
           const float dx = v.x - mean[p], dy = v.y - mean[p], dz = v.z - mean[p], dw = v.w - mean[p];
           s = (dx * dx + dy * dy) + (dz * dz + dw * dw);
         }
-        for (int off = width >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (width >= 16) {
+          s = group_sum_dpp(s, width, lane);
+        } else {
+          for (int off = width >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        }
         part[p] = s;
       }
       if (wpt > 1) {
-        if (round == 1) __syncthreads();  // red[] of round 0 has been consumed by every wave
+        __syncthreads();  // red[] of the previous round / previous tile group has been consumed by every wave
         if (lane == 0) {
 #pragma unroll
-          for (int p = 0; p < P; ++p) red[p * 4 + wave] = part[p];
+          for (int p = 0; p < P; ++p) red[p * 8 + wave] = part[p];
         }
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           float s = 0.f;
-          for (int k = 0; k < wpt; ++k) s += red[p * 4 + w0 + k];
+          for (int k = 0; k < wpt; ++k) s += red[p * 8 + w0 + k];
           part[p] = s;
         }
       }
@@ -137,7 +206,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     for (int p = 0; p < P; ++p) {
       const float rstd = rsqrtf(var[p] + eps);
       const float m = mean[p];
-      float4 v = acc[p / TW][p % TW];
+      f4 v = acc[p / TW][p % TW];
       v.x = (v.x - m) * rstd * g4.x + be4.x;
       v.y = (v.y - m) * rstd * g4.y + be4.y;
       v.z = (v.z - m) * rstd * g4.z + be4.z;
@@ -152,9 +221,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
 #pragma unroll
       for (int j = 0; j < TW; ++j) {
         const int oy = ty0 + i, ox = tx0 + j;
-        if (oy < H && ox < W) st4(yn + ((size_t)oy * W + ox) * C, acc[i][j]);
+        if (oy < H && ox < W) *reinterpret_cast<f4*>(yn + ((size_t)oy * W + ox) * C) = acc[i][j];
       }
   }
+  }  // tile-group loop
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -279,17 +349,46 @@ int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bia
                  H, W, C);
   GDRNPP_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, GDRNPP_ELIMIT,
                  "gdrnpp_dwconv7x7_ln_nhwc: C=%d must give a power-of-two quad count <= 256", C);
-  const int Q = C / 4, tiles_per_block = 256 / Q;
+  const int Q = C / 4;
   const long n_tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-  const long blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;
-  GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "gdrnpp_dwconv7x7_ln_nhwc: grid too large");
   hipStream_t st = (hipStream_t)stream;
-  if (ln_w && ln_b) {
-    hipLaunchKernelGGL(dwconv7_ln_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias, ln_w, ln_b,
-                       y, N, H, W, C, eps);
+  const size_t wbytes = (size_t)49 * C * sizeof(float);
+  const bool fuse = ln_w && ln_b;
+  if (wbytes <= 112 * 1024) {
+    // weights in LDS, persistent workgroups: 512 threads when the weight set allows only one workgroup per CU
+    const int threads = wbytes > 52 * 1024 ? 512 : 256;
+    const long n_groups = (n_tiles + threads / Q - 1) / (threads / Q);
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      GDRNPP_HIP_TRY(hipGetDevice(&dev));
+      GDRNPP_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const void* fn = fuse ? (const void*)dwconv7_ln_kernel<true, true> : (const void*)dwconv7_ln_kernel<false, true>;
+    GDRNPP_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wbytes));
+    int per_cu = 1;
+    GDRNPP_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, wbytes));
+    if (per_cu < 1) per_cu = 1;
+    long blocks = (long)n_cu * per_cu;
+    if (blocks > n_groups) blocks = n_groups;
+    if (fuse) {
+      hipLaunchKernelGGL((dwconv7_ln_kernel<true, true>), dim3((unsigned)blocks), dim3(threads), wbytes, st, x, w49c, bias,
+                         ln_w, ln_b, y, N, H, W, C, eps);
+    } else {
+      hipLaunchKernelGGL((dwconv7_ln_kernel<false, true>), dim3((unsigned)blocks), dim3(threads), wbytes, st, x, w49c, bias,
+                         nullptr, nullptr, y, N, H, W, C, eps);
+    }
   } else {
-    hipLaunchKernelGGL(dwconv7_ln_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias, nullptr,
-                       nullptr, y, N, H, W, C, eps);
+    const int tiles_per_block = 256 / Q;
+    const long blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "gdrnpp_dwconv7x7_ln_nhwc: grid too large");
+    if (fuse) {
+      hipLaunchKernelGGL((dwconv7_ln_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias, ln_w,
+                         ln_b, y, N, H, W, C, eps);
+    } else {
+      hipLaunchKernelGGL((dwconv7_ln_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias,
+                         nullptr, nullptr, y, N, H, W, C, eps);
+    }
   }
   return gdrnpp::check_launch("gdrnpp_dwconv7x7_ln_nhwc");
 }

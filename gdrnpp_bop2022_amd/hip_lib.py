@@ -385,6 +385,34 @@ def pnp_iter_from_correspondences(img_pts, mdl_pts, count, K, R_net, t_net, retu
     return (R_out, t_out, info) if return_info else (R_out, t_out)
 
 
+class LaunchTimer:
+    """Optional per-launch timing of the split-GEMM entry points with HIP events recorded on the stream the kernel is
+    launched on (bench.py's roofline leg).  records: (kind, fp32-equivalent flops, start event, end event)."""
+
+    def __init__(self):
+        self.records = []
+
+    def launch(self, kind, flops, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        self.records.append((kind, flops, e0, e1))
+        return rc
+
+
+_LAUNCH_TIMER = None
+
+
+def set_launch_timer(timer):
+    global _LAUNCH_TIMER
+    _LAUNCH_TIMER = timer
+
+
+def _timed(kind, flops, fn):
+    return _LAUNCH_TIMER.launch(kind, flops, fn) if _LAUNCH_TIMER is not None else fn()
+
+
 def pack_weight_bf16x3(weight):
     """nn.Linear weight f32[N,K] -> bf16[N/128, K/16, 3, 2, 128, 8]: exact 3-way bf16 split (w == h + m + l) of every
     128x16 tile, laid out as gdrnpp_linear_f32_split stages it (split, k-block, row, 8 k)."""
@@ -410,12 +438,12 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
         raise ValueError("weight_packed must be the contiguous bf16 tensor from pack_weight_bf16x3 with matching K")
     n = weight_packed.shape[0] * 128
     out = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
-    _check(load().gdrnpp_linear_f32_split(
-        _dev(x2d, torch.float32, "x"), weight_packed.data_ptr(),
-        _dev(bias, torch.float32, "bias") if bias is not None else None,
-        _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
-        _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
-        {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream()), "gdrnpp_linear_f32_split")
+    args = (_dev(x2d, torch.float32, "x"), weight_packed.data_ptr(),
+            _dev(bias, torch.float32, "bias") if bias is not None else None,
+            _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
+            _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
+            {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream())
+    _check(_timed("linear", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split(*args)), "gdrnpp_linear_f32_split")
     return out
 
 
@@ -435,9 +463,10 @@ def conv3x3_f32_split(x_cl, weight_packed, bias, gelu: bool = False):
         raise ValueError("weight_packed must come from pack_conv3x3_weight_bf16x3 with matching Cin")
     cout = weight_packed.shape[0] * 128
     out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
-    _check(load().gdrnpp_conv3x3_f32_split(
-        x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
-        out.data_ptr(), n, h, w, cin, cout, 1 if gelu else 0, _stream()), "gdrnpp_conv3x3_f32_split")
+    args = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
+            out.data_ptr(), n, h, w, cin, cout, 1 if gelu else 0, _stream())
+    _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split(*args)),
+           "gdrnpp_conv3x3_f32_split")
     return out
 
 
