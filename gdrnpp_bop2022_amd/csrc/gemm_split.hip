@@ -25,6 +25,7 @@
 //      ds_read_b128 lane group read 32 consecutive slots (conflict-free), a fragment is one ds_read_b128;
 //   per k-tile: 12 fragment reads (ds_read_b128) feed 24 MFMAs.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -236,6 +237,244 @@ __global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float*
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// EXPERIMENTAL (opt-in, see launch_split_epi): 256x128 tile, 8 waves, ping-pong schedule.
+// The 4-wave kernel above keeps the matrix pipe ~60 % busy (PMC:
+// SQ_VALU_MFMA_BUSY_CYCLES / elapsed): its waves sit in barriers and LDS latencies at the same moments.  Here the two
+// waves that share a SIMD (wave w and w+4 of the workgroup) alternate roles every phase:
+//   phase 1: group 0 (waves 0-3, output rows 0-127) issues its 24 MFMAs of k-tile t from fragments already in
+//            registers; group 1 splits + stores its share of k-tile t+1 into the other LDS stage, requests its share of
+//            k-tile t+2 from HBM and pre-reads its own fragments of k-tile t;
+//   phase 2: the roles swap (group 1: MFMAs of k-tile t on output rows 128-255; group 0: stage / request / pre-read).
+// Group 1 stages A rows 0-127 and the whole B tile — exactly what group 0 consumes next — and group 0 stages A rows
+// 128-255, so every fragment pre-read only depends on stores finished one barrier earlier and an MFMA phase starts
+// with all its operands in registers.  One workgroup per CU (512 threads, up to 256 VGPRs per wave).
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int BM8 = 256, PLANE8 = BM8 + 4;
+constexpr int A8_SLOTS = 3 * KB * PLANE8;          // uint4 slots of the A image of one stage
+constexpr int STAGE8_SLOTS = A8_SLOTS + OPER_SLOTS;  // + B image
+
+template <int EPI, bool CONV>
+__global__ __launch_bounds__(512) void gemm_split_kernel8(const float* __restrict__ A, const uint4* __restrict__ Wp,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ resid, float* __restrict__ C,
+                                                          int M, int N, int K, ConvGeom cg) {
+  extern __shared__ uint4 lds4[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Roles follow the hardware placement, not the wave index: the two waves that the dispatcher put on the same SIMD
+  // must land in different groups, or one SIMD gets both MFMA phases and its neighbour none.  Every wave publishes
+  // its SIMD id (HW_ID[5:4]); group = rank among the waves of that SIMD, quadrant = SIMD id.  If the placement is not
+  // two-per-SIMD the wave index decides.
+  __shared__ int s_simd[8];
+  const int my_simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3;  // HW_REG_HW_ID, offset 4, 2 bits
+  if (lane == 0) s_simd[wave] = my_simd;
+  __syncthreads();
+  int grp = 0, cnt = 0, ok_placement = 1;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    int c = 0;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) c += s_simd[v] == s_simd[w];
+    ok_placement &= c == 2;
+    if (s_simd[w] == my_simd) { grp += w < wave; ++cnt; }
+  }
+  (void)cnt;
+  int wq = my_simd;
+  if (!ok_placement) { grp = wave >> 2; wq = wave & 3; }
+  grp = __builtin_amdgcn_readfirstlane(grp);
+  wq = __builtin_amdgcn_readfirstlane(wq);
+  const int wm = wq >> 1, wn = wq & 1, tig = wq * 64 + lane;  // staging index inside the group's 256 threads
+  const int ntn = N / BN;
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int tile_m = tile / ntn, tile_n = tile % ntn;
+  const int m0 = tile_m * BM8, n0 = tile_n * BN;
+  const int nk = K / BK;
+
+  // staging share of this thread: group 1 -> A rows 0..127 (+ B), group 0 -> A rows 128..255
+  const int arow = (grp == 1 ? 0 : 128) + (tig >> 2), lkq = tig & 3;
+  const float* Ag = CONV ? A + (size_t)(m0 + arow) * cg.C + lkq * 4 : A + (size_t)(m0 + arow) * K + lkq * 4;
+  const uint4* Wg = Wp + (size_t)tile_n * nk * W_TILE_SLOTS + tig;
+  int py0 = 0, px0 = 0, py1 = 0, px1 = 0, cpt = 1;
+  if (CONV) {
+    const int p0 = (m0 + arow) % (cg.H * cg.W), p1 = (m0 + arow + 64) % (cg.H * cg.W);
+    py0 = p0 / cg.W; px0 = p0 % cg.W; py1 = p1 / cg.W; px1 = p1 % cg.W;
+    cpt = cg.C / BK;
+  }
+  struct StageA { float4 a0, a1; };
+  struct StageB { uint4 b0, b1, b2; };
+  auto gload_a = [&](int kt) {
+    StageA r;
+    if (CONV) {
+      const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const bool ok0 = (unsigned)(py0 + dy) < (unsigned)cg.H && (unsigned)(px0 + dx) < (unsigned)cg.W;
+      const bool ok1 = (unsigned)(py1 + dy) < (unsigned)cg.H && (unsigned)(px1 + dx) < (unsigned)cg.W;
+      const int off = (dy * cg.W + dx) * cg.C;
+      const float4 v0 = *reinterpret_cast<const float4*>(Ag + (ok0 ? off : 0) + c0);
+      const float4 v1 = *reinterpret_cast<const float4*>(Ag + (size_t)64 * cg.C + (ok1 ? off : 0) + c0);
+      r.a0 = ok0 ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
+      r.a1 = ok1 ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      r.a0 = *reinterpret_cast<const float4*>(Ag + kt * BK);
+      r.a1 = *reinterpret_cast<const float4*>(Ag + (size_t)64 * K + kt * BK);
+    }
+    return r;
+  };
+  auto gload_b = [&](int kt) {
+    StageB r;
+    const uint4* w = Wg + (size_t)kt * W_TILE_SLOTS;
+    r.b0 = w[0]; r.b1 = w[256]; r.b2 = w[512];
+    return r;
+  };
+  const int skb = lkq >> 1, shalf = lkq & 1;
+  auto lstore_a = [&](const StageA r, int buf) {
+    uint4* a = lds4 + buf * STAGE8_SLOTS;
+    {
+      const Split3 p0 = split_pair(r.a0.x, r.a0.y), p1 = split_pair(r.a0.z, r.a0.w);
+      uint2* dst = reinterpret_cast<uint2*>(a + skb * PLANE8 + arow) + shalf;
+      dst[0] = make_uint2(p0.h, p1.h);
+      dst[2 * KB * PLANE8] = make_uint2(p0.m, p1.m);
+      dst[4 * KB * PLANE8] = make_uint2(p0.l, p1.l);
+    }
+    {
+      const Split3 p0 = split_pair(r.a1.x, r.a1.y), p1 = split_pair(r.a1.z, r.a1.w);
+      uint2* dst = reinterpret_cast<uint2*>(a + skb * PLANE8 + 64 + arow) + shalf;
+      dst[0] = make_uint2(p0.h, p1.h);
+      dst[2 * KB * PLANE8] = make_uint2(p0.m, p1.m);
+      dst[4 * KB * PLANE8] = make_uint2(p0.l, p1.l);
+    }
+  };
+  auto lstore_b = [&](const StageB r, int buf) {
+    uint4* bd = lds4 + buf * STAGE8_SLOTS + A8_SLOTS + (tig >> 7) * PLANE + (tig & 127);
+    bd[0] = r.b0; bd[2 * PLANE] = r.b1; bd[4 * PLANE] = r.b2;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, fk = lane >> 5;
+  bf16x8 fa[3][2], fb[3][2];
+  auto read_frags = [&](int buf) {
+    const uint4* a = lds4 + buf * STAGE8_SLOTS + fk * PLANE8 + grp * 128 + wm * 64 + frow;
+    const uint4* b = lds4 + buf * STAGE8_SLOTS + A8_SLOTS + fk * PLANE + wn * 64 + frow;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[s][i] = __builtin_bit_cast(bf16x8, a[s * KB * PLANE8 + i * 32]);
+        fb[s][i] = __builtin_bit_cast(bf16x8, b[s * KB * PLANE + i * 32]);
+      }
+  };
+  auto mfma24 = [&]() {
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][0], fb[TB[t]][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][0], fb[TB[t]][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][1], fb[TB[t]][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][1], fb[TB[t]][1], acc[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // The two groups run separate loops (same barrier count) so that neither carries the other's registers or waits:
+  // every s_barrier below is executed once per phase by all eight waves.  Global loads run TWO k-tiles (four phases)
+  // ahead of their LDS store through two register stages; the loop is unrolled by two (nk is even) so each stage
+  // keeps its registers.  With one workgroup per CU nothing else hides HBM latency: at a distance of one k-tile the
+  // loop ran at exactly the memory latency (0.8 us per k-tile).
+#define KCLAMP(kt) min((kt), nk - 1)
+#define G0_STEP(ST, KT)                                                                               \
+  {                                                                                                   \
+    const int buf = (KT)&1;                                                                           \
+    mfma24();              /* phase 1: k-tile KT, output rows 0-127 */                                \
+    __syncthreads();                                                                                  \
+    lstore_a(ST, buf ^ 1); /* phase 2: A rows 128-255 of k-tile KT+1 */                               \
+    ST = gload_a(KCLAMP((KT) + 3));                                                                   \
+    read_frags(buf ^ 1);   /* own fragments of k-tile KT+1 (group 1 stored them in phase 1) */        \
+    __syncthreads();                                                                                  \
+  }
+#define G1_STEP(ST, TT, KT)                                                                           \
+  {                                                                                                   \
+    const int buf = (KT)&1;                                                                           \
+    lstore_a(ST, buf ^ 1); /* phase 1: A rows 0-127 + B of k-tile KT+1 */                             \
+    lstore_b(TT, buf ^ 1);                                                                            \
+    ST = gload_a(KCLAMP((KT) + 3));                                                                   \
+    TT = gload_b(KCLAMP((KT) + 3));                                                                   \
+    read_frags(buf);       /* own fragments of k-tile KT (rows 128-255 landed one barrier ago) */     \
+    __syncthreads();                                                                                  \
+    mfma24();              /* phase 2: k-tile KT, output rows 128-255 */                              \
+    __syncthreads();                                                                                  \
+  }
+  if (grp == 0) {
+    StageA s0 = gload_a(0);
+    lstore_a(s0, 0);
+    StageA s1 = gload_a(KCLAMP(1));
+    s0 = gload_a(KCLAMP(2));
+    __syncthreads();
+    read_frags(0);
+    for (int kt = 0; kt < nk; kt += 2) {
+      G0_STEP(s1, kt)
+      G0_STEP(s0, kt + 1)
+    }
+  } else {
+    StageA s0 = gload_a(0);
+    StageB t0 = gload_b(0);
+    lstore_a(s0, 0);
+    lstore_b(t0, 0);
+    StageA s1 = gload_a(KCLAMP(1));
+    StageB t1 = gload_b(KCLAMP(1));
+    s0 = gload_a(KCLAMP(2));
+    t0 = gload_b(KCLAMP(2));
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      G1_STEP(s1, t1, kt)
+      G1_STEP(s0, t0, kt + 1)
+    }
+  }
+#undef G0_STEP
+#undef G1_STEP
+#undef KCLAMP
+
+  float* T = reinterpret_cast<float*>(lds4) + wave * 32 * 65;  // [32][65] per wave
+  const int c4 = (lane & 15) * 4;
+  const int nb = n0 + wn * 64 + c4;
+  const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (EPI == EPI_SCALE_RES) gv = *reinterpret_cast<const float4*>(gamma + nb);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr)
+        T[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * 65 + j * 32 + (lane & 31)] = acc[i][j][rr];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): same wave reads back
+#pragma unroll 4
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = rr * 4 + (lane >> 4);
+      const float* t = T + row * 65 + c4;
+      float4 v = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
+      const size_t off = (size_t)(m0 + grp * 128 + wm * 64 + i * 32 + row) * N + nb;
+      if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+      if (EPI == EPI_SCALE_RES) {
+        const float4 rs = *reinterpret_cast<const float4*>(resid + off);
+        v.x = rs.x + gv.x * v.x; v.y = rs.y + gv.y * v.y; v.z = rs.z + gv.z * v.z; v.w = rs.w + gv.w * v.w;
+      }
+      *reinterpret_cast<float4*>(C + off) = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+}
+
 }  // namespace
 
 extern "C" int gdrnpp_pack_weight_bf16x3(const float* W, void* packed, int N, int K, void* stream) {
@@ -250,24 +489,36 @@ extern "C" int gdrnpp_pack_weight_bf16x3(const float* W, void* packed, int N, in
 
 namespace {
 
-template <bool CONV>
-int launch_split(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
-                 int M, int N, int K, int epilogue, ConvGeom cg, hipStream_t st, const char* what) {
+template <int EPI, bool CONV>
+int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
+                     int M, int N, int K, ConvGeom cg, hipStream_t st, const char* what) {
+  // The 256x128 ping-pong kernel is opt-in (GDRNPP_SPLIT_8WAVE=1, read per launch so tests can toggle it): measured on
+  // MI355X it reaches 133-174 TFLOP/s fp32-equivalent on the stage-2 MLP shapes against 144-177 for the 4-wave kernel
+  // at three workgroups per CU (tools/microbench_gemm_s2.py, same box) — see DESIGN.md §5.
+  const char* use8 = getenv("GDRNPP_SPLIT_8WAVE");
+  if (M % BM8 == 0 && use8 && use8[0] == '1') {
+    const long blocks = (long)(M / BM8) * (N / BN);
+    GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "%s: grid too large", what);
+    const int lds = 2 * STAGE8_SLOTS * (int)sizeof(uint4);  // 75 KB >= 8 * 32 * 65 * 4 (epilogue staging)
+    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel8<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((gemm_split_kernel8<EPI, CONV>), dim3((unsigned)blocks), dim3(512), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+    return gdrnpp::check_launch(what);
+  }
   const long blocks = (long)(M / BM) * (N / BN);
   GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "%s: grid too large", what);
   int lds = 2 * 2 * OPER_SLOTS * (int)sizeof(uint4);
   if (lds < 4 * 32 * 65 * (int)sizeof(float)) lds = 4 * 32 * 65 * (int)sizeof(float);
-  if (epilogue == EPI_BIAS) {
-    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI_BIAS, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((gemm_split_kernel<EPI_BIAS, CONV>), dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
-  } else if (epilogue == EPI_GELU) {
-    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI_GELU, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((gemm_split_kernel<EPI_GELU, CONV>), dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
-  } else {
-    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI_SCALE_RES, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((gemm_split_kernel<EPI_SCALE_RES, CONV>), dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
-  }
+  GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV>), dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
   return gdrnpp::check_launch(what);
+}
+
+template <bool CONV>
+int launch_split(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
+                 int M, int N, int K, int epilogue, ConvGeom cg, hipStream_t st, const char* what) {
+  if (epilogue == EPI_BIAS) return launch_split_epi<EPI_BIAS, CONV>(A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
+  if (epilogue == EPI_GELU) return launch_split_epi<EPI_GELU, CONV>(A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
+  return launch_split_epi<EPI_SCALE_RES, CONV>(A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
 }
 
 }  // namespace

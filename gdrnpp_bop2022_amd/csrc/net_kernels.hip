@@ -338,6 +338,77 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// --------------------------------------------------------------------------------------------------
+// LayerNorm over C of an NHWC tensor (timm LayerNorm2d of the ConvNeXt stem / downsample layers).  One thread holds one
+// channel quad of LN_PIX pixels (all loads issued before the first reduction); the C/4 lanes of a pixel are
+// consecutive, sums go through DPP inside the wave and, when a pixel spans several waves, through LDS.
+// Two passes over registers (mean, then centred variance), biased variance, eps inside the sqrt.
+// --------------------------------------------------------------------------------------------------
+constexpr int LN_PIX = 4;
+__global__ __launch_bounds__(256) void layernorm_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float* __restrict__ y,
+                                                             long n_pix, int C, float eps) {
+  __shared__ float red[LN_PIX * 4];
+  const int Q = C >> 2, ppb = blockDim.x / Q, q = threadIdx.x % Q, pl = threadIdx.x / Q;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int width = Q < 64 ? Q : 64, wpt = Q > 64 ? Q / 64 : 1, w0 = (wave / wpt) * wpt;
+  const f4 g4 = ld4v(w + 4 * q), b4 = ld4v(b + 4 * q);
+  const long n_groups = (n_pix + (long)ppb * LN_PIX - 1) / ((long)ppb * LN_PIX);
+  const float inv_c = 1.f / (float)C;
+  for (long group = blockIdx.x; group < n_groups; group += gridDim.x) {
+    f4 v[LN_PIX];
+    long pix[LN_PIX];
+#pragma unroll
+    for (int u = 0; u < LN_PIX; ++u) {
+      pix[u] = (group * LN_PIX + u) * ppb + pl;
+      v[u] = pix[u] < n_pix ? ld4v(x + pix[u] * C + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    float mean[LN_PIX], rstd[LN_PIX];
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      float part[LN_PIX];
+#pragma unroll
+      for (int u = 0; u < LN_PIX; ++u) {
+        float s;
+        if (round == 0) {
+          s = (v[u].x + v[u].y) + (v[u].z + v[u].w);
+        } else {
+          v[u] -= mean[u];
+          s = (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+        }
+        if (width >= 16) {
+          s = group_sum_dpp(s, width, lane);
+        } else {
+          for (int off = width >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        }
+        part[u] = s;
+      }
+      if (wpt > 1) {
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+          for (int u = 0; u < LN_PIX; ++u) red[u * 4 + wave] = part[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < LN_PIX; ++u) {
+          float s = 0.f;
+          for (int k = 0; k < wpt; ++k) s += red[u * 4 + w0 + k];
+          part[u] = s;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < LN_PIX; ++u) {
+        if (round == 0) mean[u] = part[u] * inv_c;
+        else rstd[u] = rsqrtf(part[u] * inv_c + eps);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LN_PIX; ++u)
+      if (pix[u] < n_pix) *reinterpret_cast<f4*>(y + pix[u] * C + 4 * q) = v[u] * rstd[u] * g4 + b4;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -391,6 +462,20 @@ int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bia
     }
   }
   return gdrnpp::check_launch("gdrnpp_dwconv7x7_ln_nhwc");
+}
+
+int gdrnpp_layernorm_nhwc(const float* x, const float* weight, const float* bias, float* y, long n_pix, int C,
+                          float eps, void* stream) {
+  GDRNPP_REQUIRE(x && weight && bias && y, GDRNPP_EINVAL, "gdrnpp_layernorm_nhwc: null pointer");
+  GDRNPP_REQUIRE(n_pix > 0 && C > 0, GDRNPP_EINVAL, "gdrnpp_layernorm_nhwc: n_pix=%ld C=%d", n_pix, C);
+  GDRNPP_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_layernorm_nhwc: C=%d must give a power-of-two quad count <= 256", C);
+  const int ppb = 256 / (C / 4);
+  const long n_groups = (n_pix + (long)ppb * LN_PIX - 1) / ((long)ppb * LN_PIX);
+  const long blocks = n_groups < 256 * 16 ? n_groups : 256 * 16;  // grid-stride beyond 16 workgroups per CU
+  hipLaunchKernelGGL(layernorm_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, weight, bias,
+                     y, n_pix, C, eps);
+  return gdrnpp::check_launch("gdrnpp_layernorm_nhwc");
 }
 
 int gdrnpp_upsample_bilinear2x_nhwc(const float* x, float* y, int N, int H, int W, int C, void* stream) {

@@ -27,9 +27,7 @@ class LayerNorm2d(nn.LayerNorm):
     """LayerNorm over the channel dim of an NCHW tensor (timm.models.layers.LayerNorm2d)."""
 
     def forward(self, x):
-        x = x.permute(0, 2, 3, 1)  # a view; contiguous when x is channels_last
-        x = F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
-        return x.permute(0, 3, 1, 2)
+        return hip_layers.layernorm2d(self, x)  # NHWC HIP kernel on the GPU, F.layer_norm on a permuted view otherwise
 
 
 class Mlp(nn.Module):

@@ -47,6 +47,17 @@ def groupnorm_act(gn: nn.GroupNorm, act: nn.Module | None, x: torch.Tensor) -> t
     return act(x) if act is not None else x
 
 
+def layernorm2d(ln: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+    """timm LayerNorm2d (LayerNorm over the channel dim of an NCHW tensor)."""
+    c = x.shape[1]
+    q = c // 4
+    if (enabled_for(x) and c % 4 == 0 and q <= 256 and 256 % q == 0 and ln.elementwise_affine
+            and tuple(ln.normalized_shape) == (c,)):
+        return hip_lib.layernorm_nhwc(_cl(x), ln.weight, ln.bias, ln.eps)
+    y = F.layer_norm(x.permute(0, 2, 3, 1), ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+    return y.permute(0, 3, 1, 2)
+
+
 def dwconv_ln(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor, cache: dict) -> torch.Tensor:
     """ConvNeXt block head: depthwise 7x7 then LayerNorm over C.  Returns the NHWC *view* [N,H,W,C]."""
     c = conv.in_channels

@@ -71,6 +71,7 @@ SIGNATURES = {
         c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "gdrnpp_pack_pose_records": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "gdrnpp_dwconv7x7_ln_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "gdrnpp_layernorm_nhwc": (c_int, [_P, _P, _P, _P, c_long, c_int, c_float, _P]),
     "gdrnpp_upsample_bilinear2x_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_groupnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gdrnpp_groupnorm_act_nhwc": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
@@ -313,6 +314,15 @@ def dwconv7x7_ln(x, w49c, bias, ln_w=None, ln_b=None, eps: float = 1e-6):
         _dev(ln_w, torch.float32, "ln_w") if ln_w is not None else None,
         _dev(ln_b, torch.float32, "ln_b") if ln_b is not None else None, y.data_ptr(), n, h, w, c, float(eps),
         _stream()), "gdrnpp_dwconv7x7_ln_nhwc")
+    return y
+
+
+def layernorm_nhwc(x, weight, bias, eps: float = 1e-6):
+    """x (N,C,H,W) channels_last -> LayerNorm over C per pixel, same shape/format."""
+    n, c, h, w = x.shape
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    _check(load().gdrnpp_layernorm_nhwc(_nhwc(x, "x"), _dev(weight, torch.float32, "weight"), _dev(bias, torch.float32, "bias"),
+                                        y.data_ptr(), n * h * w, c, float(eps), _stream()), "gdrnpp_layernorm_nhwc")
     return y
 
 

@@ -230,7 +230,11 @@ int gdrnpp_debug_refine_profile(long long* h_out16);
  *                 (top_down_doublemask_xyz_region_head.py:80).
  *  groupnorm_act : nn.GroupNorm(G, C, eps) [+ exact-erf GELU] of ConvModule / ConvPnPNet
  *                 (lib/torch_utils/layers/conv_module.py:222-236, conv_pnp_net.py:59-72); workspace sized by
- *                 gdrnpp_groupnorm_workspace_bytes. */
+ *                 gdrnpp_groupnorm_workspace_bytes.
+ *  layernorm    : LayerNorm over C of n_pix NHWC pixels (timm LayerNorm2d of the ConvNeXt stem and downsample
+ *                 layers): biased variance, eps inside the sqrt. */
+int gdrnpp_layernorm_nhwc(const float* x, const float* weight, const float* bias, float* y,
+                          long n_pix, int C, float eps, void* stream);
 int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bias,
                              const float* ln_w, const float* ln_b, float* y, int N,
                              int H, int W, int C, float eps, void* stream);

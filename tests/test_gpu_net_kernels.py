@@ -180,3 +180,36 @@ def test_conv3x3_f32_split_vs_fp64(hip, n, cin, cout, h, w):
     want = F.gelu(F.conv2d(x.double(), wt.double(), None, padding=1))
     e_f32 = ((F.gelu(F.conv2d(x, wt, None, padding=1)).double() - want).abs().max() / want.abs().max()).item()
     assert ((out_nb.double() - want).abs().max() / want.abs().max()).item() <= bound(e_f32)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(4, 128, 64, 64), (3, 256, 17, 9), (2, 512, 16, 16), (5, 1024, 3, 3), (2, 32, 8, 8), (1, 8, 5, 7)])
+def test_layernorm_nhwc(hip, n, c, h, w):
+    torch.manual_seed(c + h)
+    x = (torch.randn(n, c, h, w, device=DEV) * 3 + 1.5).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(c, device=DEV)
+    b = torch.randn(c, device=DEV)
+    ref = F.layer_norm(x.permute(0, 2, 3, 1), (c,), g, b, 1e-6).permute(0, 3, 1, 2)
+    y = hip.layernorm_nhwc(x, g, b, 1e-6)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_linear_f32_split_8wave_variant(hip, monkeypatch):
+    """The opt-in 256x128 ping-pong variant of the split GEMM gives the same numbers as the default kernel to fp32
+    accumulation-order noise (both add the same six partial products per k-step, in the same order within a k-step)."""
+    torch.manual_seed(5)
+    m, k, n = 1024, 512, 256
+    x = torch.randn(m, k, device=DEV)
+    w = torch.randn(n, k, device=DEV) * (k ** -0.5)
+    b = torch.randn(n, device=DEV)
+    pk = hip.pack_weight_bf16x3(w)
+    base = hip.linear_f32_split(x, pk, b, "gelu")
+    monkeypatch.setenv("GDRNPP_SPLIT_8WAVE", "1")
+    alt = hip.linear_f32_split(x, pk, b, "gelu")
+    xc = torch.randn(2, 64, 16, 16, device=DEV).contiguous(memory_format=torch.channels_last)
+    wc = torch.randn(128, 64, 3, 3, device=DEV) * 0.05
+    pkc = hip.pack_conv3x3_weight_bf16x3(wc)
+    alt_c = hip.conv3x3_f32_split(xc, pkc, None)
+    monkeypatch.delenv("GDRNPP_SPLIT_8WAVE")
+    base_c = hip.conv3x3_f32_split(xc, pkc, None)
+    assert torch.equal(alt, base) and torch.equal(alt_c, base_c)
