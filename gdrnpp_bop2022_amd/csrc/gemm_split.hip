@@ -77,14 +77,17 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, uint4* __restric
 // zero-pad 1 convolution (implicit im2col: the k-tile's 16 channels of one tap are 64 contiguous bytes per pixel).
 struct ConvGeom { int H, W, C; };
 
-template <int EPI, bool CONV>
-__global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float* __restrict__ A,
+// MI = 32-row MFMA tiles per wave along M: 2 -> 128x128 block tile (three workgroups per CU), 4 -> 256x128 block tile
+// (each wave 128x64: 18 fragment reads feed 48 MFMAs per k-tile and per barrier, two workgroups per CU).
+template <int EPI, bool CONV, int MI>
+__global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kernel(const float* __restrict__ A,
                                                                     const uint4* __restrict__ Wp,
                                                                     const float* __restrict__ bias,
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ resid,
                                                                     float* __restrict__ C, int M, int N, int K,
                                                                     ConvGeom cg) {
+  constexpr int BMT = MI * 64, PLANE_A = BMT + 4, A_SLOTS = 3 * KB * PLANE_A, STAGE_SLOTS = A_SLOTS + OPER_SLOTS;
   extern __shared__ uint4 lds4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -94,20 +97,23 @@ __global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float*
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
   const int tile_m = tile / ntn, tile_n = tile % ntn;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BMT, n0 = tile_n * BN;
   const int nk = K / BK;
 
-  // A staging: rows tid/4 and 64 + tid/4, lane%4 picks 4 consecutive k (half a k-block)
+  // A staging: rows tid/4 + 64*p (p < MI), lane%4 picks 4 consecutive k (half a k-block)
   const int lrow = tid >> 2, lkq = tid & 3;
   const float* Ag = CONV ? A + (size_t)(m0 + lrow) * cg.C + lkq * 4 : A + (size_t)(m0 + lrow) * K + lkq * 4;
   const uint4* Wg = Wp + (size_t)tile_n * nk * W_TILE_SLOTS + tid;
-  int py0 = 0, px0 = 0, py1 = 0, px1 = 0, cpt = 1;  // CONV: (y, x) of this thread's two pixels, k-tiles per tap
+  int py[MI], px[MI], cpt = 1;  // CONV: (y, x) of this thread's pixels, k-tiles per tap
   if (CONV) {
-    const int p0 = (m0 + lrow) % (cg.H * cg.W), p1 = (m0 + lrow + 64) % (cg.H * cg.W);
-    py0 = p0 / cg.W; px0 = p0 % cg.W; py1 = p1 / cg.W; px1 = p1 % cg.W;
+#pragma unroll
+    for (int p = 0; p < MI; ++p) {
+      const int pp = (m0 + lrow + 64 * p) % (cg.H * cg.W);
+      py[p] = pp / cg.W; px[p] = pp % cg.W;
+    }
     cpt = cg.C / BK;
   }
-  struct Stage { float4 a0, a1; uint4 b0, b1, b2; };
+  struct Stage { float4 a[MI]; uint4 b0, b1, b2; };
   auto gload = [&](int kt) {
     Stage r;
     if (CONV) {
@@ -115,16 +121,16 @@ __global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float*
       // would make the outstanding-load count unknown to the compiler and collapse the software pipeline
       const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      const bool ok0 = (unsigned)(py0 + dy) < (unsigned)cg.H && (unsigned)(px0 + dx) < (unsigned)cg.W;
-      const bool ok1 = (unsigned)(py1 + dy) < (unsigned)cg.H && (unsigned)(px1 + dx) < (unsigned)cg.W;
       const int off = (dy * cg.W + dx) * cg.C;
-      const float4 v0 = *reinterpret_cast<const float4*>(Ag + (ok0 ? off : 0) + c0);
-      const float4 v1 = *reinterpret_cast<const float4*>(Ag + (size_t)64 * cg.C + (ok1 ? off : 0) + c0);
-      r.a0 = ok0 ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
-      r.a1 = ok1 ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int p = 0; p < MI; ++p) {
+        const bool ok = (unsigned)(py[p] + dy) < (unsigned)cg.H && (unsigned)(px[p] + dx) < (unsigned)cg.W;
+        const float4 v = *reinterpret_cast<const float4*>(Ag + (size_t)(64 * p) * cg.C + (ok ? off : 0) + c0);
+        r.a[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     } else {
-      r.a0 = *reinterpret_cast<const float4*>(Ag + kt * BK);
-      r.a1 = *reinterpret_cast<const float4*>(Ag + (size_t)64 * K + kt * BK);
+#pragma unroll
+      for (int p = 0; p < MI; ++p) r.a[p] = *reinterpret_cast<const float4*>(Ag + (size_t)(64 * p) * K + kt * BK);
     }
     const uint4* w = Wg + (size_t)kt * W_TILE_SLOTS;
     r.b0 = w[0]; r.b1 = w[256]; r.b2 = w[512];
@@ -132,58 +138,53 @@ __global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float*
   };
   const int skb = lkq >> 1, shalf = lkq & 1;
   auto lstore = [&](const Stage r, int buf) {
-    uint4* a = lds4 + buf * 2 * OPER_SLOTS;
-    uint4* b = a + OPER_SLOTS;
-    {
-      const Split3 p0 = split_pair(r.a0.x, r.a0.y), p1 = split_pair(r.a0.z, r.a0.w);
-      uint2* dst = reinterpret_cast<uint2*>(a + skb * PLANE + lrow) + shalf;
+    uint4* a = lds4 + buf * STAGE_SLOTS;
+    uint4* b = a + A_SLOTS;
+#pragma unroll
+    for (int p = 0; p < MI; ++p) {
+      const Split3 p0 = split_pair(r.a[p].x, r.a[p].y), p1 = split_pair(r.a[p].z, r.a[p].w);
+      uint2* dst = reinterpret_cast<uint2*>(a + skb * PLANE_A + 64 * p + lrow) + shalf;
       dst[0] = make_uint2(p0.h, p1.h);
-      dst[2 * KB * PLANE] = make_uint2(p0.m, p1.m);
-      dst[4 * KB * PLANE] = make_uint2(p0.l, p1.l);
-    }
-    {
-      const Split3 p0 = split_pair(r.a1.x, r.a1.y), p1 = split_pair(r.a1.z, r.a1.w);
-      uint2* dst = reinterpret_cast<uint2*>(a + skb * PLANE + 64 + lrow) + shalf;
-      dst[0] = make_uint2(p0.h, p1.h);
-      dst[2 * KB * PLANE] = make_uint2(p0.m, p1.m);
-      dst[4 * KB * PLANE] = make_uint2(p0.l, p1.l);
+      dst[2 * KB * PLANE_A] = make_uint2(p0.m, p1.m);
+      dst[4 * KB * PLANE_A] = make_uint2(p0.l, p1.l);
     }
     // image slot i*256 + tid = plane (i*2 + tid/128), row tid%128
     uint4* bd = b + (tid >> 7) * PLANE + (tid & 127);
     bd[0] = r.b0; bd[2 * PLANE] = r.b1; bd[4 * PLANE] = r.b2;
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frow = lane & 31, fk = lane >> 5;
-  // one k-tile: 12 fragment reads, 24 MFMAs; `mid` runs after the first 8 MFMAs are queued (the split + LDS stores of
-  // the next tile, hidden behind the matrix pipe)
+  // one k-tile: 3*(MI+2) fragment reads, 12*MI MFMAs; `mid` runs after the first third of the MFMAs is queued (the
+  // split + LDS stores of the next tile, hidden behind the matrix pipe)
   auto compute = [&](int buf, auto&& mid) {
-    const uint4* a = lds4 + buf * 2 * OPER_SLOTS + fk * PLANE + wm * 64 + frow;
-    const uint4* b = lds4 + buf * 2 * OPER_SLOTS + OPER_SLOTS + fk * PLANE + wn * 64 + frow;
-    bf16x8 fa[3][2], fb[3][2];
+    const uint4* a = lds4 + buf * STAGE_SLOTS + fk * PLANE_A + wm * (MI * 32) + frow;
+    const uint4* b = lds4 + buf * STAGE_SLOTS + A_SLOTS + fk * PLANE + wn * 64 + frow;
+    bf16x8 fa[3][MI], fb[3][2];
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 3; ++s) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[s][i] = __builtin_bit_cast(bf16x8, a[s * KB * PLANE + i * 32]);
-        fb[s][i] = __builtin_bit_cast(bf16x8, b[s * KB * PLANE + i * 32]);
-      }
-    // smallest partial products first; the four accumulators rotate so no MFMA waits on its predecessor
+      for (int i = 0; i < MI; ++i) fa[s][i] = __builtin_bit_cast(bf16x8, a[s * KB * PLANE_A + i * 32]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[s][j] = __builtin_bit_cast(bf16x8, b[s * KB * PLANE + j * 32]);
+    }
+    // smallest partial products first; the accumulators rotate so no MFMA waits on its predecessor
     constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
     constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][0], fb[TB[t]][0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][0], fb[TB[t]][1], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][1], fb[TB[t]][0], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][1], fb[TB[t]][1], acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][i], fb[TB[t]][j], acc[i][j], 0, 0, 0);
       if (t == 1) mid();
     }
   };
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float*
     __syncthreads();
   }
 
-  // epilogue: lane holds column (lane & 31) of rows (r&3) + 8*(r>>2) + 4*(lane>>5).  Each wave parks one 32x64 half
+  // epilogue: lane holds column (lane & 31) of rows (r&3) + 8*(r>>2) + 4*(lane>>5).  Each wave parks one 32x64 slice
   // of its tile in LDS (the operand images are dead: the loop ends on a barrier) and writes it back row-wise as float4.
   float* T = reinterpret_cast<float*>(lds4) + wave * 32 * 65;  // [32][65] per wave
   const int c4 = (lane & 15) * 4;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float*
   float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
   if (EPI == EPI_SCALE_RES) gv = *reinterpret_cast<const float4*>(gamma + nb);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MI; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float*
       const int row = rr * 4 + (lane >> 4);
       const float* t = T + row * 65 + c4;
       float4 v = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
-      const size_t off = (size_t)(m0 + wm * 64 + i * 32 + row) * N + nb;
+      const size_t off = (size_t)(m0 + wm * (MI * 32) + i * 32 + row) * N + nb;
       if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
       if (EPI == EPI_SCALE_RES) {
         const float4 rs = *reinterpret_cast<const float4*>(resid + off);
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256, SPLIT_OCC) void gemm_split_kernel(const float*
       }
       *reinterpret_cast<float4*>(C + off) = v;
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // reads done before the second half overwrites T
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // reads done before the next slice overwrites T
   }
 }
 
@@ -504,12 +505,23 @@ int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const f
     hipLaunchKernelGGL((gemm_split_kernel8<EPI, CONV>), dim3((unsigned)blocks), dim3(512), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
     return gdrnpp::check_launch(what);
   }
+  // 256x128 tiles (MI = 4) when they still give every CU its two workgroups; measured +3 % (fc1) / +7 % (fc2) on the
+  // stage-2 MLP shapes over 128x128 tiles at three workgroups per CU.  GDRNPP_SPLIT_MI4=0/1 forces the choice (A/B).
+  const char* mi4 = getenv("GDRNPP_SPLIT_MI4");
+  const bool big = mi4 ? mi4[0] == '1' : (long)(M / 256) * (N / BN) >= 512;
+  if (M % 256 == 0 && big) {
+    const long blocks = (long)(M / 256) * (N / BN);
+    const int lds = 2 * (3 * KB * (256 + 4) + OPER_SLOTS) * (int)sizeof(uint4);
+    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI, CONV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV, 4>), dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+    return gdrnpp::check_launch(what);
+  }
   const long blocks = (long)(M / BM) * (N / BN);
   GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "%s: grid too large", what);
   int lds = 2 * 2 * OPER_SLOTS * (int)sizeof(uint4);
   if (lds < 4 * 32 * 65 * (int)sizeof(float)) lds = 4 * 32 * 65 * (int)sizeof(float);
-  GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV>), dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+  GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI, CONV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV, 2>), dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
   return gdrnpp::check_launch(what);
 }
 
