@@ -213,3 +213,22 @@ def test_linear_f32_split_8wave_variant(hip, monkeypatch):
     monkeypatch.delenv("GDRNPP_SPLIT_8WAVE")
     base_c = hip.conv3x3_f32_split(xc, pkc, None)
     assert torch.equal(alt, base) and torch.equal(alt_c, base_c)
+
+
+def test_split_gemm_gelu_epilogue_matches_fp64_gelu(hip):
+    """The GELU epilogue of the split GEMM against an fp64 GELU of the SAME pre-activations (taken from the
+    epilogue-free launch, bit-identical accumulators) over [-7, 7]: as close as PyTorch's fp32 GELU."""
+    torch.manual_seed(11)
+    m, k, n = 2048, 32, 128
+    x = torch.randn(m, k, device=DEV)
+    w = torch.randn(n, k, device=DEV) * 0.35   # pre-activations ~ N(0, 2^2): covers both erf branches and the tails
+    b = torch.linspace(-3, 3, n, device=DEV)
+    pk = hip.pack_weight_bf16x3(w)
+    pre = hip.linear_f32_split(x, pk, b, "none")
+    act = hip.linear_f32_split(x, pk, b, "gelu")
+    assert pre.abs().max().item() > 6.0 and (pre.abs() < 0.5).float().mean().item() > 0.05
+    want = F.gelu(pre.double())
+    err = (act.double() - want).abs()
+    ref32 = (F.gelu(pre).double() - want).abs()
+    assert err.max().item() <= max(1.5 * ref32.max().item(), 6e-7), (err.max().item(), ref32.max().item())
+    assert (err / pre.double().abs().clamp_min(1.0)).max().item() < 2.5e-7
