@@ -304,8 +304,13 @@ def main():
                 t_k = sum(r[2].elapsed_time(r[3]) for r in rs)
                 by_kind[kind] = dict(launches_per_step=len(rs) // args.steps, ms_per_step=t_k / args.steps,
                                      fp32_equiv_tflops=sum(r[1] for r in rs) / (t_k * 1e-3) / 1e12)
+        g_traffic = None  # HBM-side bytes per launch from the committed PMC passes (same workload only)
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc) and b == 128 and args.workload == "refine" and args.mlp_gemm == "split" and not args.no_fused_mlp:
+            g_traffic = json.load(open(pmc)).get("gemm_split_kernel", {}).get("traffic_bytes_per_launch")
         roofline = dict(kernel="gemm_split_kernel", bound="mfma", achieved=bf16_tflops, peak=BF16_MFMA_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=bf16_tflops / BF16_MFMA_PEAK_TFLOPS, traffic=None,
+                        unit="TFLOP/s", frac=bf16_tflops / BF16_MFMA_PEAK_TFLOPS, traffic=g_traffic,
+                        algorithmic_bytes_per_launch=sum(r[4] for r in gemm_timer.records) / n_l,
                         launch_ms=ms_all / n_l, launches_per_step=n_l // args.steps, ms_per_step=ms_all / args.steps,
                         flops_per_launch=6.0 * fl / n_l, fp32_equiv_tflops=fl / (ms_all * 1e-3) / 1e12,
                         fp32_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS, by_kind=by_kind,

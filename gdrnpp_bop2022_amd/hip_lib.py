@@ -397,17 +397,18 @@ def pnp_iter_from_correspondences(img_pts, mdl_pts, count, K, R_net, t_net, retu
 
 class LaunchTimer:
     """Optional per-launch timing of the split-GEMM entry points with HIP events recorded on the stream the kernel is
-    launched on (bench.py's roofline leg).  records: (kind, fp32-equivalent flops, start event, end event)."""
+    launched on (bench.py's roofline leg).  records: (kind, fp32-equivalent flops, start event, end event,
+    algorithmic bytes = operands read once + result written once)."""
 
     def __init__(self):
         self.records = []
 
-    def launch(self, kind, flops, fn):
+    def launch(self, kind, flops, fn, nbytes=0.0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn()
         e1.record()
-        self.records.append((kind, flops, e0, e1))
+        self.records.append((kind, flops, e0, e1, nbytes))
         return rc
 
 
@@ -419,8 +420,8 @@ def set_launch_timer(timer):
     _LAUNCH_TIMER = timer
 
 
-def _timed(kind, flops, fn):
-    return _LAUNCH_TIMER.launch(kind, flops, fn) if _LAUNCH_TIMER is not None else fn()
+def _timed(kind, flops, fn, nbytes=0.0):
+    return _LAUNCH_TIMER.launch(kind, flops, fn, nbytes) if _LAUNCH_TIMER is not None else fn()
 
 
 def pack_weight_bf16x3(weight):
@@ -453,7 +454,8 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
             _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
             _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
             {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream())
-    _check(_timed("linear", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split(*args)), "gdrnpp_linear_f32_split")
+    nbytes = 4.0 * m * k + 6.0 * n * k + 4.0 * m * n * (2 if epilogue == "scale_res" else 1)
+    _check(_timed("linear", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split(*args), nbytes), "gdrnpp_linear_f32_split")
     return out
 
 
@@ -475,7 +477,8 @@ def conv3x3_f32_split(x_cl, weight_packed, bias, gelu: bool = False):
     out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
     args = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
             out.data_ptr(), n, h, w, cin, cout, 1 if gelu else 0, _stream())
-    _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split(*args)),
+    nbytes = 4.0 * n * h * w * (cin + cout) + 6.0 * cout * 9 * cin
+    _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split(*args), nbytes),
            "gdrnpp_conv3x3_f32_split")
     return out
 
