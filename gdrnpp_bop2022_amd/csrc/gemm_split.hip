@@ -38,6 +38,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 #ifndef SPLIT_OCC
 #define SPLIT_OCC 2
 #endif
+
 constexpr int BM = 128, BN = 128, BK = 16, KB = BK / 8, PLANE = BM + 4;
 constexpr int OPER_SLOTS = 3 * KB * PLANE;  // uint4 slots per operand image
 constexpr int W_TILE_SLOTS = 3 * KB * BN;   // uint4 slots of one packed 128x16 weight tile
@@ -90,8 +91,11 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
                                                                     const float* __restrict__ resid,
                                                                     float* __restrict__ C, int M, int N, int K,
                                                                     ConvGeom cg) {
-  constexpr int BMT = MI * 64, PLANE_A = BMT + 4, A_SLOTS = 3 * KB * PLANE_A, STAGE_SLOTS = A_SLOTS + OPER_SLOTS;
-  extern __shared__ uint4 lds4[];
+  constexpr int BMT = MI * 64, PLANE_A = BMT + 4, A_SLOTS = 3 * KB * PLANE_A;
+  // static LDS objects per operand and stage (MI = 4: 75 KB -> two workgroups per CU, MI = 2: 50.7 KB -> three)
+  __shared__ uint4 sA[2 * A_SLOTS];
+  __shared__ uint4 sB0[OPER_SLOTS];
+  __shared__ uint4 sB1[OPER_SLOTS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = N / BN;
@@ -141,8 +145,8 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
   };
   const int skb = lkq >> 1, shalf = lkq & 1;
   auto lstore = [&](const Stage r, int buf) {
-    uint4* a = lds4 + buf * STAGE_SLOTS;
-    uint4* b = a + A_SLOTS;
+    uint4* a = sA + buf * A_SLOTS;
+    uint4* b = buf ? sB1 : sB0;
 #pragma unroll
     for (int p = 0; p < MI; ++p) {
       const Split3 p0 = split_pair(r.a[p].x, r.a[p].y), p1 = split_pair(r.a[p].z, r.a[p].w);
@@ -168,8 +172,8 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
   // one k-tile: 3*(MI+2) fragment reads, 12*MI MFMAs; `mid` runs after the first third of the MFMAs is queued (the
   // split + LDS stores of the next tile, hidden behind the matrix pipe)
   auto compute = [&](int buf, auto&& mid) {
-    const uint4* a = lds4 + buf * STAGE_SLOTS + fk * PLANE_A + wm * (MI * 32) + frow;
-    const uint4* b = lds4 + buf * STAGE_SLOTS + A_SLOTS + fk * PLANE + wn * 64 + frow;
+    const uint4* a = sA + buf * A_SLOTS + fk * PLANE_A + wm * (MI * 32) + frow;
+    const uint4* b = (buf ? sB1 : sB0) + fk * PLANE + wn * 64 + frow;
     bf16x8 fa[3][MI], fb[3][2];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -208,28 +212,30 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
     __syncthreads();
   }
 
-  // epilogue: lane holds column (lane & 31) of rows (r&3) + 8*(r>>2) + 4*(lane>>5).  Each wave parks one 32x64 slice
-  // of its tile in LDS (the operand images are dead: the loop ends on a barrier) and writes it back row-wise as float4.
-  float* T = reinterpret_cast<float*>(lds4) + wave * 32 * 65;  // [32][65] per wave
+  // epilogue: lane holds column (lane & 31) of rows (r&3) + 8*(r>>2) + 4*(lane>>5).  Each wave parks one 16x64 slice
+  // of its tile in LDS (the A images are dead: the loop ends on a barrier) and writes it back row-wise as float4.
+  static_assert(2 * A_SLOTS * sizeof(uint4) >= 4 * 16 * 65 * sizeof(float), "epilogue staging fits the A images");
+  float* T = reinterpret_cast<float*>(sA) + wave * 16 * 65;  // [16][65] per wave
   const int c4 = (lane & 15) * 4;
   const int nb = n0 + wn * 64 + c4;
   const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
   if (EPI == EPI_SCALE_RES) gv = *reinterpret_cast<const float4*>(gamma + nb);
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
+  for (int ih = 0; ih < 2 * MI; ++ih) {
+    const int i = ih >> 1, h = ih & 1;  // 32-row MFMA tile i, its 16-row half h (accumulator registers h*8 .. h*8+7)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 65 + j * 32 + (lane & 31)] = acc[i][j][r];
+      for (int r = 0; r < 8; ++r)
+        T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 65 + j * 32 + (lane & 31)] = acc[i][j][h * 8 + r];
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): same wave reads back
-#pragma unroll 4
-    for (int rr = 0; rr < 8; ++rr) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
       const int row = rr * 4 + (lane >> 4);
       const float* t = T + row * 65 + c4;
       float4 v = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
-      const size_t off = (size_t)(m0 + wm * (MI * 32) + i * 32 + row) * N + nb;
+      const size_t off = (size_t)(m0 + wm * (MI * 32) + i * 32 + h * 16 + row) * N + nb;
       if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
       if (EPI == EPI_SCALE_RES) {
         const float4 rs = *reinterpret_cast<const float4*>(resid + off);
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
       }
       // streaming store: the result is not read again by this kernel, keep it from displacing the weights in L2
       // (-4 % on the fc1 shapes, whose output is 4x their input)
-      { const f32x4v t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<f32x4v*>(C + off)); }
+      { const f32x4v t4 = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t4, reinterpret_cast<f32x4v*>(C + off)); }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // reads done before the next slice overwrites T
   }
@@ -516,17 +522,12 @@ int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const f
   const bool big = mi4 ? mi4[0] == '1' : (long)(M / 256) * (N / BN) >= 512;
   if (M % 256 == 0 && big) {
     const long blocks = (long)(M / 256) * (N / BN);
-    const int lds = 2 * (3 * KB * (256 + 4) + OPER_SLOTS) * (int)sizeof(uint4);
-    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI, CONV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV, 4>), dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+    hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV, 4>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
     return gdrnpp::check_launch(what);
   }
   const long blocks = (long)(M / BM) * (N / BN);
   GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "%s: grid too large", what);
-  int lds = 2 * 2 * OPER_SLOTS * (int)sizeof(uint4);
-  if (lds < 4 * 32 * 65 * (int)sizeof(float)) lds = 4 * 32 * 65 * (int)sizeof(float);
-  GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel<EPI, CONV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV, 2>), dim3((unsigned)blocks), dim3(256), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+  hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV, 2>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
   return gdrnpp::check_launch(what);
 }
 
