@@ -104,19 +104,26 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
   const int tile_m = tile / ntn, tile_n = tile % ntn;
-  const int m0 = tile_m * BMT, n0 = tile_n * BN;
+  const int m0 = tile_m * BMT, n0 = tile_n * BN;  // the last m-tile may hang over M: its loads are clamped to row
+                                                   // M-1 and its stores masked, so any M >= 1 is accepted
   const int nk = K / BK;
 
   // A staging: rows tid/4 + 64*p (p < MI), lane%4 picks 4 consecutive k (half a k-block)
   const int lrow = tid >> 2, lkq = tid & 3;
-  const float* Ag = CONV ? A + (size_t)(m0 + lrow) * cg.C + lkq * 4 : A + (size_t)(m0 + lrow) * K + lkq * 4;
+  const float* ap[MI];  // this thread's staging rows (pixels), clamped into [0, M): the overhang re-reads row M-1
+  int arow[MI];
+#pragma unroll
+  for (int p = 0; p < MI; ++p) {
+    arow[p] = min(m0 + lrow + 64 * p, M - 1);
+    ap[p] = A + (size_t)arow[p] * (CONV ? cg.C : K) + lkq * 4;
+  }
   const uint4* Wg = Wp + (size_t)tile_n * nk * W_TILE_SLOTS + tid;
-  int py[MI], px[MI], cpt = 1;  // CONV: (y, x) of this thread's pixels, k-tiles per tap
+  int pyx[MI], cpt = 1;  // CONV: (y << 16 | x) of this thread's pixels, k-tiles per tap
   if (CONV) {
 #pragma unroll
     for (int p = 0; p < MI; ++p) {
-      const int pp = (m0 + lrow + 64 * p) % (cg.H * cg.W);
-      py[p] = pp / cg.W; px[p] = pp % cg.W;
+      const int pp = arow[p] % (cg.H * cg.W);
+      pyx[p] = ((pp / cg.W) << 16) | (pp % cg.W);
     }
     cpt = cg.C / BK;
   }
@@ -131,13 +138,13 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
       const int off = (dy * cg.W + dx) * cg.C;
 #pragma unroll
       for (int p = 0; p < MI; ++p) {
-        const bool ok = (unsigned)(py[p] + dy) < (unsigned)cg.H && (unsigned)(px[p] + dx) < (unsigned)cg.W;
-        const float4 v = *reinterpret_cast<const float4*>(Ag + (size_t)(64 * p) * cg.C + (ok ? off : 0) + c0);
+        const bool ok = (unsigned)((pyx[p] >> 16) + dy) < (unsigned)cg.H && (unsigned)((pyx[p] & 0xffff) + dx) < (unsigned)cg.W;
+        const float4 v = *reinterpret_cast<const float4*>(ap[p] + (ok ? off : 0) + c0);
         r.a[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < MI; ++p) r.a[p] = *reinterpret_cast<const float4*>(Ag + (size_t)(64 * p) * K + kt * BK);
+      for (int p = 0; p < MI; ++p) r.a[p] = *reinterpret_cast<const float4*>(ap[p] + kt * BK);
     }
     const uint4* w = Wg + (size_t)kt * W_TILE_SLOTS;
     r.b0 = w[0]; r.b1 = w[256]; r.b2 = w[512];
@@ -235,7 +242,9 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
       const int row = rr * 4 + (lane >> 4);
       const float* t = T + row * 65 + c4;
       float4 v = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
-      const size_t off = (size_t)(m0 + wm * (MI * 32) + i * 32 + h * 16 + row) * N + nb;
+      const int grow = m0 + wm * (MI * 32) + i * 32 + h * 16 + row;
+      if (grow >= M) continue;  // overhang of the last m-tile
+      const size_t off = (size_t)grow * N + nb;
       if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
       if (EPI == EPI_SCALE_RES) {
         const float4 rs = *reinterpret_cast<const float4*>(resid + off);
@@ -525,7 +534,7 @@ int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const f
     hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV, 4>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
     return gdrnpp::check_launch(what);
   }
-  const long blocks = (long)(M / BM) * (N / BN);
+  const long blocks = (long)((M + BM - 1) / BM) * (N / BN);
   GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "%s: grid too large", what);
   hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV, 2>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
   return gdrnpp::check_launch(what);
@@ -545,8 +554,8 @@ extern "C" int gdrnpp_linear_f32_split(const float* A, const void* W_packed, con
                                        const float* resid, float* C, int M, int N, int K, int epilogue,
                                        void* stream) {
   GDRNPP_REQUIRE(A && W_packed && C, GDRNPP_EINVAL, "gdrnpp_linear_f32_split: null pointer");
-  GDRNPP_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % 32 == 0, GDRNPP_ELIMIT,
-                 "gdrnpp_linear_f32_split: M=%d N=%d K=%d must be multiples of %d/%d/32", M, N, K, BM, BN);
+  GDRNPP_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % 32 == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_linear_f32_split: N=%d K=%d must be multiples of %d/32 (M=%d is free)", N, K, BN, M);
   GDRNPP_REQUIRE(epilogue >= 0 && epilogue <= 2, GDRNPP_EINVAL, "gdrnpp_linear_f32_split: epilogue=%d", epilogue);
   GDRNPP_REQUIRE(epilogue != EPI_SCALE_RES || (gamma && resid), GDRNPP_EINVAL,
                  "gdrnpp_linear_f32_split: scale+residual epilogue needs gamma and resid");
@@ -557,10 +566,11 @@ extern "C" int gdrnpp_linear_f32_split(const float* A, const void* W_packed, con
 extern "C" int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                                         int n_img, int H, int W, int Cin, int Cout, int epilogue, void* stream) {
   GDRNPP_REQUIRE(x_nhwc && W_packed && y_nhwc, GDRNPP_EINVAL, "gdrnpp_conv3x3_f32_split: null pointer");
-  GDRNPP_REQUIRE(n_img > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GDRNPP_EINVAL, "gdrnpp_conv3x3_f32_split: bad shape");
+  GDRNPP_REQUIRE(n_img > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && H < 32768 && W < 32768, GDRNPP_EINVAL,
+                 "gdrnpp_conv3x3_f32_split: bad shape");
   const long M = (long)n_img * H * W;
-  GDRNPP_REQUIRE(M % BM == 0 && M < (1l << 31) && Cout % BN == 0 && Cin % 32 == 0, GDRNPP_ELIMIT,
-                 "gdrnpp_conv3x3_f32_split: pixels=%ld Cout=%d Cin=%d must be multiples of %d/%d/32", M, Cout, Cin, BM, BN);
+  GDRNPP_REQUIRE(M < (1l << 31) && Cout % BN == 0 && Cin % 32 == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_conv3x3_f32_split: Cout=%d Cin=%d must be multiples of %d/32 (pixels=%ld is free)", Cout, Cin, BN, M);
   GDRNPP_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_GELU, GDRNPP_EINVAL, "gdrnpp_conv3x3_f32_split: epilogue=%d", epilogue);
   return launch_split<true>(x_nhwc, (const uint4*)W_packed, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, epilogue,
                             ConvGeom{H, W, Cin}, (hipStream_t)stream, "gdrnpp_conv3x3_f32_split");

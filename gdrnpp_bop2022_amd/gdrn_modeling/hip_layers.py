@@ -113,13 +113,13 @@ def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: 
     c = x_nhwc.shape[-1]
     m = x_nhwc.numel() // c
     ok = (_MLP_GEMM != "torch" and enabled_for(x_nhwc) and x_nhwc.is_contiguous() and shortcut_nhwc.is_contiguous()
-          and m % 128 == 0 and c % 128 == 0)
+          and c % 128 == 0)
     if ok and _MLP_GEMM == "split":
         h = hip_lib.linear_f32_split(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk"), mlp.fc1.bias, "gelu")
         y = hip_lib.linear_f32_split(h, _packed(mlp.fc2, cache, "fc2_pk"), mlp.fc2.bias, "scale_res", gamma,
                                      shortcut_nhwc.view(m, c))
         return y.view(x_nhwc.shape)
-    if ok and c <= _F32_FUSED_MAX_C:
+    if ok and c <= _F32_FUSED_MAX_C and m % 128 == 0:
         h = hip_lib.linear_f32(x_nhwc.view(m, c), mlp.fc1.weight, mlp.fc1.bias, "gelu")
         y = hip_lib.linear_f32(h, mlp.fc2.weight, mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
         return y.view(x_nhwc.shape)
@@ -141,7 +141,7 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     if (_CONV_SPLIT and _MLP_GEMM == "split" and isinstance(conv, nn.Conv2d) and enabled_for(x)
             and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
             and conv.groups == 1 and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0
-            and conv.out_channels % 128 == 0 and (x.shape[0] * x.shape[2] * x.shape[3]) % 128 == 0):
+            and conv.out_channels % 128 == 0):
         cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
         w = conv.weight
         tag = (w.data_ptr(), w._version, w.device)

@@ -280,7 +280,7 @@ int gdrnpp_linear_f32(const float* A, const float* W, const float* bias, const f
  * gdrnpp_pack_weight_bf16x3: W f32[N][K] (nn.Linear weight) -> bf16[N/128][K/16][3][2][128][8]: the three splits
  * (h | m | l) of every 128x16 tile in the order the kernel stages them (split, k-block of 8, row); 6*N*K bytes,
  * done once per weight.  gdrnpp_linear_f32_split: A stays fp32 and is split on the way into LDS.
- * M, N multiples of 128, K multiple of 32. */
+ * N multiple of 128, K multiple of 32; any M >= 1 (the last row tile is clamped on load and masked on store). */
 int gdrnpp_pack_weight_bf16x3(const float* W, void* packed, int N, int K, void* stream);
 int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* bias, const float* gamma,
                             const float* resid, float* C, int M, int N, int K, int epilogue,
@@ -289,7 +289,7 @@ int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* b
 /* 3x3 / stride 1 / zero-pad 1 convolution of the geometry head (a3) as an implicit GEMM on the same kernel:
  * x f32 NHWC [n_img,H,W,Cin] -> y f32 NHWC [n_img,H,W,Cout]; W_packed = gdrnpp_pack_weight_bf16x3 of the weight
  * reordered to [Cout][ky][kx][Cin] (N = Cout, K = 9*Cin); bias may be NULL; epilogue 0 = none, 1 = GELU.
- * n_img*H*W and Cout multiples of 128, Cin multiple of 32. */
+ * Cout multiple of 128, Cin multiple of 32; any n_img*H*W. */
 int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                              int n_img, int H, int W, int Cin, int Cout, int epilogue, void* stream);
 

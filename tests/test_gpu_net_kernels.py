@@ -154,8 +154,12 @@ def test_linear_f32_split_is_fp32_accurate(hip, m, k, n):
         e_f32 = max((got32.double() - want64).abs().max().item(), (chain.double() - want64).abs().max().item()) / scale
         assert e_split <= 1.25 * e_f32 + 1.2e-7, (epi, e_split, e_f32)
         assert ((out - got32).abs().max() / scale).item() < 4e-6, epi
-    with pytest.raises(RuntimeError, match="multiples"):
-        hip.linear_f32_split(torch.randn(100, k, device=DEV), pk, b)
+    with pytest.raises(RuntimeError, match="multiples"):   # K must be a multiple of 32 (M is free)
+        import ctypes
+        rc = hip.load().gdrnpp_linear_f32_split(x.data_ptr(), pk.data_ptr(), None, None, None, x.data_ptr(), m, n, k + 8, 0,
+                                                ctypes.c_void_p(0))
+        assert rc != 0
+        raise RuntimeError(hip.load().gdrnpp_last_error().decode())
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 256, 256, 32, 32), (8, 64, 128, 16, 16), (1, 32, 128, 8, 16), (4, 96, 256, 64, 64)])
@@ -232,3 +236,77 @@ def test_split_gemm_gelu_epilogue_matches_fp64_gelu(hip):
     ref32 = (F.gelu(pre).double() - want).abs()
     assert err.max().item() <= max(1.5 * ref32.max().item(), 6e-7), (err.max().item(), ref32.max().item())
     assert (err / pre.double().abs().clamp_min(1.0)).max().item() < 2.5e-7
+
+
+@pytest.mark.parametrize("m", [1, 7, 100, 129, 448, 257 * 3])
+def test_linear_f32_split_any_row_count(hip, m):
+    """ROI counts are arbitrary in production: rows that do not fill the last 128/256-row tile are clamped on load and
+    masked on store.  Result == the same rows computed inside a padded, tile-aligned problem (bitwise), and nothing is
+    written past row M (canary rows stay intact)."""
+    torch.manual_seed(m)
+    k, n = 256, 384
+    w = torch.randn(n, k, device=DEV) * (k ** -0.5)
+    b = torch.randn(n, device=DEV)
+    gamma = torch.randn(n, device=DEV)
+    pk = hip.pack_weight_bf16x3(w)
+    mp = (m + 255) // 256 * 256
+    xp = torch.randn(mp, k, device=DEV)
+    rp = torch.randn(mp, n, device=DEV)
+    for epi in ("none", "gelu", "scale_res"):
+        full = hip.linear_f32_split(xp, pk, b, epi, *( (gamma, rp) if epi == "scale_res" else ()))
+        part = hip.linear_f32_split(xp[:m].contiguous(), pk, b, epi, *((gamma, rp[:m].contiguous()) if epi == "scale_res" else ()))
+        assert part.shape == (m, n) and torch.equal(part, full[:m]), epi
+    # canary: the output buffer is exactly m rows inside a larger allocation
+    import ctypes
+    big = torch.full((m + 4, n), 777.0, device=DEV)
+    xs = xp[:m].contiguous()
+    rc = hip.load().gdrnpp_linear_f32_split(xs.data_ptr(), pk.data_ptr(), b.data_ptr(), None, None, big.data_ptr(), m, n, k, 0,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(big[m:], torch.full((4, n), 777.0, device=DEV))
+    assert torch.equal(big[:m], hip.linear_f32_split(xs, pk, b, "none"))
+
+
+def test_conv3x3_f32_split_any_pixel_count(hip):
+    """3 images of 5x7 pixels (105 rows, not a multiple of 128): same as PyTorch's convolution to fp32 noise."""
+    torch.manual_seed(2)
+    x = torch.randn(3, 64, 5, 7, device=DEV).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(128, 64, 3, 3, device=DEV) * 0.04
+    out = hip.conv3x3_f32_split(x, hip.pack_conv3x3_weight_bf16x3(wt), None)
+    ref = F.conv2d(x.double(), wt.double(), None, padding=1)
+    assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
+
+
+def test_model_forward_odd_roi_count(hip):
+    """B = 5 ROIs: every ConvNeXt stage and the head run through the split GEMM (stage 3 has 320 rows); maps and pose
+    agree with the PyTorch operators to 1e-4."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+    from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+
+    cfg = get_cfg("ycbv_convnext_a6", ["TEST.USE_DEPTH_REFINE=True"])
+    torch.manual_seed(1)
+    model, _ = build_model_optimizer(cfg)
+    with torch.no_grad():
+        model.pnp_net.fc_t.bias.copy_(torch.tensor([0.0, 0.0, 4.0]))
+    b = 5
+    x = torch.rand(b, 3, 256, 256, device=DEV)
+    K = torch.tensor([[1066.778, 0, 312.9869], [0, 1067.487, 241.3109], [0, 0, 1]], device=DEV).repeat(b, 1, 1)
+    args = dict(roi_classes=torch.randint(0, 21, (b,), device=DEV), roi_cams=K, roi_whs=torch.full((b, 2), 120.0, device=DEV),
+                roi_centers=torch.full((b, 2), 250.0, device=DEV), resize_ratios=torch.full((b,), 64 / 180.0, device=DEV),
+                roi_coord_2d=torch.rand(b, 2, 64, 64, device=DEV), roi_extents=torch.full((b, 3), 0.1, device=DEV))
+    timer = hip.LaunchTimer()
+    with torch.no_grad():
+        hip.set_launch_timer(timer)
+        try:
+            o1 = model(x, **args)
+        finally:
+            hip.set_launch_timer(None)
+        hip_layers.set_enabled(False)
+        o2 = model(x, **args)
+        hip_layers.set_enabled(True)
+    assert sum(1 for r in timer.records if r[0] == "linear") == 72 and sum(1 for r in timer.records if r[0] == "conv3x3") >= 4
+    for key in ("mask", "coor_x", "coor_y", "coor_z", "region"):
+        assert (o1[key] - o2[key]).abs().max().item() <= 1e-4 * max(o2[key].abs().max().item(), 1.0), key
+    torch.testing.assert_close(o1["rot"], o2["rot"], rtol=0, atol=1e-4)
+    torch.testing.assert_close(o1["trans"], o2["trans"], rtol=0, atol=1e-4)
