@@ -69,6 +69,7 @@ SIGNATURES = {
     "gdrnpp_debug_stream_read": (c_int, [_P, c_size_t, c_int, _P, c_int, _P]),
     "gdrnpp_crop_resize_roi": (
         c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "gdrnpp_flow_forward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gdrnpp_pack_pose_records": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "gdrnpp_dwconv7x7_ln_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "gdrnpp_layernorm_nhwc": (c_int, [_P, _P, _P, _P, c_long, c_int, c_float, _P]),
@@ -481,6 +482,17 @@ def conv3x3_f32_split(x_cl, weight_packed, bias, gelu: bool = False):
     _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split(*args), nbytes),
            "gdrnpp_conv3x3_f32_split")
     return out
+
+
+def flow_forward(depth_src, depth_tgt, KT, Kinv):
+    """depth f32[B,1,H,W] x2, KT f32[B,3,4], Kinv f32[B,3,3] (device) -> flow f32[B,2,H,W], valid f32[B,1,H,W]."""
+    b, _, h, w = depth_src.shape
+    flow = torch.empty((b, 2, h, w), dtype=torch.float32, device=depth_src.device)
+    valid = torch.empty((b, 1, h, w), dtype=torch.float32, device=depth_src.device)
+    _check(load().gdrnpp_flow_forward(_dev(depth_src, torch.float32, "depth_src"), _dev(depth_tgt, torch.float32, "depth_tgt"),
+                                      _dev(KT, torch.float32, "KT"), _dev(Kinv, torch.float32, "Kinv"), flow.data_ptr(),
+                                      valid.data_ptr(), b, h, w, _stream()), "gdrnpp_flow_forward")
+    return flow, valid
 
 
 def linear_f32(x2d, weight, bias, epilogue: str = "none", gamma=None, resid=None):

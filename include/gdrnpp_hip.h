@@ -293,6 +293,13 @@ int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* b
 int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                              int n_img, int H, int W, int Cin, int Cout, int epilogue, void* stream);
 
+/* ---- depth-to-flow (SURVEY §8b boundary "flow") — replaces the flow_cuda torch extension,
+ * core/csrc/flow/src/flow_cuda.cpp:30-47 (kernel flow_cuda_kernel.cu:33-64).
+ * depth_src, depth_tgt f32[B,1,H,W]; KT f32[B,3,4] = K [R|t] (source -> target); Kinv f32[B,3,3]
+ * -> flow f32[B,2,H,W] (channel 0 = dh, 1 = dw), valid f32[B,1,H,W]; both fully written. */
+int gdrnpp_flow_forward(const float* depth_src, const float* depth_tgt, const float* KT, const float* Kinv,
+                        float* flow, float* valid, int B, int H, int W, void* stream);
+
 /* ---- pose record packing for the RCCL all-gather (a13) -------------------
  * rec f32[b,16] = R(9) | t(3) | score | obj_id | roi_id | valid(1) */
 int gdrnpp_pack_pose_records(const float* R, const double* t_refined,

@@ -23,7 +23,7 @@ _REF_DIR = os.path.join(_HERE, "_ref")
 REFERENCE_ROOT = "/root/reference"
 
 _C_SOURCES = ["fps_oracle.c", "nnd_oracle.c", "ransac_voting_oracle.c", "upnp_oracle.c", "raster_oracle.c",
-              "warp_oracle.c", "roi_align_oracle.c"]
+              "warp_oracle.c", "roi_align_oracle.c", "flow_oracle.c"]
 
 
 def _newer(target: str, deps) -> bool:
@@ -80,6 +80,16 @@ def build_ref(force: bool = False) -> dict:
             sys.stderr.write("[oracle] ceres-header driver did not build (kept unpinned):\n" + r.stderr[-2000:])
     if os.path.exists(upnp_so):
         out["upnp"] = upnp_so
+
+    flow_so = os.path.join(_REF_DIR, "libflow_ref.so")
+    flow_src = os.path.join(REFERENCE_ROOT, "core/csrc/flow/src/flow_cpu.cpp")
+    flow_shim = os.path.join(_HERE, "ref_shims", "flow_ref_shim.cpp")
+    if os.path.exists(flow_src) and os.path.exists(flow_shim) and (force or not os.path.exists(flow_so)):
+        # flow_kernel<scalar_t>() is plain C++; ref_shims/torch/extension.h stands in for libtorch's header
+        subprocess.run(["g++", "-shared", "-fPIC", "-O2", "-std=c++14", "-I", os.path.join(_HERE, "ref_shims"),
+                        "-o", flow_so, flow_shim, "-DFLOW_SRC=\"%s\"" % flow_src], check=True)
+    if os.path.exists(flow_so):
+        out["flow"] = flow_so
     return out
 
 
@@ -95,7 +105,7 @@ def lib() -> ctypes.CDLL:
 
 def ref_lib(name: str):
     """ctypes handle on a compiled reference library, or None if it was never built."""
-    path = {"fps": "libfps_ref.so", "nnd": "libnnd_ref.so", "upnp": "libupnp_ref.so"}[name]
+    path = {"fps": "libfps_ref.so", "nnd": "libnnd_ref.so", "upnp": "libupnp_ref.so", "flow": "libflow_ref.so"}[name]
     path = os.path.join(_REF_DIR, path)
     if not os.path.exists(path):
         build_ref()

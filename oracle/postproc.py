@@ -456,6 +456,21 @@ def roi_align(x, rois, output_size, spatial_scale=1.0, sampling_ratio=0, aligned
     return out
 
 
+def flow_forward(depth_src, depth_tgt, KT, Kinv):
+    """Depth-to-flow (oracle/flow_oracle.c): depth f32[B,1,H,W] x2, KT f32[B,3,4], Kinv f32[B,3,3] -> flow f32[B,2,H,W],
+    valid f32[B,1,H,W] (core/csrc/flow/src/flow_cuda_kernel.cu:33-64)."""
+    ds = np.ascontiguousarray(depth_src, np.float32)
+    dt = np.ascontiguousarray(depth_tgt, np.float32)
+    kt = np.ascontiguousarray(KT, np.float32)
+    ki = np.ascontiguousarray(Kinv, np.float32)
+    b, _, h, w = ds.shape
+    flow = np.zeros((b, 2, h, w), np.float32)
+    valid = np.zeros((b, 1, h, w), np.float32)
+    _lib().oracle_flow_forward(_p(ds, _f32p), _p(dt, _f32p), _p(kt, _f32p), _p(ki, _f32p), _p(flow, _f32p), _p(valid, _f32p),
+                               b, h, w)
+    return flow, valid
+
+
 # ------------------------------------------------------------------------------------------
 # net-initialised iterative PnP (gdrn_evaluator.py:241-371, pnp_type="iter")
 # ------------------------------------------------------------------------------------------

@@ -8,6 +8,8 @@ outputs on seeded inputs:
   nnd_golden.npz   core/csrc/torch_nndistance/src/nnd_cpu.cpp (forward + backward)
   upnp_golden.npz  uncertainty_pnp.cpp:16-34 cost evaluated through the vendored ceres/jet.h +
                    ceres/rotation.h, and the optimum found by the vendored ceres::TinySolver
+  flow_golden.npz  core/csrc/flow/src/flow_cpu.cpp flow_kernel<float> (one image per call: the file's pointer bump
+                   makes batches > 1 meaningless)
 The fixtures travel to the GPU box; /root/reference does not.
 """
 import ctypes
@@ -29,9 +31,36 @@ def P(a, t):
     return a.ctypes.data_as(t)
 
 
+def make_flow_case(rng, h, w, motion):
+    """A smooth surface seen from two nearby poses: depth_src analytic, depth_tgt = z-buffer splat of the warped source
+    points (+ 1 mm noise, 5 % holes), so a large share of the pixels passes the reference's 3 mm consistency test."""
+    K = np.array([[572.4114 * w / 640, 0, 325.2611 * w / 640], [0, 573.57043 * h / 480, 242.04899 * h / 480], [0, 0, 1]])
+    yy, xx = np.mgrid[0:h, 0:w]
+    ds = (0.8 + 0.1 * np.sin(xx / 9.0) * np.cos(yy / 7.0)).astype(np.float32)
+    ds[rng.random((h, w)) < 0.05] = 0.0
+    ax = rng.standard_normal(3); ax /= np.linalg.norm(ax)
+    ang = motion * 0.5
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+    t = rng.standard_normal(3) * motion * 0.2
+    KT = (K @ np.concatenate([R, t[:, None]], 1)).astype(np.float32)[None]
+    Kinv = np.linalg.inv(K).astype(np.float32)[None]
+    pts = (np.linalg.inv(K) @ np.stack([xx.ravel(), yy.ravel(), np.ones(h * w)])) * ds.ravel()
+    pr = K @ (R @ pts + t[:, None])
+    dt = np.zeros((h, w), np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u, v = np.rint(pr[0] / pr[2]).astype(int), np.rint(pr[1] / pr[2]).astype(int)
+    ok = (ds.ravel() > 0) & (u >= 0) & (u < w) & (v >= 0) & (v < h)
+    for i in np.argsort(-pr[2]):   # far first, near overwrites
+        if ok[i]:
+            dt[v[i], u[i]] = pr[2, i]
+    dt += (rng.standard_normal((h, w)) * 1e-3).astype(np.float32) * (dt > 0)
+    return np.ascontiguousarray(ds[None, None]), np.ascontiguousarray(dt[None, None]), np.ascontiguousarray(KT), np.ascontiguousarray(Kinv)
+
+
 def main():
     libs = oracle.build_ref(force=True)
-    assert set(libs) == {"fps", "nnd", "upnp"}, libs
+    assert set(libs) == {"fps", "nnd", "upnp", "flow"}, libs
     rng = np.random.default_rng(20220925)
 
     # ---- FPS -------------------------------------------------------------------------
@@ -111,6 +140,18 @@ def main():
         out.update({f"lm_p2_{k}": p2, f"lm_p3_{k}": p3, f"lm_w_{k}": w, f"lm_init_{k}": init, f"lm_opt_{k}": res,
                     f"lm_gt_{k}": rt})
     np.savez_compressed(os.path.join(HERE, "upnp_golden.npz"), **out)
+
+    # ---- depth-to-flow ------------------------------------------------------------------
+    ref = ctypes.CDLL(libs["flow"])
+    out = {}
+    for k, (h, w, motion) in enumerate([(48, 64, 0.01), (60, 80, 0.05), (33, 47, 0.3)]):
+        ds, dt, KT, Kinv = make_flow_case(rng, h, w, motion)
+        flow = np.full((1, 2, h, w), np.nan, np.float32)
+        valid = np.full((1, 1, h, w), np.nan, np.float32)
+        ref.ref_flow_forward(P(ds, f32p), P(dt, f32p), P(KT, f32p), P(Kinv, f32p), P(flow, f32p), P(valid, f32p), 1, h, w)
+        assert np.isfinite(flow).all() and 0.05 < valid.mean() < 0.999, valid.mean()
+        out.update({f"ds{k}": ds, f"dt{k}": dt, f"KT{k}": KT, f"Kinv{k}": Kinv, f"flow{k}": flow, f"valid{k}": valid})
+    np.savez_compressed(os.path.join(HERE, "flow_golden.npz"), **out)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -387,3 +387,33 @@ def test_net_iter_pnp_from_correspondences(hip):
             err_pnp.append(np.linalg.norm(t[i] - det["t_gt"][i]))
     assert cnt[2] == 0 and np.array_equal(R[2], R_net[2]) and np.array_equal(t[2], t_net[2])
     assert np.median(err_pnp) < 0.5 * np.median(err_net)
+
+
+def test_flow_forward_bit_exact(hip, golden_dir):
+    """gdrnpp_flow_forward vs the oracle (and through it the reference's flow_cpu.cpp golden): flow and valid bit-exact,
+    single images and a mixed batch; plus the flow_torch shim (pose inputs)."""
+    import os
+    from oracle import postproc as P
+    g = np.load(os.path.join(golden_dir, "flow_golden.npz"))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    for k in range(3):
+        f, v = hip.flow_forward(T(g[f"ds{k}"]), T(g[f"dt{k}"]), T(g[f"KT{k}"]), T(g[f"Kinv{k}"]))
+        assert np.array_equal(f.cpu().numpy(), g[f"flow{k}"]) and np.array_equal(v.cpu().numpy(), g[f"valid{k}"])
+    rng = np.random.default_rng(3)
+    b, h, w = 5, 96, 128
+    yy, xx = np.mgrid[0:h, 0:w]
+    ds = np.stack([(0.7 + 0.05 * i + 0.1 * np.sin(xx / (9.0 + i)) * np.cos(yy / 7.0))[None] for i in range(b)]).astype(np.float32)
+    ds[rng.random(ds.shape) < 0.1] = 0
+    dt = (ds + rng.normal(0, 1.5e-3, ds.shape)).astype(np.float32)
+    K = np.array([[500.0, 0, 64], [0, 500.0, 48], [0, 0, 1]], np.float32)
+    KT = np.stack([K @ np.concatenate([np.eye(3, dtype=np.float32), rng.normal(0, 2e-3, (3, 1)).astype(np.float32)], 1) for _ in range(b)])
+    Kinv = np.stack([np.linalg.inv(K).astype(np.float32)] * b)
+    fo, vo = P.flow_forward(ds, dt, KT, Kinv)
+    f, v = hip.flow_forward(T(ds), T(dt), T(KT), T(Kinv))
+    assert np.array_equal(f.cpu().numpy(), fo) and np.array_equal(v.cpu().numpy(), vo) and 0.1 < vo.mean() < 0.95
+    from gdrnpp_bop2022_amd.core.csrc.flow.flow_torch import flow as flow_fn
+    pose = torch.eye(3, 4, device=DEV).repeat(b, 1, 1)
+    f2, v2 = flow_fn(T(ds), T(ds), pose, pose, T(np.stack([K] * b)))
+    # identity motion onto itself: valid wherever there is depth, except border pixels whose re-projection rounds outside
+    assert v2.shape == (b, 1, h, w) and not ((v2 > 0) & ~(T(ds) > 1e-3)).any() and v2.mean().item() > 0.85
+    assert f2.abs().max().item() < 1e-3

@@ -79,3 +79,29 @@ def test_upnp_exact_data_recovers_pose():
     w = np.tile([1.0, 0.0, 1.0], (8, 1))
     out = P.uncertainty_pnp(p2, p3, w, K, rt + rng.uniform(0, 0.1, 6))  # the reference's own demo (cpp:98-156)
     np.testing.assert_allclose(out, rt, atol=1e-6)
+
+
+def test_flow_oracle_matches_reference_golden(golden_dir):
+    """oracle/flow_oracle.c == the reference's flow_cpu.cpp (compiled unmodified, one image per call), bit for bit."""
+    g = np.load(os.path.join(golden_dir, "flow_golden.npz"))
+    k = 0
+    while f"ds{k}" in g:
+        flow, valid = P.flow_forward(g[f"ds{k}"], g[f"dt{k}"], g[f"KT{k}"], g[f"Kinv{k}"])
+        assert np.array_equal(flow, g[f"flow{k}"]) and np.array_equal(valid, g[f"valid{k}"])
+        assert 0.05 < valid.mean() < 0.999
+        k += 1
+    assert k == 3
+
+
+def test_flow_oracle_batches_are_per_image(golden_dir):
+    """Batch semantics of the CUDA kernel (Kinv/KT indexed per image): a stacked batch equals the images one by one."""
+    g = np.load(os.path.join(golden_dir, "flow_golden.npz"))
+    ds = np.concatenate([g["ds0"], g["ds0"][:, :, ::-1].copy()])
+    dt = np.concatenate([g["dt0"], g["dt0"][:, :, ::-1].copy()])
+    KT = np.concatenate([g["KT0"], g["KT0"] * np.float32(1.0)])
+    KT[1, :, 3] += np.float32(0.01)
+    Kinv = np.concatenate([g["Kinv0"], g["Kinv0"]])
+    fb, vb = P.flow_forward(ds, dt, KT, Kinv)
+    for i in range(2):
+        f1, v1 = P.flow_forward(ds[i:i + 1], dt[i:i + 1], KT[i:i + 1], Kinv[i:i + 1])
+        assert np.array_equal(fb[i:i + 1], f1) and np.array_equal(vb[i:i + 1], v1)
