@@ -196,6 +196,28 @@ def rois_from_detections(bboxes_xyxy, im_H: int, im_W: int, dzi_pad_scale: float
                 resize_ratio=(out_res / scale))
 
 
+def detections_from_yolox(dets: torch.Tensor, count: torch.Tensor, cam, extents, ratio: float = 1.0, max_per_image: int = 0) -> dict:
+    """Hand-off from the detector to the pose path without the JSON file of the reference (dataset_utils.py:146-239):
+    ``hip_lib.yolox_postprocess`` output (dets f32[B,max_det,7], count i32[B]) -> the ``detections`` dict of
+    ``batch_data_test_gpu``.  Boxes are divided by ``ratio`` (YOLOX's test-time resize, predictor_yolo.py:170-176), the
+    score is obj_conf * class_conf and the class column becomes ``roi_cls``; rows keep NMS order within an image."""
+    import numpy as np
+
+    counts = count.tolist()
+    rows, im_idx = [], []
+    for i, n in enumerate(counts):
+        n = min(n, dets.shape[1], max_per_image or n)
+        if n > 0:
+            rows.append(dets[i, :n])
+            im_idx += [i] * n
+    if not rows:
+        return dict(bbox=np.zeros((0, 4), np.float32), im_idx=np.zeros((0,), np.int64), roi_cls=np.zeros((0,), np.int64),
+                    score=np.zeros((0,), np.float32), cam=cam, extents=extents)
+    d = torch.cat(rows, 0).cpu().numpy()
+    return dict(bbox=d[:, :4] / np.float32(ratio), im_idx=np.asarray(im_idx, np.int64), roi_cls=d[:, 6].astype(np.int64),
+                score=d[:, 4] * d[:, 5], cam=cam, extents=extents)
+
+
 def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, device=None) -> dict:
     """``read_data_test`` + ``batch_data_test`` (data_loader.py:647-818, engine_utils.py:213-241) with the crops made
     on the GPU.  images u8[n_im,H,W,3] (BGR, device), depths f32[n_im,H,W] or None, detections:

@@ -69,6 +69,8 @@ SIGNATURES = {
     "gdrnpp_debug_stream_read": (c_int, [_P, c_size_t, c_int, _P, c_int, _P]),
     "gdrnpp_crop_resize_roi": (
         c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "gdrnpp_yolox_postprocess_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gdrnpp_yolox_postprocess": (c_int, [_P, c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, c_int, _P, c_size_t, _P]),
     "gdrnpp_flow_forward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gdrnpp_pack_pose_records": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "gdrnpp_dwconv7x7_ln_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
@@ -482,6 +484,24 @@ def conv3x3_f32_split(x_cl, weight_packed, bias, gelu: bool = False):
     _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split(*args), nbytes),
            "gdrnpp_conv3x3_f32_split")
     return out
+
+
+def yolox_postprocess(det_preds, num_classes: int, conf_thre: float = 0.7, nms_thre: float = 0.45, class_agnostic: bool = False,
+                      max_det: int = 0):
+    """det_preds f32[B,A,5+C] (device) -> (dets f32[B,max_det,7], count i32[B]); rows = (x1,y1,x2,y2,obj,class_conf,class)
+    in NMS keep order.  max_det = 0 sizes the output for every anchor."""
+    b, a, s = det_preds.shape
+    if s != 5 + num_classes:
+        raise ValueError(f"det_preds last dim {s} != 5 + num_classes {num_classes}")
+    max_det = max_det or a
+    dets = torch.zeros((b, max_det, 7), dtype=torch.float32, device=det_preds.device)
+    count = torch.zeros((b,), dtype=torch.int32, device=det_preds.device)
+    nbytes = load().gdrnpp_yolox_postprocess_workspace_bytes(b, a)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=det_preds.device)
+    _check(load().gdrnpp_yolox_postprocess(_dev(det_preds, torch.float32, "det_preds"), b, a, num_classes, float(conf_thre),
+                                           float(nms_thre), 1 if class_agnostic else 0, dets.data_ptr(), count.data_ptr(), max_det,
+                                           ws.data_ptr(), nbytes, _stream()), "gdrnpp_yolox_postprocess")
+    return dets, count
 
 
 def flow_forward(depth_src, depth_tgt, KT, Kinv):

@@ -300,6 +300,18 @@ int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const fl
 int gdrnpp_flow_forward(const float* depth_src, const float* depth_tgt, const float* KT, const float* Kinv,
                         float* flow, float* valid, int B, int H, int W, void* stream);
 
+/* ---- YOLOX detection post-processing — det/yolox/utils/boxes.py:34-74 (`postprocess`):
+ * (cx,cy,w,h) -> corners, class max / first argmax, obj*class_conf >= conf_thre, then torchvision.ops.batched_nms
+ * (class_agnostic = 0: boxes offset by class * (max_coordinate + 1)) or nms (class_agnostic = 1), restated.
+ * det_preds f32[B,A,5+C] (read only; the reference overwrites its first four columns in place)
+ * -> out_dets f32[B,max_det,7] = (x1,y1,x2,y2,obj_conf,class_conf,class) in keep order (descending score, ties by
+ * anchor index), out_count i32[B] = number kept (may exceed max_det: only the first max_det rows are written).
+ * A <= 16384.  workspace: gdrnpp_yolox_postprocess_workspace_bytes(B, A) bytes of device memory. */
+size_t gdrnpp_yolox_postprocess_workspace_bytes(int B, int A);
+int gdrnpp_yolox_postprocess(const float* det_preds, int B, int A, int C, float conf_thre, float nms_thre,
+                             int class_agnostic, float* out_dets, int* out_count, int max_det,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- pose record packing for the RCCL all-gather (a13) -------------------
  * rec f32[b,16] = R(9) | t(3) | score | obj_id | roi_id | valid(1) */
 int gdrnpp_pack_pose_records(const float* R, const double* t_refined,

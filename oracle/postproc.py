@@ -456,6 +456,21 @@ def roi_align(x, rois, output_size, spatial_scale=1.0, sampling_ratio=0, aligned
     return out
 
 
+def yolox_postprocess(det_preds, num_classes, conf_thre=0.7, nms_thre=0.45, class_agnostic=False):
+    """det/yolox/utils/boxes.py:34-74 restated (oracle/nms_oracle.c): det_preds f32[B,A,5+C] -> list of f32[n_i,7]
+    (x1, y1, x2, y2, obj_conf, class_conf, class) per image in NMS keep order (None when nothing survives)."""
+    det = np.ascontiguousarray(det_preds, np.float32)
+    b, a, s = det.shape
+    assert s == 5 + num_classes
+    outs = []
+    for i in range(b):
+        out = np.zeros((a, 7), np.float32)
+        n = _lib().oracle_yolox_postprocess(_p(det[i], _f32p), a, num_classes, ctypes.c_float(conf_thre), ctypes.c_float(nms_thre),
+                                            1 if class_agnostic else 0, _p(out, _f32p))
+        outs.append(out[:n].copy() if n else None)
+    return outs
+
+
 def flow_forward(depth_src, depth_tgt, KT, Kinv):
     """Depth-to-flow (oracle/flow_oracle.c): depth f32[B,1,H,W] x2, KT f32[B,3,4], Kinv f32[B,3,3] -> flow f32[B,2,H,W],
     valid f32[B,1,H,W] (core/csrc/flow/src/flow_cuda_kernel.cu:33-64)."""

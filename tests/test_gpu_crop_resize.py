@@ -89,3 +89,42 @@ def test_batch_data_test_gpu_end_to_end(hip):
         assert np.array_equal(batch["roi_img"][i].cpu().numpy(), o_img)
         assert np.array_equal(batch["roi_depth"][i].cpu().numpy(), o_dep)
         assert np.array_equal(batch["roi_coord_2d"][i].cpu().numpy(), o_c2d)
+
+
+def test_detector_output_to_pose_records_on_device(hip):
+    """YOLOX head output -> gdrnpp_yolox_postprocess -> detections -> GPU crops -> GDRN_Net -> refine -> records: the
+    whole detection-to-pose chain without a host-side NMS or a JSON hand-off."""
+    from gdrnpp_bop2022_amd import synthetic as S
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+    from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+    from gdrnpp_bop2022_amd.hip_lib import MeshSet
+
+    cfg = get_cfg("ycbv_convnext_a6", ["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"])
+    rng = np.random.default_rng(4)
+    n_im, a, c = 2, 8400, 21
+    det = np.zeros((n_im, a, 5 + c), np.float32)
+    det[..., 0] = rng.uniform(0, 640, (n_im, a)); det[..., 1] = rng.uniform(0, 480, (n_im, a))
+    det[..., 2:4] = rng.uniform(10, 60, (n_im, a, 2)); det[..., 4] = rng.uniform(0, 0.2, (n_im, a)); det[..., 5:] = rng.uniform(0, 0.5, (n_im, a, c))
+    true = [(0, 200, 150, 120, 90, 3), (0, 420, 300, 80, 140, 7), (1, 320, 240, 150, 150, 11)]
+    for k, (im, cx, cy, w, h, cl) in enumerate(true):       # three confident objects, each predicted by 4 jittered anchors
+        for j in range(4):
+            row = det[im, 100 * k + j]
+            row[:4] = (cx + j, cy - j, w + 2 * j, h - j); row[4] = 0.95 - 0.01 * j; row[5:] = 0.01; row[5 + cl] = 0.97
+    dets, count = hip.yolox_postprocess(torch.from_numpy(det).to(DEV), c, 0.5, 0.45)
+    assert count.tolist() == [2, 1]
+    verts, faces, ext = S.make_models(21, np.random.default_rng(20220925), 3)
+    d = engine.detections_from_yolox(dets, count, S.YCBV_K, ext.astype(np.float32))
+    assert sorted(d["roi_cls"].tolist()) == [3, 7, 11] and d["im_idx"].tolist() == [0, 0, 1]
+    images = rng.integers(0, 256, (n_im, 480, 640, 3), dtype=np.uint8)
+    depths = rng.uniform(0.4, 1.5, (n_im, 480, 640)).astype(np.float32)
+    batch = engine.batch_data_test_gpu(cfg, torch.from_numpy(images).to(DEV), torch.from_numpy(depths).to(DEV), d)
+    torch.manual_seed(0)
+    model, _ = build_model_optimizer(cfg)
+    with torch.no_grad():
+        model.pnp_net.fc_t.bias.copy_(torch.tensor([0.0, 0.0, 4.0]))
+    post = engine.GdrnHipPost(cfg, MeshSet(verts, faces))
+    rec = engine.inference_step(model, post, batch, torch.arange(3, dtype=torch.int32, device=DEV))
+    rec = rec.cpu().numpy()
+    assert rec.shape == (3, 16) and np.isfinite(rec).all()
+    assert rec[:, 14].astype(int).tolist() == [0, 1, 2] and (rec[:, 15] == 1).all() and (rec[:, 11] > 0.05).all()

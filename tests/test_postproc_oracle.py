@@ -180,3 +180,39 @@ def test_load_ply_ascii_and_binary(tmp_path):
     np.testing.assert_allclose(mb["pts"], v.astype(np.float64) * 0.001, rtol=1e-7)
     assert np.array_equal(ma["faces"], f) and ma["colors"].shape == (len(v), 3)
     assert len(mb["faces"]) == len(f) // 2 + 2 and np.array_equal(mb["faces"][-2:], [[0, 1, 2], [0, 2, 3]])
+
+
+def test_yolox_postprocess_oracle_matches_plain_numpy_nms():
+    """oracle/nms_oracle.c against an independent NumPy statement of the same rules on a small case (per-class NMS by
+    looping over classes instead of the coordinate-offset trick: identical keeps when boxes stay well inside the offset)."""
+    import numpy as np
+    from oracle import postproc as P
+    rng = np.random.default_rng(5)
+    a, c = 400, 6
+    det = np.zeros((1, a, 5 + c), np.float32)
+    det[0, :, 0:2] = rng.uniform(50, 500, (a, 2)); det[0, :, 2:4] = rng.uniform(20, 150, (a, 2))
+    det[0, :, 4] = rng.uniform(0, 1, a); det[0, :, 5:] = rng.uniform(0, 1, (a, c))
+    out = P.yolox_postprocess(det, c, 0.25, 0.45, False)[0]
+    x = det[0]
+    boxes = np.stack([x[:, 0] - x[:, 2] / 2, x[:, 1] - x[:, 3] / 2, x[:, 0] + x[:, 2] / 2, x[:, 1] + x[:, 3] / 2], 1).astype(np.float32)
+    cls = x[:, 5:].argmax(1); cc = x[:, 5:].max(1); score = (x[:, 4] * cc).astype(np.float32)
+    idx = np.where(score >= np.float32(0.25))[0]
+    order = idx[np.lexsort((idx, -score[idx]))]
+    keep = []
+    for i in order:
+        ok = True
+        for k in keep:
+            if cls[k] != cls[i]:
+                continue
+            xx1, yy1 = max(boxes[k, 0], boxes[i, 0]), max(boxes[k, 1], boxes[i, 1])
+            xx2, yy2 = min(boxes[k, 2], boxes[i, 2]), min(boxes[k, 3], boxes[i, 3])
+            inter = max(xx2 - xx1, 0) * max(yy2 - yy1, 0)
+            ak = (boxes[k, 2] - boxes[k, 0]) * (boxes[k, 3] - boxes[k, 1]); ai = (boxes[i, 2] - boxes[i, 0]) * (boxes[i, 3] - boxes[i, 1])
+            if inter / (ak + ai - inter) > 0.45 + 1e-4:
+                ok = False
+                break
+            assert not (abs(inter / (ak + ai - inter) - 0.45) < 1e-4), "test case too close to the threshold"
+        if ok:
+            keep.append(i)
+    assert len(out) == len(keep) and np.array_equal(out[:, 6].astype(int), cls[keep])
+    assert np.allclose(out[:, :4], boxes[keep], atol=0) and np.array_equal(out[:, 4], x[keep, 4])
