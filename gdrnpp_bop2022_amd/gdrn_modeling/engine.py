@@ -129,7 +129,8 @@ def gather_records(rec: torch.Tensor, n_local_max: int, group=None) -> torch.Ten
 
 
 def records_to_bop(rec: torch.Tensor, scene_im_ids, obj_ids, times=None):
-    """BOP result dicts as ``pose_prediction_to_json`` writes them (gdrn_evaluator.py:636-665): t in mm."""
+    """BOP result dicts as ``pose_prediction_to_json`` writes them (gdrn_evaluator.py:636-665): R flattened row-major
+    (``to_list(rot)``), t in mm."""
     rec = rec.detach().cpu()
     results = []
     for r in rec:
@@ -139,10 +140,28 @@ def records_to_bop(rec: torch.Tensor, scene_im_ids, obj_ids, times=None):
         scene_id, im_id = scene_im_ids[i].split("/")
         results.append({
             "scene_id": scene_id, "im_id": int(im_id), "obj_id": int(obj_ids[int(r[13])]), "score": float(r[12]),
-            "R": r[:9].reshape(3, 3).tolist(), "t": (1000.0 * r[9:12]).tolist(),
+            "R": r[:9].tolist(), "t": (1000.0 * r[9:12]).tolist(),
             "time": float(times[i]) if times is not None else -1.0,
         })
     return results
+
+
+BOP_CSV_HEADER = "scene_id,im_id,obj_id,score,R,t,time"
+
+
+def save_bop_csv(results, path: str) -> None:
+    """The BOP results file of ``save_and_eval_results`` (core/gdrn_modeling/engine/test_utils.py:33-52): one header line,
+    then one line per estimate with R (9 values) and t (3 values, mm) space-separated inside their comma fields, every
+    value formatted with ``"{}".format`` like the reference's ``_to_str``."""
+    keys = BOP_CSV_HEADER.split(",")
+
+    def to_str(item):
+        return " ".join("{}".format(e) for e in item) if isinstance(item, (list, tuple)) else "{}".format(item)
+
+    with open(path, "w") as f:
+        f.write(BOP_CSV_HEADER + "\n")
+        for res in results:
+            f.write(",".join(to_str(res[k]) for k in keys) + "\n")
 
 
 class GraphedInference:

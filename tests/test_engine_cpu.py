@@ -121,3 +121,28 @@ def test_rois_from_detections_rules():
     np.testing.assert_allclose(r["scale"], [300.0, 640.0, 1.5])          # 200*1.5, clipped to max(H,W), bw/bh >= 1
     np.testing.assert_allclose(r["roi_wh"], [[80, 200], [639.5, 479], [1, 1]])
     np.testing.assert_allclose(r["resize_ratio"], 64 / r["scale"])
+
+
+def test_records_to_bop_and_csv_format(tmp_path):
+    """Pose records -> BOP dicts (R flattened row-major, t in mm, invalid rows dropped) -> the CSV layout of
+    save_and_eval_results (test_utils.py:33-52)."""
+    import numpy as np
+    import torch
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+
+    rec = torch.zeros(3, 16)
+    rec[0, :9] = torch.arange(9, dtype=torch.float32) * 0.125
+    rec[0, 9:12] = torch.tensor([0.01, -0.02, 0.75]); rec[0, 12] = 0.5; rec[0, 13] = 2; rec[0, 14] = 1; rec[0, 15] = 1
+    rec[1, 15] = 0                                     # padding row
+    rec[2, :9] = torch.eye(3).reshape(9); rec[2, 9:12] = torch.tensor([0.0, 0.0, 1.0]); rec[2, 12] = 1.0; rec[2, 13] = 0
+    rec[2, 14] = 0; rec[2, 15] = 1
+    res = engine.records_to_bop(rec, ["48/1", "50/17"], obj_ids=[1, 5, 9], times=[0.25, 0.5])
+    assert len(res) == 2 and res[0]["scene_id"] == "50" and res[0]["im_id"] == 17 and res[0]["obj_id"] == 9
+    assert res[0]["R"] == [i * 0.125 for i in range(9)] and res[0]["time"] == 0.5
+    assert np.allclose(res[0]["t"], [10.0, -20.0, 750.0]) and res[1]["t"] == [0.0, 0.0, 1000.0]
+    path = tmp_path / "out.csv"
+    engine.save_bop_csv(res, str(path))
+    lines = path.read_text().splitlines()
+    assert lines[0] == "scene_id,im_id,obj_id,score,R,t,time" and len(lines) == 3
+    f = lines[2].split(",")
+    assert f[:4] == ["48", "1", "1", "1.0"] and f[4] == "1.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 1.0" and f[5] == "0.0 0.0 1000.0" and f[6] == "0.25"
