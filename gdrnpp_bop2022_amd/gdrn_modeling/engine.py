@@ -146,6 +146,33 @@ def records_to_bop(rec: torch.Tensor, scene_im_ids, obj_ids, times=None):
     return results
 
 
+def mask_rles(cfg, batch: dict, out_dict: dict, key: str = "mask", compressed: bool = True) -> list:
+    """SAVE_RESULTS_ONLY instance masks (gdrn_evaluator.py:914-945): ``get_out_mask`` (engine_utils.py:315-333) on the raw
+    ``out_dict[key]`` maps, boxes = roi_center -/+ scale/2, then paste + threshold + COCO RLE fused on the device
+    (``gdrnpp_paste_masks_rle``).  Returns one ``{"counts", "size"}`` dict per ROI like ``binary_mask_to_rle``."""
+    from ..lib.utils.mask_utils import rle_from_counts
+
+    net_cfg = cfg.MODEL.POSE_NET
+    raw = out_dict[key]
+    loss_type = net_cfg.LOSS_CFG.MASK_LOSS_TYPE
+    bs = raw.shape[0]
+    if loss_type == "L1":                     # per-ROI (m - min) / (max - min), no epsilon (reference behaviour)
+        flat = raw.reshape(bs, -1)
+        mn, mx = flat.min(1).values.view(bs, 1, 1, 1), flat.max(1).values.view(bs, 1, 1, 1)
+        prob = (raw - mn) / (mx - mn)
+    elif loss_type in ("BCE", "RW_BCE", "dice"):
+        prob = torch.sigmoid(raw)
+    elif loss_type == "CE":
+        prob = torch.argmax(raw, dim=1, keepdim=True).to(torch.float32)
+    else:
+        raise NotImplementedError(f"unknown mask loss type: {loss_type}")
+    scale = batch["scale"].view(bs, 1).to(torch.float32)
+    boxes = torch.cat([batch["roi_center"] - scale / 2, batch["roi_center"] + scale / 2], 1).contiguous()
+    im_h, im_w = int(batch["im_H"][0]), int(batch["im_W"][0])
+    counts = hip_lib.paste_masks_rle(prob[:, 0].contiguous(), boxes, im_h, im_w, float(net_cfg.GEO_HEAD.MASK_THR_TEST))
+    return [rle_from_counts(c, im_h, im_w, compressed) for c in counts]
+
+
 BOP_CSV_HEADER = "scene_id,im_id,obj_id,score,R,t,time"
 
 

@@ -71,6 +71,7 @@ SIGNATURES = {
         c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "gdrnpp_yolox_postprocess_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gdrnpp_yolox_postprocess": (c_int, [_P, c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, c_int, _P, c_size_t, _P]),
+    "gdrnpp_paste_masks_rle": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, _P]),
     "gdrnpp_flow_forward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gdrnpp_pack_pose_records": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "gdrnpp_dwconv7x7_ln_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
@@ -502,6 +503,23 @@ def yolox_postprocess(det_preds, num_classes: int, conf_thre: float = 0.7, nms_t
                                            float(nms_thre), 1 if class_agnostic else 0, dets.data_ptr(), count.data_ptr(), max_det,
                                            ws.data_ptr(), nbytes, _stream()), "gdrnpp_yolox_postprocess")
     return dets, count
+
+
+def paste_masks_rle(mask_probs, boxes_xyxy, im_h: int, im_w: int, threshold: float = 0.5, max_runs: int = 4096):
+    """mask_probs f32[B,hm,wm], boxes f32[B,4] (device) -> list of B uncompressed COCO count lists (column-major, first
+    run = zeros).  The launch is repeated with a larger buffer if an instance needs more than ``max_runs`` runs."""
+    b, hm, wm = mask_probs.shape
+    while True:
+        counts = torch.empty((b, max_runs), dtype=torch.int32, device=mask_probs.device)
+        n_runs = torch.empty((b,), dtype=torch.int32, device=mask_probs.device)
+        _check(load().gdrnpp_paste_masks_rle(_dev(mask_probs, torch.float32, "mask_probs"), _dev(boxes_xyxy, torch.float32, "boxes"),
+                                             b, hm, wm, im_h, im_w, float(threshold), counts.data_ptr(), n_runs.data_ptr(), max_runs,
+                                             _stream()), "gdrnpp_paste_masks_rle")
+        n = n_runs.tolist()
+        if max(n) <= max_runs:
+            c = counts.cpu().numpy().view("uint32")
+            return [c[i, :n[i]].astype("int64").tolist() for i in range(b)]
+        max_runs = max(n)
 
 
 def flow_forward(depth_src, depth_tgt, KT, Kinv):

@@ -312,6 +312,16 @@ int gdrnpp_yolox_postprocess(const float* det_preds, int B, int A, int C, float 
                              int class_agnostic, float* out_dets, int* out_count, int max_det,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- instance masks for SAVE_RESULTS_ONLY — gdrn_evaluator.py:914-945:
+ * detectron2 paste_masks_in_image(mask_probs, boxes, (im_H, im_W), threshold) + the uncompressed COCO run-length
+ * encoding of lib/utils/mask_utils.py:96-109, fused: the full-size masks are never materialised.
+ * mask_probs f32[B,mask_h,mask_w]; boxes_xyxy f32[B,4] (x0,y0,x1,y1 = roi_center -/+ scale/2)
+ * -> counts u32[B,max_runs] (column-major runs, the first run counts zeros), n_runs i32[B] (> max_runs = overflow:
+ * re-run with a larger max_runs; im_H*im_W+1 always suffices). */
+int gdrnpp_paste_masks_rle(const float* mask_probs, const float* boxes_xyxy, int B, int mask_h, int mask_w,
+                           int im_H, int im_W, float threshold, unsigned* counts, int* n_runs, int max_runs,
+                           void* stream);
+
 /* ---- pose record packing for the RCCL all-gather (a13) -------------------
  * rec f32[b,16] = R(9) | t(3) | score | obj_id | roi_id | valid(1) */
 int gdrnpp_pack_pose_records(const float* R, const double* t_refined,

@@ -23,7 +23,7 @@ _REF_DIR = os.path.join(_HERE, "_ref")
 REFERENCE_ROOT = "/root/reference"
 
 _C_SOURCES = ["fps_oracle.c", "nnd_oracle.c", "ransac_voting_oracle.c", "upnp_oracle.c", "raster_oracle.c",
-              "warp_oracle.c", "roi_align_oracle.c", "flow_oracle.c", "nms_oracle.c"]
+              "warp_oracle.c", "roi_align_oracle.c", "flow_oracle.c", "nms_oracle.c", "mask_rle_oracle.c"]
 
 
 def _newer(target: str, deps) -> bool:

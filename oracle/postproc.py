@@ -471,6 +471,22 @@ def yolox_postprocess(det_preds, num_classes, conf_thre=0.7, nms_thre=0.45, clas
     return outs
 
 
+def paste_mask_rle(mask_prob, box_xyxy, im_h, im_w, threshold=0.5, want_binary=False):
+    """One instance of gdrn_evaluator.py:914-945 (oracle/mask_rle_oracle.c): mask f32[hm,wm], box (x0,y0,x1,y1) ->
+    uncompressed COCO counts (list of int, column-major, first run = zeros) [+ the pasted binary mask u8[H,W]]."""
+    m = np.ascontiguousarray(mask_prob, np.float32)
+    box = np.ascontiguousarray(box_xyxy, np.float32).reshape(4)
+    cap = im_h * im_w + 1
+    counts = np.zeros(cap, np.uint32)
+    binary = np.zeros((im_h, im_w), np.uint8) if want_binary else None
+    n = _lib().oracle_paste_mask_rle(_p(m, _f32p), m.shape[0], m.shape[1], _p(box, _f32p), im_h, im_w, ctypes.c_float(threshold),
+                                     binary.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)) if want_binary else None,
+                                     counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint)), cap)
+    assert n > 0
+    out = counts[:n].astype(np.int64).tolist()
+    return (out, binary) if want_binary else out
+
+
 def flow_forward(depth_src, depth_tgt, KT, Kinv):
     """Depth-to-flow (oracle/flow_oracle.c): depth f32[B,1,H,W] x2, KT f32[B,3,4], Kinv f32[B,3,3] -> flow f32[B,2,H,W],
     valid f32[B,1,H,W] (core/csrc/flow/src/flow_cuda_kernel.cu:33-64)."""

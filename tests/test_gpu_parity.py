@@ -447,3 +447,33 @@ def test_yolox_postprocess_bit_exact(hip, conf, agnostic):
             n_tot += len(w)
     if conf < 0.9:
         assert n_tot > 50
+
+
+def test_paste_masks_rle_bit_exact(hip):
+    """gdrnpp_paste_masks_rle vs the oracle: identical COCO run lengths per instance (boxes inside, partly outside and
+    tiny; an empty and a full mask; a buffer that is too small and gets re-run), and the evaluator-side helper."""
+    from oracle import postproc as P
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+    from gdrnpp_bop2022_amd.lib.utils import mask_utils as M
+    rng = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:64, 0:64]
+    H, W = 480, 640
+    boxes = np.array([[100.3, 50.7, 260.9, 200.2], [-40.0, 300.0, 120.0, 520.0], [500.0, 100.0, 700.0, 300.0], [320.2, 240.1, 326.9, 249.7],
+                      [10.0, 10.0, 200.0, 200.0], [10.0, 10.0, 200.0, 200.0]], np.float32)
+    masks = np.stack([(np.clip(1.4 - np.hypot(yy - 31.5 + k, xx - 31.5) / (12.0 + 2 * k), 0, 1) * 0.9 + 0.1 * rng.random((64, 64))) for k in range(6)]).astype(np.float32)
+    masks[4] = 0.0
+    masks[5] = 1.0
+    got = hip.paste_masks_rle(torch.from_numpy(masks).to(DEV), torch.from_numpy(boxes).to(DEV), H, W, 0.5, max_runs=64)
+    for i in range(6):
+        want = P.paste_mask_rle(masks[i], boxes[i], H, W, 0.5)
+        assert got[i] == want, i
+    assert got[4] == [H * W] and len(got[5]) > 100
+    cfg = get_cfg("ycbv_convnext_a6", [])
+    raw = torch.from_numpy(masks[:4, None] * 3.0 - 1.0).to(DEV)          # un-normalised L1 maps
+    centre = torch.from_numpy((boxes[:4, :2] + boxes[:4, 2:]) / 2).to(DEV)
+    scale = torch.from_numpy(boxes[:4, 2] - boxes[:4, 0]).to(DEV)
+    batch = dict(roi_center=centre, scale=scale, im_H=torch.full((4,), H), im_W=torch.full((4,), W))
+    rles = engine.mask_rles(cfg, batch, {"mask": raw})
+    assert len(rles) == 4 and all(r["size"] == [H, W] and isinstance(r["counts"], str) for r in rles)
+    assert 0 < M.rle_to_binary_mask(rles[0]).sum() < H * W

@@ -216,3 +216,36 @@ def test_yolox_postprocess_oracle_matches_plain_numpy_nms():
             keep.append(i)
     assert len(out) == len(keep) and np.array_equal(out[:, 6].astype(int), cls[keep])
     assert np.allclose(out[:, :4], boxes[keep], atol=0) and np.array_equal(out[:, 4], x[keep, 4])
+
+
+def test_paste_mask_oracle_matches_torch_grid_sample():
+    """oracle/mask_rle_oracle.c against detectron2's `_do_paste_mask` restated with torch's own F.grid_sample (CPU):
+    identical binary masks (no pixel within 1e-6 of the threshold in these cases), run lengths sum to H*W and decode back."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle import postproc as P
+    from gdrnpp_bop2022_amd.lib.utils import mask_utils as M
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:64, 0:64]
+    H, W = 120, 160
+    for k, box in enumerate([(30.3, 20.7, 110.9, 90.2), (-20.5, 40.0, 60.0, 130.5), (100.0, 5.0, 170.0, 60.0), (70.2, 50.1, 75.9, 58.7)]):
+        m = (np.clip(1.4 - np.hypot(yy - 31.5 + 3 * k, xx - 31.5) / (12.0 + 3 * k), 0, 1) * 0.9 + 0.1 * rng.random((64, 64))).astype(np.float32)
+        counts, binary = P.paste_mask_rle(m, box, H, W, 0.5, True)
+        x0, y0, x1, y1 = [torch.tensor([[v]], dtype=torch.float32) for v in box]
+        img_y = (torch.arange(0, H, dtype=torch.float32) + 0.5 - y0) / (y1 - y0) * 2 - 1
+        img_x = (torch.arange(0, W, dtype=torch.float32) + 0.5 - x0) / (x1 - x0) * 2 - 1
+        grid = torch.stack([img_x[:, None, :].expand(1, H, W), img_y[:, :, None].expand(1, H, W)], 3)
+        val = F.grid_sample(torch.from_numpy(m)[None, None], grid, align_corners=False)[0, 0].numpy()
+        assert (np.abs(val - 0.5) < 1e-6).sum() == 0
+        assert np.array_equal(binary, (val >= 0.5).astype(np.uint8))
+        assert sum(counts) == H * W and binary.sum() > 0
+        rle = M.rle_from_counts(counts, H, W)
+        assert np.array_equal(M.rle_to_binary_mask(rle), binary)
+
+
+def test_coco_rle_string_codec():
+    from gdrnpp_bop2022_amd.lib.utils import mask_utils as M
+    assert M.rle_counts_to_string([307200]) == "PP\\9"          # pycocotools' encoding of an empty 480x640 mask
+    for counts in ([10, 3, 7], [0, 5, 100000, 2, 3, 40, 1], [5, 1, 5, 1, 5, 1, 700, 33, 2], [1, 1, 1, 1, 1, 1, 1, 1, 1, 1]):
+        assert M.rle_string_to_counts(M.rle_counts_to_string(counts)) == counts
