@@ -146,6 +146,34 @@ def records_to_bop(rec: torch.Tensor, scene_im_ids, obj_ids, times=None):
     return results
 
 
+def render_roi_xyz_batch(meshes: hip_lib.MeshSet, roi_cls, ego_rot, trans, roi_zoom_K, out_res: int = 64, xyz_bp: bool = False,
+                         z_near: float = 0.25, z_far: float = 6.0):
+    """Online XYZ targets of the training-side ``batch_data`` (engine_utils.py:131-172) in ONE launch instead of a Python
+    loop of GL renders + CUDA-GL copies: object-space surface points per ROI pixel (``pc_obj_tensor[:, :, :3]``) or, with
+    ``xyz_bp`` (``XYZ_BP``), the rendered depth back-projected through ``calc_xyz_bp_batch`` (lib/pysixd/misc.py:412-448;
+    integer pixel coordinates like the reference).  Returns (roi_xyz f32[bs,res,res,3], roi_mask_obj f32[bs,res,res]):
+    the mask is the reference's "all three coordinates non-zero" test.  z_near / z_far default to the EGL renderer's."""
+    bs = ego_rot.shape[0]
+    dev = ego_rot.device
+    out = hip_lib.render_depth(meshes, roi_cls.to(torch.int32).contiguous(), roi_zoom_K.reshape(bs, 3, 3).contiguous().float(),
+                               ego_rot.contiguous().float(), trans.contiguous().float(), out_res, z_near, z_far,
+                               want_xyz=not xyz_bp)
+    depth, xyz = (out, None) if xyz_bp else out
+    if xyz_bp:
+        K = roi_zoom_K.reshape(bs, 3, 3).float()
+        gy, gx = torch.meshgrid(torch.arange(out_res, device=dev, dtype=torch.float32),
+                                torch.arange(out_res, device=dev, dtype=torch.float32), indexing="ij")
+        X = gx.expand(bs, out_res, out_res) - K[:, 0, 2].view(bs, 1, 1)
+        Y = gy.expand(bs, out_res, out_res) - K[:, 1, 2].view(bs, 1, 1)
+        cam = torch.stack((X * depth / K[:, 0, 0].view(bs, 1, 1), Y * depth / K[:, 1, 1].view(bs, 1, 1), depth), dim=-1)
+        mask = (depth != 0).to(depth).unsqueeze(-1)
+        roi_xyz = torch.einsum("bij,bhwj->bhwi", ego_rot.transpose(1, 2).float(), cam - trans.view(bs, 1, 1, 3).float()) * mask
+    else:
+        roi_xyz = xyz
+    roi_mask_obj = ((roi_xyz[..., 0] != 0) & (roi_xyz[..., 1] != 0) & (roi_xyz[..., 2] != 0)).to(torch.float32)
+    return roi_xyz, roi_mask_obj
+
+
 def mask_rles(cfg, batch: dict, out_dict: dict, key: str = "mask", compressed: bool = True) -> list:
     """SAVE_RESULTS_ONLY instance masks (gdrn_evaluator.py:914-945): ``get_out_mask`` (engine_utils.py:315-333) on the raw
     ``out_dict[key]`` maps, boxes = roi_center -/+ scale/2, then paste + threshold + COCO RLE fused on the device

@@ -152,3 +152,29 @@ def test_hipgraph_replay_equals_eager(hip):
         torch.cuda.synchronize()
         torch.testing.assert_close(r_graph, r_eager, rtol=0, atol=1e-4)
         assert torch.equal(r_graph[:, 12:], r_eager[:, 12:])  # score / obj / roi id / valid are exact
+
+
+def test_online_xyz_targets_one_launch(hip):
+    """engine.render_roi_xyz_batch (training-side online XYZ of engine_utils.py:131-172): object-space points lie on the
+    ellipsoid surface, the object mask is the reference's non-zero test, and the XYZ_BP variant (depth back-projection
+    with integer pixel coordinates) agrees with the direct render up to its half-pixel convention."""
+    from gdrnpp_bop2022_amd import synthetic as S
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+    from gdrnpp_bop2022_amd.hip_lib import MeshSet
+    rng = np.random.default_rng(2)
+    verts, faces, ext = S.make_models(5, np.random.default_rng(20220925), 4)
+    meshes = MeshSet(verts, faces)
+    det = S.make_detections(8, 5, ext, rng)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    K_crop = S.zoom_K_np(det["roi_cam"], det["roi_center"], det["scale"], 64).astype(np.float32)
+    cls = T(det["roi_cls"].astype(np.int64))
+    R, t = T(det["R_gt"].astype(np.float32)), T(det["t_gt"].astype(np.float32))
+    xyz, m = engine.render_roi_xyz_batch(meshes, cls, R, t, T(K_crop), 64)
+    assert xyz.shape == (8, 64, 64, 3) and m.shape == (8, 64, 64) and 0.05 < m.mean().item() < 0.9
+    half = T((ext[det["roi_cls"]] / 2).astype(np.float32)).view(8, 1, 1, 3)
+    q = ((xyz / half) ** 2).sum(-1)
+    assert ((q - 1).abs()[m > 0] < 0.02).all()            # icosphere facets sit slightly inside the ellipsoid
+    xyz_bp, m_bp = engine.render_roi_xyz_batch(meshes, cls, R, t, T(K_crop), 64, xyz_bp=True)
+    both = (m > 0) & (m_bp > 0)
+    assert (m - m_bp).abs().mean().item() < 0.01
+    assert ((xyz - xyz_bp).abs()[both].mean() / half.mean()).item() < 0.05
