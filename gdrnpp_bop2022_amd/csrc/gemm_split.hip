@@ -79,7 +79,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, uint4* __restric
 
 // CONV: A is an NHWC image [.,H,W,Cin] and the GEMM row m = output pixel, k = (tap, channel) of a 3x3 / stride 1 /
 // zero-pad 1 convolution (implicit im2col: the k-tile's 16 channels of one tap are 64 contiguous bytes per pixel).
-struct ConvGeom { int H, W, C; };
+struct ConvGeom { int H, W, C; int nk_split; };  // nk_split > 0: split-K, blockIdx.y-th chunk of nk_split k-tiles -> partial C
 
 // MI = 32-row MFMA tiles per wave along M: 2 -> 128x128 block tile (three workgroups per CU), 4 -> 256x128 block tile
 // (each wave 128x64: 18 fragment reads feed 48 MFMAs per k-tile and per barrier, two workgroups per CU).
@@ -106,7 +106,12 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
   const int tile_m = tile / ntn, tile_n = tile % ntn;
   const int m0 = tile_m * BMT, n0 = tile_n * BN;  // the last m-tile may hang over M: its loads are clamped to row
                                                    // M-1 and its stores masked, so any M >= 1 is accepted
-  const int nk = K / BK;
+  // split-K (skinny problems: few rows, long K): workgroup (x, y) accumulates k-tiles [y*nk, (y+1)*nk) into its own
+  // partial result C + y*M*N; gdrnpp_linear_f32_splitk sums the partials and applies the bias afterwards
+  const int nk_total = K / BK;
+  const int nk = cg.nk_split > 0 ? cg.nk_split : nk_total;
+  const int kt0 = cg.nk_split > 0 ? (int)blockIdx.y * nk : 0;
+  if (cg.nk_split > 0) C += (size_t)blockIdx.y * M * N;
 
   // A staging: rows tid/4 + 64*p (p < MI), lane%4 picks 4 consecutive k (half a k-block)
   const int lrow = tid >> 2, lkq = tid & 3;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
     arow[p] = min(m0 + lrow + 64 * p, M - 1);
     ap[p] = A + (size_t)arow[p] * (CONV ? cg.C : K) + lkq * 4;
   }
-  const uint4* Wg = Wp + (size_t)tile_n * nk * W_TILE_SLOTS + tid;
+  const uint4* Wg = Wp + ((size_t)tile_n * nk_total + kt0) * W_TILE_SLOTS + tid;
   int pyx[MI], cpt = 1;  // CONV: (y << 16 | x) of this thread's pixels, k-tiles per tap
   if (CONV) {
 #pragma unroll
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < MI; ++p) r.a[p] = *reinterpret_cast<const float4*>(ap[p] + kt * BK);
+      for (int p = 0; p < MI; ++p) r.a[p] = *reinterpret_cast<const float4*>(ap[p] + (kt0 + kt) * BK);
     }
     const uint4* w = Wg + (size_t)kt * W_TILE_SLOTS;
     r.b0 = w[0]; r.b1 = w[256]; r.b2 = w[512];
@@ -550,6 +555,53 @@ int launch_split(const float* A, const uint4* Wp, const float* bias, const float
 
 }  // namespace
 
+namespace {
+
+// out[m][n] = bias[n] + sum over s of part[s][m][n]   (fixed order: deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+                                     long mn4, int N, int splits) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= mn4) return;
+  const int n = (int)((i * 4) % N);
+  float4 acc = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < splits; ++s) {
+    const float4 v = reinterpret_cast<const float4*>(part)[(size_t)s * mn4 + i];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = acc;
+}
+
+}  // namespace
+
+extern "C" size_t gdrnpp_linear_f32_splitk_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 0;
+  int nkc = 8;                                   // k-tiles (of 16) per workgroup: 128 k per split
+  while ((K / BK) % nkc) nkc >>= 1;              // nk_total is even, so this stops at >= 2
+  return (size_t)((K / BK) / nkc) * M * N * sizeof(float);
+}
+
+extern "C" int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, const float* bias, float* C, int M, int N,
+                                        int K, void* workspace, size_t workspace_bytes, void* stream) {
+  GDRNPP_REQUIRE(A && W_packed && C && workspace, GDRNPP_EINVAL, "gdrnpp_linear_f32_splitk: null pointer");
+  GDRNPP_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % 32 == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_linear_f32_splitk: N=%d K=%d must be multiples of %d/32 (M=%d is free)", N, K, BN, M);
+  GDRNPP_REQUIRE(workspace_bytes >= gdrnpp_linear_f32_splitk_workspace_bytes(M, N, K), GDRNPP_EINVAL,
+                 "gdrnpp_linear_f32_splitk: workspace too small");
+  int nkc = 8;
+  while ((K / BK) % nkc) nkc >>= 1;
+  const int splits = (K / BK) / nkc;
+  const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
+  GDRNPP_REQUIRE(tiles < 65536 && splits < 65536, GDRNPP_ELIMIT, "gdrnpp_linear_f32_splitk: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((gemm_split_kernel<EPI_BIAS, false, 2>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st, A,
+                     (const uint4*)W_packed, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (float*)workspace, M, N, K, ConvGeom{0, 0, 0, nkc});
+  const long mn4 = (long)M * N / 4;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, st, (const float*)workspace, bias, C,
+                     mn4, N, splits);
+  return gdrnpp::check_launch("gdrnpp_linear_f32_splitk");
+}
+
 extern "C" int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* bias, const float* gamma,
                                        const float* resid, float* C, int M, int N, int K, int epilogue,
                                        void* stream) {
@@ -559,7 +611,7 @@ extern "C" int gdrnpp_linear_f32_split(const float* A, const void* W_packed, con
   GDRNPP_REQUIRE(epilogue >= 0 && epilogue <= 2, GDRNPP_EINVAL, "gdrnpp_linear_f32_split: epilogue=%d", epilogue);
   GDRNPP_REQUIRE(epilogue != EPI_SCALE_RES || (gamma && resid), GDRNPP_EINVAL,
                  "gdrnpp_linear_f32_split: scale+residual epilogue needs gamma and resid");
-  return launch_split<false>(A, (const uint4*)W_packed, bias, gamma, resid, C, M, N, K, epilogue, ConvGeom{0, 0, 0},
+  return launch_split<false>(A, (const uint4*)W_packed, bias, gamma, resid, C, M, N, K, epilogue, ConvGeom{0, 0, 0, 0},
                              (hipStream_t)stream, "gdrnpp_linear_f32_split");
 }
 
@@ -573,5 +625,5 @@ extern "C" int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packe
                  "gdrnpp_conv3x3_f32_split: Cout=%d Cin=%d must be multiples of %d/32 (pixels=%ld is free)", Cout, Cin, BN, M);
   GDRNPP_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_GELU, GDRNPP_EINVAL, "gdrnpp_conv3x3_f32_split: epilogue=%d", epilogue);
   return launch_split<true>(x_nhwc, (const uint4*)W_packed, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, epilogue,
-                            ConvGeom{H, W, Cin}, (hipStream_t)stream, "gdrnpp_conv3x3_f32_split");
+                            ConvGeom{H, W, Cin, 0}, (hipStream_t)stream, "gdrnpp_conv3x3_f32_split");
 }

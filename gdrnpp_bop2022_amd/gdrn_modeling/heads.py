@@ -243,8 +243,8 @@ class ConvPnPNet(nn.Module):
             x = torch.cat([x, mask_attention], dim=1)
         x = run_features(self.features, x)
         x = x.flatten(2).flatten(1)  # NCHW order, like the reference (weights of fc1 depend on it)
-        x = self.act(self.fc1(x))
-        x = self.act(self.fc2(x))
+        x = self.act(hip_layers.linear(self.fc1, x))
+        x = self.act(hip_layers.linear(self.fc2, x))
         return self.fc_r(x), self.fc_t(x)
 
 

@@ -151,3 +151,14 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
             cache["w_pk"] = hit
         return hip_lib.conv3x3_f32_split(_cl(x), hit[1], conv.bias)
     return conv(x)
+
+
+def linear(fc: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """nn.Linear on a [M, K] activation with few rows and a long K (Patch-PnP fc1: 8192 -> 1024 on one row per ROI):
+    hipBLASLt picks a 256x16 macro-tile for it and streams the 33 MB weight at ~70 GB/s (0.49 ms at 128 ROIs); the split-K
+    form of the split GEMM spreads K over 64 workgroups per output tile."""
+    if (_MLP_GEMM == "split" and enabled_for(x) and x.dim() == 2 and x.is_contiguous() and fc.out_features % 128 == 0
+            and fc.in_features % 32 == 0 and fc.in_features >= 1024 and x.shape[0] <= 1024):
+        cache = fc.__dict__.setdefault("_gdrnpp_cache", {})
+        return hip_lib.linear_f32_splitk(x, _packed(fc, cache, "w_pk"), fc.bias)
+    return fc(x)

@@ -64,6 +64,8 @@ SIGNATURES = {
     "gdrnpp_linear_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_pack_weight_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_linear_f32_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gdrnpp_linear_f32_splitk": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "gdrnpp_conv3x3_f32_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_roi_align": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     "gdrnpp_debug_stream_read": (c_int, [_P, c_size_t, c_int, _P, c_int, _P]),
@@ -460,6 +462,21 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
             {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream())
     nbytes = 4.0 * m * k + 6.0 * n * k + 4.0 * m * n * (2 if epilogue == "scale_res" else 1)
     _check(_timed("linear", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split(*args), nbytes), "gdrnpp_linear_f32_split")
+    return out
+
+
+def linear_f32_splitk(x2d, weight_packed, bias):
+    """x2d f32[M,K] @ W^T + bias for skinny M (split-K over chunks of 128, deterministic reduction)."""
+    m, k = x2d.shape
+    if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or weight_packed.shape[1] * 16 != k:
+        raise ValueError("weight_packed must be the contiguous bf16 tensor from pack_weight_bf16x3 with matching K")
+    n = weight_packed.shape[0] * 128
+    out = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
+    nbytes = load().gdrnpp_linear_f32_splitk_workspace_bytes(m, n, k)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x2d.device)
+    _check(load().gdrnpp_linear_f32_splitk(_dev(x2d, torch.float32, "x"), weight_packed.data_ptr(),
+                                           _dev(bias, torch.float32, "bias") if bias is not None else None, out.data_ptr(), m, n, k,
+                                           ws.data_ptr(), nbytes, _stream()), "gdrnpp_linear_f32_splitk")
     return out
 
 

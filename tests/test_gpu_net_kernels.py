@@ -310,3 +310,19 @@ def test_model_forward_odd_roi_count(hip):
         assert (o1[key] - o2[key]).abs().max().item() <= 1e-4 * max(o2[key].abs().max().item(), 1.0), key
     torch.testing.assert_close(o1["rot"], o2["rot"], rtol=0, atol=1e-4)
     torch.testing.assert_close(o1["trans"], o2["trans"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("m,k,n", [(128, 8192, 1024), (5, 8192, 1024), (300, 1024, 256), (64, 96, 128)])
+def test_linear_f32_splitk(hip, m, k, n):
+    """Split-K form (Patch-PnP fc layers): vs fp64, as accurate as the fp32 GEMM; deterministic across runs."""
+    torch.manual_seed(k + m)
+    x = torch.randn(m, k, device=DEV)
+    w = torch.randn(n, k, device=DEV) * (k ** -0.5)
+    b = torch.randn(n, device=DEV)
+    pk = hip.pack_weight_bf16x3(w)
+    out = hip.linear_f32_splitk(x, pk, b)
+    ref64 = x.double() @ w.double().t() + b.double()
+    scale = ref64.abs().max().item()
+    e_f32 = (F.linear(x, w, b).double() - ref64).abs().max().item() / scale
+    assert (out.double() - ref64).abs().max().item() / scale <= 1.25 * e_f32 + 1.2e-7
+    assert torch.equal(out, hip.linear_f32_splitk(x, pk, b))
