@@ -77,13 +77,17 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, uint4* __restric
   img[(2 * KB + kb) * BN + row] = make_uint4(p0.l, p1.l, p2.l, p3.l);
 }
 
-// CONV: A is an NHWC image [.,H,W,Cin] and the GEMM row m = output pixel, k = (tap, channel) of a 3x3 / stride 1 /
-// zero-pad 1 convolution (implicit im2col: the k-tile's 16 channels of one tap are 64 contiguous bytes per pixel).
-struct ConvGeom { int H, W, C; int nk_split; };  // nk_split > 0: split-K, blockIdx.y-th chunk of nk_split k-tiles -> partial C
+// CONV: A is an NHWC image [.,H,W,Cin] and the GEMM row m = output pixel, k = (tap, channel) of a KHxKW convolution with
+// stride and symmetric zero padding (implicit im2col: the k-tile's 16 channels of one tap are 64 contiguous bytes per
+// pixel).  Every row keeps a pointer to its anchor input pixel (oy*stride, ox*stride), which is always inside the image.
+// H, W, C: input image; OH, OW: output image; KW x (K / (KW*C)) taps, stride, zero padding `pad` on every side.
+// nk_split > 0: split-K (linear only), blockIdx.y-th chunk of nk_split k-tiles -> partial C
+struct ConvGeom { int H, W, C, OH, OW, KW, stride, pad; int nk_split; };
 
 // MI = 32-row MFMA tiles per wave along M: 2 -> 128x128 block tile (three workgroups per CU), 4 -> 256x128 block tile
 // (each wave 128x64: 18 fragment reads feed 48 MFMAs per k-tile and per barrier, two workgroups per CU).
-template <int EPI, bool CONV, int MI>
+// CONV: 0 = linear, 1 = 3x3 / stride 1 / pad 1 (geometry folded at compile time: the head's hot convolutions), 2 = general
+template <int EPI, int CONV, int MI>
 __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kernel(const float* __restrict__ A,
                                                                     const uint4* __restrict__ Wp,
                                                                     const float* __restrict__ bias,
@@ -116,22 +120,23 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
   // A staging: rows tid/4 + 64*p (p < MI), lane%4 picks 4 consecutive k (half a k-block)
   const int lrow = tid >> 2, lkq = tid & 3;
   const float* ap[MI];  // this thread's staging rows (pixels), clamped into [0, M): the overhang re-reads row M-1
-  int arow[MI];
+  int pyx[MI], cpt = 1;  // CONV: (y << 16 | x) of the anchor input pixel of this thread's rows, k-tiles per tap
 #pragma unroll
   for (int p = 0; p < MI; ++p) {
-    arow[p] = min(m0 + lrow + 64 * p, M - 1);
-    ap[p] = A + (size_t)arow[p] * (CONV ? cg.C : K) + lkq * 4;
-  }
-  const uint4* Wg = Wp + ((size_t)tile_n * nk_total + kt0) * W_TILE_SLOTS + tid;
-  int pyx[MI], cpt = 1;  // CONV: (y << 16 | x) of this thread's pixels, k-tiles per tap
-  if (CONV) {
-#pragma unroll
-    for (int p = 0; p < MI; ++p) {
-      const int pp = arow[p] % (cg.H * cg.W);
-      pyx[p] = ((pp / cg.W) << 16) | (pp % cg.W);
+    const int arow = min(m0 + lrow + 64 * p, M - 1);
+    if (CONV) {
+      const int OH = CONV == 1 ? cg.H : cg.OH, OW = CONV == 1 ? cg.W : cg.OW, stride = CONV == 1 ? 1 : cg.stride;
+      const int img = arow / (OH * OW), pp = arow - img * (OH * OW);
+      const int iy = (pp / OW) * stride, ix = (pp % OW) * stride;
+      pyx[p] = (iy << 16) | ix;
+      ap[p] = A + (((size_t)img * cg.H + iy) * cg.W + ix) * cg.C + lkq * 4;
+    } else {
+      pyx[p] = 0;
+      ap[p] = A + (size_t)arow * K + lkq * 4;
     }
-    cpt = cg.C / BK;
   }
+  if (CONV) cpt = cg.C / BK;
+  const uint4* Wg = Wp + ((size_t)tile_n * nk_total + kt0) * W_TILE_SLOTS + tid;
   struct Stage { float4 a[MI]; uint4 b0, b1, b2; };
   auto gload = [&](int kt) {
     Stage r;
@@ -139,7 +144,8 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
       // the loads are unconditional (address clamped to the centre pixel, value zeroed afterwards): a predicated load
       // would make the outstanding-load count unknown to the compiler and collapse the software pipeline
       const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const int KW = CONV == 1 ? 3 : cg.KW, pad = CONV == 1 ? 1 : cg.pad;
+      const int ky = tap / KW, dy = ky - pad, dx = tap - ky * KW - pad;
       const int off = (dy * cg.W + dx) * cg.C;
 #pragma unroll
       for (int p = 0; p < MI; ++p) {
@@ -521,8 +527,9 @@ int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const f
   // The 256x128 ping-pong kernel is opt-in (GDRNPP_SPLIT_8WAVE=1, read per launch so tests can toggle it): measured on
   // MI355X it reaches 133-174 TFLOP/s fp32-equivalent on the stage-2 MLP shapes against 144-177 for the 4-wave kernel
   // at three workgroups per CU (tools/microbench_gemm_s2.py, same box) — see DESIGN.md §5.
+  const bool fast3x3 = CONV && cg.KW == 3 && cg.stride == 1 && cg.pad == 1 && K == 9 * cg.C;
   const char* use8 = getenv("GDRNPP_SPLIT_8WAVE");
-  if (M % BM8 == 0 && use8 && use8[0] == '1') {
+  if (M % BM8 == 0 && use8 && use8[0] == '1' && (!CONV || fast3x3)) {
     const long blocks = (long)(M / BM8) * (N / BN);
     GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "%s: grid too large", what);
     const int lds = 2 * STAGE8_SLOTS * (int)sizeof(uint4);  // 75 KB >= 8 * 32 * 65 * 4 (epilogue staging)
@@ -533,15 +540,18 @@ int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const f
   // 256x128 tiles (MI = 4) when they still give every CU its two workgroups; measured +3 % (fc1) / +7 % (fc2) on the
   // stage-2 MLP shapes over 128x128 tiles at three workgroups per CU.  GDRNPP_SPLIT_MI4=0/1 forces the choice (A/B).
   const char* mi4 = getenv("GDRNPP_SPLIT_MI4");
-  const bool big = mi4 ? mi4[0] == '1' : (long)(M / 256) * (N / BN) >= 512;
+  // (the general convolution form needs a few more registers than 256x128 tiles leave: it stays on 128x128 tiles)
+  const bool big = (mi4 ? mi4[0] == '1' : (long)(M / 256) * (N / BN) >= 512) && !(CONV && !fast3x3);
   if (M % 256 == 0 && big) {
     const long blocks = (long)(M / 256) * (N / BN);
-    hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV, 4>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+    if (CONV && fast3x3) hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV ? 1 : 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+    else hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV ? 2 : 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
     return gdrnpp::check_launch(what);
   }
   const long blocks = (long)((M + BM - 1) / BM) * (N / BN);
   GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "%s: grid too large", what);
-  hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV, 2>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+  if (CONV && fast3x3) hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV ? 1 : 0, 2>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+  else hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV ? 2 : 0, 2>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
   return gdrnpp::check_launch(what);
 }
 
@@ -593,9 +603,9 @@ extern "C" int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, co
   const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
   GDRNPP_REQUIRE(tiles < 65536 && splits < 65536, GDRNPP_ELIMIT, "gdrnpp_linear_f32_splitk: grid too large");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((gemm_split_kernel<EPI_BIAS, false, 2>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st, A,
+  hipLaunchKernelGGL((gemm_split_kernel<EPI_BIAS, 0, 2>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st, A,
                      (const uint4*)W_packed, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                     (float*)workspace, M, N, K, ConvGeom{0, 0, 0, nkc});
+                     (float*)workspace, M, N, K, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, nkc});
   const long mn4 = (long)M * N / 4;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, st, (const float*)workspace, bias, C,
                      mn4, N, splits);
@@ -611,19 +621,29 @@ extern "C" int gdrnpp_linear_f32_split(const float* A, const void* W_packed, con
   GDRNPP_REQUIRE(epilogue >= 0 && epilogue <= 2, GDRNPP_EINVAL, "gdrnpp_linear_f32_split: epilogue=%d", epilogue);
   GDRNPP_REQUIRE(epilogue != EPI_SCALE_RES || (gamma && resid), GDRNPP_EINVAL,
                  "gdrnpp_linear_f32_split: scale+residual epilogue needs gamma and resid");
-  return launch_split<false>(A, (const uint4*)W_packed, bias, gamma, resid, C, M, N, K, epilogue, ConvGeom{0, 0, 0, 0},
+  return launch_split<false>(A, (const uint4*)W_packed, bias, gamma, resid, C, M, N, K, epilogue, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0},
                              (hipStream_t)stream, "gdrnpp_linear_f32_split");
+}
+
+extern "C" int gdrnpp_conv2d_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
+                                       int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                       int epilogue, void* stream) {
+  GDRNPP_REQUIRE(x_nhwc && W_packed && y_nhwc, GDRNPP_EINVAL, "gdrnpp_conv2d_f32_split: null pointer");
+  GDRNPP_REQUIRE(n_img > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && H < 32768 && W < 32768 && KH > 0 && KW > 0 &&
+                     stride > 0 && pad >= 0 && pad < KH && pad < KW,
+                 GDRNPP_EINVAL, "gdrnpp_conv2d_f32_split: bad shape");
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  GDRNPP_REQUIRE(OH > 0 && OW > 0 && (OH - 1) * stride < H && (OW - 1) * stride < W, GDRNPP_EINVAL,
+                 "gdrnpp_conv2d_f32_split: empty output or anchor pixel outside the image");
+  const long M = (long)n_img * OH * OW;
+  GDRNPP_REQUIRE(M < (1l << 31) && Cout % BN == 0 && Cin % 32 == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_conv2d_f32_split: Cout=%d Cin=%d must be multiples of %d/32 (pixels=%ld is free)", Cout, Cin, BN, M);
+  GDRNPP_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_GELU, GDRNPP_EINVAL, "gdrnpp_conv2d_f32_split: epilogue=%d", epilogue);
+  return launch_split<true>(x_nhwc, (const uint4*)W_packed, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, KH * KW * Cin, epilogue,
+                            ConvGeom{H, W, Cin, OH, OW, KW, stride, pad, 0}, (hipStream_t)stream, "gdrnpp_conv2d_f32_split");
 }
 
 extern "C" int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                                         int n_img, int H, int W, int Cin, int Cout, int epilogue, void* stream) {
-  GDRNPP_REQUIRE(x_nhwc && W_packed && y_nhwc, GDRNPP_EINVAL, "gdrnpp_conv3x3_f32_split: null pointer");
-  GDRNPP_REQUIRE(n_img > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && H < 32768 && W < 32768, GDRNPP_EINVAL,
-                 "gdrnpp_conv3x3_f32_split: bad shape");
-  const long M = (long)n_img * H * W;
-  GDRNPP_REQUIRE(M < (1l << 31) && Cout % BN == 0 && Cin % 32 == 0, GDRNPP_ELIMIT,
-                 "gdrnpp_conv3x3_f32_split: Cout=%d Cin=%d must be multiples of %d/32 (pixels=%ld is free)", Cout, Cin, BN, M);
-  GDRNPP_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_GELU, GDRNPP_EINVAL, "gdrnpp_conv3x3_f32_split: epilogue=%d", epilogue);
-  return launch_split<true>(x_nhwc, (const uint4*)W_packed, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, epilogue,
-                            ConvGeom{H, W, Cin, 0}, (hipStream_t)stream, "gdrnpp_conv3x3_f32_split");
+  return gdrnpp_conv2d_f32_split(x_nhwc, W_packed, bias, y_nhwc, n_img, H, W, Cin, Cout, 3, 3, 1, 1, epilogue, stream);
 }

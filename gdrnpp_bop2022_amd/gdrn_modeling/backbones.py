@@ -71,7 +71,9 @@ class ConvNeXtStage(nn.Module):
         self.blocks = nn.Sequential(*[ConvNeXtBlock(out_chs) for _ in range(depth)])
 
     def forward(self, x):
-        return self.blocks(self.downsample(x))
+        if isinstance(self.downsample, nn.Sequential):   # LayerNorm2d -> 2x2 / stride-2 conv (implicit GEMM on the GPU)
+            x = hip_layers.conv2d(self.downsample[1], self.downsample[0](x))
+        return self.blocks(x)
 
 
 class ConvNeXtFeatures(nn.Module):

@@ -136,20 +136,26 @@ def set_conv_split(flag: bool) -> None:
 
 
 def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
-    """nn.Conv2d forward; 3x3 / stride 1 / pad 1 / dense convolutions with 128-aligned shapes run as an implicit GEMM
-    in ``gdrnpp_conv3x3_f32_split`` (bf16 matrix cores, fp32-accurate), everything else in MIOpen."""
+    """nn.Conv2d forward; dense convolutions with square kernel / stride / padding, Cin % 32 == 0 and Cout % 128 == 0 (the
+    head's 3x3/1, ConvNeXt's 2x2/2 downsamples, Patch-PnP's 3x3/2) run as an implicit GEMM in ``gdrnpp_conv2d_f32_split``
+    (bf16 matrix cores, fp32-accurate), everything else in MIOpen."""
     if (_CONV_SPLIT and _MLP_GEMM == "split" and isinstance(conv, nn.Conv2d) and enabled_for(x)
-            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
-            and conv.groups == 1 and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0
-            and conv.out_channels % 128 == 0):
+            and conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1]
+            and conv.padding[0] == conv.padding[1] and isinstance(conv.padding[0], int) and conv.padding[0] < conv.kernel_size[0]
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0
+            and conv.out_channels % 128 == 0
+            and (x.shape[2] + 2 * conv.padding[0] - conv.kernel_size[0]) // conv.stride[0] * conv.stride[0] < x.shape[2]):
         cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
         w = conv.weight
         tag = (w.data_ptr(), w._version, w.device)
         hit = cache.get("w_pk")
         if hit is None or hit[0] != tag:
-            hit = (tag, hip_lib.pack_conv3x3_weight_bf16x3(w.detach()))
+            hit = (tag, hip_lib.pack_conv_weight_bf16x3(w.detach()))
             cache["w_pk"] = hit
-        return hip_lib.conv3x3_f32_split(_cl(x), hit[1], conv.bias)
+        if conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1):
+            return hip_lib.conv3x3_f32_split(_cl(x), hit[1], conv.bias)
+        return hip_lib.conv2d_f32_split(_cl(x), hit[1], conv.bias, conv.kernel_size[0], conv.kernel_size[1], conv.stride[0],
+                                       conv.padding[0])
     return conv(x)
 
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "gdrnpp_linear_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_linear_f32_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gdrnpp_linear_f32_splitk": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "gdrnpp_conv2d_f32_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_conv3x3_f32_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_roi_align": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     "gdrnpp_debug_stream_read": (c_int, [_P, c_size_t, c_int, _P, c_int, _P]),
@@ -480,10 +481,32 @@ def linear_f32_splitk(x2d, weight_packed, bias):
     return out
 
 
-def pack_conv3x3_weight_bf16x3(weight):
-    """nn.Conv2d weight f32[Cout,Cin,3,3] -> packed split image of the [Cout, (ky,kx,Cin)] GEMM weight."""
-    cout, cin = weight.shape[:2]
-    return pack_weight_bf16x3(weight.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous())
+def pack_conv_weight_bf16x3(weight):
+    """nn.Conv2d weight f32[Cout,Cin,KH,KW] -> packed split image of the [Cout, (ky,kx,Cin)] GEMM weight."""
+    cout, cin, kh, kw = weight.shape
+    return pack_weight_bf16x3(weight.permute(0, 2, 3, 1).reshape(cout, kh * kw * cin).contiguous())
+
+
+pack_conv3x3_weight_bf16x3 = pack_conv_weight_bf16x3
+
+
+def conv2d_f32_split(x_cl, weight_packed, bias, kh: int, kw: int, stride: int, pad: int, gelu: bool = False):
+    """KHxKW / stride / zero-pad convolution of a channels_last tensor [N,Cin,H,W] on the bf16 matrix cores (fp32-accurate
+    split GEMM, implicit im2col) -> channels_last [N,Cout,OH,OW]."""
+    n, cin, h, w = x_cl.shape
+    if not x_cl.is_contiguous(memory_format=torch.channels_last) or x_cl.dtype != torch.float32 or not x_cl.is_cuda:
+        raise ValueError("conv2d_f32_split expects a float32 channels_last device tensor")
+    if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or weight_packed.shape[1] * 16 != kh * kw * cin:
+        raise ValueError("weight_packed must come from pack_conv_weight_bf16x3 with matching Cin and kernel size")
+    cout = weight_packed.shape[0] * 128
+    oh, ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    out = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
+    args = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
+            out.data_ptr(), n, h, w, cin, cout, kh, kw, stride, pad, 1 if gelu else 0, _stream())
+    nbytes = 4.0 * n * (h * w * cin + oh * ow * cout) + 6.0 * cout * kh * kw * cin
+    _check(_timed("conv", 2.0 * n * oh * ow * cout * kh * kw * cin, lambda: load().gdrnpp_conv2d_f32_split(*args), nbytes),
+           "gdrnpp_conv2d_f32_split")
+    return out
 
 
 def conv3x3_f32_split(x_cl, weight_packed, bias, gelu: bool = False):

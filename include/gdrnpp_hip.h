@@ -296,6 +296,12 @@ int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* b
  * x f32 NHWC [n_img,H,W,Cin] -> y f32 NHWC [n_img,H,W,Cout]; W_packed = gdrnpp_pack_weight_bf16x3 of the weight
  * reordered to [Cout][ky][kx][Cin] (N = Cout, K = 9*Cin); bias may be NULL; epilogue 0 = none, 1 = GELU.
  * Cout multiple of 128, Cin multiple of 32; any n_img*H*W. */
+/* General form: KH x KW taps, stride, symmetric zero padding (pad < KH, KW); W_packed = gdrnpp_pack_weight_bf16x3 of the
+ * weight reordered to [Cout][ky][kx][Cin].  Used for the 2x2/2 downsample convolutions of ConvNeXt and the 3x3/2
+ * convolutions of Patch-PnP as well.  OH = (H + 2 pad - KH) / stride + 1 (likewise OW); y is [n_img,OH,OW,Cout]. */
+int gdrnpp_conv2d_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
+                            int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                            int epilogue, void* stream);
 int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                              int n_img, int H, int W, int Cin, int Cout, int epilogue, void* stream);
 
