@@ -298,7 +298,7 @@ def main():
         n_l = len(gemm_timer.records)
         bf16_tflops = 6.0 * fl / (ms_all * 1e-3) / 1e12
         by_kind = {}
-        for kind in ("linear", "conv3x3", "conv"):
+        for kind in ("linear", "linear_splitk", "conv3x3", "conv"):
             rs = [r for r in gemm_timer.records if r[0] == kind]
             if rs:
                 t_k = sum(r[2].elapsed_time(r[3]) for r in rs)

@@ -567,8 +567,10 @@ int launch_split(const float* A, const uint4* Wp, const float* bias, const float
 
 namespace {
 
-// out[m][n] = bias[n] + sum over s of part[s][m][n]   (fixed order: deterministic)
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+// out = epilogue(bias[n] + sum over s of part[s][m][n])   (fixed order: deterministic)
+template <int EPI>
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                     const float* __restrict__ gamma, const float* __restrict__ resid, float* __restrict__ out,
                                      long mn4, int N, int splits) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= mn4) return;
@@ -578,37 +580,55 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
     const float4 v = reinterpret_cast<const float4*>(part)[(size_t)s * mn4 + i];
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
+  if (EPI == EPI_GELU) { acc.x = gelu_erf(acc.x); acc.y = gelu_erf(acc.y); acc.z = gelu_erf(acc.z); acc.w = gelu_erf(acc.w); }
+  if (EPI == EPI_SCALE_RES) {
+    const float4 g = *reinterpret_cast<const float4*>(gamma + n), r = reinterpret_cast<const float4*>(resid)[i];
+    acc.x = r.x + g.x * acc.x; acc.y = r.y + g.y * acc.y; acc.z = r.z + g.z * acc.z; acc.w = r.w + g.w * acc.w;
+  }
   reinterpret_cast<float4*>(out)[i] = acc;
+}
+
+// k-tiles (of 16) per split: halve the chunk (keeping it even) until every CU has about three workgroups
+inline int splitk_chunk(int M, int N, int K) {
+  const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
+  const int nk = K / BK;
+  int c = nk;
+  while (c % 4 == 0 && tiles * (nk / c) < 768) c /= 2;
+  return c;
 }
 
 }  // namespace
 
 extern "C" size_t gdrnpp_linear_f32_splitk_workspace_bytes(int M, int N, int K) {
-  if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 0;
-  int nkc = 8;                                   // k-tiles (of 16) per workgroup: 128 k per split
-  while ((K / BK) % nkc) nkc >>= 1;              // nk_total is even, so this stops at >= 2
-  return (size_t)((K / BK) / nkc) * M * N * sizeof(float);
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 || N % BN) return 0;
+  return (size_t)((K / BK) / splitk_chunk(M, N, K)) * M * N * sizeof(float);
 }
 
-extern "C" int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, const float* bias, float* C, int M, int N,
-                                        int K, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, const float* bias, const float* gamma,
+                                        const float* resid, float* C, int M, int N, int K, int epilogue, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
   GDRNPP_REQUIRE(A && W_packed && C && workspace, GDRNPP_EINVAL, "gdrnpp_linear_f32_splitk: null pointer");
   GDRNPP_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % 32 == 0, GDRNPP_ELIMIT,
                  "gdrnpp_linear_f32_splitk: N=%d K=%d must be multiples of %d/32 (M=%d is free)", N, K, BN, M);
+  GDRNPP_REQUIRE(epilogue >= 0 && epilogue <= 2, GDRNPP_EINVAL, "gdrnpp_linear_f32_splitk: epilogue=%d", epilogue);
+  GDRNPP_REQUIRE(epilogue != EPI_SCALE_RES || (gamma && resid), GDRNPP_EINVAL,
+                 "gdrnpp_linear_f32_splitk: scale+residual epilogue needs gamma and resid");
   GDRNPP_REQUIRE(workspace_bytes >= gdrnpp_linear_f32_splitk_workspace_bytes(M, N, K), GDRNPP_EINVAL,
                  "gdrnpp_linear_f32_splitk: workspace too small");
-  int nkc = 8;
-  while ((K / BK) % nkc) nkc >>= 1;
+  const int nkc = splitk_chunk(M, N, K);
   const int splits = (K / BK) / nkc;
   const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
-  GDRNPP_REQUIRE(tiles < 65536 && splits < 65536, GDRNPP_ELIMIT, "gdrnpp_linear_f32_splitk: grid too large");
+  GDRNPP_REQUIRE(tiles < (1l << 31) && splits < 65536, GDRNPP_ELIMIT, "gdrnpp_linear_f32_splitk: grid too large");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL((gemm_split_kernel<EPI_BIAS, 0, 2>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st, A,
                      (const uint4*)W_packed, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                      (float*)workspace, M, N, K, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, nkc});
   const long mn4 = (long)M * N / 4;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, st, (const float*)workspace, bias, C,
-                     mn4, N, splits);
+  const dim3 grid((unsigned)((mn4 + 255) / 256));
+  const float* ws = (const float*)workspace;
+  if (epilogue == EPI_BIAS) hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS>, grid, dim3(256), 0, st, ws, bias, gamma, resid, C, mn4, N, splits);
+  else if (epilogue == EPI_GELU) hipLaunchKernelGGL(splitk_reduce_kernel<EPI_GELU>, grid, dim3(256), 0, st, ws, bias, gamma, resid, C, mn4, N, splits);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<EPI_SCALE_RES>, grid, dim3(256), 0, st, ws, bias, gamma, resid, C, mn4, N, splits);
   return gdrnpp::check_launch("gdrnpp_linear_f32_splitk");
 }
 

@@ -81,6 +81,7 @@ def dwconv_ln(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor, cache: dict) -
 #                     1.21 vs 1.25 ms at C=256, and loses 2-5 % to hipBLASLt's 256x256 macro-tile at C >= 512);
 #   "torch"           hipBLASLt + separate elementwise kernels everywhere.
 _MLP_GEMM = "split"
+_SPLITK_BELOW_TILES = 512
 _F32_FUSED_MAX_C = 256
 
 
@@ -115,9 +116,11 @@ def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: 
     ok = (_MLP_GEMM != "torch" and enabled_for(x_nhwc) and x_nhwc.is_contiguous() and shortcut_nhwc.is_contiguous()
           and c % 128 == 0)
     if ok and _MLP_GEMM == "split":
-        h = hip_lib.linear_f32_split(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk"), mlp.fc1.bias, "gelu")
-        y = hip_lib.linear_f32_split(h, _packed(mlp.fc2, cache, "fc2_pk"), mlp.fc2.bias, "scale_res", gamma,
-                                     shortcut_nhwc.view(m, c))
+        # fewer than two output tiles per CU (small ROI counts at the deep stages): split K as well, or most of the chip idles
+        f1 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, 4 * c) < _SPLITK_BELOW_TILES else hip_lib.linear_f32_split
+        f2 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, c) < _SPLITK_BELOW_TILES else hip_lib.linear_f32_split
+        h = f1(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk"), mlp.fc1.bias, "gelu")
+        y = f2(h, _packed(mlp.fc2, cache, "fc2_pk"), mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
         return y.view(x_nhwc.shape)
     if ok and c <= _F32_FUSED_MAX_C and m % 128 == 0:
         h = hip_lib.linear_f32(x_nhwc.view(m, c), mlp.fc1.weight, mlp.fc1.bias, "gelu")

@@ -65,7 +65,7 @@ SIGNATURES = {
     "gdrnpp_pack_weight_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_linear_f32_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "gdrnpp_linear_f32_splitk": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "gdrnpp_linear_f32_splitk": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "gdrnpp_conv2d_f32_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_conv3x3_f32_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_roi_align": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
@@ -466,8 +466,9 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
     return out
 
 
-def linear_f32_splitk(x2d, weight_packed, bias):
-    """x2d f32[M,K] @ W^T + bias for skinny M (split-K over chunks of 128, deterministic reduction)."""
+def linear_f32_splitk(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None):
+    """Same contract as linear_f32_split for problems with few output tiles: split-K with a deterministic reduction that
+    also applies bias and epilogue."""
     m, k = x2d.shape
     if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or weight_packed.shape[1] * 16 != k:
         raise ValueError("weight_packed must be the contiguous bf16 tensor from pack_weight_bf16x3 with matching K")
@@ -475,10 +476,18 @@ def linear_f32_splitk(x2d, weight_packed, bias):
     out = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
     nbytes = load().gdrnpp_linear_f32_splitk_workspace_bytes(m, n, k)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x2d.device)
-    _check(load().gdrnpp_linear_f32_splitk(_dev(x2d, torch.float32, "x"), weight_packed.data_ptr(),
-                                           _dev(bias, torch.float32, "bias") if bias is not None else None, out.data_ptr(), m, n, k,
-                                           ws.data_ptr(), nbytes, _stream()), "gdrnpp_linear_f32_splitk")
+    args = (_dev(x2d, torch.float32, "x"), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
+            _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
+            _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
+            {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], ws.data_ptr(), nbytes, _stream())
+    nb = 4.0 * m * k + 6.0 * n * k + 4.0 * m * n * (2 if epilogue == "scale_res" else 1)
+    _check(_timed("linear_splitk", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_splitk(*args), nb), "gdrnpp_linear_f32_splitk")
     return out
+
+
+def split_gemm_tiles(m: int, n: int) -> int:
+    """Output tiles (128x128) of an [m, n] result — the dispatch quantity between the plain and the split-K launch."""
+    return ((m + 127) // 128) * (n // 128)
 
 
 def pack_conv_weight_bf16x3(weight):

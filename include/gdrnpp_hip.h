@@ -282,12 +282,14 @@ int gdrnpp_linear_f32(const float* A, const float* W, const float* bias, const f
  * done once per weight.  gdrnpp_linear_f32_split: A stays fp32 and is split on the way into LDS.
  * N multiple of 128, K multiple of 32; any M >= 1 (the last row tile is clamped on load and masked on store). */
 int gdrnpp_pack_weight_bf16x3(const float* W, void* packed, int N, int K, void* stream);
-/* Split-K form for skinny problems (few rows, long K: the Patch-PnP fc1, 8192 -> 1024 on B rows): K is cut into chunks
- * of 128, every (row tile, column tile, chunk) is one workgroup, partial products go to the workspace
- * (gdrnpp_linear_f32_splitk_workspace_bytes) and are summed in a fixed order with the bias.  C = A W^T + bias. */
+/* Split-K form for problems with too few output tiles to fill the chip (the Patch-PnP fc layers: one row per ROI,
+ * K = 8192; the stage-2/3 ConvNeXt MLPs at small ROI counts): K is cut into chunks so that every CU gets about three
+ * workgroups, partial products go to the workspace (gdrnpp_linear_f32_splitk_workspace_bytes) and are summed in a
+ * fixed order; bias and the epilogue (0 none, 1 GELU, 2 resid + gamma * y) are applied by the reduction. */
 size_t gdrnpp_linear_f32_splitk_workspace_bytes(int M, int N, int K);
-int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, const float* bias, float* C, int M, int N, int K,
-                             void* workspace, size_t workspace_bytes, void* stream);
+int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, const float* bias, const float* gamma,
+                             const float* resid, float* C, int M, int N, int K, int epilogue, void* workspace,
+                             size_t workspace_bytes, void* stream);
 int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* bias, const float* gamma,
                             const float* resid, float* C, int M, int N, int K, int epilogue,
                             void* stream);
