@@ -334,3 +334,21 @@ def test_linear_f32_splitk(hip, m, k, n):
         e_f32 = (got32.double() - want64).abs().max().item() / scale
         assert (out.double() - want64).abs().max().item() / scale <= 1.25 * e_f32 + 1.2e-7, epi
         assert torch.equal(out, hip.linear_f32_splitk(x, pk, b, epi, *extra))
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,stride,pad", [(4, 128, 256, 32, 32, 2, 2, 0), (3, 128, 128, 17, 20, 3, 2, 1), (2, 64, 128, 9, 9, 3, 1, 0),
+                                                          (2, 32, 128, 12, 16, 4, 4, 0), (1, 64, 128, 10, 11, 5, 2, 2)])
+def test_conv2d_f32_split_general(hip, n, cin, cout, h, w, k, stride, pad):
+    """KxK / stride / zero-pad implicit GEMM (ConvNeXt 2x2/2 downsamples, Patch-PnP 3x3/2, ...) vs an fp64 convolution."""
+    torch.manual_seed(cin + k + stride)
+    x = torch.randn(n, cin, h, w, device=DEV).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(cout, cin, k, k, device=DEV) * (k * k * cin) ** -0.5
+    b = torch.randn(cout, device=DEV)
+    out = hip.conv2d_f32_split(x, hip.pack_conv_weight_bf16x3(wt), b, k, k, stride, pad)
+    ref64 = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=pad)
+    ref32 = F.conv2d(x, wt, b, stride=stride, padding=pad)
+    assert out.shape == ref32.shape and out.is_contiguous(memory_format=torch.channels_last)
+    scale = ref64.abs().max().item()
+    e_split = (out.double() - ref64).abs().max().item() / scale
+    e_f32 = (ref32.double() - ref64).abs().max().item() / scale
+    assert e_split <= max(1.5 * e_f32 + 1.5e-7, 4e-8 * (k * k * cin) ** 0.5), (e_split, e_f32)
