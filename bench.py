@@ -69,6 +69,8 @@ def parse():
                    help="run the reference's full 1470-channel output layer + gather instead of the class-sliced one")
     p.add_argument("--no-hip-layers", action="store_true", help="A/B: run the memory-bound network layers with PyTorch ops")
     p.add_argument("--no-fused-mlp", action="store_true", help="A/B: hipBLASLt GEMMs + separate GELU / addcmul")
+    p.add_argument("--library-below-tiles", type=int, default=None,
+                   help="ConvNeXt blocks whose fc2 has fewer output tiles than this use hipBLASLt (A/B for small batches)")
     p.add_argument("--no-conv-split", action="store_true", help="A/B: 3x3 head convolutions in MIOpen (fp32 MFMA)")
     p.add_argument("--mlp-gemm", choices=["split", "f32", "torch"], default="split",
                    help="ConvNeXt MLP GEMM engine: split = exact 3-way bf16 split on the bf16 matrix cores (six partial "
@@ -148,6 +150,8 @@ def main():
     hip_layers.set_enabled(not args.no_hip_layers)
     hip_layers.set_mlp_gemm("torch" if args.no_fused_mlp else args.mlp_gemm)
     hip_layers.set_conv_split(not args.no_conv_split)
+    if args.library_below_tiles is not None:
+        hip_layers.set_library_below_tiles(args.library_below_tiles)
 
     streams = []  # one (cfg, model, post, batch, det, K_crop, meshes, verts, faces) per dataset of the stream
     for di, ds in enumerate(datasets):

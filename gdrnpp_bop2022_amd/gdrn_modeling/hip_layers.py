@@ -82,6 +82,8 @@ def dwconv_ln(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor, cache: dict) -
 #   "torch"           hipBLASLt + separate elementwise kernels everywhere.
 _MLP_GEMM = "split"
 _SPLITK_BELOW_TILES = 512
+_LIBRARY_BELOW_TILES = 128  # blocks whose fc2 has fewer output tiles than this go to hipBLASLt (measured: batch 8
+                            # 1071 -> 1210 ROIs/s, batch 16 unchanged, 300 already hurts batch 16)
 _F32_FUSED_MAX_C = 256
 
 
@@ -90,6 +92,13 @@ def set_mlp_gemm(mode: str) -> None:
     if mode not in ("split", "f32", "torch"):
         raise ValueError(f"unknown MLP GEMM mode {mode!r}")
     _MLP_GEMM = mode
+
+
+def set_library_below_tiles(n: int) -> None:
+    """ConvNeXt blocks whose fc2 result has fewer than ``n`` 128x128 tiles run on hipBLASLt + elementwise kernels instead
+    of the split GEMM (one image's worth of ROIs leaves the deep stages with a handful of tiles)."""
+    global _LIBRARY_BELOW_TILES
+    _LIBRARY_BELOW_TILES = int(n)
 
 
 def set_fused_mlp(flag: bool) -> None:
@@ -115,14 +124,14 @@ def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: 
     m = x_nhwc.numel() // c
     ok = (_MLP_GEMM != "torch" and enabled_for(x_nhwc) and x_nhwc.is_contiguous() and shortcut_nhwc.is_contiguous()
           and c % 128 == 0)
-    if ok and _MLP_GEMM == "split":
+    if ok and _MLP_GEMM == "split" and hip_lib.split_gemm_tiles(m, c) >= _LIBRARY_BELOW_TILES:
         # fewer than two output tiles per CU (small ROI counts at the deep stages): split K as well, or most of the chip idles
         f1 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, 4 * c) < _SPLITK_BELOW_TILES else hip_lib.linear_f32_split
         f2 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, c) < _SPLITK_BELOW_TILES else hip_lib.linear_f32_split
         h = f1(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk"), mlp.fc1.bias, "gelu")
         y = f2(h, _packed(mlp.fc2, cache, "fc2_pk"), mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
         return y.view(x_nhwc.shape)
-    if ok and c <= _F32_FUSED_MAX_C and m % 128 == 0:
+    if ok and _MLP_GEMM == "f32" and c <= _F32_FUSED_MAX_C and m % 128 == 0:
         h = hip_lib.linear_f32(x_nhwc.view(m, c), mlp.fc1.weight, mlp.fc1.bias, "gelu")
         y = hip_lib.linear_f32(h, mlp.fc2.weight, mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
         return y.view(x_nhwc.shape)
