@@ -87,10 +87,12 @@ def test_model_forward_hip_layers_vs_torch_ops(hip, mlp_gemm):
     with torch.no_grad():
         hip_layers.set_enabled(True)
         hip_layers.set_mlp_gemm(mlp_gemm)
+        hip_layers.set_library_below_tiles(0)      # keep every block on the HIP GEMM at this small ROI count
         try:
             o1 = model(x, **args)
         finally:
             hip_layers.set_mlp_gemm("split")
+            hip_layers.set_library_below_tiles(128)
         hip_layers.set_enabled(False)
         o2 = model(x, **args)
         hip_layers.set_enabled(True)
@@ -294,11 +296,17 @@ def test_model_forward_odd_roi_count(hip):
     args = dict(roi_classes=torch.randint(0, 21, (b,), device=DEV), roi_cams=K, roi_whs=torch.full((b, 2), 120.0, device=DEV),
                 roi_centers=torch.full((b, 2), 250.0, device=DEV), resize_ratios=torch.full((b,), 64 / 180.0, device=DEV),
                 roi_coord_2d=torch.rand(b, 2, 64, 64, device=DEV), roi_extents=torch.full((b, 3), 0.1, device=DEV))
-    timer = hip.LaunchTimer()
+    timer, timer_default = hip.LaunchTimer(), hip.LaunchTimer()
     with torch.no_grad():
         hip.set_launch_timer(timer)
+        hip_layers.set_library_below_tiles(0)      # every block on the HIP GEMM
         try:
             o1 = model(x, **args)
+        finally:
+            hip_layers.set_library_below_tiles(128)
+        hip.set_launch_timer(timer_default)        # default dispatch: deep stages (few tiles at 5 ROIs) go to hipBLASLt
+        try:
+            o3 = model(x, **args)
         finally:
             hip.set_launch_timer(None)
         hip_layers.set_enabled(False)
@@ -307,6 +315,8 @@ def test_model_forward_odd_roi_count(hip):
     # 36 blocks x (fc1, fc2) + the two Patch-PnP fc layers, plain or split-K depending on the tile count
     assert sum(1 for r in timer.records if r[0] in ("linear", "linear_splitk")) == 74
     assert sum(1 for r in timer.records if r[0] == "conv3x3") >= 4
+    assert sum(1 for r in timer_default.records if r[0] in ("linear", "linear_splitk")) == 3 * 2 + 2   # stage 0 + Patch-PnP fc
+    torch.testing.assert_close(o3["trans"], o1["trans"], rtol=0, atol=1e-4)
     for key in ("mask", "coor_x", "coor_y", "coor_z", "region"):
         assert (o1[key] - o2[key]).abs().max().item() <= 1e-4 * max(o2[key].abs().max().item(), 1.0), key
     torch.testing.assert_close(o1["rot"], o2["rot"], rtol=0, atol=1e-4)
