@@ -21,24 +21,24 @@ __global__ __launch_bounds__(256) void flow_kernel(const float* __restrict__ dep
     const int bi = (int)(index / width / height);
     const float* ki = Kinv + 9 * bi;
     const float* kt = KT + 12 * bi;
-    const float d_src = depth_src[index];
-    const float x = (w * ki[0] + h * ki[1] + ki[2]) * d_src;
-    const float y = (w * ki[3] + h * ki[4] + ki[5]) * d_src;
-    const float z = d_src;
+    const float zs = depth_src[index];
+    const float x = (w * ki[0] + h * ki[1] + ki[2]) * zs;
+    const float y = (w * ki[3] + h * ki[4] + ki[5]) * zs;
+    const float z = zs;
     float f0 = 0.f, f1 = 0.f, v = 0.f;
-    if ((double)d_src > 1E-3) {
-      const float x_proj = x * kt[0] + y * kt[1] + z * kt[2] + kt[3];
-      const float y_proj = x * kt[4] + y * kt[5] + z * kt[6] + kt[7];
-      const float z_proj = (float)((double)(x * kt[8] + y * kt[9] + z * kt[10] + kt[11]) + 1E-15);
-      const float w_proj = x_proj / z_proj;
-      const float h_proj = y_proj / z_proj;
-      const int w_proj_i = (int)roundf(w_proj);
-      const int h_proj_i = (int)roundf(h_proj);
-      if (w_proj >= 0 && w_proj <= width - 1 && h_proj >= 0 && h_proj <= height - 1) {
-        const float d_tgt = depth_tgt[((long)bi * height + h_proj_i) * width + w_proj_i];
-        if ((double)fabsf(z_proj - d_tgt) < 3E-3) {
-          f0 = h_proj - h;
-          f1 = w_proj - w;
+    if ((double)zs > 1E-3) {
+      const float hx = x * kt[0] + y * kt[1] + z * kt[2] + kt[3];
+      const float hy = x * kt[4] + y * kt[5] + z * kt[6] + kt[7];
+      const float hz = (float)((double)(x * kt[8] + y * kt[9] + z * kt[10] + kt[11]) + 1E-15);
+      const float u = hx / hz;
+      const float v_ = hy / hz;
+      const int ui = (int)roundf(u);
+      const int vi = (int)roundf(v_);
+      if (u >= 0 && u <= width - 1 && v_ >= 0 && v_ <= height - 1) {
+        const float zt = depth_tgt[((long)bi * height + vi) * width + ui];
+        if ((double)fabsf(hz - zt) < 3E-3) {
+          f0 = v_ - h;
+          f1 = u - w;
           v = 1.f;
         }
       }

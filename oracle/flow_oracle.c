@@ -3,8 +3,8 @@
  *
  * Per pixel (h, w) of image b: back-project with Kinv and the source depth, transform/project with KT = K [R|t],
  * round to the nearest target pixel, accept when the projected depth agrees with the target depth within 3 mm;
- * flow = (h_proj - h, w_proj - w) in channels (0, 1), valid = 1, else zeros.
- * Semantics kept: float arithmetic left to right without FMA (build with -ffp-contract=off), `d_src > 1E-3` and
+ * flow = (v_ - h, u - w) in channels (0, 1), valid = 1, else zeros.
+ * Semantics kept: float arithmetic left to right without FMA (build with -ffp-contract=off), `zs > 1E-3` and
  * `|dz| < 3E-3` compared in double, `+ 1E-15` added in double before the store to float, round-half-away (round()),
  * bounds tested on the UNROUNDED projection.  Kinv / KT are indexed per image (the CUDA kernel's behaviour with one
  * pixel per thread); the cumulative pointer bump of the CPU file for batch > 1 is a reference bug and not copied. */
@@ -18,24 +18,24 @@ void oracle_flow_forward(const float* depth_src, const float* depth_tgt, const f
     for (int h = 0; h < height; ++h)
       for (int w = 0; w < width; ++w) {
         const int index = (bi * height + h) * width + w;
-        const float d_src = depth_src[index];
-        const float x = (w * ki[0] + h * ki[1] + ki[2]) * d_src;
-        const float y = (w * ki[3] + h * ki[4] + ki[5]) * d_src;
-        const float z = d_src;
+        const float zs = depth_src[index];
+        const float x = (w * ki[0] + h * ki[1] + ki[2]) * zs;
+        const float y = (w * ki[3] + h * ki[4] + ki[5]) * zs;
+        const float z = zs;
         int ok = 0;
-        if (d_src > 1E-3) {
-          const float x_proj = x * kt[0] + y * kt[1] + z * kt[2] + kt[3];
-          const float y_proj = x * kt[4] + y * kt[5] + z * kt[6] + kt[7];
-          const float z_proj = (float)(x * kt[8] + y * kt[9] + z * kt[10] + kt[11] + 1E-15);
-          const float w_proj = x_proj / z_proj;
-          const float h_proj = y_proj / z_proj;
-          const int w_proj_i = (int)roundf(w_proj);
-          const int h_proj_i = (int)roundf(h_proj);
-          if (w_proj >= 0 && w_proj <= width - 1 && h_proj >= 0 && h_proj <= height - 1) {
-            const float d_tgt = depth_tgt[(bi * height + h_proj_i) * width + w_proj_i];
-            if (fabsf(z_proj - d_tgt) < 3E-3) {
-              flow[((bi * 2 + 0) * height + h) * width + w] = h_proj - h;
-              flow[((bi * 2 + 1) * height + h) * width + w] = w_proj - w;
+        if (zs > 1E-3) {
+          const float hx = x * kt[0] + y * kt[1] + z * kt[2] + kt[3];
+          const float hy = x * kt[4] + y * kt[5] + z * kt[6] + kt[7];
+          const float hz = (float)(x * kt[8] + y * kt[9] + z * kt[10] + kt[11] + 1E-15);
+          const float u = hx / hz;
+          const float v_ = hy / hz;
+          const int ui = (int)roundf(u);
+          const int vi = (int)roundf(v_);
+          if (u >= 0 && u <= width - 1 && v_ >= 0 && v_ <= height - 1) {
+            const float zt = depth_tgt[(bi * height + vi) * width + ui];
+            if (fabsf(hz - zt) < 3E-3) {
+              flow[((bi * 2 + 0) * height + h) * width + w] = v_ - h;
+              flow[((bi * 2 + 1) * height + h) * width + w] = u - w;
               valid[index] = 1.f;
               ok = 1;
             }
