@@ -146,3 +146,29 @@ def test_records_to_bop_and_csv_format(tmp_path):
     assert lines[0] == "scene_id,im_id,obj_id,score,R,t,time" and len(lines) == 3
     f = lines[2].split(",")
     assert f[:4] == ["48", "1", "1", "1.0"] and f[4] == "1.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 1.0" and f[5] == "0.0 0.0 1000.0" and f[6] == "0.25"
+
+
+def test_detections_from_yolox_handoff():
+    """Detector output (dets [B,max_det,7], count [B]) -> the detections dict of batch_data_test_gpu: per-image order kept,
+    boxes divided by the test-time resize ratio, score = obj * class_conf, empty images skipped, per-image cap."""
+    import numpy as np
+    import torch
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+
+    dets = torch.zeros(3, 4, 7)
+    dets[0, 0] = torch.tensor([10.0, 20.0, 110.0, 220.0, 0.9, 0.8, 3.0])
+    dets[0, 1] = torch.tensor([50.0, 60.0, 70.0, 90.0, 0.5, 0.5, 1.0])
+    dets[2, 0] = torch.tensor([5.0, 6.0, 7.0, 8.0, 1.0, 0.25, 20.0])
+    count = torch.tensor([2, 0, 1], dtype=torch.int32)
+    K = np.eye(3, dtype=np.float32)
+    ext = np.full((21, 3), 0.1, np.float32)
+    d = engine.detections_from_yolox(dets, count, K, ext, ratio=2.0)
+    assert d["im_idx"].tolist() == [0, 0, 2] and d["roi_cls"].tolist() == [3, 1, 20]
+    assert np.allclose(d["bbox"], [[5, 10, 55, 110], [25, 30, 35, 45], [2.5, 3, 3.5, 4]])
+    assert np.allclose(d["score"], [0.72, 0.25, 0.25]) and d["cam"] is K and d["extents"] is ext
+    d1 = engine.detections_from_yolox(dets, count, K, ext, max_per_image=1)
+    assert d1["im_idx"].tolist() == [0, 2] and d1["roi_cls"].tolist() == [3, 20]
+    d0 = engine.detections_from_yolox(dets, torch.zeros(3, dtype=torch.int32), K, ext)
+    assert d0["bbox"].shape == (0, 4) and len(d0["roi_cls"]) == 0
+    r = engine.rois_from_detections(d["bbox"], 480, 640)
+    assert np.allclose(r["bbox_center"][0], [30, 60]) and np.allclose(r["scale"][0], 150.0) and np.allclose(r["resize_ratio"][0], 64 / 150.0)
