@@ -174,6 +174,34 @@ def render_roi_xyz_batch(meshes: hip_lib.MeshSet, roi_cls, ego_rot, trans, roi_z
     return roi_xyz, roi_mask_obj
 
 
+def upnp_weights_from_cov(covar) -> "np.ndarray":
+    """Weights of ``GDRN_Evaluator.pose_from_upnp`` (gdrn_evaluator.py:612-629): W = inv(sqrtm(C)) per 2x2 keypoint
+    covariance, returned as (w_xx, w_xy, w_yy) f32[pn,3]; degenerate covariances (C[0,0] < 1e-6 or NaN) get zero weight.
+    The reference calls ``scipy.linalg.sqrtm``; a symmetric positive-definite 2x2 matrix has the closed form
+    sqrtm(C) = (C + s I) / t with s = sqrt(det C), t = sqrt(trace C + 2 s) (Cayley-Hamilton), used here so that no per-keypoint
+    SciPy call is needed.  tests/ pin it against scipy.linalg.sqrtm."""
+    import numpy as np
+
+    c = np.asarray(covar, np.float64).reshape(-1, 2, 2)
+    bad = (c[:, 0, 0] < 1e-6) | np.isnan(c).any(axis=(1, 2))
+    cs = np.where(bad[:, None, None], np.eye(2)[None], c)
+    det = cs[:, 0, 0] * cs[:, 1, 1] - cs[:, 0, 1] * cs[:, 1, 0]
+    s = np.sqrt(np.maximum(det, 0.0))
+    t = np.sqrt(cs[:, 0, 0] + cs[:, 1, 1] + 2.0 * s)
+    root = (cs + s[:, None, None] * np.eye(2)[None]) / t[:, None, None]
+    inv = np.linalg.inv(root)
+    inv[bad] = 0.0
+    # the reference stacks float32 zeros with float64 inverses and keeps columns (0, 1, 3) of the flattened 2x2
+    return inv.reshape(-1, 4)[:, (0, 1, 3)]
+
+
+def pose_from_upnp(mean_pts2d, covar, points_3d, K, init_rt=None):
+    """``GDRN_Evaluator.pose_from_upnp`` (gdrn_evaluator.py:612-629): covariance -> weights -> uncertainty-PnP (HIP, fp64)."""
+    from ..core.csrc.uncertainty_pnp.un_pnp_utils import uncertainty_pnp
+
+    return uncertainty_pnp(mean_pts2d, upnp_weights_from_cov(covar), points_3d, K, init_rt=init_rt)
+
+
 def mask_rles(cfg, batch: dict, out_dict: dict, key: str = "mask", compressed: bool = True) -> list:
     """SAVE_RESULTS_ONLY instance masks (gdrn_evaluator.py:914-945): ``get_out_mask`` (engine_utils.py:315-333) on the raw
     ``out_dict[key]`` maps, boxes = roi_center -/+ scale/2, then paste + threshold + COCO RLE fused on the device

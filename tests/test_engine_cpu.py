@@ -172,3 +172,24 @@ def test_detections_from_yolox_handoff():
     assert d0["bbox"].shape == (0, 4) and len(d0["roi_cls"]) == 0
     r = engine.rois_from_detections(d["bbox"], 480, 640)
     assert np.allclose(r["bbox_center"][0], [30, 60]) and np.allclose(r["scale"][0], 150.0) and np.allclose(r["resize_ratio"][0], 64 / 150.0)
+
+
+def test_upnp_weights_match_scipy_sqrtm():
+    """pose_from_upnp's weights inv(sqrtm(C)) (gdrn_evaluator.py:612-626): closed form vs the reference's own dependency,
+    scipy.linalg.sqrtm, incl. the degenerate-covariance rule."""
+    import numpy as np
+    import scipy.linalg
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(40, 2, 2))
+    cov = a @ a.transpose(0, 2, 1) + 0.05 * np.eye(2)
+    cov[3] = 0.0                       # C[0,0] < 1e-6 -> zero weight
+    cov[7, 0, 1] = np.nan              # NaN -> zero weight
+    w = engine.upnp_weights_from_cov(cov)
+    assert w.shape == (40, 3) and not w[3].any() and not w[7].any()
+    for i in range(40):
+        if i in (3, 7):
+            continue
+        ref = np.linalg.inv(scipy.linalg.sqrtm(cov[i])).reshape(4)[[0, 1, 3]]
+        np.testing.assert_allclose(w[i], ref.real, rtol=1e-10, atol=1e-12)
