@@ -29,6 +29,22 @@ def shard_range(n: int, rank: int, world: int):
     return begin, end
 
 
+def coor_planes(cfg, out_dict: dict):
+    """``get_out_coor`` (engine_utils.py:295-312) as three single-channel planes.  Regression heads (one channel per axis)
+    pass through; the classification flavour (``XYZ_LOSS_TYPE`` CE / CE_coor: XYZ_BIN + 1 logits per axis) becomes
+    argmax-bin / (XYZ_BIN - 1) with the background bin mapped to 0, as the reference does before any post-processing."""
+    planes = [out_dict["coor_x"], out_dict["coor_y"], out_dict["coor_z"]]
+    if all(p.shape[1] == 1 for p in planes):
+        return [p.contiguous() for p in planes]
+    nbin = int(cfg.MODEL.POSE_NET.GEO_HEAD.XYZ_BIN)
+    out = []
+    for p in planes:
+        idx = torch.argmax(p, dim=1, keepdim=True)
+        idx = torch.where(idx == nbin, torch.zeros_like(idx), idx)
+        out.append((idx.to(torch.float32) / float(nbin - 1)).contiguous())
+    return out
+
+
 class GdrnHipPost:
     """Batched, device-resident replacement of ``GDRN_Evaluator.process / process_depth_refine``."""
 
@@ -54,9 +70,9 @@ class GdrnHipPost:
         b = out_dict["trans"].shape[0]
         K_crop = hip_lib.zoom_K(batch["roi_cam"].reshape(b, 9).contiguous(), batch["roi_center"].contiguous(),
                                 batch["scale"].reshape(b).contiguous(), self.out_res)
+        cx, cy, cz = coor_planes(cfg, out_dict)
         return hip_lib.depth_refine(
-            self.meshes, batch["roi_cls"].to(torch.int32), out_dict["coor_x"].contiguous(),
-            out_dict["coor_y"].contiguous(), out_dict["coor_z"].contiguous(), out_dict["mask"].contiguous(),
+            self.meshes, batch["roi_cls"].to(torch.int32), cx, cy, cz, out_dict["mask"].contiguous(),
             batch["roi_depth"].contiguous(), K_crop, out_dict["rot"].reshape(b, 9).contiguous(),
             out_dict["trans"].contiguous(), res=self.out_res, iters=cfg.TEST.DEPTH_REFINE_ITER,
             threshold=cfg.TEST.DEPTH_REFINE_THRESHOLD, mask_type=self.mask_type,
@@ -65,9 +81,9 @@ class GdrnHipPost:
     def process_correspondences(self, batch: dict, out_dict: dict):
         """2D-3D correspondences for the PnP variants (gdrn_evaluator.py:115-153,255-311), all ROIs at once."""
         imwh = torch.stack([batch["im_W"], batch["im_H"]], 1).float().contiguous()
+        cx, cy, cz = coor_planes(self.cfg, out_dict)
         return hip_lib.decode_correspondences(
-            out_dict["coor_x"].contiguous(), out_dict["coor_y"].contiguous(), out_dict["coor_z"].contiguous(),
-            out_dict["mask"].contiguous(), batch["roi_coord_2d"].contiguous(), batch["roi_extent"].contiguous(), imwh,
+            cx, cy, cz, out_dict["mask"].contiguous(), batch["roi_coord_2d"].contiguous(), batch["roi_extent"].contiguous(), imwh,
             mask_type=self.mask_type, mask_thr=self.cfg.MODEL.POSE_NET.GEO_HEAD.MASK_THR_TEST)
 
     def process_net_and_pnp(self, batch: dict, out_dict: dict):

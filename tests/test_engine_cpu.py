@@ -193,3 +193,26 @@ def test_upnp_weights_match_scipy_sqrtm():
             continue
         ref = np.linalg.inv(scipy.linalg.sqrtm(cov[i])).reshape(4)[[0, 1, 3]]
         np.testing.assert_allclose(w[i], ref.real, rtol=1e-10, atol=1e-12)
+
+
+def test_coor_planes_regression_and_classification():
+    """get_out_coor (engine_utils.py:295-312): regression maps pass through; classification logits -> argmax bin / (BIN-1),
+    background bin -> 0."""
+    import torch
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+
+    cfg = get_cfg("ycbv_convnext_a6", [])
+    nbin = cfg.MODEL.POSE_NET.GEO_HEAD.XYZ_BIN
+    reg = {k: torch.rand(2, 1, 4, 4) for k in ("coor_x", "coor_y", "coor_z")}
+    out = engine.coor_planes(cfg, reg)
+    assert all(torch.equal(o, reg[k]) for o, k in zip(out, ("coor_x", "coor_y", "coor_z")))
+    logits = torch.full((1, nbin + 1, 2, 2), -5.0)
+    logits[0, 0, 0, 0] = 9.0            # bin 0
+    logits[0, nbin - 1, 0, 1] = 9.0     # last foreground bin -> 1.0
+    logits[0, nbin, 1, 0] = 9.0         # background bin -> 0
+    logits[0, 21, 1, 1] = 9.0
+    cls = {k: logits.clone() for k in ("coor_x", "coor_y", "coor_z")}
+    px, py, pz = engine.coor_planes(cfg, cls)
+    want = torch.tensor([[0.0, 1.0], [0.0, 21.0 / (nbin - 1)]])
+    assert px.shape == (1, 1, 2, 2) and torch.allclose(px[0, 0], want) and torch.equal(px, py) and torch.equal(py, pz)
