@@ -336,6 +336,39 @@ def detections_from_yolox(dets: torch.Tensor, count: torch.Tensor, cam, extents,
                 score=d[:, 4] * d[:, 5], cam=cam, extents=extents)
 
 
+def detections_from_bop_json(detections: dict, scene_im_ids, obj_ids, cam, extents, top_k_per_obj: int = 1,
+                             score_thr: float = 0.0, train_obj_ids=None) -> dict:
+    """The offline hand-off of the reference: a BOP detection file ``{scene_im_id: [{"obj_id", "bbox_est": [x, y, w, h],
+    "score", "time"}]}`` -> the ``detections`` dict of ``batch_data_test_gpu``, with the selection rules of
+    ``load_detections_into_dataset`` (core/utils/dataset_utils.py:146-227): drop score < score_thr and objects the model
+    was not trained on, keep the ``top_k_per_obj`` highest scores per object (stable for ties), objects in the dataset's
+    class order, images without detections skipped.  ``scene_im_ids[i]`` names image ``i`` of the batch; ``obj_ids`` is
+    the dataset's object-id list in class order.  Also returns ``time`` (detector time per ROI) for the BOP results."""
+    import numpy as np
+
+    obj_ids = [int(o) for o in obj_ids]
+    keep = set(obj_ids if train_obj_ids is None else [int(o) for o in train_obj_ids])
+    bbox, im_idx, cls, score, times = [], [], [], [], []
+    for i, key in enumerate(scene_im_ids):
+        per_obj = {o: [] for o in obj_ids}
+        for det in detections.get(key, []):
+            o, sc = int(det["obj_id"]), float(det.get("score", 1.0))
+            if sc < score_thr or o not in per_obj or o not in keep:
+                continue
+            per_obj[o].append((sc, det))
+        for o in obj_ids:
+            for sc, det in sorted(per_obj[o], key=lambda pair: pair[0], reverse=True)[:top_k_per_obj]:
+                x, y, w, h = [float(v) for v in det["bbox_est"]]
+                bbox.append([x, y, x + w, y + h])           # BoxMode.XYWH_ABS -> XYXY_ABS
+                im_idx.append(i)
+                cls.append(obj_ids.index(o))
+                score.append(sc)
+                times.append(float(det.get("time", 0.0)))
+    return dict(bbox=np.asarray(bbox, np.float32).reshape(-1, 4), im_idx=np.asarray(im_idx, np.int64),
+                roi_cls=np.asarray(cls, np.int64), score=np.asarray(score, np.float32), cam=cam, extents=extents,
+                time=np.asarray(times, np.float32))
+
+
 def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, device=None) -> dict:
     """``read_data_test`` + ``batch_data_test`` (data_loader.py:647-818, engine_utils.py:213-241) with the crops made
     on the GPU.  images u8[n_im,H,W,3] (BGR, device), depths f32[n_im,H,W] or None, detections:

@@ -216,3 +216,30 @@ def test_coor_planes_regression_and_classification():
     px, py, pz = engine.coor_planes(cfg, cls)
     want = torch.tensor([[0.0, 1.0], [0.0, 21.0 / (nbin - 1)]])
     assert px.shape == (1, 1, 2, 2) and torch.allclose(px[0, 0], want) and torch.equal(px, py) and torch.equal(py, pz)
+
+
+def test_detections_from_bop_json_selection_rules():
+    """load_detections_into_dataset (dataset_utils.py:146-227): score threshold, unknown / untrained objects dropped,
+    top-k per object by score (stable for ties), dataset class order, xywh -> xyxy, images without detections skipped."""
+    import numpy as np
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+
+    dets = {
+        "48/1": [
+            {"obj_id": 5, "bbox_est": [10, 20, 30, 40], "score": 0.6, "time": 0.1},
+            {"obj_id": 5, "bbox_est": [11, 21, 31, 41], "score": 0.9, "time": 0.1},
+            {"obj_id": 1, "bbox_est": [1, 2, 3, 4], "score": 0.5},
+            {"obj_id": 1, "bbox_est": [5, 6, 7, 8], "score": 0.5},        # tie: first one stays first
+            {"obj_id": 99, "bbox_est": [0, 0, 1, 1], "score": 1.0},       # not an object of the dataset
+            {"obj_id": 9, "bbox_est": [0, 0, 9, 9], "score": 0.05},       # below the threshold
+        ],
+        "50/7": [{"obj_id": 9, "bbox_est": [100, 100, 50, 60], "score": 0.7, "time": 0.3}],
+    }
+    d = engine.detections_from_bop_json(dets, ["48/1", "49/3", "50/7"], obj_ids=[1, 5, 9], cam=None, extents=None,
+                                        top_k_per_obj=1, score_thr=0.1)
+    assert d["im_idx"].tolist() == [0, 0, 2] and d["roi_cls"].tolist() == [0, 1, 2]
+    assert np.allclose(d["bbox"], [[1, 2, 4, 6], [11, 21, 42, 62], [100, 100, 150, 160]])
+    assert np.allclose(d["score"], [0.5, 0.9, 0.7]) and np.allclose(d["time"], [0.0, 0.1, 0.3])
+    d2 = engine.detections_from_bop_json(dets, ["48/1"], obj_ids=[1, 5, 9], cam=None, extents=None, top_k_per_obj=2,
+                                         train_obj_ids=[5])
+    assert d2["roi_cls"].tolist() == [1, 1] and np.allclose(d2["score"], [0.9, 0.6])
