@@ -154,7 +154,7 @@ def test_linear_f32_split_is_fp32_accurate(hip, m, k, n):
         e_split = (out.double() - want64).abs().max().item() / scale
         chain = hip.linear_f32(x, w, b, epi, gamma if epi == "scale_res" else None, res if epi == "scale_res" else None)
         e_f32 = max((got32.double() - want64).abs().max().item(), (chain.double() - want64).abs().max().item()) / scale
-        assert e_split <= 1.25 * e_f32 + 1.2e-7, (epi, e_split, e_f32)
+        assert e_split <= max(1.25 * e_f32 + 1.2e-7, 4e-8 * k ** 0.5), (epi, e_split, e_f32)
         assert ((out - got32).abs().max() / scale).item() < 4e-6, epi
     # K must be a multiple of 32 (M is free): the C entry point refuses with a status and a message, nothing is launched
     import ctypes
@@ -342,7 +342,8 @@ def test_linear_f32_splitk(hip, m, k, n):
         out = hip.linear_f32_splitk(x, pk, b, epi, *extra)
         scale = want64.abs().max().item()
         e_f32 = (got32.double() - want64).abs().max().item() / scale
-        assert (out.double() - want64).abs().max().item() / scale <= 1.25 * e_f32 + 1.2e-7, epi
+        # floor: the library may pick a more accurate algorithm on another box; ~sqrt(K) ulp is what fp32 accumulation allows
+        assert (out.double() - want64).abs().max().item() / scale <= max(1.25 * e_f32 + 1.2e-7, 4e-8 * k ** 0.5), epi
         assert torch.equal(out, hip.linear_f32_splitk(x, pk, b, epi, *extra))
 
 
