@@ -381,7 +381,7 @@ def main():
 
     if rank == 0:
         cpu = None
-        if refine and not args.no_cpu_baseline:
+        if refine and not args.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N=1 only
             out = forward_only()
             torch.cuda.synchronize()
             out_np = {k: out[k].detach().cpu().numpy() for k in ("mask", "coor_x", "coor_y", "coor_z", "rot", "trans")}
