@@ -90,6 +90,19 @@ def build_ref(force: bool = False) -> dict:
                         "-o", flow_so, flow_shim, "-DFLOW_SRC=\"%s\"" % flow_src], check=True)
     if os.path.exists(flow_so):
         out["flow"] = flow_so
+
+    rv_so = os.path.join(_REF_DIR, "libransac_ref.so")
+    rv_src = os.path.join(REFERENCE_ROOT, "core/csrc/ransac_voting/src/ransac_voting_kernel.cu")
+    rv_shim = os.path.join(_HERE, "ref_shims", "ransac_ref_shim.cpp")
+    if os.path.exists(rv_src) and os.path.exists(rv_shim) and (force or not os.path.exists(rv_so)):
+        # no nvcc: the four kernels (plain C per thread, no shared memory / atomics / barriers) are extracted verbatim
+        # into a generated include under _ref/ and compiled for the host behind a grid emulator
+        inc = os.path.join(_REF_DIR, "ransac_kernels_extracted.inc")
+        subprocess.run([sys.executable, os.path.join(_HERE, "ref_shims", "extract_cuda_kernels.py"), rv_src, inc], check=True)
+        subprocess.run(["g++", "-shared", "-fPIC", "-O2", "-std=c++14", "-o", rv_so, rv_shim,
+                        "-DRANSAC_KERNELS_INC=\"%s\"" % inc], check=True)
+    if os.path.exists(rv_so):
+        out["ransac"] = rv_so
     return out
 
 
@@ -105,7 +118,7 @@ def lib() -> ctypes.CDLL:
 
 def ref_lib(name: str):
     """ctypes handle on a compiled reference library, or None if it was never built."""
-    path = {"fps": "libfps_ref.so", "nnd": "libnnd_ref.so", "upnp": "libupnp_ref.so", "flow": "libflow_ref.so"}[name]
+    path = {"fps": "libfps_ref.so", "nnd": "libnnd_ref.so", "upnp": "libupnp_ref.so", "flow": "libflow_ref.so", "ransac": "libransac_ref.so"}[name]
     path = os.path.join(_REF_DIR, path)
     if not os.path.exists(path):
         build_ref()

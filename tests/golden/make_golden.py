@@ -10,6 +10,8 @@ outputs on seeded inputs:
                    ceres/rotation.h, and the optimum found by the vendored ceres::TinySolver
   flow_golden.npz  core/csrc/flow/src/flow_cpu.cpp flow_kernel<float> (one image per call: the file's pointer bump
                    makes batches > 1 meaningless)
+  ransac_golden.npz  the four kernels of core/csrc/ransac_voting/src/ransac_voting_kernel.cu, extracted verbatim and
+                   compiled for the host behind a grid emulator (oracle/ref_shims/ransac_ref_shim.cpp)
 The fixtures travel to the GPU box; /root/reference does not.
 """
 import ctypes
@@ -60,7 +62,7 @@ def make_flow_case(rng, h, w, motion):
 
 def main():
     libs = oracle.build_ref(force=True)
-    assert set(libs) == {"fps", "nnd", "upnp", "flow"}, libs
+    assert set(libs) == {"fps", "nnd", "upnp", "flow", "ransac"}, libs
     rng = np.random.default_rng(20220925)
 
     # ---- FPS -------------------------------------------------------------------------
@@ -152,6 +154,30 @@ def main():
         assert np.isfinite(flow).all() and 0.05 < valid.mean() < 0.999, valid.mean()
         out.update({f"ds{k}": ds, f"dt{k}": dt, f"KT{k}": KT, f"Kinv{k}": Kinv, f"flow{k}": flow, f"valid{k}": valid})
     np.savez_compressed(os.path.join(HERE, "flow_golden.npz"), **out)
+
+    # ---- RANSAC voting kernels -------------------------------------------------------------
+    ref = ctypes.CDLL(libs["ransac"])
+    u8p = ctypes.POINTER(ctypes.c_ubyte)
+    out = {}
+    for k, (tn, vn, hn) in enumerate([(500, 9, 128), (37, 3, 16), (1500, 9, 96)]):
+        coords = np.stack([rng.uniform(0, 64, tn), rng.uniform(0, 64, tn)], 1).astype(np.float32)
+        kpts = rng.uniform(-20, 84, (vn, 2))
+        d = kpts[None] - coords[:, None].astype(np.float64)
+        d /= np.linalg.norm(d, axis=2, keepdims=True)
+        direct = (d + rng.normal(0, 0.05, d.shape)).astype(np.float32)
+        direct[rng.integers(0, tn, 3)] = 0.0                                    # zero-norm directions
+        idxs = rng.integers(0, tn, (hn, vn, 2)).astype(np.int32)
+        idxs[0, :, 1] = idxs[0, :, 0]                                           # degenerate pairs: kernel returns early
+        out.update({f"direct{k}": direct, f"coords{k}": coords, f"idxs{k}": idxs})
+        for vp in (0, 1):
+            hypo = np.zeros((hn, vn, 3 if vp else 2), np.float32)
+            ref.ref_generate_hypothesis(P(direct, f32p), P(coords, f32p), P(idxs, i32p), P(hypo, f32p), tn, vn, hn, vp)
+            inl = np.zeros((hn, vn, tn), np.uint8)
+            ref.ref_voting_for_hypothesis(P(direct, f32p), P(coords, f32p), P(hypo, f32p), inl.ctypes.data_as(u8p), tn, vn, hn,
+                                          ctypes.c_float(0.99), vp)
+            assert np.isfinite(hypo).all() and 0 < inl.mean() < 0.9, (k, vp, inl.mean())
+            out.update({f"hypo{k}_{vp}": hypo, f"inl{k}_{vp}": np.packbits(inl, axis=-1)})
+    np.savez_compressed(os.path.join(HERE, "ransac_golden.npz"), **out)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -105,3 +105,20 @@ def test_flow_oracle_batches_are_per_image(golden_dir):
     for i in range(2):
         f1, v1 = P.flow_forward(ds[i:i + 1], dt[i:i + 1], KT[i:i + 1], Kinv[i:i + 1])
         assert np.array_equal(fb[i:i + 1], f1) and np.array_equal(vb[i:i + 1], v1)
+
+
+def test_ransac_voting_oracle_matches_reference_kernels(golden_dir):
+    """oracle/ransac_voting_oracle.c == the reference's own CUDA kernels (ransac_voting_kernel.cu, bodies extracted
+    verbatim and compiled for the host): hypotheses bit for bit (degenerate pairs untouched = 0), inlier flags identical."""
+    g = np.load(os.path.join(golden_dir, "ransac_golden.npz"))
+    k = 0
+    while f"direct{k}" in g:
+        direct, coords, idxs = g[f"direct{k}"], g[f"coords{k}"], g[f"idxs{k}"]
+        tn = direct.shape[0]
+        for vp in (0, 1):
+            hypo = P.generate_hypothesis(direct, coords, idxs, vanishing_point=bool(vp))
+            assert np.array_equal(hypo, g[f"hypo{k}_{vp}"])
+            inl = P.voting_for_hypothesis(direct, coords, hypo, 0.99, vanishing_point=bool(vp))
+            assert np.array_equal(inl, np.unpackbits(g[f"inl{k}_{vp}"], axis=-1)[..., :tn])
+        k += 1
+    assert k == 3
