@@ -1,0 +1,112 @@
+"""Golden vectors from the reference's own PYTHON functions (authoring container only: needs /root/reference).
+
+The reference's modules cannot be imported here (cv2 / mmcv / detectron2 / transforms3d / timm are missing), but the
+functions on the post-processing path are plain torch / NumPy.  Their source text is cut out of the reference files with
+`ast`, executed UNMODIFIED in a namespace that holds only numpy, torch and the names they need, and their outputs on
+seeded inputs are recorded in pyref_golden.npz:
+
+  get_out_mask, get_out_coor                 core/gdrn_modeling/engine/engine_utils.py
+  get_img_model_points_with_coords2d         core/gdrn_modeling/engine/gdrn_evaluator.py (method; `self` unused)
+  get_K_crop_resize                          core/utils/camera_geometry.py
+  rot6d_to_mat_batch                         core/utils/rot_reps.py
+  pose_from_predictions_test                 core/gdrn_modeling/models/pose_from_pred_centroid_z.py
+  allocentric_to_egocentric                  core/utils/utils.py
+The one third-party call inside that chain, transforms3d.axangles.axangle2mat (not installed), is served by
+scipy.spatial.transform.Rotation (same rotation, an independent implementation) — noted in DESIGN.md.
+"""
+import ast
+import math
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.spatial.transform import Rotation
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def cut(path, name):
+    """Source text of function (or method) `name` in the reference file, dedented."""
+    src = open(os.path.join(REF, path)).read()
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            lines = src.splitlines()[node.lineno - 1:node.end_lineno]
+            indent = len(lines[0]) - len(lines[0].lstrip())
+            return "\n".join(l[indent:] for l in lines) + "\n"
+    raise KeyError(name)
+
+
+def axangle2mat(axis, angle, is_normalized=False):
+    axis = np.asarray(axis, np.float64)
+    return Rotation.from_rotvec(axis / np.linalg.norm(axis) * angle).as_matrix()
+
+
+def main():
+    ns = dict(np=np, torch=torch, F=F, math=math, random=random, axangle2mat=axangle2mat)
+    for path, name in [("core/gdrn_modeling/engine/engine_utils.py", "get_out_mask"),
+                       ("core/gdrn_modeling/engine/engine_utils.py", "get_out_coor"),
+                       ("core/gdrn_modeling/engine/gdrn_evaluator.py", "get_img_model_points_with_coords2d"),
+                       ("core/utils/camera_geometry.py", "get_K_crop_resize"),
+                       ("core/utils/rot_reps.py", "rot6d_to_mat_batch"),
+                       ("core/utils/utils.py", "allocentric_to_egocentric"),
+                       ("core/gdrn_modeling/models/pose_from_pred_centroid_z.py", "pose_from_predictions_test")]:
+        exec(compile(cut(path, name), os.path.join(REF, path), "exec"), ns)
+    cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(POSE_NET=types.SimpleNamespace(
+        LOSS_CFG=types.SimpleNamespace(MASK_LOSS_TYPE="L1"), GEO_HEAD=types.SimpleNamespace(XYZ_BIN=64))))
+    rng = np.random.default_rng(20220925)
+    out = {}
+
+    # maps: smooth object-like fields so that the selection thresholds are not hit exactly
+    b = 6
+    yy, xx = np.mgrid[0:64, 0:64]
+    blob = np.stack([np.clip(1.3 - np.hypot(yy - 30 - k, xx - 33 + k) / (14.0 + k), 0, 1) for k in range(b)])
+    raw_mask = (blob * 2.5 - 0.7 + rng.normal(0, 0.03, blob.shape)).astype(np.float32)[:, None]
+    coor = [(0.5 + 0.45 * np.sin(xx / (7.0 + i) + k) * np.cos(yy / 9.0) * blob[k] + 0.0 * k).astype(np.float32)
+            for i in range(3) for k in range(b)]
+    coor = np.stack(coor).reshape(3, b, 1, 64, 64)
+    coor[:, :, :, :3, :] = 0.5                      # exact mid-values: |xyz - 0.5| * extent == 0 fails the > test
+    mask_prob = ns["get_out_mask"](cfg, torch.from_numpy(raw_mask)).numpy()
+    xyz = ns["get_out_coor"](cfg, *[torch.from_numpy(c) for c in coor]).numpy()
+    out.update(raw_mask=raw_mask, coor=coor, mask_prob=mask_prob, xyz=xyz)
+    extents = rng.uniform(0.05, 0.25, (b, 3)).astype(np.float32)
+    coord2d = rng.uniform(0, 1, (b, 64, 64, 2)).astype(np.float32)
+    counts, ip, mp = [], [], []
+    for i in range(b):
+        fn = ns["get_img_model_points_with_coords2d"]
+        lead = (None,) if fn.__code__.co_varnames[0] == "self" else ()   # the file holds a method and a free-function twin
+        img_pts, mdl_pts = fn(*lead, mask_prob[i, 0].copy(), xyz[i].transpose(1, 2, 0).copy(), coord2d[i], 480, 640, extents[i],
+                              mask_thr=0.5)
+        counts.append(len(img_pts)); ip.append(img_pts); mp.append(mdl_pts)
+    assert min(counts) > 50 and max(counts) < 4096
+    out.update(extents=extents, coord2d=coord2d, corr_counts=np.asarray(counts), corr_img=np.concatenate(ip), corr_mdl=np.concatenate(mp))
+
+    # K crop/resize, rot6d, pose from prediction
+    n = 16
+    K = np.repeat(np.array([[1066.778, 0, 312.9869], [0, 1067.487, 241.3109], [0, 0, 1]], np.float32)[None], n, 0)
+    centers = np.stack([rng.uniform(80, 560, n), rng.uniform(80, 400, n)], 1).astype(np.float32)
+    scales = rng.uniform(60, 300, n).astype(np.float32)
+    crop_xy = centers - scales[:, None] / 2
+    ratio = (64 / scales)[:, None].astype(np.float32)
+    out.update(K=K, centers=centers, scales=scales,
+               K_crop=ns["get_K_crop_resize"](torch.from_numpy(K), torch.from_numpy(crop_xy), torch.from_numpy(ratio)).numpy())
+    d6 = rng.normal(size=(n, 6)).astype(np.float32)
+    R_allo = ns["rot6d_to_mat_batch"](torch.from_numpy(d6))
+    out.update(d6=d6, R_allo=R_allo.numpy())
+    cent = rng.normal(0, 0.1, (n, 2)).astype(np.float32)
+    zval = rng.uniform(0.5, 3.0, (n, 1)).astype(np.float32)
+    whs = rng.uniform(40, 200, (n, 2)).astype(np.float32)
+    R_ego, trans = ns["pose_from_predictions_test"](R_allo, torch.from_numpy(cent), torch.from_numpy(zval), torch.from_numpy(K.copy()),
+                                                     torch.from_numpy(centers), torch.from_numpy(ratio[:, 0]), torch.from_numpy(whs),
+                                                     eps=1e-4, is_allo=True, z_type="REL")
+    out.update(pred_centroids=cent, pred_z=zval, roi_whs=whs, resize_ratio=ratio[:, 0], R_ego=R_ego.numpy(), trans=trans.numpy())
+    np.savez_compressed(os.path.join(HERE, "pyref_golden.npz"), **out)
+    print("pyref_golden.npz", os.path.getsize(os.path.join(HERE, "pyref_golden.npz")), "correspondences per ROI:", counts)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -122,3 +122,28 @@ def test_ransac_voting_oracle_matches_reference_kernels(golden_dir):
             assert np.array_equal(inl, np.unpackbits(g[f"inl{k}_{vp}"], axis=-1)[..., :tn])
         k += 1
     assert k == 3
+
+
+def test_postproc_oracle_matches_reference_python_functions(golden_dir):
+    """oracle/postproc.py against the reference's OWN Python functions executed from their source text
+    (tests/golden/make_golden_pyref.py): get_out_mask / get_out_coor, the 2D-3D correspondence selection (indices, order
+    and values bit for bit), get_K_crop_resize, rot6d_to_mat_batch, pose_from_predictions_test."""
+    g = np.load(os.path.join(golden_dir, "pyref_golden.npz"))
+    mask_prob = P.get_out_mask(g["raw_mask"])
+    assert np.array_equal(mask_prob, g["mask_prob"])
+    xyz = P.get_out_coor(*g["coor"])
+    assert np.array_equal(xyz, g["xyz"])
+    off = 0
+    for i, n in enumerate(g["corr_counts"]):
+        ip, mp, _ = P.get_img_model_points_with_coords2d(mask_prob[i, 0], xyz[i].transpose(1, 2, 0), g["coord2d"][i], 480, 640,
+                                                         g["extents"][i], mask_thr=0.5)
+        assert len(ip) == n and np.array_equal(ip, g["corr_img"][off:off + n]) and np.array_equal(mp, g["corr_mdl"][off:off + n])
+        off += n
+    crop_xy = g["centers"] - g["scales"][:, None] / 2
+    assert np.array_equal(P.get_K_crop_resize(g["K"], crop_xy, (64 / g["scales"])[:, None].astype(np.float32)), g["K_crop"])
+    assert np.array_equal(P.zoom_K(g["K"], g["centers"], g["scales"], 64), g["K_crop"])
+    np.testing.assert_allclose(P.rot6d_to_mat_batch(g["d6"]), g["R_allo"], rtol=0, atol=2e-7)   # torch vs NumPy reductions
+    R_ego, trans = P.pose_from_predictions_test(g["R_allo"], g["pred_centroids"], g["pred_z"], g["K"], g["centers"],
+                                                g["resize_ratio"], g["roi_whs"])
+    assert np.array_equal(trans, g["trans"])
+    np.testing.assert_allclose(R_ego, g["R_ego"], rtol=0, atol=1e-6)   # transforms3d stood in by scipy when recorded
