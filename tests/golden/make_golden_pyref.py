@@ -11,6 +11,12 @@ seeded inputs are recorded in pyref_golden.npz:
   rot6d_to_mat_batch                         core/utils/rot_reps.py
   pose_from_predictions_test                 core/gdrn_modeling/models/pose_from_pred_centroid_z.py
   allocentric_to_egocentric                  core/utils/utils.py
+  process_depth_refine (+ batch_data_inference_roi, pose_prediction_to_json)
+                                             core/gdrn_modeling/engine/gdrn_evaluator.py, engine_utils.py — the refine loop of
+                                             the north-star path, run with a stand-in `self`: the GL renderer and cv2.resize
+                                             (neither exists here) are served by the oracle's rasteriser and its restated
+                                             INTER_LINEAR x4, everything else (q-map, threshold, median, centroid ray,
+                                             inv(K_crop), translation update) is the reference's own code
 The one third-party call inside that chain, transforms3d.axangles.axangle2mat (not installed), is served by
 scipy.spatial.transform.Rotation (same rotation, an independent implementation) — noted in DESIGN.md.
 """
@@ -44,6 +50,82 @@ def cut(path, name):
 def axangle2mat(axis, angle, is_normalized=False):
     axis = np.asarray(axis, np.float64)
     return Rotation.from_rotvec(axis / np.linalg.norm(axis) * angle).as_matrix()
+
+
+def refine_case(ns, cfg_maps):
+    """Run the reference's process_depth_refine on a synthetic batch (two images, 3 + 2 ROIs, three object classes)."""
+    import time as _time
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from gdrnpp_bop2022_amd import synthetic as S
+    from oracle import postproc as P
+
+    for path, name in [("core/gdrn_modeling/engine/engine_utils.py", "batch_data_inference_roi"),
+                       ("core/gdrn_modeling/engine/gdrn_evaluator.py", "pose_prediction_to_json"),
+                       ("core/gdrn_modeling/engine/gdrn_evaluator.py", "process_depth_refine"),
+                       ("core/gdrn_modeling/engine/test_utils.py", "to_list")]:
+        exec(compile(cut(path, name), os.path.join(REF, path), "exec"), ns)
+    orig_bdi = ns["batch_data_inference_roi"]
+    ns["batch_data_inference_roi"] = lambda cfg, data: orig_bdi(cfg, data, device="cpu")   # the text defaults to 'cuda'
+    ns["cv2"] = types.SimpleNamespace(resize=lambda a, size: P.resize_depth_x4_linear(a))  # 256 -> 64, INTER_LINEAR restated
+    ns["time"] = _time
+
+    rng = np.random.default_rng(20220925 + 8)
+    verts, faces, ext = S.make_models(3, rng, 3)
+    b = 5
+    det = S.make_detections(b, 3, ext, rng)
+
+    def render_fn(obj, K, R, t, res):
+        d, x = zip(*[P.render_depth(verts[obj[i]], faces[obj[i]], K[i], R[i], t[i].astype(np.float64), res_w=res, want_xyz=True)
+                     for i in range(len(obj))])
+        return np.stack(d), np.stack(x)
+
+    maps = S.make_map_inputs(det, verts, faces, render_fn, rng)
+
+    class Ren:                                   # stand-in for lib/render_vispy Renderer: GL gets float32 uniforms
+        def clear(self): pass
+        def set_cam(self, K): self.K = np.asarray(K, np.float32)
+        def draw_model(self, model, pose): self.model, self.pose = model, np.asarray(pose, np.float32)
+        def finish(self):
+            v, f = self.model
+            return None, P.render_depth(v, f, self.K, self.pose[:, :3], self.pose[:, 3].astype(np.float64), res_w=64)
+
+    names = ["obj_a", "obj_b", "obj_c"]
+    cfg = types.SimpleNamespace(
+        MODEL=types.SimpleNamespace(POSE_NET=types.SimpleNamespace(
+            OUTPUT_RES=64, LOSS_CFG=types.SimpleNamespace(MASK_LOSS_TYPE="L1"), GEO_HEAD=types.SimpleNamespace(XYZ_BIN=64))),
+        TEST=types.SimpleNamespace(DEPTH_REFINE_ITER=2, USE_COOR_Z_REFINE=False))
+    me = types.SimpleNamespace(
+        cfg=cfg, _cpu_device=torch.device("cpu"), out_res=64, depth_refine_threshold=0.8, _predictions=[],
+        _maybe_adapt_label_cls_name=lambda label: (int(label), names[int(label)]),
+        data_ref=types.SimpleNamespace(obj2id={n: i + 1 for i, n in enumerate(names)}, objects=names),
+        ren_models=[(verts[i], faces[i]) for i in range(3)], ren=Ren())
+    me.pose_prediction_to_json = lambda *a, **k: ns["pose_prediction_to_json"](me, *a, **k)
+    T = torch.from_numpy
+    split = [(0, 3), (3, 5)]
+    inputs = [dict(roi_img=[None] * (hi - lo), cam=T(det["roi_cam"][lo:hi]), roi_cls=T(det["roi_cls"][lo:hi]), score=T(det["score"][lo:hi]),
+                   scene_im_id=[f"48/{k}" for k in range(lo, hi)], roi_depth=T(maps["roi_depth"][lo:hi]),
+                   bbox_center=T(det["roi_center"][lo:hi]), scale=T(det["scale"][lo:hi]), resize_ratio=T(det["resize_ratio"][lo:hi]))
+              for lo, hi in split]
+    for d in inputs:   # batch_data_inference_roi concatenates roi_img tensors; give it real (empty-payload) ones
+        d["roi_img"] = torch.zeros(len(d["roi_img"]), 1)
+    out_dict = dict(coor_x=T(maps["coor_x"]), coor_y=T(maps["coor_y"]), coor_z=T(maps["coor_z"]), mask=T(maps["mask"]),
+                    rot=T(det["R_gt"]), trans=T(maps["t_init"]))
+    # NOTE the reference indexes zoom_K with inst_i (the per-image index) instead of out_i (gdrn_evaluator.py:493) — a bug for
+    # batches of several images; one image per call keeps the recorded behaviour the intended one
+    t_ref = []
+    for k, (lo, hi) in enumerate(split):
+        me._predictions = []
+        od = {key: v[lo:hi] for key, v in out_dict.items()}
+        ns["process_depth_refine"](me, [inputs[k]], [dict(time=0.0)], od)
+        assert len(me._predictions) == hi - lo
+        t_ref += [np.asarray(p["t"], np.float64) / 1000.0 for p in me._predictions]
+    t_ref = np.stack(t_ref)
+    moved = np.abs(t_ref[:, 2] - maps["t_init"][:, 2])
+    assert (moved > 1e-4).all(), moved
+    return {"rf_" + k: v for k, v in dict(
+        verts=np.stack(verts), faces=np.stack(faces), roi_cls=det["roi_cls"], R=det["R_gt"], t_init=maps["t_init"], K_crop=maps["K_crop"],
+        coor_x=maps["coor_x"], coor_y=maps["coor_y"], coor_z=maps["coor_z"], mask=maps["mask"], roi_depth=maps["roi_depth"],
+        t_gt=det["t_gt"], t_refined=t_ref).items()}
 
 
 def main():
@@ -104,6 +186,7 @@ def main():
                                                      torch.from_numpy(centers), torch.from_numpy(ratio[:, 0]), torch.from_numpy(whs),
                                                      eps=1e-4, is_allo=True, z_type="REL")
     out.update(pred_centroids=cent, pred_z=zval, roi_whs=whs, resize_ratio=ratio[:, 0], R_ego=R_ego.numpy(), trans=trans.numpy())
+    out.update(refine_case(ns, cfg))
     np.savez_compressed(os.path.join(HERE, "pyref_golden.npz"), **out)
     print("pyref_golden.npz", os.path.getsize(os.path.join(HERE, "pyref_golden.npz")), "correspondences per ROI:", counts)
 

@@ -147,3 +147,22 @@ def test_postproc_oracle_matches_reference_python_functions(golden_dir):
                                                 g["resize_ratio"], g["roi_whs"])
     assert np.array_equal(trans, g["trans"])
     np.testing.assert_allclose(R_ego, g["R_ego"], rtol=0, atol=1e-6)   # transforms3d stood in by scipy when recorded
+
+
+def test_depth_refine_oracle_matches_reference_process_depth_refine(golden_dir):
+    """oracle.postproc.depth_refine_roi against the reference's OWN process_depth_refine (gdrn_evaluator.py:461-573 executed
+    from source with a stand-in `self`; renderer and cv2.resize served by the oracle's rasteriser / restated INTER_LINEAR):
+    the refined translation agrees to 1e-9 m.  (Not bit for bit: torch's CPU `norm` accumulates x*x, fma(y,y,.), fma(z,z,.)
+    in float32 on this host, the oracle and the HIP kernel use the uncontracted chain — a 1-ulp difference in ~2 % of the
+    q-map weights, 1e-10 relative in t; SURVEY §8a lists this reduction among the order-dependent, tolerance-checked ones.)"""
+    g = np.load(os.path.join(golden_dir, "pyref_golden.npz"))
+    mask = P.get_out_mask(g["rf_mask"])
+    n = len(g["rf_roi_cls"])
+    for i in range(n):
+        o = int(g["rf_roi_cls"][i])
+        xyz = np.concatenate([g["rf_coor_x"][i], g["rf_coor_y"][i], g["rf_coor_z"][i]], 0).transpose(1, 2, 0)
+        t = P.depth_refine_roi(xyz, mask[i, 0], g["rf_roi_depth"][i, 0], g["rf_K_crop"][i], g["rf_R"][i], g["rf_t_init"][i],
+                               g["rf_verts"][o], g["rf_faces"][o], iters=2, threshold=0.8)
+        np.testing.assert_allclose(t, g["rf_t_refined"][i], rtol=0, atol=1e-9)
+        # and the refinement does what it is for: closer to the ground-truth depth than the initial estimate
+        assert abs(t[2] - g["rf_t_gt"][i, 2]) < abs(g["rf_t_init"][i, 2] - g["rf_t_gt"][i, 2]) + 1e-3
