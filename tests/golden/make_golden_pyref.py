@@ -128,6 +128,62 @@ def refine_case(ns, cfg_maps):
         t_gt=det["t_gt"], t_refined=t_ref).items()}
 
 
+def ransac_layer_case(ns):
+    """The reference's ransac_voting_layer (core/csrc/ransac_voting/ransac_voting_gpu.py:7-104) executed from source on CPU
+    tensors, its torch extension served by the reference's own kernels compiled for the host (oracle/_ref/libransac_ref.so);
+    the random index draw is recorded so that the oracle can replay it."""
+    import ctypes
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import oracle
+    lib = ctypes.CDLL(oracle.build_ref()["ransac"])
+    f32p, i32p, u8p = (ctypes.POINTER(t) for t in (ctypes.c_float, ctypes.c_int, ctypes.c_ubyte))
+    draws = []
+
+    class RV:
+        @staticmethod
+        def generate_hypothesis(direct, coords, idxs):
+            d, c, i = (np.ascontiguousarray(t.numpy()) for t in (direct, coords, idxs))
+            if not draws or draws[-1] is not idxs:
+                draws.append(idxs)
+            hyp = np.zeros((i.shape[0], d.shape[1], 2), np.float32)
+            lib.ref_generate_hypothesis(d.ctypes.data_as(f32p), c.ctypes.data_as(f32p), i.ctypes.data_as(i32p), hyp.ctypes.data_as(f32p),
+                                        d.shape[0], d.shape[1], i.shape[0], 0)
+            return torch.from_numpy(hyp)
+
+        @staticmethod
+        def voting_for_hypothesis(direct, coords, hyp, inlier, thresh):
+            d, c, h = (np.ascontiguousarray(t.numpy()) for t in (direct, coords, hyp))
+            buf = np.zeros(tuple(inlier.shape), np.uint8)
+            lib.ref_voting_for_hypothesis(d.ctypes.data_as(f32p), c.ctypes.data_as(f32p), h.ctypes.data_as(f32p), buf.ctypes.data_as(u8p),
+                                          d.shape[0], d.shape[1], h.shape[0], ctypes.c_float(thresh), 0)
+            inlier.copy_(torch.from_numpy(buf))
+
+    ns["ransac_voting"] = RV
+    exec(compile(cut("core/csrc/ransac_voting/ransac_voting_gpu.py", "ransac_voting_layer"), "ransac_voting_gpu.py", "exec"), ns)
+    rng = np.random.default_rng(20220925 + 9)
+    b, h, w, vn = 3, 64, 64, 9
+    yy, xx = np.mgrid[0:h, 0:w]
+    mask = np.stack([(np.hypot(yy - 30 - 2 * k, xx - 34 + k) < 14 + 2 * k) for k in range(b)]).astype(np.float32)
+    mask[2] = 0
+    mask[2, 10, 10:13] = 1                                      # fewer than min_num foreground pixels -> zeros
+    kpts = rng.uniform(5, 60, (b, vn, 2))
+    vec = kpts[:, None, None] - np.stack([xx, yy], -1)[None, :, :, None].astype(np.float64)
+    vec /= np.linalg.norm(vec, axis=-1, keepdims=True) + 1e-9
+    vertex = (vec + rng.normal(0, 0.03, vec.shape)).astype(np.float32)
+    torch.manual_seed(7)
+    # the reference was written for torch 1.x, where masked_select accepted uint8 masks; give today's torch that behaviour
+    orig_ms = torch.Tensor.masked_select
+    torch.Tensor.masked_select = lambda self, m: orig_ms(self, m.bool() if m.dtype == torch.uint8 else m)
+    try:
+        win = ns["ransac_voting_layer"](torch.from_numpy(mask), torch.from_numpy(vertex), 128, inlier_thresh=0.99, max_iter=5)
+    finally:
+        torch.Tensor.masked_select = orig_ms
+    assert win.shape == (b, vn, 2) and len(draws) == 2 and not win[2].any()
+    err = np.abs(win[:2].numpy() - kpts[:2]).max()
+    assert err < 1.0, err
+    return dict(rv_mask=mask, rv_vertex=vertex, rv_win=win.numpy(), rv_idxs=np.stack([d.numpy() for d in draws]), rv_kpts=kpts.astype(np.float32))
+
+
 def main():
     ns = dict(np=np, torch=torch, F=F, math=math, random=random, axangle2mat=axangle2mat)
     for path, name in [("core/gdrn_modeling/engine/engine_utils.py", "get_out_mask"),
@@ -187,6 +243,7 @@ def main():
                                                      eps=1e-4, is_allo=True, z_type="REL")
     out.update(pred_centroids=cent, pred_z=zval, roi_whs=whs, resize_ratio=ratio[:, 0], R_ego=R_ego.numpy(), trans=trans.numpy())
     out.update(refine_case(ns, cfg))
+    out.update(ransac_layer_case(ns))
     np.savez_compressed(os.path.join(HERE, "pyref_golden.npz"), **out)
     print("pyref_golden.npz", os.path.getsize(os.path.join(HERE, "pyref_golden.npz")), "correspondences per ROI:", counts)
 

@@ -166,3 +166,18 @@ def test_depth_refine_oracle_matches_reference_process_depth_refine(golden_dir):
         np.testing.assert_allclose(t, g["rf_t_refined"][i], rtol=0, atol=1e-9)
         # and the refinement does what it is for: closer to the ground-truth depth than the initial estimate
         assert abs(t[2] - g["rf_t_gt"][i, 2]) < abs(g["rf_t_init"][i, 2] - g["rf_t_gt"][i, 2]) + 1e-3
+
+
+def test_ransac_voting_layer_oracle_matches_reference_python_layer(golden_dir):
+    """oracle.postproc.ransac_voting_layer against the reference's own ransac_voting_layer (ransac_voting_gpu.py:7-104 executed
+    from source, its extension served by the reference kernels compiled for the host), replaying the recorded index draw
+    (the reference draws ONE index set per image and reuses it in every round): voted keypoints within float32 LSQ noise,
+    the too-few-pixels image gives zeros."""
+    g = np.load(os.path.join(golden_dir, "pyref_golden.npz"))
+    mask, vertex, win, idxs = g["rv_mask"], g["rv_vertex"], g["rv_win"], g["rv_idxs"]
+    for i in range(2):
+        got, n_iter = P.ransac_voting_layer(mask[i], vertex[i], [idxs[i]] * 8, inlier_thresh=0.99, max_iter=5)
+        np.testing.assert_allclose(got, win[i], rtol=0, atol=2e-3)
+        assert np.abs(got - g["rv_kpts"][i]).max() < 1.0
+    z = P.ransac_voting_layer(mask[2], vertex[2], [idxs[0]], inlier_thresh=0.99, max_iter=5)
+    assert not np.asarray(z if not isinstance(z, tuple) else z[0]).any() and not win[2].any()
