@@ -97,10 +97,12 @@ def build_ref(force: bool = False) -> dict:
     if os.path.exists(rv_src) and os.path.exists(rv_shim) and (force or not os.path.exists(rv_so)):
         # no nvcc: the four kernels (plain C per thread, no shared memory / atomics / barriers) are extracted verbatim
         # into a generated include under _ref/ and compiled for the host behind a grid emulator
-        inc = os.path.join(_REF_DIR, "ransac_kernels_extracted.inc")
-        subprocess.run([sys.executable, os.path.join(_HERE, "ref_shims", "extract_cuda_kernels.py"), rv_src, inc], check=True)
-        subprocess.run(["g++", "-shared", "-fPIC", "-O2", "-std=c++14", "-o", rv_so, rv_shim,
-                        "-DRANSAC_KERNELS_INC=\"%s\"" % inc], check=True)
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:   # the extracted text is a build intermediate: only the .so is kept
+            inc = os.path.join(tmp, "ransac_kernels_extracted.inc")
+            subprocess.run([sys.executable, os.path.join(_HERE, "ref_shims", "extract_cuda_kernels.py"), rv_src, inc], check=True)
+            subprocess.run(["g++", "-shared", "-fPIC", "-O2", "-std=c++14", "-o", rv_so, rv_shim,
+                            "-DRANSAC_KERNELS_INC=\"%s\"" % inc], check=True)
     if os.path.exists(rv_so):
         out["ransac"] = rv_so
     return out
