@@ -5,11 +5,18 @@ around the C restatements in this directory.  Each function cites the reference 
 follows (paths relative to /root/reference).  NumPy >= 2 (NEP 50) float32 scalar semantics are
 fixed here, as stated in SURVEY.md §8a ("Threshold scalars and NumPy promotion").
 
-PARITY STATUS: the reference has no golden vectors or tests for any of this and
-cannot be imported here (cv2 / vispy / transforms3d / detectron2 missing), so these
-restatements are pinned only by (a) the reference sources that do compile (FPS, nnd_cpu —
-see tests), (b) the vendored Ceres jet/rotation headers for the uncertainty-PnP cost, and
-(c) closed-form checks (analytic depth of planes/spheres, exact inverse problems).
+PARITY STATUS: the reference has no golden vectors or tests for any of this and its modules
+cannot be imported here (cv2 / vispy / transforms3d / detectron2 missing).  What pins these restatements:
+(a) the reference sources that do compile — FPS, nnd_cpu, flow_cpu, the ransac_voting CUDA kernel bodies behind a host
+    grid emulator (tests/golden/make_golden.py);
+(b) the reference's own PYTHON functions executed from their source text — get_out_mask / get_out_coor, the correspondence
+    selection, get_K_crop_resize, rot6d_to_mat_batch, pose_from_predictions_test, process_depth_refine,
+    ransac_voting_layer (tests/golden/make_golden_pyref.py);
+(c) the vendored Ceres jet/rotation headers and TinySolver for the uncertainty-PnP cost / optimum;
+(d) torch's own grid_sample (mask paste), scipy (axangle2mat, sqrtm) and closed-form checks (analytic depth of
+    planes/spheres, exact inverse problems).
+Still unpinned (third-party code that is absent): OpenCV's warpAffine / resize / solvePnP, the GL rasteriser,
+detectron2's ROIAlign, torchvision's NMS, libceres' minimiser schedule.
 """
 from __future__ import annotations
 

@@ -7,8 +7,9 @@
  *   voting_for_hypothesis_vanishing_point_kernel :280-309.
  * fp32 evaluation, left-to-right, no FMA (build with -ffp-contract=off);
  * `x<1e-6` compares after promotion to double exactly as the C++ source does.
- * PARITY UNPINNED by the reference's own tests: the .cu cannot be compiled
- * here (no nvcc) and the reference has no golden vectors for it.
+ * PINNED by the reference's own kernels: the .cu cannot be built as CUDA here (no nvcc) and the reference has no golden
+ * vectors, but the four kernel bodies are plain C per thread; oracle/ref_shims/ compiles them verbatim for
+ * the host (libransac_ref.so) and tests/golden/ransac_golden.npz holds their outputs — this file reproduces them bit for bit.
  */
 #include <math.h>
 #include <string.h>
