@@ -1,7 +1,8 @@
 """core/csrc/ransac_voting/ransac_voting_gpu.py:7-309 with the same signatures; the RANSAC rounds use the fused
 vote+count kernel so the ``[round_hyp_num, vn, tn]`` u8 tensor (4.7 MB per round at 128x9x4096) is never
 written; only the final single-hypothesis vote materialises flags (they feed the 2x2 least squares).
-``idxs`` can be injected for reproducible parity tests (the reference draws them with ``Tensor.random_``)."""
+``idxs_fn(bi, round_hyp_num, vn, tn)`` injects the index draw for parity tests (the reference draws with
+``Tensor.random_``); like the reference, the layers draw ONE index set per image and reuse it in every round."""
 import numpy as np
 import torch
 
@@ -20,69 +21,94 @@ def _foreground(cur_mask, vertex_bi, max_num):
 
 
 def _b_inv(b_mat):
+    """ransac_voting_gpu.py:105-120: batched inverse by solving against the identity; a singular batch -> identity."""
     eye = b_mat.new_ones(b_mat.size(-1)).diag().expand_as(b_mat)
     try:
         return torch.linalg.solve(b_mat, eye)
-    except Exception:  # noqa: BLE001  singular ATA -> identity (ransac_voting_gpu.py:115-120)
+    except Exception:  # noqa: BLE001  (https://github.com/zju3dv/clean-pvnet/issues/8)
         return eye
 
 
-def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
-                           min_num=5, max_num=30000, idxs_fn=None):
-    """mask [b,h,w], vertex [b,h,w,vn,2] -> [b,vn,2]  (ransac_voting_gpu.py:123-218)."""
-    b, h, w, vn, _ = vertex.shape
-    batch_win_pts = []
-    for bi in range(b):
-        hyp_num = 0
-        cur_mask = mask[bi].to(torch.bool)
-        if torch.sum(cur_mask) < min_num:
-            batch_win_pts.append(torch.zeros([1, vn, 2], dtype=torch.float32, device=mask.device))
-            continue
-        coords, direct = _foreground(cur_mask, vertex[bi], max_num)
-        tn = coords.shape[0]
-        all_win_ratio = torch.zeros([vn], dtype=torch.float32, device=mask.device)
-        all_win_pts = torch.zeros([vn, 2], dtype=torch.float32, device=mask.device)
-        cur_iter = 0
-        while True:
-            if idxs_fn is not None:
-                idxs = idxs_fn(bi, cur_iter, round_hyp_num, vn, tn)
-            else:
-                idxs = torch.zeros([round_hyp_num, vn, 2], dtype=torch.int32, device=mask.device).random_(0, tn)
-            cur_hyp_pts = ransac_voting.generate_hypothesis(direct, coords, idxs)          # [hn,vn,2]
-            cur_inlier_counts = ransac_voting.vote_count(direct, coords, cur_hyp_pts, inlier_thresh)  # [hn,vn]
-            cur_win_idx = torch.argmax(cur_inlier_counts, 0)  # first maximum (torch.max leaves ties unspecified)
-            cur_win_counts = cur_inlier_counts.gather(0, cur_win_idx[None])[0]
-            cur_win_pts = cur_hyp_pts[cur_win_idx, torch.arange(vn, device=mask.device)]
-            cur_win_ratio = cur_win_counts.float() / tn
-            larger_mask = all_win_ratio < cur_win_ratio
-            all_win_pts[larger_mask, :] = cur_win_pts[larger_mask, :]
-            all_win_ratio[larger_mask] = cur_win_ratio[larger_mask]
-            hyp_num += round_hyp_num
-            cur_iter += 1
-            cur_min_ratio = torch.min(all_win_ratio)
-            if (1 - (1 - cur_min_ratio ** 2) ** hyp_num) > confidence or cur_iter > max_iter:
-                break
-        # mean intersection of the inliers of the winning hypothesis (:186-213)
-        normal = torch.zeros_like(direct)
-        normal[:, :, 0] = direct[:, :, 1]
-        normal[:, :, 1] = -direct[:, :, 0]
-        all_inlier = torch.zeros([1, vn, tn], dtype=torch.uint8, device=mask.device)
-        ransac_voting.voting_for_hypothesis(direct, coords, all_win_pts[None].contiguous(), all_inlier, inlier_thresh)
-        all_inlier = torch.squeeze(all_inlier.float(), 0)                 # [vn,tn]
-        normal = normal.permute(1, 0, 2) * all_inlier[:, :, None]          # [vn,tn,2]
-        bvec = torch.sum(normal * coords[None], 2)                          # [vn,tn]
-        ATA = torch.matmul(normal.permute(0, 2, 1), normal)                 # [vn,2,2]
-        ATb = torch.sum(normal * bvec[:, :, None], 1)                       # [vn,2]
-        win = torch.matmul(_b_inv(ATA), ATb[:, :, None])                    # [vn,2,1]
-        batch_win_pts.append(win[None, :, :, 0])
-    return torch.cat(batch_win_pts)
+def _draw(idxs_fn, bi, round_hyp_num, vn, tn, device):
+    """The hypothesis index draw — ONE set per image, made before the round loop and reused by every round
+    (ransac_voting_gpu.py:48,164): the confidence test can only be met by the first round's hypotheses, later rounds
+    re-vote the same set.  Reference behaviour, kept."""
+    if idxs_fn is not None:
+        return idxs_fn(bi, round_hyp_num, vn, tn)
+    return torch.zeros([round_hyp_num, vn, 2], dtype=torch.int32, device=device).random_(0, tn)
+
+
+def _ransac_rounds(mask, vertex, bi, round_hyp_num, inlier_thresh, confidence, max_iter, max_num, idxs_fn):
+    """Rounds + inlier normal equations of one image -> (ATA [vn,2,2], ATb [vn,2])."""
+    vn = vertex.shape[3]
+    cur_mask = mask[bi].to(torch.bool)
+    coords, direct = _foreground(cur_mask, vertex[bi], max_num)
+    tn = coords.shape[0]
+    idxs = _draw(idxs_fn, bi, round_hyp_num, vn, tn, mask.device)
+    all_win_ratio = torch.zeros([vn], dtype=torch.float32, device=mask.device)
+    all_win_pts = torch.zeros([vn, 2], dtype=torch.float32, device=mask.device)
+    hyp_num, cur_iter = 0, 0
+    while True:
+        cur_hyp_pts = ransac_voting.generate_hypothesis(direct, coords, idxs)          # [hn,vn,2]
+        cur_inlier_counts = ransac_voting.vote_count(direct, coords, cur_hyp_pts, inlier_thresh)  # [hn,vn]
+        cur_win_idx = torch.argmax(cur_inlier_counts, 0)  # first maximum (torch.max leaves ties unspecified)
+        cur_win_counts = cur_inlier_counts.gather(0, cur_win_idx[None])[0]
+        cur_win_pts = cur_hyp_pts[cur_win_idx, torch.arange(vn, device=mask.device)]
+        cur_win_ratio = cur_win_counts.float() / tn
+        larger_mask = all_win_ratio < cur_win_ratio
+        all_win_pts[larger_mask, :] = cur_win_pts[larger_mask, :]
+        all_win_ratio[larger_mask] = cur_win_ratio[larger_mask]
+        hyp_num += round_hyp_num
+        cur_iter += 1
+        cur_min_ratio = torch.min(all_win_ratio)
+        if (1 - (1 - cur_min_ratio ** 2) ** hyp_num) > confidence or cur_iter > max_iter:
+            break
+    # mean intersection of the inliers of the winning hypothesis (:82-94 / :186-203)
+    normal = torch.zeros_like(direct)
+    normal[:, :, 0] = direct[:, :, 1]
+    normal[:, :, 1] = -direct[:, :, 0]
+    all_inlier = torch.zeros([1, vn, tn], dtype=torch.uint8, device=mask.device)
+    ransac_voting.voting_for_hypothesis(direct, coords, all_win_pts[None].contiguous(), all_inlier, inlier_thresh)
+    all_inlier = torch.squeeze(all_inlier.float(), 0)                 # [vn,tn]
+    normal = normal.permute(1, 0, 2) * all_inlier[:, :, None]          # [vn,tn,2]
+    bvec = torch.sum(normal * coords[None], 2)                          # [vn,tn]
+    ATA = torch.matmul(normal.permute(0, 2, 1), normal)                 # [vn,2,2]
+    ATb = torch.sum(normal * bvec[:, :, None], 1)                       # [vn,2]
+    return ATA, ATb
 
 
 def ransac_voting_layer(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20, min_num=5,
                         max_num=30000, idxs_fn=None):
-    """ransac_voting_gpu.py:7-104 — identical to v3 except for the singular-ATA fallback (zeros instead of identity)."""
-    return ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh, confidence, max_iter, min_num, max_num,
-                                  idxs_fn)
+    """mask [b,h,w], vertex [b,h,w,vn,2] -> [b,vn,2]  (ransac_voting_gpu.py:7-104).  ``torch.inverse(ATA)``; an image
+    whose inverse raises contributes zeros (:96-101)."""
+    b, h, w, vn, _ = vertex.shape
+    batch_win_pts = []
+    for bi in range(b):
+        if torch.sum(mask[bi].to(torch.bool)) < min_num:
+            batch_win_pts.append(torch.zeros([1, vn, 2], dtype=torch.float32, device=mask.device))
+            continue
+        ATA, ATb = _ransac_rounds(mask, vertex, bi, round_hyp_num, inlier_thresh, confidence, max_iter, max_num, idxs_fn)
+        try:
+            win = torch.matmul(torch.inverse(ATA), ATb[:, :, None])         # [vn,2,1]
+            batch_win_pts.append(win[None, :, :, 0])
+        except Exception:  # noqa: BLE001  the reference's bare except
+            batch_win_pts.append(torch.zeros([1, ATA.size(0), 2], device=ATA.device))
+    return torch.cat(batch_win_pts)
+
+
+def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
+                           min_num=5, max_num=30000, idxs_fn=None):
+    """ransac_voting_gpu.py:123-218 — as above, the final solve through ``b_inv`` (singular -> identity, :105-120)."""
+    b, h, w, vn, _ = vertex.shape
+    batch_win_pts = []
+    for bi in range(b):
+        if torch.sum(mask[bi].to(torch.bool)) < min_num:
+            batch_win_pts.append(torch.zeros([1, vn, 2], dtype=torch.float32, device=mask.device))
+            continue
+        ATA, ATb = _ransac_rounds(mask, vertex, bi, round_hyp_num, inlier_thresh, confidence, max_iter, max_num, idxs_fn)
+        win = torch.matmul(_b_inv(ATA), ATb[:, :, None])                    # [vn,2,1]
+        batch_win_pts.append(win[None, :, :, 0])
+    return torch.cat(batch_win_pts)
 
 
 def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256, min_hyp_num=4096, topk=128,
@@ -103,7 +129,7 @@ def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256
         cur_hyp_pts, cur_inlier_ratio = [], []
         for round_idx in range(int(np.ceil(min_hyp_num / round_hyp_num))):
             if idxs_fn is not None:
-                idxs = idxs_fn(bi, round_idx, round_hyp_num, vn, tn)
+                idxs = idxs_fn(bi, round_hyp_num, vn, tn, round_idx)
             else:
                 idxs = torch.zeros([round_hyp_num, vn, 2], dtype=torch.int32, device=mask.device).random_(0, tn)
             hyp_pts = ransac_voting.generate_hypothesis(direct, coords, idxs)

@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip_lib
+from . import hip_layers
 from .backbones import create_backbone
 from .heads import HEADS
 
@@ -83,11 +84,12 @@ class GDRN_DoubleMask(nn.Module):
     def _sliced_out_layer(self, feat, roi_classes):
         """Per-ROI 70-channel output layer = the class-aware gather folded into the weights."""
         ol = self.geo_head_net.out_layer
-        if self._sliced_w is None or self.training or self._sliced_w[0].device != feat.device:
+        tag = hip_layers.weight_tag(ol.weight, ol.bias)
+        if self._sliced_w is None or self.training or self._sliced_w[0] != tag:
             w = ol.weight.view(ol.out_channels, -1)[self._cls_rows]  # [C,70,256]
             b = ol.bias[self._cls_rows]                               # [C,70]
-            self._sliced_w = (w.contiguous(), b.contiguous())
-        w, b = self._sliced_w
+            self._sliced_w = (tag, w.contiguous(), b.contiguous())
+        _, w, b = self._sliced_w
         bs, ch, h, wd = feat.shape
         x = feat.reshape(bs, ch, h * wd)  # NCHW-logical [B,256,4096]; one copy if feat is channels-last
         out = torch.baddbmm(b[roi_classes].unsqueeze(-1), w[roi_classes], x)  # [B,70,4096]
@@ -229,10 +231,33 @@ def build_model_optimizer(cfg, is_test=True):
     return model, None
 
 
-def load_checkpoint(model, path, strict=False):
-    """core/utils/my_checkpoint.py:28-83: ``{"model": state_dict}``, keys may carry a ``_module.`` / ``module.`` prefix."""
+_ALLOWED_UNEXPECTED = ("num_batches_tracked",)
+
+
+def load_checkpoint(model, path, strict=True):
+    """core/utils/my_checkpoint.py:28-83: ``{"model": state_dict}``, keys may carry a leading ``_module.`` / ``module.``
+    prefix (DDP / lightning wrappers) — stripped as a PREFIX only, repeatedly.  A checkpoint that leaves parameters
+    uninitialised or brings keys this model does not have is an error unless ``strict=False`` (then it is reported loudly):
+    the timm ConvNeXt key naming of ``backbones.py`` is unverified against a real GDRNPP checkpoint, and a silent
+    mismatch would leave the backbone random while poses still come out finite."""
     sd = torch.load(path, map_location="cpu")
     sd = sd.get("model", sd)
-    sd = {k.replace("_module.", "", 1).replace("module.", "", 1) if k.startswith(("_module.", "module.")) else k: v
-          for k, v in sd.items()}
-    return model.load_state_dict(sd, strict=strict)
+    clean = {}
+    for k, v in sd.items():
+        stripped = True
+        while stripped:
+            stripped = False
+            for pre in ("_module.", "module."):
+                if k.startswith(pre):
+                    k, stripped = k[len(pre):], True
+        clean[k] = v
+    res = model.load_state_dict(clean, strict=False)
+    unexpected = [k for k in res.unexpected_keys if not k.endswith(_ALLOWED_UNEXPECTED)]
+    if res.missing_keys or unexpected:
+        msg = (f"checkpoint {path}: {len(res.missing_keys)} parameters not found in the file (first: "
+               f"{res.missing_keys[:5]}), {len(unexpected)} keys of the file not used (first: {unexpected[:5]})")
+        if strict:
+            raise RuntimeError(msg)
+        import warnings
+        warnings.warn(msg)
+    return res

@@ -21,6 +21,12 @@ def enabled_for(x: torch.Tensor) -> bool:
     return _ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
 
 
+def weight_tag(*tensors):
+    """Identity of parameter values for the eval-time derived-weight caches: storage, in-place version counter (bumped by
+    load_state_dict / optimiser steps) and device of every tensor the cached form is derived from."""
+    return tuple((t.data_ptr(), t._version, t.device) for t in tensors if t is not None)
+
+
 def _cl(x):
     return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
 
@@ -63,11 +69,12 @@ def dwconv_ln(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor, cache: dict) -
     c = conv.in_channels
     q = c // 4
     if enabled_for(x) and conv.kernel_size == (7, 7) and conv.groups == c and c % 4 == 0 and q <= 256 and 256 % q == 0:
-        w = cache.get("w49c")
-        if w is None or w.device != x.device:
-            w = conv.weight.detach().reshape(c, 49).t().contiguous()  # tap-major [49, C]
-            cache["w49c"] = w
-        y = hip_lib.dwconv7x7_ln(_cl(x), w, conv.bias, ln.weight, ln.bias, ln.eps)
+        tag = weight_tag(conv.weight)
+        hit = cache.get("w49c")
+        if hit is None or hit[0] != tag:
+            hit = (tag, conv.weight.detach().reshape(c, 49).t().contiguous())  # tap-major [49, C]
+            cache["w49c"] = hit
+        y = hip_lib.dwconv7x7_ln(_cl(x), hit[1], conv.bias, ln.weight, ln.bias, ln.eps)
         return y.permute(0, 2, 3, 1)
     y = conv(x).permute(0, 2, 3, 1)
     return F.layer_norm(y, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
@@ -108,7 +115,7 @@ def set_fused_mlp(flag: bool) -> None:
 
 def _packed(linear: nn.Linear, cache: dict, key: str) -> torch.Tensor:
     w = linear.weight
-    tag = (w.data_ptr(), w._version, w.device)
+    tag = weight_tag(w)
     hit = cache.get(key)
     if hit is None or hit[0] != tag:
         hit = (tag, hip_lib.pack_weight_bf16x3(w.detach()))
@@ -159,7 +166,7 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
             and (x.shape[2] + 2 * conv.padding[0] - conv.kernel_size[0]) // conv.stride[0] * conv.stride[0] < x.shape[2]):
         cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
         w = conv.weight
-        tag = (w.data_ptr(), w._version, w.device)
+        tag = weight_tag(w)
         hit = cache.get("w_pk")
         if hit is None or hit[0] != tag:
             hit = (tag, hip_lib.pack_conv_weight_bf16x3(w.detach()))

@@ -161,3 +161,50 @@ def make_map_inputs(det: dict, verts, faces, render_fn, rng: np.random.Generator
     return dict(coor_x=coor[0], coor_y=coor[1], coor_z=coor[2], mask=mask_raw, roi_depth=roi_depth,
                 K_crop=K_crop.astype(f32), t_init=t_init.astype(f32),
                 roi_coord_2d=coord2d_roi(det["roi_center"], det["scale"], out_res))
+
+
+# ---- platform-independent seeded values (network parity fixtures) -------------------------------------------------------
+def seeded_uniform(name: str, shape, seed: int = 0) -> np.ndarray:
+    """f32 array of ``shape`` with values in [-1, 1) that depend only on (name, seed, flat index): splitmix64 of a counter
+    keyed by sha256(name) — no library RNG stream involved, so the recipe that wrote a fixture in the authoring container
+    and the test that rebuilds its inputs on the GPU box get bit-identical tensors."""
+    import hashlib
+    key = int.from_bytes(hashlib.sha256(f"{seed}:{name}".encode()).digest()[:8], "little")
+    n = int(np.prod(shape)) if len(shape) else 1
+    with np.errstate(over="ignore"):
+        z = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(key)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -23) - np.float32(1.0)   # 24 bits: exact in f32
+    return u.reshape(shape)
+
+
+def seeded_param(name: str, shape, seed: int = 0) -> np.ndarray:
+    """Seeded value of one network parameter/buffer, scaled by its role so that activations stay O(1) through the whole
+    graph (the reference's std=0.001 initialisers would make every map ~1e-20 and hide mistakes):
+    >= 2-D weights U(-a, a) with a = sqrt(6 / fan_in) (variance 2 / fan_in); 1-D ``weight`` (norm scales) 1 + 0.2 u;
+    ConvNeXt layer scale ``gamma`` 0.4 + 0.2 u; ``running_var`` 1 + 0.2 u; everything else 1-D (biases, means) 0.1 u."""
+    shape = tuple(int(s) for s in shape)
+    u = seeded_uniform(name, shape, seed)
+    leaf = name.rsplit(".", 1)[-1]
+    if len(shape) >= 2:
+        fan_in = int(np.prod(shape[1:]))
+        return (u * np.float32(np.sqrt(6.0 / fan_in))).astype(np.float32)
+    if leaf == "num_batches_tracked":
+        return np.zeros(shape, np.int64)
+    if leaf == "gamma":
+        return (np.float32(0.4) + np.float32(0.2) * u).astype(np.float32)
+    if leaf in ("weight", "running_var"):
+        return (np.float32(1.0) + np.float32(0.2) * u).astype(np.float32)
+    return (np.float32(0.1) * u).astype(np.float32)
+
+
+def seeded_state_dict(named_shapes, seed: int = 0, alias=None) -> dict:
+    """{key: torch tensor} for ``named_shapes`` = iterable of (key, shape).  ``alias(key)`` maps a key to the name its
+    value is derived from (the reference's ConvModule registers its norm twice: ``norm.*`` and ``gn.*`` are one tensor)."""
+    import torch
+    out = {}
+    for k, shp in named_shapes:
+        out[k] = torch.from_numpy(seeded_param(alias(k) if alias else k, shp, seed))
+    return out

@@ -1,0 +1,59 @@
+"""Shared by tests/golden/make_golden_net.py (authoring container, runs the reference's modules) and the tests that replay
+its fixtures: the ROI batch of the network parity case and the seeded parameters, both platform-independent."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from gdrnpp_bop2022_amd import synthetic as S
+
+SEED = 20220925
+B = 4
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def norm_alias(key):
+    """The reference's ConvModule registers one norm module under two names (conv_module.py:175-182): ``norm.*`` and
+    ``gn.*`` are the same tensor, so both get the values derived from the ``gn`` name."""
+    if key.startswith("geo_head_net.") and ".norm." in key:
+        return key.replace(".norm.", ".gn.")
+    return key
+
+
+def net_image(b=B, seed=SEED):
+    return (S.seeded_uniform("roi_img", (b, 3, 256, 256), seed) + np.float32(1)) * np.float32(0.5)
+
+
+def net_detections(num_classes, b=B, seed=SEED):
+    """Authoring-side only (NumPy Generator stream): the arrays are stored in the fixture."""
+    rng = np.random.default_rng(seed + num_classes)
+    ext = rng.uniform(0.05, 0.25, (num_classes, 3)).astype(np.float32)
+    det = S.make_detections(b, num_classes, ext, rng)
+    det["roi_cls"] = np.array([0, num_classes - 1, 7 % num_classes, 13 % num_classes][:b], np.int64)
+    det["roi_extent"] = ext[det["roi_cls"]]
+    return det
+
+
+def load_fixture(ds):
+    z = np.load(os.path.join(GOLDEN, f"net_golden_{ds}.npz"))
+    fx = {k: z[k] for k in z.files}
+    fx["cfg"] = json.loads(str(fx.pop("cfg_json")))
+    fx["head_keys"] = [(k, tuple(s)) for k, s in json.loads(str(fx.pop("head_keys")))]
+    return fx
+
+
+def seeded_reference_state_dict(model, fx):
+    """The state_dict the reference model held when the fixture was recorded: geo head + Patch-PnP entries by the
+    REFERENCE's key/shape manifest (incl. its duplicate ``norm.*`` keys), backbone entries by this model's own keys."""
+    named = [(k, tuple(v.shape)) for k, v in model.state_dict().items() if k.startswith("backbone.")]
+    named += list(fx["head_keys"])
+    return S.seeded_state_dict(named, SEED, alias=norm_alias)
+
+
+def forward_kwargs(fx, device):
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    coord2d = S.coord2d_roi(fx["roi_center"], fx["scale"])
+    return dict(roi_classes=T(fx["roi_cls"]), roi_cams=T(fx["roi_cam"]), roi_whs=T(fx["roi_wh"]),
+                roi_centers=T(fx["roi_center"]), resize_ratios=T(fx["resize_ratio"]), roi_coord_2d=T(coord2d),
+                roi_extents=T(fx["roi_extent"]))

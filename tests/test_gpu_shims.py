@@ -53,6 +53,30 @@ def test_un_pnp_utils_like_pose_from_upnp():
         uncertainty_pnp(p2, w, p3, K)  # cv2 absent: must not silently invent an initialiser
 
 
+def test_ransac_voting_layer_replays_reference_draw(golden_dir):
+    """The shim against the REFERENCE's ransac_voting_layer (executed from source over its host-compiled kernels,
+    tests/golden/make_golden_pyref.py): the recorded single index draw per image is replayed through idxs_fn and the
+    voted keypoints must agree; an image below min_num foreground pixels gives zeros."""
+    from gdrnpp_bop2022_amd.core.csrc.ransac_voting.ransac_voting_gpu import ransac_voting_layer, ransac_voting_layer_v3
+
+    g = np.load(f"{golden_dir}/pyref_golden.npz")
+    mask, vertex, win_ref, draws = g["rv_mask"], g["rv_vertex"], g["rv_win"], g["rv_idxs"]
+    calls = []
+
+    def idxs_fn(bi, hn_, vn_, tn_):
+        calls.append(bi)
+        assert draws[bi].shape == (hn_, vn_, 2) and draws[bi].max() < tn_
+        return torch.from_numpy(draws[bi]).to(DEV)
+
+    for layer in (ransac_voting_layer, ransac_voting_layer_v3):
+        calls.clear()
+        out = layer(torch.from_numpy(mask).to(DEV), torch.from_numpy(vertex).to(DEV), 128, inlier_thresh=0.99, max_iter=5,
+                    idxs_fn=idxs_fn).cpu().numpy()
+        assert calls == [0, 1]                               # ONE draw per image with enough foreground, none for image 2
+        np.testing.assert_allclose(out[:2], win_ref[:2], atol=2e-3)   # 2x2 inverse in fp32, different summation order
+        assert np.array_equal(out[2], np.zeros_like(out[2]))
+
+
 def test_ransac_voting_layer_matches_oracle():
     from gdrnpp_bop2022_amd.core.csrc.ransac_voting.ransac_voting_gpu import (
         estimate_voting_distribution_with_mean, ransac_voting_layer_v3)
@@ -70,14 +94,14 @@ def test_ransac_voting_layer_matches_oracle():
     vertex = vertex / np.maximum(np.linalg.norm(vertex, axis=-1, keepdims=True), 1e-6)
     vertex = (vertex + rng.normal(0, 0.02, vertex.shape)).astype(np.float32)
     tn0 = int(mask[0].sum())
-    rounds = [rng.integers(0, tn0, (hn, vn, 2)).astype(np.int32) for _ in range(25)]
+    draw = rng.integers(0, tn0, (hn, vn, 2)).astype(np.int32)
 
-    def idxs_fn(bi, it, hn_, vn_, tn_):
-        return torch.from_numpy(rounds[it]).to(DEV)
+    def idxs_fn(bi, hn_, vn_, tn_):
+        return torch.from_numpy(draw).to(DEV)
 
     out = ransac_voting_layer_v3(torch.from_numpy(mask).to(DEV), torch.from_numpy(vertex).to(DEV), hn, idxs_fn=idxs_fn)
     out = out.cpu().numpy()
-    ref, iters = P.ransac_voting_layer(mask[0], vertex[0], rounds)
+    ref, iters = P.ransac_voting_layer(mask[0], vertex[0], [draw] * 25)   # the same set in every round, like the reference
     np.testing.assert_allclose(out[0], ref, atol=2e-3)      # fp32 torch LSQ vs fp64 NumPy
     assert np.abs(out[0] - kp[0]).max() < 1.0                # the keypoints are recovered
     assert np.array_equal(out[1], np.zeros((vn, 2), np.float32))

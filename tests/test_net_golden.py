@@ -1,0 +1,158 @@
+"""The network graph against the reference's OWN modules (tests/golden/make_golden_net.py ran
+core/gdrn_modeling/models/GDRN_double_mask.py: build_model_optimizer + GDRN_DoubleMask.forward with the reference's head,
+Patch-PnP, ConvModule, pose_from_pred_centroid_z and the reference's config files, and recorded every output).
+
+CPU part (-m "not gpu"): the reference's state_dict loads strict=True into this repo's modules, the config values agree,
+and the plain-PyTorch graph (both the reference-order gather and the class-sliced output layer) reproduces the recorded
+maps and Patch-PnP outputs.  GPU part: tests/test_gpu_net_golden.py."""
+import numpy as np
+import pytest
+import torch
+
+from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
+from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+from tests import netgolden as NG
+
+DATASETS = ["ycbv", "tless"]
+
+
+def _flat(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flat(v, prefix + k + "."))
+        else:
+            out[prefix + k] = list(v) if isinstance(v, (tuple, list)) else v
+    return out
+
+
+@pytest.mark.parametrize("ds", DATASETS)
+def test_config_values_equal_the_reference_files(ds):
+    """Every key this build's config carries has the value the reference's merged config files give it."""
+    fx = NG.load_fixture(ds)
+    ref = _flat(fx["cfg"])
+    ours = _flat({k: dict(get_cfg(f"{ds}_convnext_a6"))[k] for k in ("MODEL", "TEST", "INPUT")})
+    ours.pop("MODEL.DEVICE")                       # ours defaults to "cuda" like the reference; the recipe set "cpu"
+    missing = [k for k in ours if k not in ref]
+    assert not missing, missing
+    diff = {k: (ours[k], ref[k]) for k in ours if ours[k] != ref[k] and k != "MODEL.POSE_NET.BACKBONE.INIT_CFG.pretrained"}
+    assert not diff, diff
+
+
+@pytest.fixture(scope="module", params=DATASETS)
+def case(request):
+    ds = request.param
+    fx = NG.load_fixture(ds)
+    cfg = get_cfg(f"{ds}_convnext_a6", opts=["TEST.USE_DEPTH_REFINE=True", "MODEL.DEVICE=cpu"])
+    model, _ = build_model_optimizer(cfg)
+    sd = NG.seeded_reference_state_dict(model, fx)
+    res = model.load_state_dict(sd, strict=True)          # the reference's key set, duplicates and all
+    return ds, fx, model, res
+
+
+def test_reference_state_dict_loads_strict(case):
+    ds, fx, model, res = case
+    assert not res.missing_keys and not res.unexpected_keys
+    ours = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.startswith("backbone.")}
+    ref = {k: s for k, s in fx["head_keys"] if ".norm." not in k}     # ConvModule's second registration of its norm
+    assert ours == ref
+
+
+def _close(a, ref, tol, scale=None):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    s = np.abs(ref).max() if scale is None else scale
+    err = np.abs(a - ref).max() / s
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("order", ["class_sliced", "reference_order"])
+def test_pytorch_graph_reproduces_reference_outputs(case, order):
+    ds, fx, model, _ = case
+    hip_layers.set_enabled(False)
+    torch.set_grad_enabled(False)
+    try:
+        model.exact_reference_order = order == "reference_order"
+        x = torch.from_numpy(NG.net_image())
+        kw = NG.forward_kwargs(fx, "cpu")
+        feat = model.backbone(x)[0]
+        _close(feat.numpy()[:, ::8], fx["conv_feat_sub"], 1e-5)
+        rot6, t3, maps = model.forward_maps(x, kw["roi_classes"], kw["roi_coord_2d"], None, kw["roi_extents"])
+    finally:
+        hip_layers.set_enabled(True)
+        torch.set_grad_enabled(True)
+        model.exact_reference_order = False
+    for k in ("mask", "full_mask", "coor_x", "coor_y", "coor_z"):
+        assert maps[k].shape == fx[k].shape
+        _close(maps[k].numpy(), fx[k], 2e-5)
+    region = maps["region"].numpy()
+    assert region.shape == (NG.B, 65, 64, 64)
+    _close(region[:, :, 1::4, 2::4], fx["region_sub"], 2e-5, scale=float(fx["region_absmax"]))
+    agree = (region.argmax(1) == fx["region_argmax"]).mean()
+    assert agree > 0.999, agree                           # argmax flips only at numerical ties
+    _close(rot6.numpy(), fx["pred_rot_"], 5e-5)
+    _close(t3.numpy(), fx["pred_t_"], 5e-5)
+
+
+def test_load_checkpoint_prefix_strip_and_loud_mismatch(case, tmp_path):
+    """my_checkpoint.py:28-83 behaviour kept (``{"model": sd}``, wrapper prefixes), silent partial loads refused."""
+    from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import load_checkpoint
+    ds, fx, model, _ = case
+    sd = NG.seeded_reference_state_dict(model, fx)
+    path = str(tmp_path / "ckpt.pth")
+    torch.save({"model": {"module." + k: v for k, v in sd.items()}}, path)
+    res = load_checkpoint(model, path)
+    assert not res.missing_keys
+    # a key with "module." in the middle must keep it (prefix strip only)
+    bad = dict(sd)
+    bad["geo_head_net.module.extra"] = torch.zeros(1)
+    torch.save({"model": bad}, path)
+    with pytest.raises(RuntimeError, match="geo_head_net.module.extra"):
+        load_checkpoint(model, path)
+    # a backbone whose names do not match (e.g. un-flattened timm names) is refused instead of staying random
+    renamed = {k.replace("backbone.stages_", "backbone.stages."): v for k, v in sd.items()}
+    torch.save({"model": renamed}, path)
+    with pytest.raises(RuntimeError, match="parameters not found"):
+        load_checkpoint(model, path)
+    with pytest.warns(UserWarning):
+        load_checkpoint(model, path, strict=False)
+
+
+def _timm067_convnext_keys(depths=(3, 3, 27, 3), dims=(128, 256, 512, 1024), in_chans=3):
+    """Parameter names/shapes of ``timm.create_model("convnext_base", features_only=True, out_indices=(3,))`` as published
+    in timm 0.6.7 (timm/models/convnext.py: ``stem = Sequential(Conv2d 4x4/4, LayerNorm2d)``; ``stages[i] =
+    ConvNeXtStage(downsample = Sequential(LayerNorm2d, Conv2d 2x2/2) for i > 0, blocks = Sequential(ConvNeXtBlock))``;
+    ``ConvNeXtBlock(conv_dw 7x7 depthwise, norm = LayerNorm, mlp = Mlp(fc1, fc2), gamma)``) after FeatureListNet's
+    ``flatten_sequential=True`` renaming of the top-level Sequentials (``stem.0`` -> ``stem_0``, ``stages.2`` ->
+    ``stages_2``; timm/models/features.py ``_module_list``).  timm is not installed and no GDRNPP checkpoint is available
+    offline, so this manifest is written from the published source, NOT executed — it catches a drift of backbones.py's
+    names, it cannot prove a real checkpoint loads."""
+    k = {"stem_0.weight": (dims[0], in_chans, 4, 4), "stem_0.bias": (dims[0],),
+         "stem_1.weight": (dims[0],), "stem_1.bias": (dims[0],)}
+    prev = dims[0]
+    for i, (d, c) in enumerate(zip(depths, dims)):
+        s = f"stages_{i}."
+        if i > 0:
+            k[s + "downsample.0.weight"] = (prev,)
+            k[s + "downsample.0.bias"] = (prev,)
+            k[s + "downsample.1.weight"] = (c, prev, 2, 2)
+            k[s + "downsample.1.bias"] = (c,)
+        for j in range(d):
+            b = s + f"blocks.{j}."
+            k[b + "gamma"] = (c,)
+            k[b + "conv_dw.weight"] = (c, 1, 7, 7)
+            k[b + "conv_dw.bias"] = (c,)
+            k[b + "norm.weight"] = (c,)
+            k[b + "norm.bias"] = (c,)
+            k[b + "mlp.fc1.weight"] = (4 * c, c)
+            k[b + "mlp.fc1.bias"] = (4 * c,)
+            k[b + "mlp.fc2.weight"] = (c, 4 * c)
+            k[b + "mlp.fc2.bias"] = (c,)
+        prev = c
+    return k
+
+
+def test_backbone_key_manifest_matches_published_timm_names(case):
+    ds, fx, model, _ = case
+    ours = {k[len("backbone."):]: tuple(v.shape) for k, v in model.state_dict().items() if k.startswith("backbone.")}
+    assert ours == _timm067_convnext_keys()
