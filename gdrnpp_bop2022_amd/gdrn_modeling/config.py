@@ -93,6 +93,10 @@ def gdrn_base() -> dict:
         TEST=dict(EVAL_PERIOD=0, VIS=False, TEST_BBOX_TYPE="est", USE_PNP=False, SAVE_RESULTS_ONLY=False,
                   PNP_TYPE="ransac_pnp", USE_DEPTH_REFINE=False, DEPTH_REFINE_ITER=2, DEPTH_REFINE_THRESHOLD=0.8,
                   USE_COOR_Z_REFINE=False, AMP_TEST=False),
+        # configs/_base_/common_base.py VAL block (the keys that name the BOP results file, test_utils.py:33-52) and EXP_ID
+        # (core/utils/default_args_setup.py derives it from the config file name)
+        VAL=dict(DATASET_NAME="lm", SPLIT="test", SPLIT_TYPE="", SAVE_BOP_CSV_ONLY=True),
+        EXP_ID="gdrn_hip",
         DIST_PARAMS=dict(backend="nccl"),
     )
 
@@ -120,12 +124,19 @@ def _gdrnpp_convnext(num_classes: int) -> dict:
     )
 
 
+# VAL.DATASET_NAME of the seven convnext_a6 configs (configs/gdrn/<dataset>/convnext_a6_*_classAware_<dataset>.py); all of
+# them set SPLIT="test", SPLIT_TYPE=""
+_VAL_DATASET_NAME = {"hb": "hbs"}
+
+
 def get_cfg(name: str = "ycbv_convnext_a6", opts=None) -> Config:
     """Named configs covering BASELINE.json's `configs`."""
     base = gdrn_base()
     num_cls = {"ycbv": 21, "tless": 30, "lmo": 8, "icbin": 2, "hb": 16, "itodd": 28, "tudl": 3}
     if name.endswith("_convnext_a6"):
-        cfg = _merge(base, _gdrnpp_convnext(num_cls[name.split("_")[0]]))
+        ds = name.split("_")[0]
+        cfg = _merge(base, _gdrnpp_convnext(num_cls[ds]))
+        cfg = _merge(cfg, dict(VAL=dict(DATASET_NAME=_VAL_DATASET_NAME.get(ds, ds), SPLIT="test", SPLIT_TYPE=""), EXP_ID=name))
     elif name == "lmo_resnet34_ape":
         # BASELINE config 1: base GDRN (ResNet-34, single object, class-agnostic head)
         cfg = _merge(base, dict(MODEL=dict(POSE_NET=dict(NUM_CLASSES=1))))

@@ -97,6 +97,8 @@ class GdrnHipPost:
 
     def process(self, batch: dict, out_dict: dict, roi_ids: torch.Tensor | None = None) -> torch.Tensor:
         """-> pose records f32[b,16] = R(9) | t(3, metres) | score | obj | roi_id | valid."""
+        if out_dict["trans"].shape[0] == 0:       # an image / a rank without detections: nothing to launch (the reference
+            return torch.zeros((0, 16), dtype=torch.float32, device=out_dict["trans"].device)   # skips such images)
         if self.cfg.TEST.USE_PNP:
             if self.cfg.TEST.PNP_TYPE != "net_iter_pnp":
                 raise NotImplementedError(
@@ -115,6 +117,8 @@ class GdrnHipPost:
 @torch.no_grad()
 def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor | None = None) -> torch.Tensor:
     """One pass of the hot path over one batch of ROIs (the unit ``bench.py`` times)."""
+    if batch["roi_img"].shape[0] == 0:            # empty shard (shard_range may give trailing ranks nothing): the caller
+        return torch.zeros((0, 16), dtype=torch.float32, device=batch["roi_img"].device)   # still reaches gather_records
     out_dict = model(
         batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"], roi_whs=batch["roi_wh"],
         roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"],

@@ -1,0 +1,239 @@
+"""``GDRN_Evaluator`` + ``gdrn_inference_on_dataset`` — the evaluator hook of the reference
+(core/gdrn_modeling/engine/gdrn_evaluator.py:39-113,155-239,461-585,636-665 and the loop :668-809), same protocol
+(detectron2 ``DatasetEvaluator``: ``reset() / process(inputs, outputs, out_dict) / evaluate()``), same per-image
+list-of-dict inputs (``read_data_test`` layout, data_loader.py:647-818) and the same BOP result records, with the per-ROI
+Python/NumPy/GL body of ``process*`` replaced by ONE batched pass of the HIP post-processing (``engine.GdrnHipPost``):
+
+    reference, per image, per ROI:  D2H of all maps -> get_out_mask/get_out_coor -> cv2.resize -> 2 x GL render + readback
+                                    -> NumPy compare -> dict
+    here, per call:                 concat the per-image ROI scalars -> zoom_K / decode / PnP / depth-refine / pack kernels
+                                    on every ROI of the batch -> ONE D2H of f32[n,16] records -> dicts
+
+Deviations, on purpose: (1) ``zoom_K`` is indexed by the ROI's position in the flattened batch — the reference indexes it
+with the per-image instance index (gdrn_evaluator.py:493), which is only right for one image per batch; (2) the batched
+post-processing time is charged to every image of the batch (each image waits for the whole batch), the reference charges
+each image its own share of the Python loop; (3) ``score`` is stored as a float (the reference leaves a 0-dim tensor).
+"""
+from __future__ import annotations
+
+import itertools
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import hip_lib
+from .engine import BOP_CSV_HEADER, GdrnHipPost, save_bop_csv
+
+logger = logging.getLogger(__name__)
+
+_ROI_KEYS_F32 = ("im_H", "im_W", "roi_img", "inst_id", "roi_coord_2d", "roi_coord_2d_rel", "score", "time", "roi_extent",
+                 "bbox", "bbox_est", "bbox_mode", "roi_wh", "scale", "resize_ratio")
+
+
+def _cat(data, key, device, dtype=None):
+    parts = [torch.as_tensor(d[key]) for d in data]
+    parts = [p.reshape(1) if p.dim() == 0 else p for p in parts]
+    return torch.cat(parts, dim=0).to(device=device, dtype=dtype, non_blocking=True)
+
+
+def batch_data_test(cfg, data, device="cuda"):
+    """engine_utils.py:213-241: concatenate the per-image dicts of ``read_data_test`` into one ROI batch on the device."""
+    batch = {}
+    keys = list(_ROI_KEYS_F32) + (["roi_depth"] if cfg.INPUT.WITH_DEPTH else [])
+    for key in keys:
+        if key in data[0]:
+            batch[key] = _cat(data, key, device, torch.float32)
+    batch["roi_cls"] = _cat(data, "roi_cls", device, torch.long)
+    batch["roi_cam"] = _cat(data, "cam", device)
+    batch["roi_center"] = _cat(data, "bbox_center", device)
+    for key in ("scene_im_id", "file_name", "model_info"):
+        if key in data[0]:
+            batch[key] = list(itertools.chain(*[d[key] for d in data]))
+    return batch
+
+
+def bop_csv_name(cfg, name: str = "iter0") -> str:
+    """The results file name of ``save_and_eval_results`` (test_utils.py:40-41)."""
+    val = cfg.VAL
+    split_type_str = f"-{val.SPLIT_TYPE}" if val.SPLIT_TYPE != "" else ""
+    method_name = f"{cfg.EXP_ID.replace('_', '-')}-{name}"
+    return f"{method_name}_{val.DATASET_NAME}-{val.SPLIT}{split_type_str}.csv"
+
+
+class GDRN_Evaluator:
+    """Drop-in for the reference class of the same name.  The dataset registry (``MetadataCatalog`` / ``ref.<dataset>``)
+    is not rebuilt: the two facts the hot path needs from it are passed in — ``obj_names`` (class order of the dataset,
+    ``self._metadata.objs``) and ``obj2id`` (``data_ref.obj2id``) — plus the object meshes for the depth refinement
+    (``hip_lib.MeshSet`` in class order, replacing ``lib.render_vispy.model3d.load_models``)."""
+
+    def __init__(self, cfg, dataset_name=None, distributed=False, output_dir=None, train_objs=None, *, obj_names, obj2id,
+                 meshes: "hip_lib.MeshSet | None" = None):
+        self.cfg = cfg
+        self.dataset_name = dataset_name
+        self._distributed = distributed
+        self._output_dir = output_dir
+        self._cpu_device = torch.device("cpu")
+        self.train_objs = train_objs
+        self.obj_names = list(obj_names)
+        self.obj2id = dict(obj2id)
+        self.obj_ids = [self.obj2id[n] for n in self.obj_names]
+        self.depth_refine_threshold = cfg.TEST.DEPTH_REFINE_THRESHOLD
+        self.post = GdrnHipPost(cfg, meshes)
+        self._predictions = []
+
+    # ---- protocol ------------------------------------------------------------------------------------------------
+    def reset(self):
+        self._predictions = []
+
+    def _maybe_adapt_label_cls_name(self, label):
+        """gdrn_evaluator.py:95-103: with ``train_objs`` (model trained on a subset) the label is re-indexed, untrained
+        classes are skipped."""
+        label = int(label)
+        cls_name = self.obj_names[label]
+        if self.train_objs is not None:
+            if cls_name not in self.train_objs:
+                return None, None
+            label = self.train_objs.index(cls_name)
+        return label, cls_name
+
+    def _roi_batch(self, inputs, device):
+        """``batch_data_inference_roi`` (engine_utils.py:243-266) + the per-ROI scalars ``GdrnHipPost`` consumes."""
+        b = {"roi_cam": _cat(inputs, "cam", device, torch.float32),
+             "roi_center": _cat(inputs, "bbox_center", device, torch.float32),
+             "scale": _cat(inputs, "scale", device, torch.float32),
+             "roi_cls": _cat(inputs, "roi_cls", device, torch.long),
+             "score": _cat(inputs, "score", device, torch.float32)}
+        for key in ("roi_depth", "roi_coord_2d", "roi_extent", "im_H", "im_W"):
+            if key in inputs[0]:
+                b[key] = _cat(inputs, key, device, torch.float32)
+        return b
+
+    def process(self, inputs, outputs, out_dict):
+        """inputs: list of per-image dicts; outputs: list of ``{"time": forward time}``; out_dict: ``GDRN_Net.forward``'s.
+        Appends one BOP record per ROI to ``self._predictions`` (gdrn_evaluator.py:155-239 direct, :241-459 PnP variants,
+        :461-573 depth refinement — selected by the same ``cfg.TEST`` switches)."""
+        start = time.perf_counter()
+        n_per_image = [len(d["roi_cls"]) for d in inputs]
+        n = sum(n_per_image)
+        if n == 0:
+            return
+        dev = out_dict["trans"].device
+        batch = self._roi_batch(inputs, dev)
+        rec = self.post.process(batch, out_dict, torch.arange(n, device=dev, dtype=torch.int32))
+        rec = rec.to(self._cpu_device).numpy()           # the one synchronising copy: 64 B per ROI
+        spent = time.perf_counter() - start
+        out_i = -1
+        for _input, output in zip(inputs, outputs):
+            json_results = []
+            for inst_i in range(len(_input["roi_cls"])):
+                out_i += 1
+                _, cls_name = self._maybe_adapt_label_cls_name(_input["roi_cls"][inst_i])
+                if cls_name is None:
+                    continue
+                scene_id, im_id = _input["scene_im_id"][inst_i].split("/")
+                r = rec[out_i]
+                json_results.append({
+                    "scene_id": scene_id, "im_id": int(im_id), "obj_id": self.obj2id[cls_name],
+                    "score": float(_input["score"][inst_i]), "R": r[:9].tolist(),
+                    "t": (1000.0 * r[9:12]).tolist(), "time": output["time"]})
+            output["time"] += spent
+            for item in json_results:
+                item["time"] = output["time"]
+            self._predictions.extend(json_results)
+
+    def evaluate(self):
+        """gdrn_evaluator.py:575-585: gather every rank's records (the reference pickles its dict lists through
+        ``comm.all_gather``, my_comm.py:70-171 — a one-off at the end of the dataset, kept as an object gather), then the
+        main process writes the BOP csv.  The per-step device-side pose gather of the hot path is ``engine.gather_records``."""
+        if self._distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()
+            parts = [None] * dist.get_world_size()
+            dist.all_gather_object(parts, self._predictions)
+            self._predictions = list(itertools.chain(*parts))
+            if dist.get_rank() != 0:
+                return
+        return self._eval_predictions()
+
+    def _process_time_of_preds(self, results):
+        """gdrn_evaluator.py:598-610: every record of an image carries the largest time recorded for that image."""
+        times = {}
+        for item in results:
+            times.setdefault("{}/{}".format(item["scene_id"], item["im_id"]), []).append(item["time"])
+        for item in results:
+            item["time"] = float(np.max(times["{}/{}".format(item["scene_id"], item["im_id"])]))
+
+    def _eval_predictions(self):
+        """gdrn_evaluator.py:587-596 up to the BOP results file (test_utils.py:33-52); running the BOP toolkit on it is
+        the reference's offline tooling and stays there."""
+        self._process_time_of_preds(self._predictions)
+        if self._output_dir:
+            os.makedirs(self._output_dir, exist_ok=True)
+            path = os.path.join(self._output_dir, bop_csv_name(self.cfg))
+            save_bop_csv(self._predictions, path)
+            logger.info("wrote %d BOP records (%s) to %s", len(self._predictions), BOP_CSV_HEADER, path)
+        return {}
+
+
+def gdrn_inference_on_dataset(cfg, model, data_loader, evaluator, amp_test=False):
+    """gdrn_evaluator.py:668-809: the inference loop with the reference's timing protocol — host ``perf_counter``, device
+    synchronise before the clock stops, the first ``min(5, total - 1)`` iterations discarded — returning
+    ``evaluator.evaluate()`` (or ``{}``).  ``stats`` of the run are left on ``gdrn_inference_on_dataset.last_stats``."""
+    if amp_test:
+        raise NotImplementedError("TEST.AMP_TEST: the parity configuration is fp32 (common_base.py:219)")
+    total = len(data_loader)
+    evaluator.reset()
+    num_warmup = min(5, total - 1)
+    start_time = time.perf_counter()
+    total_compute_time = total_process_time = 0.0
+    was_training = model.training
+    model.eval()
+    dev = next(model.parameters()).device
+    n_rois = 0
+    with torch.no_grad():
+        for idx, inputs in enumerate(data_loader):
+            if idx == num_warmup:
+                start_time = time.perf_counter()
+                total_compute_time = total_process_time = 0.0
+                n_rois = 0
+            start_compute_time = time.perf_counter()
+            if not isinstance(inputs, list):
+                inputs = [inputs]
+            batch = batch_data_test(cfg, inputs, device=dev)
+            if getattr(evaluator, "train_objs", None) is not None:
+                names = [evaluator.obj_names[_l] for _l in batch["roi_cls"].cpu().numpy().tolist()]
+                if all(_o not in evaluator.train_objs for _o in names):
+                    continue
+            out_dict = model(
+                batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"], roi_whs=batch["roi_wh"],
+                roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"],
+                roi_coord_2d=batch.get("roi_coord_2d", None), roi_coord_2d_rel=batch.get("roi_coord_2d_rel", None),
+                roi_extents=batch.get("roi_extent", None))
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            cur_compute_time = time.perf_counter() - start_compute_time
+            total_compute_time += cur_compute_time
+            outputs = [{} for _ in range(len(inputs))]
+            for _i in range(len(outputs)):
+                det_time = 0
+                if "time" in inputs[_i]:
+                    det_time = float(torch.as_tensor(inputs[_i]["time"]).reshape(-1)[0])
+                outputs[_i]["time"] = cur_compute_time + det_time
+            start_process_time = time.perf_counter()
+            evaluator.process(inputs, outputs, out_dict)
+            total_process_time += time.perf_counter() - start_process_time
+            n_rois += int(batch["roi_cls"].shape[0])
+    total_time = time.perf_counter() - start_time
+    denom = max(total - num_warmup, 1)
+    gdrn_inference_on_dataset.last_stats = dict(
+        total_s=total_time, s_per_iter=total_time / denom, compute_s_per_iter=total_compute_time / denom,
+        process_s_per_iter=total_process_time / denom, rois=n_rois, rois_per_s=n_rois / total_time if total_time > 0 else 0.0,
+        warmup_iters=num_warmup, iters=total)
+    logger.info("Total inference time: %.6f s / iter per device; pure compute %.6f; post process %.6f",
+                total_time / denom, total_compute_time / denom, total_process_time / denom)
+    model.train(was_training)
+    results = evaluator.evaluate()
+    return {} if results is None else results

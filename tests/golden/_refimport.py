@@ -11,7 +11,8 @@ only supply initialisers, registries, loggers and base classes.  This module the
   ``CONV_LAYERS`` registry (``Conv2d`` -> ``nn.Conv2d``), ``timm.models.layers.StdConv2d`` (unused unless
   ``use_ws``), ``detectron2.utils.env.TORCH_VERSION``, ``detectron2.evaluation.DatasetEvaluator`` (a plain base class)
   and ``transforms3d.axangles.axangle2mat`` (served by ``scipy.spatial.transform.Rotation``);
-* restores the NumPy < 1.24 aliases the reference's ``lib/pysixd`` still uses (``np.float``, ``np.maximum_sctype``).
+* restores the NumPy < 1.24 aliases the reference's ``lib/pysixd`` still uses (``np.float``, ``np.maximum_sctype``) and
+  the pre-3.10 ``collections.Sequence`` aliases (``core/utils/data_utils.py:1``).
 
 After ``install()`` the reference's modules import from their files and run unmodified, e.g.
 ``from core.gdrn_modeling.models.GDRN_double_mask import GDRN_DoubleMask, build_model_optimizer``.
@@ -34,6 +35,10 @@ STUB_ROOTS = {
     "ref", "pytorch3d", "kornia", "pyassimp", "skimage", "trimesh", "pyximport", "numba", "seaborn", "dr", "torchcontrib",
     "ranger", "horovod", "apex", "wandb", "tensorboard", "egl_renderer", "gin", "pprofile", "pympler", "petrel_client", "mc",
 }
+
+
+# compiled extension modules that live INSIDE the reference's packages (absent: nothing was built)
+STUB_FULL = {"lib.egl_renderer.CppEGLRenderer", "lib.egl_renderer.egl_renderer_v3"}  # the latter binds EGL through ctypes at import
 
 
 class _Inert:
@@ -73,8 +78,13 @@ class _StubModule(types.ModuleType):
 
 
 class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    """Fallback (end of sys.meta_path): fabricates modules for the absent third-party roots only."""
+
+    def wants(self, fullname):
+        return fullname.split(".")[0] in STUB_ROOTS
+
     def find_spec(self, fullname, path, target=None):
-        if fullname.split(".")[0] in STUB_ROOTS:
+        if self.wants(fullname):
             return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
         return None
 
@@ -85,6 +95,13 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 
     def exec_module(self, module):
         pass
+
+
+class _FrontFinder(_Finder):
+    """Ahead of the path finder: reference modules that exist as files but cannot be executed here."""
+
+    def wants(self, fullname):
+        return fullname in STUB_FULL
 
 
 def _normal_init(module, mean=0, std=1, bias=0):          # mmcv/cnn/utils/weight_init.py
@@ -150,10 +167,16 @@ def install():
     if not os.path.isdir(REF):
         raise RuntimeError(f"{REF} is not present: golden vectors are generated in the authoring container only")
     sys.meta_path.append(_Finder())
+    sys.meta_path.insert(0, _FrontFinder())
     sys.path.insert(0, REF)
     if not hasattr(np, "float"):
         np.float = float
         np.int = int
+    import collections
+    import collections.abc
+    for name in ("Sequence", "Mapping", "Iterable", "MutableMapping"):   # removed from `collections` in Python 3.10
+        if not hasattr(collections, name):
+            setattr(collections, name, getattr(collections.abc, name))
     if not hasattr(np, "maximum_sctype"):
         np.maximum_sctype = lambda t: np.float64  # noqa: E731
 

@@ -58,7 +58,29 @@ def jsonable(o):
     return repr(o)
 
 
+ALL_CONFIGS = {
+    "ycbv": CONFIGS["ycbv"], "tless": CONFIGS["tless"],
+    "lmo": "configs/gdrn/lmo_pbr/convnext_a6_AugCosyAAEGray_BG05_mlL1_DMask_amodalClipBox_classAware_lmo.py",
+    "icbin": "configs/gdrn/icbin_pbr/convnext_a6_AugCosyAAEGray_BG05_mlL1_DMask_amodalClipBox_classAware_icbin.py",
+    "hb": "configs/gdrn/hb_pbr/convnext_a6_AugCosyAAEGray_BG05_mlL1_DMask_amodalClipBox_classAware_hb.py",
+    "itodd": "configs/gdrn/itodd_pbr/convnext_a6_AugCosyAAEGray_BG05_mlL1_DMask_amodalClipBox_classAware_itodd.py",
+    "tudl": "configs/gdrn/tudl/convnext_a6_AugCosyAAEGray_BG05_mlL1_DMask_amodalClipBox_classAware_tudl.py",
+}
+
+
+def write_config_fixture():
+    """The merged MODEL / TEST / INPUT / VAL subtrees of the seven BOP convnext_a6 config files -> cfg_golden.json."""
+    out = {}
+    for ds, path in ALL_CONFIGS.items():
+        raw = _refimport.load_ref_config(path)
+        out[ds] = jsonable({k: raw[k] for k in ("MODEL", "TEST", "INPUT", "VAL")})
+    with open(os.path.join(HERE, "cfg_golden.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("wrote cfg_golden.json")
+
+
 def main():
+    write_config_fixture()
     torch.set_num_threads(os.cpu_count())
     torch.set_grad_enabled(False)
     hip_layers.set_enabled(False)

@@ -1,0 +1,92 @@
+"""-m gpu: the evaluator hook end to end.  ``GDRN_Evaluator.process`` (HIP post-processing, one batched pass) must emit the
+records the reference's own ``GDRN_Evaluator.process / process_depth_refine`` emitted for the same two images
+(tests/golden/make_golden_eval.py): R and score identical, t within 1e-4 m (north_star) — measured ~1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from gdrnpp_bop2022_amd import hip_lib
+from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+from gdrnpp_bop2022_amd.gdrn_modeling.gdrn_evaluator import GDRN_Evaluator, gdrn_inference_on_dataset
+from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+from tests import evalgolden as EG
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _meshes(e):
+    m = e["maps"]
+    return hip_lib.MeshSet([m["verts"][i] for i in range(3)], [m["faces"][i] for i in range(3)], DEV)
+
+
+@pytest.mark.parametrize("branch", ["direct", "refine"])
+@pytest.mark.parametrize("images_per_call", [1, 2])
+def test_process_emits_the_reference_records(hip, tmp_path, branch, images_per_call):
+    e = EG.load()
+    cfg = get_cfg("ycbv_convnext_a6", opts=[f"TEST.USE_DEPTH_REFINE={branch == 'refine'}", "INPUT.WITH_DEPTH=True"])
+    cfg.EXP_ID = e["exp_id"]
+    ev = GDRN_Evaluator(cfg, "ycbv_test", False, str(tmp_path), obj_names=e["names"], obj2id=e["obj2id"],
+                        meshes=_meshes(e) if branch == "refine" else None)
+    ev.reset()
+    inputs, od = EG.image_inputs(e, DEV), EG.out_dict(e, DEV)
+    if images_per_call == 2:                         # both images in one call (the reference's zoom_K index bug, fixed here)
+        ev.process(inputs, [dict(time=float(t)) for t in e["fwd_time"]], od)
+    else:
+        for k, (lo, hi) in enumerate(e["split"]):
+            ev.process([inputs[k]], [dict(time=float(e["fwd_time"][k]))], {key: v[lo:hi] for key, v in od.items()})
+    ref = e[f"{branch}_predictions"]
+    assert len(ev._predictions) == len(ref) == 5
+    for p, r in zip(ev._predictions, ref):
+        assert (p["scene_id"], p["im_id"], p["obj_id"]) == (r["scene_id"], r["im_id"], r["obj_id"])
+        assert p["score"] == r["score"] and p["R"] == r["R"]            # passed through untouched
+        assert np.abs(np.array(p["t"]) - np.array(r["t"])).max() <= 1e-4 * 1000.0     # mm
+        assert p["time"] >= [t for t, (lo, hi) in zip(e["fwd_time"], e["split"])][0]
+    if branch == "direct":
+        assert all(p["t"] == r["t"] for p, r in zip(ev._predictions, ref))
+    assert ev.evaluate() == {}
+    rows = open(tmp_path / e[f"{branch}_csv_name"]).read().strip().split("\n")
+    assert rows[0] == "scene_id,im_id,obj_id,score,R,t,time" and len(rows) == 6
+
+
+def test_train_objs_subset_skips_untrained_classes(hip, tmp_path):
+    e = EG.load()
+    cfg = get_cfg("ycbv_convnext_a6")
+    keep = [n for n in e["names"] if n != e["names"][int(e["roi_cls"][0])]]
+    ev = GDRN_Evaluator(cfg, "ycbv_test", False, None, train_objs=keep, obj_names=e["names"], obj2id=e["obj2id"])
+    ev.reset()
+    ev.process(EG.image_inputs(e, DEV), [dict(time=0.0), dict(time=0.0)], EG.out_dict(e, DEV))
+    dropped = int((e["roi_cls"] == e["roi_cls"][0]).sum())
+    assert len(ev._predictions) == 5 - dropped
+    assert e["obj2id"][e["names"][int(e["roi_cls"][0])]] not in [p["obj_id"] for p in ev._predictions]
+
+
+def test_inference_loop_protocol(hip, tmp_path):
+    """gdrn_inference_on_dataset: warm-up rule, one record per ROI, evaluate() writes the csv."""
+    from gdrnpp_bop2022_amd import synthetic as S
+
+    e = EG.load()
+    cfg = get_cfg("ycbv_convnext_a6", opts=["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"])
+    names = [f"obj_{i:02d}" for i in range(21)]
+    rng = np.random.default_rng(3)
+    verts, faces, ext = S.make_models(21, rng, 2)
+    ev = GDRN_Evaluator(cfg, "ycbv_test", False, str(tmp_path), obj_names=names, obj2id={n: i + 1 for i, n in enumerate(names)},
+                        meshes=hip_lib.MeshSet(verts, faces, DEV))
+    torch.manual_seed(0)
+    model, _ = build_model_optimizer(cfg)
+    loader = []
+    for im in range(4):
+        n = 2 + im % 2
+        det = S.make_detections(n, 21, ext, rng)
+        T = torch.from_numpy
+        loader.append([dict(
+            roi_img=torch.rand(n, 3, 256, 256), roi_cls=T(det["roi_cls"]), cam=T(det["roi_cam"]), roi_wh=T(det["roi_wh"]),
+            bbox_center=T(det["roi_center"]), resize_ratio=T(det["resize_ratio"]), scale=T(det["scale"]), score=T(det["score"]),
+            roi_coord_2d=T(S.coord2d_roi(det["roi_center"], det["scale"])), roi_extent=T(det["roi_extent"]),
+            roi_depth=torch.rand(n, 1, 256, 256) + 0.5, scene_im_id=[f"50/{im}"] * n, time=torch.full((n,), 0.01))])
+    assert gdrn_inference_on_dataset(cfg, model, loader, ev) == {}
+    st = gdrn_inference_on_dataset.last_stats
+    assert st["warmup_iters"] == 3 and st["iters"] == 4 and st["rois"] == len(loader[3][0]["roi_cls"])
+    assert len(ev._predictions) == sum(len(b[0]["roi_cls"]) for b in loader)
+    assert all(np.isfinite(p["t"]).all() and p["time"] > 0.01 for p in ev._predictions)
+    assert len(open(tmp_path / "ycbv-convnext-a6-iter0_ycbv-test.csv").read().strip().split("\n")) == 1 + len(ev._predictions)
