@@ -276,7 +276,13 @@ def depth_refine(meshes: MeshSet, obj, coor_x, coor_y, coor_z, mask_raw, roi_dep
     b = obj.shape[0]
     t_out = out if out is not None else torch.empty((b, 3), dtype=torch.float64, device=obj.device)
     dbg = torch.zeros((b, iters, res, res), dtype=torch.float32, device=obj.device) if debug else None
-    assert roi_depth.shape[-1] == 4 * res and roi_depth.shape[-2] == 4 * res
+    if roi_depth.shape[-1] != 4 * res or roi_depth.shape[-2] != 4 * res:
+        raise RuntimeError(f"depth_refine: roi_depth is {tuple(roi_depth.shape[-2:])}, the kernel reads the INPUT_RES = 4 x "
+                           f"OUTPUT_RES crop ({4 * res} x {4 * res}) the way cv2.resize(..., ({res}, {res})) does")
+    ev = None
+    if _REFINE_EVENT_SINK is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _check(lib.gdrnpp_depth_refine(
         meshes.c, _dev(obj, torch.int32, "obj"), _dev(coor_x, torch.float32, "coor_x"),
         _dev(coor_y, torch.float32, "coor_y"), _dev(coor_z, torch.float32, "coor_z"),
@@ -284,7 +290,24 @@ def depth_refine(meshes: MeshSet, obj, coor_x, coor_y, coor_z, mask_raw, roi_dep
         _dev(K_crop, torch.float32, "K_crop"), _dev(R, torch.float32, "R"), _dev(t, torch.float32, "t"),
         _dev(t_out, torch.float64, "t_out"), dbg.data_ptr() if debug else None, b, res, iters, float(threshold),
         mask_type, 1 if use_coor_z else 0, z_near, z_far, _stream()), "gdrnpp_depth_refine")
+    if ev is not None:
+        ev[1].record()
+        _REFINE_EVENT_SINK.append(ev)
     return (t_out, dbg) if debug else t_out
+
+
+_REFINE_EVENT_SINK = None
+
+
+def set_refine_event_sink(sink):
+    """bench.py's roofline pass: a list that receives one (start, stop) HIP event pair per depth-refine launch, recorded
+    on the launch stream (torch's current stream); None switches it off."""
+    global _REFINE_EVENT_SINK
+    _REFINE_EVENT_SINK = sink
+
+
+def refine_kernel_name() -> str:
+    return "depth_refine_staged_kernel"
 
 
 def pack_pose_records(R, t_refined, t_net, score, obj_id, roi_id):

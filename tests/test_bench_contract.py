@@ -37,4 +37,40 @@ def test_committed_bench_lines_follow_the_contract():
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1 and "traffic" in r
         c = d["cpu_baseline"]
         assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+        if f.split("/")[-1].startswith("r01"):
+            continue
+        st = c["stages"]                                  # round 2 on: one entry per stage, 1 thread and all cores
+        assert st["refine_1thread"]["cores"] == 1 and st["refine_allcores"]["cores"] == c["host_cores_available"]
+        assert st["refine_allcores"]["value"] > st["refine_1thread"]["value"]
+        assert {"upnp_pn9_1thread", "upnp_pn4096_1thread", "fps_reference_1thread", "nnd_reference_1thread"} <= set(st)
+        assert any("cv2 unavailable" == v.get("note") for v in st.values())
+        assert d["config"]["timed_entry_point"].startswith("engine.inference_step")
         assert abs(d["value"] - d["n_gpus"] * d["config"]["rois_per_gpu"] * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
+def test_gpus_flag_spawns_ranks_and_gathers_every_roi_once():
+    """`python bench.py --gpus 2` without a launcher: spawn, rendezvous on 127.0.0.1, contiguous ROI shards, one all-gather
+    of the records, ROI-id permutation check, MAX-over-ranks timing, one JSON line from rank 0 — on CPU through the gloo
+    backend with the GPU step stubbed (the same code path the RCCL run takes)."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-step",
+                        "--steps", "3", "--warmup", "1", "--batch", "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 10 and d["config"]["rois_per_gpu"] == 5
+    assert d["scaling"] == "weak" and d["gather_ms"] > 0 and d["config"]["parallelism"] == "roi-shard x2"
+    assert abs(d["value"] - 10 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
+def test_world_size_must_match_gpus_flag():
+    import subprocess
+    import sys
+
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-step"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
