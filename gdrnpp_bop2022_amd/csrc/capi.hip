@@ -10,6 +10,9 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+static int g_opt_glds = 1, g_opt_mi4 = -1;
+int option_split_gemm_glds() { return g_opt_glds; }
+int option_split_gemm_mi4() { return g_opt_mi4; }
 }  // namespace gdrnpp
 
 namespace {
@@ -43,6 +46,13 @@ int gdrnpp_debug_stream_read(const float* p, size_t n, int lane_bytes, float* ou
     hipLaunchKernelGGL(stream_read_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, out_blocks);
   return gdrnpp::check_launch("gdrnpp_debug_stream_read");
 }
-int gdrnpp_version(void) { return 100; /* 0.1.0 */ }
+int gdrnpp_set_option(const char* name, int value) {
+  GDRNPP_REQUIRE(name, GDRNPP_EINVAL, "gdrnpp_set_option: null name");
+  if (!strcmp(name, "split_gemm_glds")) { gdrnpp::g_opt_glds = value != 0; return 0; }
+  if (!strcmp(name, "split_gemm_mi4")) { gdrnpp::g_opt_mi4 = value < 0 ? -1 : (value != 0); return 0; }
+  gdrnpp::set_error("gdrnpp_set_option: unknown option '%s'", name);
+  return GDRNPP_EINVAL;
+}
+int gdrnpp_version(void) { return 110; /* 0.1.1 */ }
 const char* gdrnpp_last_error(void) { return gdrnpp::g_err; }
 }

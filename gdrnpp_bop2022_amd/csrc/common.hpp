@@ -39,4 +39,8 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;  // CDNA4 wavefront
 
+// process-wide tuning switches (gdrnpp_set_option): read on the launch path instead of getenv
+int option_split_gemm_glds();   // 1: 256-row split-GEMM tiles use the LDS-DMA kernel
+int option_split_gemm_mi4();    // -1: by tile count, 0 / 1: force 128- / 256-row tiles (A/B measurements)
+
 }  // namespace gdrnpp

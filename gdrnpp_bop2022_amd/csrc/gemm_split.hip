@@ -25,7 +25,6 @@
 //      ds_read_b128 lane group read 32 consecutive slots (conflict-free), a fragment is one ds_read_b128;
 //   per k-tile: 12 fragment reads (ds_read_b128) feed 24 MFMAs.
 #include "common.hpp"
-#include <cstdlib>
 
 namespace {
 
@@ -270,240 +269,200 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// EXPERIMENTAL (opt-in, see launch_split_epi): 256x128 tile, 8 waves, ping-pong schedule.
-// The 4-wave kernel above keeps the matrix pipe ~60 % busy (PMC:
-// SQ_VALU_MFMA_BUSY_CYCLES / elapsed): its waves sit in barriers and LDS latencies at the same moments.  Here the two
-// waves that share a SIMD (wave w and w+4 of the workgroup) alternate roles every phase:
-//   phase 1: group 0 (waves 0-3, output rows 0-127) issues its 24 MFMAs of k-tile t from fragments already in
-//            registers; group 1 splits + stores its share of k-tile t+1 into the other LDS stage, requests its share of
-//            k-tile t+2 from HBM and pre-reads its own fragments of k-tile t;
-//   phase 2: the roles swap (group 1: MFMAs of k-tile t on output rows 128-255; group 0: stage / request / pre-read).
-// Group 1 stages A rows 0-127 and the whole B tile — exactly what group 0 consumes next — and group 0 stages A rows
-// 128-255, so every fragment pre-read only depends on stores finished one barrier earlier and an MFMA phase starts
-// with all its operands in registers.  One workgroup per CU (512 threads, up to 256 VGPRs per wave).
+// LDS-DMA form of the same GEMM (gdrnpp_set_option("split_gemm_glds", 1)): 256x128x16 block tile, 4 waves stacked along M
+// (each wave 64 rows x 128 columns = 2 x 4 MFMA tiles), NO register staging and NO ds_write in the k-loop:
+//   A  stays fp32 in HBM and goes HBM -> LDS by global_load_lds_dwordx4 (16 B per lane, four lanes cover one 64-byte row
+//      segment, so the loads stay coalesced).  The LDS image is lane-linear (slot = 4*row + p); which 16-byte chunk q of
+//      the row segment a lane fetches is swizzled, q = p ^ ((row >> 2) & 3), so that the 16 lanes of a ds_read_b128 lane
+//      group hit 16 different bank quads when a fragment (32 rows x 8 k) is read back.  The exact 3-way bf16 split is
+//      done at fragment-read time in registers; with the waves stacked along M every A row is read and split by exactly
+//      one wave (same VALU work as splitting before the LDS store), and each wave stages precisely the rows it consumes;
+//   W  packed image (already the LDS image) by three global_load_lds_dwordx4 per wave and k-tile;
+//   two LDS stages of 28 KB: the DMA of k-tile t+1 is issued before the MFMAs of k-tile t and waited for (vmcnt(0), the
+//      only VMEM traffic of the loop) in front of the one barrier per k-tile; two workgroups per CU.
+//   CONV taps outside the image fetch from a zero page instead of being predicated.
+// The DMA is issued from inline asm (the compiler would otherwise drain it in front of every LDS read it cannot prove
+// disjoint); M0 is set and restored inside the statement (cdna_hip_programming.md §5.7).
 // ----------------------------------------------------------------------------------------------------------------
-constexpr int BM8 = 256, PLANE8 = BM8 + 4;
-constexpr int A8_SLOTS = 3 * KB * PLANE8;          // uint4 slots of the A image of one stage
-constexpr int STAGE8_SLOTS = A8_SLOTS + OPER_SLOTS;  // + B image
+__device__ __attribute__((aligned(64))) float g_zero_page[16];
 
-template <int EPI, bool CONV>
-__global__ __launch_bounds__(512) void gemm_split_kernel8(const float* __restrict__ A, const uint4* __restrict__ Wp,
-                                                          const float* __restrict__ bias,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ resid, float* __restrict__ C,
-                                                          int M, int N, int K, ConvGeom cg) {
-  extern __shared__ uint4 lds4[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // Roles follow the hardware placement, not the wave index: the two waves that the dispatcher put on the same SIMD
-  // must land in different groups, or one SIMD gets both MFMA phases and its neighbour none.  Every wave publishes
-  // its SIMD id (HW_ID[5:4]); group = rank among the waves of that SIMD, quadrant = SIMD id.  If the placement is not
-  // two-per-SIMD the wave index decides.
-  __shared__ int s_simd[8];
-  const int my_simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3;  // HW_REG_HW_ID, offset 4, 2 bits
-  if (lane == 0) s_simd[wave] = my_simd;
-  __syncthreads();
-  int grp = 0, cnt = 0, ok_placement = 1;
-#pragma unroll
-  for (int w = 0; w < 8; ++w) {
-    int c = 0;
-#pragma unroll
-    for (int v = 0; v < 8; ++v) c += s_simd[v] == s_simd[w];
-    ok_placement &= c == 2;
-    if (s_simd[w] == my_simd) { grp += w < wave; ++cnt; }
-  }
-  (void)cnt;
-  int wq = my_simd;
-  if (!ok_placement) { grp = wave >> 2; wq = wave & 3; }
-  grp = __builtin_amdgcn_readfirstlane(grp);
-  wq = __builtin_amdgcn_readfirstlane(wq);
-  const int wm = wq >> 1, wn = wq & 1, tig = wq * 64 + lane;  // staging index inside the group's 256 threads
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+constexpr int GA_SLOTS = 256 * 4;   // fp32 A image of one stage: 256 rows x 4 chunks of 16 B
+constexpr int GB_SLOTS = 3 * KB * BN;  // packed weight tile image
+
+template <int EPI, int CONV>
+__global__ __launch_bounds__(256, 2) void gemm_split_glds_kernel(const float* __restrict__ A, const uint4* __restrict__ Wp,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ resid, float* __restrict__ C,
+                                                                 int M, int N, int K, ConvGeom cg) {
+  __shared__ uint4 sA[2 * GA_SLOTS];
+  __shared__ uint4 sB[2 * GB_SLOTS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntn = N / BN;
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
   const int tile_m = tile / ntn, tile_n = tile % ntn;
-  const int m0 = tile_m * BM8, n0 = tile_n * BN;
+  const int m0 = tile_m * 256, n0 = tile_n * BN;
   const int nk = K / BK;
 
-  // staging share of this thread: group 1 -> A rows 0..127 (+ B), group 0 -> A rows 128..255
-  const int arow = (grp == 1 ? 0 : 128) + (tig >> 2), lkq = tig & 3;
-  const float* Ag = CONV ? A + (size_t)(m0 + arow) * cg.C + lkq * 4 : A + (size_t)(m0 + arow) * K + lkq * 4;
-  const uint4* Wg = Wp + (size_t)tile_n * nk * W_TILE_SLOTS + tig;
-  int py0 = 0, px0 = 0, py1 = 0, px1 = 0, cpt = 1;
-  if (CONV) {
-    const int p0 = (m0 + arow) % (cg.H * cg.W), p1 = (m0 + arow + 64) % (cg.H * cg.W);
-    py0 = p0 / cg.W; px0 = p0 % cg.W; py1 = p1 / cg.W; px1 = p1 % cg.W;
-    cpt = cg.C / BK;
+  // A staging: DMA c (0..3) of this wave fills slots (wave*4 + c)*64 + lane = rows wave*64 + c*16 + lane/4
+  const int prow = lane >> 2, pq = lane & 3;
+  const float* ap[4];
+  int pyx[4], cpt = 1;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int lrow = wave * 64 + c * 16 + prow;
+    const int q = pq ^ ((lrow >> 2) & 3);
+    const int arow = min(m0 + lrow, M - 1);
+    if (CONV) {
+      const int OH = CONV == 1 ? cg.H : cg.OH, OW = CONV == 1 ? cg.W : cg.OW, stride = CONV == 1 ? 1 : cg.stride;
+      const int img = arow / (OH * OW), pp = arow - img * (OH * OW);
+      const int iy = (pp / OW) * stride, ix = (pp % OW) * stride;
+      pyx[c] = (iy << 16) | ix;
+      ap[c] = A + (((size_t)img * cg.H + iy) * cg.W + ix) * cg.C + q * 4;
+    } else {
+      pyx[c] = 0;
+      ap[c] = A + (size_t)arow * K + q * 4;
+    }
   }
-  struct StageA { float4 a0, a1; };
-  struct StageB { uint4 b0, b1, b2; };
-  auto gload_a = [&](int kt) {
-    StageA r;
+  if (CONV) cpt = cg.C / BK;
+  const uint4* Wg = Wp + (size_t)tile_n * nk * W_TILE_SLOTS + (wave * 3) * 64 + lane;
+  const unsigned ldsA = lds_addr(sA) + (unsigned)(wave * 4) * 1024u;
+  const unsigned ldsB = lds_addr(sB) + (unsigned)(wave * 3) * 1024u;
+
+  auto issue = [&](int kt, int stage) {
+    const unsigned da = ldsA + (unsigned)stage * (GA_SLOTS * 16u), db = ldsB + (unsigned)stage * (GB_SLOTS * 16u);
     if (CONV) {
       const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      const bool ok0 = (unsigned)(py0 + dy) < (unsigned)cg.H && (unsigned)(px0 + dx) < (unsigned)cg.W;
-      const bool ok1 = (unsigned)(py1 + dy) < (unsigned)cg.H && (unsigned)(px1 + dx) < (unsigned)cg.W;
-      const int off = (dy * cg.W + dx) * cg.C;
-      const float4 v0 = *reinterpret_cast<const float4*>(Ag + (ok0 ? off : 0) + c0);
-      const float4 v1 = *reinterpret_cast<const float4*>(Ag + (size_t)64 * cg.C + (ok1 ? off : 0) + c0);
-      r.a0 = ok0 ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
-      r.a1 = ok1 ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int KW = CONV == 1 ? 3 : cg.KW, pad = CONV == 1 ? 1 : cg.pad;
+      const int ky = tap / KW, dy = ky - pad, dx = tap - ky * KW - pad;
+      const int off = (dy * cg.W + dx) * cg.C + c0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool ok = (unsigned)((pyx[c] >> 16) + dy) < (unsigned)cg.H && (unsigned)((pyx[c] & 0xffff) + dx) < (unsigned)cg.W;
+        glds16(ok ? (const void*)(ap[c] + off) : (const void*)g_zero_page, da + c * 1024u);
+      }
     } else {
-      r.a0 = *reinterpret_cast<const float4*>(Ag + kt * BK);
-      r.a1 = *reinterpret_cast<const float4*>(Ag + (size_t)64 * K + kt * BK);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) glds16(ap[c] + kt * BK, da + c * 1024u);
     }
-    return r;
-  };
-  auto gload_b = [&](int kt) {
-    StageB r;
     const uint4* w = Wg + (size_t)kt * W_TILE_SLOTS;
-    r.b0 = w[0]; r.b1 = w[256]; r.b2 = w[512];
-    return r;
-  };
-  const int skb = lkq >> 1, shalf = lkq & 1;
-  auto lstore_a = [&](const StageA r, int buf) {
-    uint4* a = lds4 + buf * STAGE8_SLOTS;
-    {
-      const Split3 p0 = split_pair(r.a0.x, r.a0.y), p1 = split_pair(r.a0.z, r.a0.w);
-      uint2* dst = reinterpret_cast<uint2*>(a + skb * PLANE8 + arow) + shalf;
-      dst[0] = make_uint2(p0.h, p1.h);
-      dst[2 * KB * PLANE8] = make_uint2(p0.m, p1.m);
-      dst[4 * KB * PLANE8] = make_uint2(p0.l, p1.l);
-    }
-    {
-      const Split3 p0 = split_pair(r.a1.x, r.a1.y), p1 = split_pair(r.a1.z, r.a1.w);
-      uint2* dst = reinterpret_cast<uint2*>(a + skb * PLANE8 + 64 + arow) + shalf;
-      dst[0] = make_uint2(p0.h, p1.h);
-      dst[2 * KB * PLANE8] = make_uint2(p0.m, p1.m);
-      dst[4 * KB * PLANE8] = make_uint2(p0.l, p1.l);
-    }
-  };
-  auto lstore_b = [&](const StageB r, int buf) {
-    uint4* bd = lds4 + buf * STAGE8_SLOTS + A8_SLOTS + (tig >> 7) * PLANE + (tig & 127);
-    bd[0] = r.b0; bd[2 * PLANE] = r.b1; bd[4 * PLANE] = r.b2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) glds16(w + c * 64, db + c * 1024u);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frow = lane & 31, fk = lane >> 5;
-  bf16x8 fa[3][2], fb[3][2];
-  auto read_frags = [&](int buf) {
-    const uint4* a = lds4 + buf * STAGE8_SLOTS + fk * PLANE8 + grp * 128 + wm * 64 + frow;
-    const uint4* b = lds4 + buf * STAGE8_SLOTS + A8_SLOTS + fk * PLANE + wn * 64 + frow;
+  // fragment slots of this lane in the A image: row wave*64 + i*32 + frow, chunks 2*fk and 2*fk + 1 (swizzled)
+  int aslot[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lrow = wave * 64 + i * 32 + frow, g = (lrow >> 2) & 3;
+    aslot[i][0] = 4 * lrow + ((2 * fk) ^ g);
+    aslot[i][1] = 4 * lrow + ((2 * fk + 1) ^ g);
+  }
+  auto compute = [&](int stage) {
+    const uint4* a = sA + stage * GA_SLOTS;
+    const uint4* b = sB + stage * GB_SLOTS + fk * BN + frow;
+    bf16x8 fb[3][4];
+    float4 ra[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i][0] = __builtin_bit_cast(float4, a[aslot[i][0]]);
+      ra[i][1] = __builtin_bit_cast(float4, a[aslot[i][1]]);
+    }
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[s][i] = __builtin_bit_cast(bf16x8, a[s * KB * PLANE8 + i * 32]);
-        fb[s][i] = __builtin_bit_cast(bf16x8, b[s * KB * PLANE + i * 32]);
-      }
-  };
-  auto mfma24 = [&]() {
+      for (int j = 0; j < 4; ++j) fb[s][j] = __builtin_bit_cast(bf16x8, b[s * KB * BN + j * 32]);
     constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
     constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][0], fb[TB[t]][0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][0], fb[TB[t]][1], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][1], fb[TB[t]][0], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]][1], fb[TB[t]][1], acc[1][1], 0, 0, 0);
+    for (int i = 0; i < 2; ++i) {
+      const Split3 p0 = split_pair(ra[i][0].x, ra[i][0].y), p1 = split_pair(ra[i][0].z, ra[i][0].w);
+      const Split3 p2 = split_pair(ra[i][1].x, ra[i][1].y), p3 = split_pair(ra[i][1].z, ra[i][1].w);
+      bf16x8 fa[3];
+      fa[0] = __builtin_bit_cast(bf16x8, make_uint4(p0.h, p1.h, p2.h, p3.h));
+      fa[1] = __builtin_bit_cast(bf16x8, make_uint4(p0.m, p1.m, p2.m, p3.m));
+      fa[2] = __builtin_bit_cast(bf16x8, make_uint4(p0.l, p1.l, p2.l, p3.l));
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]], fb[TB[t]][j], acc[i][j], 0, 0, 0);
     }
-    __builtin_amdgcn_s_setprio(0);
   };
 
-  // The two groups run separate loops (same barrier count) so that neither carries the other's registers or waits:
-  // every s_barrier below is executed once per phase by all eight waves.  Global loads run TWO k-tiles (four phases)
-  // ahead of their LDS store through two register stages; the loop is unrolled by two (nk is even) so each stage
-  // keeps its registers.  With one workgroup per CU nothing else hides HBM latency: at a distance of one k-tile the
-  // loop ran at exactly the memory latency (0.8 us per k-tile).
-#define KCLAMP(kt) min((kt), nk - 1)
-#define G0_STEP(ST, KT)                                                                               \
-  {                                                                                                   \
-    const int buf = (KT)&1;                                                                           \
-    mfma24();              /* phase 1: k-tile KT, output rows 0-127 */                                \
-    __syncthreads();                                                                                  \
-    lstore_a(ST, buf ^ 1); /* phase 2: A rows 128-255 of k-tile KT+1 */                               \
-    ST = gload_a(KCLAMP((KT) + 3));                                                                   \
-    read_frags(buf ^ 1);   /* own fragments of k-tile KT+1 (group 1 stored them in phase 1) */        \
-    __syncthreads();                                                                                  \
-  }
-#define G1_STEP(ST, TT, KT)                                                                           \
-  {                                                                                                   \
-    const int buf = (KT)&1;                                                                           \
-    lstore_a(ST, buf ^ 1); /* phase 1: A rows 0-127 + B of k-tile KT+1 */                             \
-    lstore_b(TT, buf ^ 1);                                                                            \
-    ST = gload_a(KCLAMP((KT) + 3));                                                                   \
-    TT = gload_b(KCLAMP((KT) + 3));                                                                   \
-    read_frags(buf);       /* own fragments of k-tile KT (rows 128-255 landed one barrier ago) */     \
-    __syncthreads();                                                                                  \
-    mfma24();              /* phase 2: k-tile KT, output rows 128-255 */                              \
-    __syncthreads();                                                                                  \
-  }
-  if (grp == 0) {
-    StageA s0 = gload_a(0);
-    lstore_a(s0, 0);
-    StageA s1 = gload_a(KCLAMP(1));
-    s0 = gload_a(KCLAMP(2));
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {   // nk is even (K % 32 == 0); the tail re-stages the last tile into the idle buffer
+    issue(kt + 1, 1);
+    compute(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    read_frags(0);
-    for (int kt = 0; kt < nk; kt += 2) {
-      G0_STEP(s1, kt)
-      G0_STEP(s0, kt + 1)
-    }
-  } else {
-    StageA s0 = gload_a(0);
-    StageB t0 = gload_b(0);
-    lstore_a(s0, 0);
-    lstore_b(t0, 0);
-    StageA s1 = gload_a(KCLAMP(1));
-    StageB t1 = gload_b(KCLAMP(1));
-    s0 = gload_a(KCLAMP(2));
-    t0 = gload_b(KCLAMP(2));
+    issue(min(kt + 2, nk - 1), 0);
+    compute(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-      G1_STEP(s1, t1, kt)
-      G1_STEP(s0, t0, kt + 1)
-    }
   }
-#undef G0_STEP
-#undef G1_STEP
-#undef KCLAMP
 
-  float* T = reinterpret_cast<float*>(lds4) + wave * 32 * 65;  // [32][65] per wave
+  // epilogue: as in gemm_split_kernel, per wave one 16x64 slice at a time through LDS (the A images are dead)
+  static_assert(2 * GA_SLOTS * sizeof(uint4) >= 4 * 16 * 65 * sizeof(float), "epilogue staging fits the A images");
+  float* T = reinterpret_cast<float*>(sA) + wave * 16 * 65;
   const int c4 = (lane & 15) * 4;
-  const int nb = n0 + wn * 64 + c4;
-  const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
-  if (EPI == EPI_SCALE_RES) gv = *reinterpret_cast<const float4*>(gamma + nb);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int jh = 0; jh < 2; ++jh) {
+    const int nb = n0 + jh * 64 + c4;
+    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (EPI == EPI_SCALE_RES) gv = *reinterpret_cast<const float4*>(gamma + nb);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int ih = 0; ih < 4; ++ih) {
+      const int i = ih >> 1, h = ih & 1;
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr)
-        T[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * 65 + j * 32 + (lane & 31)] = acc[i][j][rr];
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): same wave reads back
-#pragma unroll 4
-    for (int rr = 0; rr < 8; ++rr) {
-      const int row = rr * 4 + (lane >> 4);
-      const float* t = T + row * 65 + c4;
-      float4 v = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
-      const size_t off = (size_t)(m0 + grp * 128 + wm * 64 + i * 32 + row) * N + nb;
-      if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-      if (EPI == EPI_SCALE_RES) {
-        const float4 rs = *reinterpret_cast<const float4*>(resid + off);
-        v.x = rs.x + gv.x * v.x; v.y = rs.y + gv.y * v.y; v.z = rs.z + gv.z * v.z; v.w = rs.w + gv.w * v.w;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 65 + j * 32 + (lane & 31)] = acc[i][jh * 2 + j][h * 8 + r];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = rr * 4 + (lane >> 4);
+        const float* t = T + row * 65 + c4;
+        float4 v = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
+        const int grow = m0 + wave * 64 + i * 32 + h * 16 + row;
+        if (grow >= M) continue;
+        const size_t off = (size_t)grow * N + nb;
+        if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        if (EPI == EPI_SCALE_RES) {
+          const float4 rs = *reinterpret_cast<const float4*>(resid + off);
+          v.x = rs.x + gv.x * v.x; v.y = rs.y + gv.y * v.y; v.z = rs.z + gv.z * v.z; v.w = rs.w + gv.w * v.w;
+        }
+        { const f32x4v t4 = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t4, reinterpret_cast<f32x4v*>(C + off)); }
       }
-      *reinterpret_cast<float4*>(C + off) = v;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
   }
 }
 
@@ -524,28 +483,22 @@ namespace {
 template <int EPI, bool CONV>
 int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
                      int M, int N, int K, ConvGeom cg, hipStream_t st, const char* what) {
-  // The 256x128 ping-pong kernel is opt-in (GDRNPP_SPLIT_8WAVE=1, read per launch so tests can toggle it): measured on
-  // MI355X it reaches 133-174 TFLOP/s fp32-equivalent on the stage-2 MLP shapes against 144-177 for the 4-wave kernel
-  // at three workgroups per CU (tools/microbench_gemm_s2.py, same box) — see DESIGN.md §5.
   const bool fast3x3 = CONV && cg.KW == 3 && cg.stride == 1 && cg.pad == 1 && K == 9 * cg.C;
-  const char* use8 = getenv("GDRNPP_SPLIT_8WAVE");
-  if (M % BM8 == 0 && use8 && use8[0] == '1' && (!CONV || fast3x3)) {
-    const long blocks = (long)(M / BM8) * (N / BN);
-    GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "%s: grid too large", what);
-    const int lds = 2 * STAGE8_SLOTS * (int)sizeof(uint4);  // 75 KB >= 8 * 32 * 65 * 4 (epilogue staging)
-    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_kernel8<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((gemm_split_kernel8<EPI, CONV>), dim3((unsigned)blocks), dim3(512), lds, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+  const long tiles256 = (long)((M + 255) / 256) * (N / BN);
+  GDRNPP_REQUIRE(tiles256 < (1l << 30), GDRNPP_ELIMIT, "%s: grid too large", what);
+  // 256-row tiles when they still give every CU its two workgroups (measured +3 % / +7 % on the stage-2 MLP shapes over
+  // 128x128 tiles at three workgroups per CU); gdrnpp_set_option("split_gemm_mi4", 0/1) forces the choice (A/B).
+  const int force = gdrnpp::option_split_gemm_mi4();
+  const bool big = force >= 0 ? force == 1 : tiles256 >= 512;
+  if (big && gdrnpp::option_split_gemm_glds()) {   // LDS-DMA kernel: any M, any of the three A forms
+    if (CONV && fast3x3) hipLaunchKernelGGL((gemm_split_glds_kernel<EPI, CONV ? 1 : 0>), dim3((unsigned)tiles256), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+    else hipLaunchKernelGGL((gemm_split_glds_kernel<EPI, CONV ? 2 : 0>), dim3((unsigned)tiles256), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
     return gdrnpp::check_launch(what);
   }
-  // 256x128 tiles (MI = 4) when they still give every CU its two workgroups; measured +3 % (fc1) / +7 % (fc2) on the
-  // stage-2 MLP shapes over 128x128 tiles at three workgroups per CU.  GDRNPP_SPLIT_MI4=0/1 forces the choice (A/B).
-  const char* mi4 = getenv("GDRNPP_SPLIT_MI4");
   // (the general convolution form needs a few more registers than 256x128 tiles leave: it stays on 128x128 tiles)
-  const bool big = (mi4 ? mi4[0] == '1' : (long)(M / 256) * (N / BN) >= 512) && !(CONV && !fast3x3);
-  if (M % 256 == 0 && big) {
-    const long blocks = (long)(M / 256) * (N / BN);
-    if (CONV && fast3x3) hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV ? 1 : 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
-    else hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV ? 2 : 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+  if (M % 256 == 0 && big && !(CONV && !fast3x3)) {
+    if (CONV && fast3x3) hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV ? 1 : 0, 4>), dim3((unsigned)tiles256), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+    else hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV ? 2 : 0, 4>), dim3((unsigned)tiles256), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
     return gdrnpp::check_launch(what);
   }
   const long blocks = (long)((M + BM - 1) / BM) * (N / BN);

@@ -80,23 +80,19 @@ def dwconv_ln(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor, cache: dict) -
     return F.layer_norm(y, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
 
 
-# GEMM engine of the ConvNeXt MLP:
-#   "split" (default) gdrnpp_linear_f32_split: bf16 matrix cores, exact 3-way operand split, six partial products,
-#                     fp32 accumulate — error vs fp64 at or below the fp32 fma chain, ~1.4x the fp32-MFMA rate;
-#   "f32"             fp32 MFMA: gdrnpp_linear_f32 (fused epilogues) for C <= 256, hipBLASLt + GELU/addcmul above
-#                     (the fused fp32 kernel wins only where the epilogue passes dominate: 1.41 vs 1.67 ms at C=128,
-#                     1.21 vs 1.25 ms at C=256, and loses 2-5 % to hipBLASLt's 256x256 macro-tile at C >= 512);
-#   "torch"           hipBLASLt + separate elementwise kernels everywhere.
+# GEMM engine of the ConvNeXt MLPs / head convolutions:
+#   "split" (default) gdrnpp_linear_f32_split / gdrnpp_conv2d_f32_split: bf16 matrix cores, exact 3-way operand split, six
+#                     partial products, fp32 accumulate — error vs fp64 at or below an fp32 fma chain, ~1.4x the fp32-MFMA rate;
+#   "torch"           hipBLASLt / MIOpen fp32 + separate elementwise kernels everywhere (A/B measurements).
 _MLP_GEMM = "split"
 _SPLITK_BELOW_TILES = 512
 _LIBRARY_BELOW_TILES = 128  # blocks whose fc2 has fewer output tiles than this go to hipBLASLt (measured: batch 8
                             # 1071 -> 1210 ROIs/s, batch 16 unchanged, 300 already hurts batch 16)
-_F32_FUSED_MAX_C = 256
 
 
 def set_mlp_gemm(mode: str) -> None:
     global _MLP_GEMM
-    if mode not in ("split", "f32", "torch"):
+    if mode not in ("split", "torch"):
         raise ValueError(f"unknown MLP GEMM mode {mode!r}")
     _MLP_GEMM = mode
 
@@ -137,10 +133,6 @@ def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: 
         f2 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, c) < _SPLITK_BELOW_TILES else hip_lib.linear_f32_split
         h = f1(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk"), mlp.fc1.bias, "gelu")
         y = f2(h, _packed(mlp.fc2, cache, "fc2_pk"), mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
-        return y.view(x_nhwc.shape)
-    if ok and _MLP_GEMM == "f32" and c <= _F32_FUSED_MAX_C and m % 128 == 0:
-        h = hip_lib.linear_f32(x_nhwc.view(m, c), mlp.fc1.weight, mlp.fc1.bias, "gelu")
-        y = hip_lib.linear_f32(h, mlp.fc2.weight, mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
         return y.view(x_nhwc.shape)
     return torch.addcmul(shortcut_nhwc, mlp(x_nhwc), gamma)
 

@@ -36,6 +36,7 @@ class gdrnpp_meshes(ctypes.Structure):
 _P = c_void_p
 SIGNATURES = {
     "gdrnpp_version": (c_int, []),
+    "gdrnpp_set_option": (c_int, [ctypes.c_char_p, c_int]),
     "gdrnpp_last_error": (c_char_p, []),
     "farthest_point_sampling": (None, [_P, _P, c_int, c_int]),
     "farthest_point_sampling_init_center": (None, [_P, _P, c_int, c_int]),
@@ -61,7 +62,6 @@ SIGNATURES = {
         c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
                 c_int, c_int, c_float, c_float, _P]),
     "gdrnpp_debug_refine_profile": (c_int, [_P]),
-    "gdrnpp_linear_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_pack_weight_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_linear_f32_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -104,6 +104,11 @@ def load(path: str | None = None) -> ctypes.CDLL:
     if path is None:
         _lib = lib
     return lib
+
+
+def set_option(name: str, value: int) -> None:
+    """Process-wide tuning switch of the library (``gdrnpp_set_option``)."""
+    _check(load().gdrnpp_set_option(name.encode(), int(value)), "gdrnpp_set_option")
 
 
 def _check(rc: int, what: str) -> None:
@@ -471,7 +476,7 @@ def unpack_weight_bf16x3(packed):
 
 
 def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None):
-    """Same contract as linear_f32 with the weight given as pack_weight_bf16x3(weight); runs on the bf16 matrix cores
+    """out = epilogue(x2d @ W^T + bias) with the weight given as pack_weight_bf16x3(weight); runs on the bf16 matrix cores
     with six partial products per fp32 product (fp32-accurate, see csrc/gemm_split.hip)."""
     m, k = x2d.shape
     if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or not weight_packed.is_contiguous() \
@@ -603,18 +608,3 @@ def flow_forward(depth_src, depth_tgt, KT, Kinv):
                                       _dev(KT, torch.float32, "KT"), _dev(Kinv, torch.float32, "Kinv"), flow.data_ptr(),
                                       valid.data_ptr(), b, h, w, _stream()), "gdrnpp_flow_forward")
     return flow, valid
-
-
-def linear_f32(x2d, weight, bias, epilogue: str = "none", gamma=None, resid=None):
-    """x2d f32[M,K] (contiguous rows), weight f32[N,K] -> f32[M,N] with the fused epilogue
-    ("none" | "gelu" | "scale_res": resid + gamma * (x W^T + b))."""
-    m, k = x2d.shape
-    n = weight.shape[0]
-    out = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
-    _check(load().gdrnpp_linear_f32(
-        _dev(x2d, torch.float32, "x"), _dev(weight, torch.float32, "weight"),
-        _dev(bias, torch.float32, "bias") if bias is not None else None,
-        _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
-        _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
-        {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream()), "gdrnpp_linear_f32")
-    return out

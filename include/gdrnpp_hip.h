@@ -19,7 +19,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
  *   - return 0 = ok, negative = argument error (GDRNPP_E*), positive = hipError_t;
  *   - no allocation inside; scratch is passed in, sized by *_workspace_bytes();
- *   - no global state; safe from several host threads on different streams.
+ *   - no global state apart from the process-wide tuning switches of gdrnpp_set_option; safe from several host
+ *     threads on different streams.
  */
 #ifndef GDRNPP_HIP_H_
 #define GDRNPP_HIP_H_
@@ -38,6 +39,12 @@ extern "C" {
 int gdrnpp_version(void);
 /* message for the last non-zero status returned on this host thread */
 const char* gdrnpp_last_error(void);
+/* process-wide tuning switches, read on the launch path (no environment lookups there):
+ *   "split_gemm_glds"  0 / 1   256-row tiles of the split GEMM / convolution use the register-staged kernel / the
+ *                              LDS-DMA kernel (default 1; results are bitwise identical)
+ *   "split_gemm_mi4"   -1 / 0 / 1   tile height by tile count (default) / force 128 rows / force 256 rows
+ * unknown name -> GDRNPP_EINVAL. */
+int gdrnpp_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------ */
 /* (1) reference-ABI symbols (host pointers)                                 */
@@ -267,14 +274,10 @@ int gdrnpp_roi_align(const float* x, const float* rois, float* out, int n_rois, 
 
 /* ---- fp32 linear layer with fused epilogue (ConvNeXt Mlp of GDRN_Net, a3) --------------------------------------
  * C[M,N] = A[M,K] * W[N,K]^T + bias[N]; epilogue 0 = none, 1 = exact-erf GELU (timm Mlp.fc1 + act),
- * 2 = resid[M,N] + gamma[N] * C (Mlp.fc2 + layer scale + residual).  fp32 MFMA (exact fp32 fma chain).
- * M, N multiples of 128, K multiple of 32. */
-int gdrnpp_linear_f32(const float* A, const float* W, const float* bias, const float* gamma,
-                      const float* resid, float* C, int M, int N, int K, int epilogue,
-                      void* stream);
+ * 2 = resid[M,N] + gamma[N] * C (Mlp.fc2 + layer scale + residual). */
 
 /* ---- fp32-accurate linear layer on the bf16 matrix cores (a3) -------------------------------------------------
- * Same contract as gdrnpp_linear_f32.  Every fp32 operand is split EXACTLY into three bf16 values (x = h + m + l);
+ * Every fp32 operand is split EXACTLY into three bf16 values (x = h + m + l);
  * six of the nine partial products (all terms above 2^-26 relative) are accumulated in fp32 by
  * v_mfma_f32_32x32x16_bf16.  Error against an fp64 product is below that of the fp32 fma chain.
  * gdrnpp_pack_weight_bf16x3: W f32[N][K] (nn.Linear weight) -> bf16[N/128][K/16][3][2][128][8]: the three splits

@@ -60,7 +60,7 @@ def test_groupnorm_act(hip, n, c, g, h, w, gelu):
     torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("mlp_gemm", ["split", "f32"])
+@pytest.mark.parametrize("mlp_gemm", ["split", "torch"])
 def test_model_forward_hip_layers_vs_torch_ops(hip, mlp_gemm):
     """Whole GDRN_Net forward with the HIP layers on vs off (same weights): maps within 1e-4, pose within 1e-4.
     Both MLP GEMM engines (bf16x6 split on the bf16 matrix cores, fp32 MFMA) against hipBLASLt + PyTorch ops."""
@@ -103,24 +103,6 @@ def test_model_forward_hip_layers_vs_torch_ops(hip, mlp_gemm):
     torch.testing.assert_close(o1["trans"], o2["trans"], rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize("m,k,n", [(128 * 64, 128, 512), (128 * 16, 512, 128), (256, 1024, 4096), (128, 32, 128)])
-def test_linear_f32_fused_epilogues(hip, m, k, n):
-    """fp32 MFMA GEMM with fused epilogues vs F.linear (+ exact GELU / layer-scale + residual): 2e-6 relative to the
-    output scale (both are fp32 fma chains over K, in different orders)."""
-    torch.manual_seed(m + k)
-    x = torch.randn(m, k, device=DEV)
-    w = torch.randn(n, k, device=DEV) * (k ** -0.5)
-    b = torch.randn(n, device=DEV)
-    gamma = torch.randn(n, device=DEV)
-    res = torch.randn(m, n, device=DEV)
-    ref = F.linear(x, w, b)
-    for epi, want in (("none", ref), ("gelu", F.gelu(ref)), ("scale_res", torch.addcmul(res, ref, gamma))):
-        out = hip.linear_f32(x, w, b, epi, gamma if epi == "scale_res" else None, res if epi == "scale_res" else None)
-        assert ((out - want).abs().max() / want.abs().max()).item() < 2e-6, epi
-    with pytest.raises(RuntimeError, match="multiples"):
-        hip.linear_f32(torch.randn(100, k, device=DEV), w, b)
-
-
 def test_pack_weight_bf16x3_is_exact(hip):
     """w == h + m + l exactly for every element (incl. tiny / huge magnitudes), and the tile layout round-trips."""
     torch.manual_seed(3)
@@ -134,9 +116,8 @@ def test_pack_weight_bf16x3_is_exact(hip):
 
 @pytest.mark.parametrize("m,k,n", [(128 * 64, 128, 512), (128 * 16, 512, 128), (256, 2048, 512), (128, 32, 128), (128 * 9, 64, 384)])
 def test_linear_f32_split_is_fp32_accurate(hip, m, k, n):
-    """bf16x6 split GEMM vs an fp64 product: its error must not exceed that of an fp32 GEMM — the k-ordered fp32 fma
-    chain of gdrnpp_linear_f32 or hipBLASLt, whichever accumulates worse at this shape (hipBLASLt splits K at small
-    M) — by more than rounding noise, for all three epilogues; and it agrees with fp32 to 4e-6 of the output scale."""
+    """bf16x6 split GEMM vs an fp64 product: its error must not exceed that of the fp32 GEMM of PyTorch-ROCm (hipBLASLt)
+    by more than rounding noise, for all three epilogues; and it agrees with fp32 to 4e-6 of the output scale."""
     torch.manual_seed(m + k + n)
     x = torch.randn(m, k, device=DEV)
     w = torch.randn(n, k, device=DEV) * (k ** -0.5)
@@ -152,8 +133,7 @@ def test_linear_f32_split_is_fp32_accurate(hip, m, k, n):
         out = hip.linear_f32_split(x, pk, b, epi, gamma if epi == "scale_res" else None, res if epi == "scale_res" else None)
         scale = want64.abs().max().item()
         e_split = (out.double() - want64).abs().max().item() / scale
-        chain = hip.linear_f32(x, w, b, epi, gamma if epi == "scale_res" else None, res if epi == "scale_res" else None)
-        e_f32 = max((got32.double() - want64).abs().max().item(), (chain.double() - want64).abs().max().item()) / scale
+        e_f32 = (got32.double() - want64).abs().max().item() / scale
         assert e_split <= max(1.25 * e_f32 + 1.2e-7, 4e-8 * k ** 0.5), (epi, e_split, e_f32)
         assert ((out - got32).abs().max() / scale).item() < 4e-6, epi
     # K must be a multiple of 32 (M is free): the C entry point refuses with a status and a message, nothing is launched
@@ -199,25 +179,37 @@ def test_layernorm_nhwc(hip, n, c, h, w):
     torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
 
 
-def test_linear_f32_split_8wave_variant(hip, monkeypatch):
-    """The opt-in 256x128 ping-pong variant of the split GEMM gives the same numbers as the default kernel to fp32
-    accumulation-order noise (both add the same six partial products per k-step, in the same order within a k-step)."""
+def test_split_gemm_lds_dma_kernel_is_bitwise_equal_to_register_staged(hip):
+    """The two 256-row kernels (register-staged A split before the LDS store vs LDS-DMA of fp32 A with the split at
+    fragment-read time) add the same six partial products per k-step in the same order: identical bits, for the linear,
+    3x3 and general convolution forms, ragged M included."""
     torch.manual_seed(5)
-    m, k, n = 1024, 512, 256
-    x = torch.randn(m, k, device=DEV)
-    w = torch.randn(n, k, device=DEV) * (k ** -0.5)
-    b = torch.randn(n, device=DEV)
-    pk = hip.pack_weight_bf16x3(w)
-    base = hip.linear_f32_split(x, pk, b, "gelu")
-    monkeypatch.setenv("GDRNPP_SPLIT_8WAVE", "1")
-    alt = hip.linear_f32_split(x, pk, b, "gelu")
-    xc = torch.randn(2, 64, 16, 16, device=DEV).contiguous(memory_format=torch.channels_last)
-    wc = torch.randn(128, 64, 3, 3, device=DEV) * 0.05
-    pkc = hip.pack_conv3x3_weight_bf16x3(wc)
-    alt_c = hip.conv3x3_f32_split(xc, pkc, None)
-    monkeypatch.delenv("GDRNPP_SPLIT_8WAVE")
-    base_c = hip.conv3x3_f32_split(xc, pkc, None)
-    assert torch.equal(alt, base) and torch.equal(alt_c, base_c)
+    try:
+        hip.set_option("split_gemm_mi4", 1)            # force 256-row tiles at these small sizes
+        outs = []
+        for glds in (0, 1):
+            hip.set_option("split_gemm_glds", glds)
+            m, k, n = 1024 + 37, 512, 256
+            x = torch.randn(m, k, device=DEV)
+            w = torch.randn(n, k, device=DEV) * (k ** -0.5)
+            b = torch.randn(n, device=DEV)
+            g = torch.randn(n, device=DEV)
+            r = torch.randn(m, n, device=DEV)
+            pk = hip.pack_weight_bf16x3(w)
+            xc = torch.randn(3, 64, 16, 24, device=DEV).contiguous(memory_format=torch.channels_last)
+            wc = torch.randn(128, 64, 3, 3, device=DEV) * 0.05
+            wd = torch.randn(128, 64, 2, 2, device=DEV) * 0.05
+            outs.append((hip.linear_f32_split(x, pk, b, "gelu"), hip.linear_f32_split(x, pk, b, "scale_res", g, r),
+                         hip.conv3x3_f32_split(xc, hip.pack_conv_weight_bf16x3(wc), None),
+                         hip.conv2d_f32_split(xc, hip.pack_conv_weight_bf16x3(wd), None, 2, 2, 2, 0)))
+            torch.manual_seed(5)
+    finally:
+        hip.set_option("split_gemm_mi4", -1)
+        hip.set_option("split_gemm_glds", 1)
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    ref = F.conv2d(xc, wc, None, padding=1)
+    assert ((outs[1][2] - ref).abs().max() / ref.abs().max()).item() < 4e-6
 
 
 def test_split_gemm_gelu_epilogue_matches_fp64_gelu(hip):
