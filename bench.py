@@ -85,6 +85,8 @@ def parse(argv=None):
     p.add_argument("--mlp-gemm", choices=["split", "torch"], default="split",
                    help="GEMM engine of the ConvNeXt MLPs / head convolutions: split = exact 3-way bf16 operand split on the "
                         "bf16 matrix cores (fp32-accurate); torch = hipBLASLt / MIOpen fp32 + separate elementwise kernels")
+    p.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
+                   help="library tuning switch (gdrnpp_set_option), e.g. --opt split_gemm_glds=0 for A/B measurements")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --stub-step: CPU test of the launch path")
     p.add_argument("--stub-step", action="store_true",
                    help="(tests) replace the GPU step by a host stub that emits this rank's records: exercises spawn, "
@@ -237,7 +239,7 @@ def worker(args):
                 "roi_prep_on_gpu": bool(args.with_crop), "hipgraph": bool(args.graph), "input_res": 256, "output_res": 64,
                 "parallelism": f"roi-shard x{world}", "collective": "all_gather f32[n,16] pose records" if world > 1 else None,
                 "class_sliced_out_layer": not args.exact_reference_order, "hip_network_layers": not args.no_hip_layers,
-                "mlp_gemm": args.mlp_gemm, "timed_entry_point": "engine.inference_step + engine.gather_records",
+                "mlp_gemm": args.mlp_gemm, "library_options": args.opt, "timed_entry_point": "engine.inference_step + engine.gather_records",
                 "stub_step": bool(args.stub_step)},
             "gather_ms": gather_ms,
         }
@@ -258,6 +260,9 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, roi_ids):
     from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
 
     hip_lib.load()
+    for o in args.opt:
+        k_, v_ = o.split("=")
+        hip_lib.set_option(k_, int(v_))
     torch.backends.cudnn.benchmark = True  # MIOpen find mode during warm-up
     hip_layers.set_enabled(not args.no_hip_layers)
     hip_layers.set_mlp_gemm(args.mlp_gemm)

@@ -119,6 +119,70 @@ def test_config2_and_config4_shard_end_to_end(hip, name, b, refine):
         assert shard_range(1024, 3, 8) == (384, 512)
 
 
+def _seeded_model(cfg, z_prior=4.7):
+    """Model with platform-independent O(1) parameters (synthetic.seeded_param) so that every map is non-trivial; the
+    translation head gets small weights + the dataset z prior so that the predicted poses land inside the frustum."""
+    model, _ = build_model_optimizer(cfg)
+    sd = S.seeded_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], 20220925)
+    model.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        model.pnp_net.fc_t.weight.mul_(0.02)
+        model.pnp_net.fc_t.bias.copy_(torch.tensor([0.0, 0.0, z_prior]))
+    return model
+
+
+def _refine_step_vs_oracle_all_rois(hip, name, b, seed, subdiv=3):
+    cfg = get_cfg(name, ["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"])
+    C = cfg.MODEL.POSE_NET.NUM_CLASSES
+    rng = np.random.default_rng(seed)
+    model = _seeded_model(cfg)
+    verts, faces, ext = S.make_models(C, rng, subdiv=subdiv)
+    meshes = hip.MeshSet(verts, faces)
+    det = S.make_detections(b, C, ext, rng)
+    batch = _batch(det, b)
+    K_crop = S.zoom_K_np(det["roi_cam"], det["roi_center"], det["scale"], 64)
+    depth = hip.render_depth(meshes, T(det["roi_cls"].astype(np.int32)), T(K_crop), T(det["R_gt"]), T(det["t_gt"]), 64)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    big = depth.repeat_interleave(4, 1).repeat_interleave(4, 2)
+    noisy = torch.where(big > 0, big + 0.002 * torch.randn(big.shape, device=DEV, generator=g), big)
+    batch["roi_depth"] = torch.where(torch.rand(big.shape, device=DEV, generator=g) < 0.05, torch.zeros_like(big), noisy)[:, None].contiguous()
+    post = GdrnHipPost(cfg, meshes)
+    rec = inference_step(model, post, batch, torch.arange(b, dtype=torch.int32, device=DEV)).cpu().numpy()
+    with torch.no_grad():
+        out = model(batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"], roi_whs=batch["roi_wh"],
+                    roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"], roi_coord_2d=batch["roi_coord_2d"],
+                    roi_extents=batch["roi_extent"])
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    assert np.isfinite(rec).all() and (rec[:, 15] == 1).all() and np.array_equal(rec[:, 14], np.arange(b))
+    assert np.array_equal(rec[:, :9], o["rot"].reshape(b, 9))                 # refinement leaves R untouched
+    mask = P.get_out_mask(o["mask"])
+    rd = batch["roi_depth"].cpu().numpy()
+    moved = 0
+    for i in range(b):                                                         # EVERY ROI against the oracle
+        c = int(det["roi_cls"][i])
+        xyz = np.concatenate([o[k][i] for k in ("coor_x", "coor_y", "coor_z")], 0).transpose(1, 2, 0)
+        t = P.depth_refine_roi(xyz, mask[i, 0], rd[i, 0], K_crop[i], o["rot"][i], o["trans"][i], verts[c], faces[c])
+        assert np.abs(rec[i, 9:12] - t).max() <= 1e-5, (i, rec[i, 9:12], t)   # north-star bar: 1e-4
+        moved += np.abs(t - o["trans"][i]).max() > 1e-4
+    return moved
+
+
+def test_config3_ycbv_128_rois_refine_every_roi_vs_oracle(hip):
+    """BASELINE configs[2] exactly — YCB-V convnext_a6, 128 ROIs, fast depth refine (2 iterations), 2562-vertex meshes:
+    the records of engine.inference_step against the CPU oracle (pinned by the reference's process_depth_refine) on
+    all 128 ROIs, with O(1) seeded network parameters."""
+    moved = _refine_step_vs_oracle_all_rois(hip, "ycbv_convnext_a6", 128, seed=128, subdiv=4)
+    assert moved >= 64          # the refinement does something for most ROIs (the rest fall outside the sensor depth)
+
+
+def test_config5_bop7_stream_step_vs_oracle(hip):
+    """BASELINE configs[4]: one step of the BOP-7 mixed stream — the seven datasets' models (2..30 classes) one after the
+    other, 16 ROIs each, refine on; every ROI of every dataset against the oracle."""
+    for i, ds in enumerate(("lmo", "ycbv", "tless", "icbin", "hb", "itodd", "tudl")):
+        _refine_step_vs_oracle_all_rois(hip, f"{ds}_convnext_a6", 16, seed=500 + i)
+        torch.cuda.empty_cache()
+
+
 def test_hipgraph_replay_equals_eager(hip):
     """Small-batch serving path: the captured hipGraph of the whole step reproduces the eager records (R/t within
     1e-4; MIOpen/hipBLASLt may pick other kernels under capture), also after the static inputs are overwritten."""
