@@ -2,8 +2,9 @@
 
 The reference initialises with ``cv2.solvePnP(..., SOLVEPNP_EPNP)`` on the 4 highest-weight points
 (:27-44) — OpenCV is a third-party dependency outside the tree and is not installed here.  When ``cv2`` is
-importable it is used exactly like the reference; otherwise the caller must pass ``init_rt`` (6-vector,
-angle-axis + t), and a missing initialiser raises instead of silently substituting one."""
+importable it is used exactly like the reference; otherwise the same four points go through the device EPnP
+(``gdrnpp_epnp_batched``, OpenCV's published epnp.cpp restated; float32 points like the device path everywhere).
+``init_rt`` (6-vector, angle-axis + t) overrides both."""
 import numpy as np
 
 from ._ext import ffi, lib
@@ -25,12 +26,36 @@ def _rodrigues(rvec):
     return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * K
 
 
+def _rodrigues_inv(R):
+    """cv2.Rodrigues(R)[0] (matrix -> angle-axis), float64."""
+    R = np.asarray(R, np.float64)
+    c = np.clip((np.trace(R) - 1.0) * 0.5, -1.0, 1.0)
+    th = np.arccos(c)
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    if th < 1e-12:
+        return 0.5 * v
+    if np.pi - th < 1e-6:      # near pi: axis from the diagonal of (R + I) / 2
+        a = np.sqrt(np.maximum((np.diag(R) + 1.0) * 0.5, 0.0))
+        k = int(np.argmax(a))
+        a = np.where(np.arange(3) == k, a, np.copysign(a, (R[k] + R[:, k])))
+        return th * a / np.linalg.norm(a)
+    return th * v / (2.0 * np.sin(th))
+
+
 def _init_pose(points_3d, points_2d, camera_matrix, idxs, init_rt):
     if init_rt is not None:
         return np.ascontiguousarray(np.asarray(init_rt, np.float64).reshape(6, 1))
     if cv2 is None:
-        raise RuntimeError("uncertainty_pnp: cv2 (EPnP initialiser, un_pnp_utils.py:34-44) is not available; "
-                           "pass init_rt=(angle-axis, t)")
+        import torch
+
+        from .... import hip_lib
+
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()  # noqa: E731
+        R, t, status = hip_lib.epnp_batched(T(points_2d[idxs][None]), T(points_3d[idxs][None]), T(camera_matrix.reshape(1, 9)))
+        if int(status.item()) != 1:
+            raise RuntimeError("uncertainty_pnp: EPnP on the four best-weighted points is degenerate; pass init_rt")
+        return np.ascontiguousarray(np.concatenate([_rodrigues_inv(R[0].cpu().numpy().astype(np.float64)),
+                                                    t[0].cpu().numpy().astype(np.float64)]).reshape(6, 1))
     dist_coeffs = np.zeros(shape=[8, 1], dtype=np.float64)
     _, R_exp, t = cv2.solvePnP(np.expand_dims(points_3d[idxs, :], 0), np.expand_dims(points_2d[idxs, :], 0),
                                camera_matrix, dist_coeffs, None, None, False, flags=cv2.SOLVEPNP_EPNP)

@@ -95,17 +95,56 @@ class GdrnHipPost:
             img_pts, mdl_pts, count, batch["roi_cam"].reshape(b, 9).contiguous(),
             out_dict["rot"].reshape(b, 9).contiguous(), out_dict["trans"].contiguous())
 
+    def process_pnp_ransac(self, batch: dict, out_dict: dict, iters: int = 100, draws=None):
+        """``TEST.USE_PNP`` with ``PNP_TYPE="ransac_pnp"`` (gdrn_evaluator.py:373-459): decode, compact, then
+        ``misc.pnp_v2(..., method=EPNP, ransac=True, ransac_reprojErr=3, ransac_iter=100)`` for every ROI on the device.
+        ROIs with fewer than 4 correspondences get the reference's sentinel pose -100 (:445-447); a RANSAC that finds no
+        model leaves R = I, t = 0 (status 0).  -> (R f32[b,3,3], t f32[b,3], status i32[b])."""
+        b = out_dict["trans"].shape[0]
+        count, _, img_pts, mdl_pts, _ = self.process_correspondences(batch, out_dict)
+        R, t, _, status, _ = hip_lib.epnp_ransac(img_pts, mdl_pts, count, batch["roi_cam"].reshape(b, 9).contiguous(),
+                                                 iters=iters, reproj_err=3.0, draws=draws)
+        few = (count < 4).view(b, 1)
+        R = torch.where(few.view(b, 1, 1), torch.full_like(R, -100.0), R)
+        t = torch.where(few, torch.full_like(t, -100.0), t)
+        return R, t, status
+
+    def process_net_and_ransac(self, batch: dict, out_dict: dict, rot_only: bool = False, draws=None):
+        """``PNP_TYPE="net_ransac_pnp"`` / ``"net_ransac_pnp_rot"`` (gdrn_evaluator.py:241-371 with pnp_type "ransac" /
+        "ransac_rot"): solvePnPRansac(EPNP, reprojErr 3, 20 iterations) on the correspondences (the extrinsic guess is
+        ignored by EPnP).  "ransac": translation falls back to the network's when it moved by more than 1 m (:347-351);
+        "ransac_rot": rotation from RANSAC, translation always the network's; fewer than 4 correspondences or no model:
+        the network pose (:355-358)."""
+        b = out_dict["trans"].shape[0]
+        count, _, img_pts, mdl_pts, _ = self.process_correspondences(batch, out_dict)
+        R, t, _, status, _ = hip_lib.epnp_ransac(img_pts, mdl_pts, count, batch["roi_cam"].reshape(b, 9).contiguous(),
+                                                 iters=20, reproj_err=3.0, draws=draws)
+        R_net, t_net = out_dict["rot"].reshape(b, 3, 3).float(), out_dict["trans"].float()
+        use = ((count >= 4) & (status == 1)).view(b, 1)
+        far = (t - t_net).norm(dim=1, keepdim=True) > 1.0
+        t = t_net if rot_only else torch.where(use & ~far, t, t_net)
+        R = torch.where(use.view(b, 1, 1), R, R_net)
+        return R, t
+
     def process(self, batch: dict, out_dict: dict, roi_ids: torch.Tensor | None = None) -> torch.Tensor:
         """-> pose records f32[b,16] = R(9) | t(3, metres) | score | obj | roi_id | valid."""
         if out_dict["trans"].shape[0] == 0:       # an image / a rank without detections: nothing to launch (the reference
             return torch.zeros((0, 16), dtype=torch.float32, device=out_dict["trans"].device)   # skips such images)
-        if self.cfg.TEST.USE_PNP:
-            if self.cfg.TEST.PNP_TYPE != "net_iter_pnp":
-                raise NotImplementedError(
-                    f"TEST.PNP_TYPE={self.cfg.TEST.PNP_TYPE}: the OpenCV RANSAC/EPnP variants stay host-side "
-                    "(DESIGN.md §7); use process_correspondences() to feed them")
-            R, t = self.process_net_and_pnp(batch, out_dict)
-            out_dict = dict(out_dict, rot=R, trans=t)
+        if self.cfg.TEST.USE_PNP:      # gdrn_evaluator.py:165-176 (the PnP variants return without the depth refinement)
+            pnp_type = self.cfg.TEST.PNP_TYPE.lower()
+            if pnp_type == "ransac_pnp":
+                R, t, _ = self.process_pnp_ransac(batch, out_dict)
+            elif pnp_type == "net_iter_pnp":
+                R, t = self.process_net_and_pnp(batch, out_dict)
+            elif pnp_type in ("net_ransac_pnp", "net_ransac_pnp_rot"):
+                R, t = self.process_net_and_ransac(batch, out_dict, rot_only=pnp_type.endswith("_rot"))
+            else:
+                raise NotImplementedError(f"TEST.PNP_TYPE={self.cfg.TEST.PNP_TYPE}")
+            b = t.shape[0]
+            return hip_lib.pack_pose_records(
+                R.reshape(b, 9).contiguous(), None, t.contiguous(),
+                batch["score"].float().contiguous() if "score" in batch else None,
+                batch["roi_cls"].to(torch.int32).contiguous(), roi_ids)
         t_ref = self.process_depth_refine(batch, out_dict) if self.cfg.TEST.USE_DEPTH_REFINE else None
         b = out_dict["trans"].shape[0]
         return hip_lib.pack_pose_records(

@@ -37,6 +37,10 @@ _P = c_void_p
 SIGNATURES = {
     "gdrnpp_version": (c_int, []),
     "gdrnpp_set_option": (c_int, [ctypes.c_char_p, c_int]),
+    "gdrnpp_epnp_ransac_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gdrnpp_epnp_ransac": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_int, ctypes.c_float, ctypes.c_double, _P, _P, _P, _P, _P,
+                                   c_int, _P, c_size_t, _P]),
+    "gdrnpp_epnp_batched": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, _P]),
     "gdrnpp_last_error": (c_char_p, []),
     "farthest_point_sampling": (None, [_P, _P, c_int, c_int]),
     "farthest_point_sampling_init_center": (None, [_P, _P, c_int, c_int]),
@@ -428,6 +432,51 @@ def pnp_iter_from_correspondences(img_pts, mdl_pts, count, K, R_net, t_net, retu
         stride, _dev(K, torch.float32, "K"), _dev(R_net, torch.float32, "R_net"), _dev(t_net, torch.float32, "t_net"),
         R_out.data_ptr(), t_out.data_ptr(), info.data_ptr(), b, _stream()), "gdrnpp_pnp_iter_from_correspondences")
     return (R_out, t_out, info) if return_info else (R_out, t_out)
+
+
+def epnp_ransac(img_pts, mdl_pts, count, K, iters: int = 100, reproj_err: float = 3.0, confidence: float = 0.99,
+                draws: "torch.Tensor | None" = None):
+    """cv2.solvePnPRansac(flags=SOLVEPNP_EPNP) for every ROI (``gdrnpp_epnp_ransac``): img_pts f32[b,stride,2], mdl_pts
+    f32[b,stride,3], count i32[b] (``decode_correspondences`` outputs), K f32[b,9|3,3]; ``draws`` i32/u32[b,n] injects the
+    random words of the minimal sets (default: OpenCV's fixed-seed cv::RNG).  -> (R f32[b,3,3], t f32[b,3], n_inliers
+    i32[b], status i32[b], inlier_mask u8[b,stride])."""
+    lib = load()
+    b, stride, _ = img_pts.shape
+    dev = img_pts.device
+    Rm = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
+    t = torch.empty((b, 3), dtype=torch.float32, device=dev)
+    n_inl = torch.empty((b,), dtype=torch.int32, device=dev)
+    status = torch.empty((b,), dtype=torch.int32, device=dev)
+    mask = torch.empty((b, stride), dtype=torch.uint8, device=dev)
+    if b == 0:
+        return Rm, t, n_inl, status, mask
+    nbytes = lib.gdrnpp_epnp_ransac_workspace_bytes(b, stride, iters)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    n_draws = 0
+    if draws is not None:
+        if draws.dtype not in (torch.int32, torch.uint32) or not draws.is_cuda or not draws.is_contiguous() or draws.shape[0] != b:
+            raise RuntimeError("draws must be a contiguous 32-bit integer CUDA(HIP) tensor [b, n_words]")
+        n_draws = int(draws.shape[1])
+    _check(lib.gdrnpp_epnp_ransac(
+        _dev(img_pts, torch.float32, "img_pts"), _dev(mdl_pts, torch.float32, "mdl_pts"), _dev(count, torch.int32, "count"),
+        stride, _dev(K.reshape(b, 9), torch.float32, "K"), draws.data_ptr() if draws is not None else None, n_draws, int(iters),
+        float(reproj_err), float(confidence), Rm.data_ptr(), t.data_ptr(), n_inl.data_ptr(), status.data_ptr(), mask.data_ptr(),
+        b, ws.data_ptr(), nbytes, _stream()), "gdrnpp_epnp_ransac")
+    return Rm, t, n_inl, status, mask
+
+
+def epnp_batched(img_pts, mdl_pts, K):
+    """Plain EPnP on all n >= 4 points of each problem: img_pts f32[b,n,2], mdl_pts f32[b,n,3], K f32[b,9|3,3]
+    -> (R f32[b,3,3], t f32[b,3], status i32[b])."""
+    b, n, _ = img_pts.shape
+    dev = img_pts.device
+    Rm = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
+    t = torch.empty((b, 3), dtype=torch.float32, device=dev)
+    status = torch.empty((b,), dtype=torch.int32, device=dev)
+    _check(load().gdrnpp_epnp_batched(_dev(img_pts, torch.float32, "img_pts"), _dev(mdl_pts, torch.float32, "mdl_pts"), n,
+                                      _dev(K.reshape(b, 9), torch.float32, "K"), Rm.data_ptr(), t.data_ptr(), status.data_ptr(),
+                                      b, _stream()), "gdrnpp_epnp_batched")
+    return Rm, t, status
 
 
 class LaunchTimer:

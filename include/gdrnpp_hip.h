@@ -129,6 +129,29 @@ int gdrnpp_uncertainty_pnp_batched(const double* pts2d, const double* pts3d,
                                    const double* init_rt, double* result_rt,
                                    int* info, int b, int pn, void* stream);
 
+/* ---- EPnP + RANSAC on the decoded correspondences (a7: "ransac_pnp", "net_ransac_pnp", "net_ransac_pnp_rot") ------
+ * cv2.solvePnPRansac(objectPoints, imagePoints, K, dist = 0, flags = SOLVEPNP_EPNP, reprojectionError, iterationsCount,
+ * confidence = 0.99) as called at lib/pysixd/misc.py:182-193 (reprojErr 3, 100 iterations) and
+ * gdrn_evaluator.py:319-330 (20 iterations), for every ROI of the batch.  OpenCV is a third-party dependency that is not
+ * in the reference tree: its published algorithms are restated (calib3d epnp.cpp, ptsetreg.cpp, solvepnp.cpp) — 5-point
+ * minimal sets, float32 squared reprojection error <= reprojErr^2, best = strictly more inliers, adaptive iteration
+ * count, final EPnP over the inliers of the best hypothesis.
+ * img_pts f32[b,stride,2], mdl_pts f32[b,stride,3], count i32[b]: outputs of gdrnpp_decode_correspondences; K f32[b,9].
+ * draws: NULL -> every ROI draws from cv::RNG(2^64-1) like OpenCV does; else u32[b,n_draws] words consumed in order
+ * (index = word % count, redrawn while it repeats), n_draws >= 5*iters.
+ * R_out f32[b,9], t_out f32[b,3], n_inliers i32[b], status i32[b] (1 = pose found; 0 = fewer than 4 points, no
+ * hypothesis with at least 5 inliers, or a degenerate system: R = I, t = 0 and the caller applies the reference's
+ * fallback), inlier_mask u8[b,stride].  workspace: gdrnpp_epnp_ransac_workspace_bytes(b, stride, iters). */
+size_t gdrnpp_epnp_ransac_workspace_bytes(int b, int stride, int iters);
+int gdrnpp_epnp_ransac(const float* img_pts, const float* mdl_pts, const int* count, int stride, const float* K,
+                       const unsigned* draws, int n_draws, int iters, float reproj_err, double confidence,
+                       float* R_out, float* t_out, int* n_inliers, int* status, unsigned char* inlier_mask,
+                       int b, void* workspace, size_t workspace_bytes, void* stream);
+/* plain EPnP on all n >= 4 points of each problem (cv2.solvePnP(flags=SOLVEPNP_EPNP); un_pnp_utils.py:27-44 runs it on the
+ * four best-weighted keypoints to initialise uncertainty-PnP): img_pts f32[b,n,2], mdl_pts f32[b,n,3], K f32[b,9]. */
+int gdrnpp_epnp_batched(const float* img_pts, const float* mdl_pts, int n, const float* K, float* R_out,
+                        float* t_out, int* status, int b, void* stream);
+
 /* ---- net-initialised iterative PnP on the decoded correspondences (a7, "net_iter_pnp") ------------------------
  * gdrn_evaluator.py:241-371 with pnp_type="iter": cv2.solvePnP(SOLVEPNP_ITERATIVE, useExtrinsicGuess=True) seeded
  * with the network pose = Levenberg-Marquardt on the plain reprojection error.  OpenCV's own LM is third-party and

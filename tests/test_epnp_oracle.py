@@ -1,0 +1,64 @@
+"""The EPnP / RANSAC oracle (oracle/epnp.py, OpenCV's published algorithms restated — cv2 is not installed, so the anchors
+are closed-form: exact correspondences recover the pose they were projected with; with gross outliers the inlier set is the
+set of uncontaminated points; cv::RNG reproduces the multiply-with-carry recurrence)."""
+import numpy as np
+
+from gdrnpp_bop2022_amd import synthetic as S
+from oracle import epnp as E
+
+K = S.YCBV_K.astype(np.float64)
+
+
+def _case(rng, n, noise=0.0, outliers=0.0):
+    R = S.random_rotation(rng)
+    t = np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), rng.uniform(0.5, 1.5)])
+    pw = rng.uniform(-0.1, 0.1, (n, 3)).astype(np.float32)
+    cam = pw.astype(np.float64) @ R.T + t
+    uv = cam[:, :2] / cam[:, 2:] * [K[0, 0], K[1, 1]] + [K[0, 2], K[1, 2]] + rng.normal(0, noise, (n, 2)) if noise else \
+        cam[:, :2] / cam[:, 2:] * [K[0, 0], K[1, 1]] + [K[0, 2], K[1, 2]]
+    bad = rng.uniform(0, 1, n) < outliers
+    uv[bad] += rng.uniform(20, 100, (int(bad.sum()), 2)) * rng.choice([-1, 1], (int(bad.sum()), 2))
+    return R, t, pw, uv, bad
+
+
+def test_epnp_recovers_exact_pose():
+    rng = np.random.default_rng(0)
+    for n in (5, 6, 9, 50, 3000):
+        R, t, pw, uv, _ = _case(rng, n)
+        Re, te = E.epnp(pw, uv, K)
+        assert np.abs(Re - R).max() < 1e-6 and np.abs(te - t).max() < 1e-6, n
+        assert abs(np.linalg.det(Re) - 1) < 1e-9
+
+
+def test_cv_rng_recurrence():
+    r = E.CvRNG()
+    s = 0xFFFFFFFFFFFFFFFF
+    for _ in range(5):
+        s = ((s & 0xFFFFFFFF) * 4164903690 + (s >> 32)) & 0xFFFFFFFFFFFFFFFF
+        assert r.next() == (s & 0xFFFFFFFF)
+    assert 0 <= E.CvRNG().uniform(0, 7) < 7
+
+
+def test_get_subset_redraws_duplicates():
+    words = iter([3, 3, 10, 3 + 7, 4, 5, 6])       # % 7 -> 3, 3(dup), 3(dup), 3(dup), 4, 5, 6
+    assert E.get_subset(lambda: next(words), 7, 4) == [3, 4, 5, 6]
+
+
+def test_update_num_iters():
+    assert E.update_num_iters(0.99, 0.0, 5, 100) == 0                     # all inliers: stop
+    assert E.update_num_iters(0.99, 0.5, 5, 100) == 100                   # log(0.01)/log(1-0.5^5) = 145 > 100
+    assert E.update_num_iters(0.99, 0.3, 5, 100) == int(np.rint(np.log(0.01) / np.log(1 - 0.7 ** 5)))
+    assert E.update_num_iters(0.99, 1.0, 5, 100) == 100
+
+
+def test_ransac_inlier_set_is_the_uncontaminated_points():
+    rng = np.random.default_rng(1)
+    R, t, pw, uv, bad = _case(rng, 1500, noise=0.4, outliers=0.3)
+    ok, Re, te, mask = E.solve_pnp_ransac_epnp(pw, uv, K)
+    assert ok and np.array_equal(mask, ~bad)
+    assert np.abs(Re - R).max() < 2e-3 and np.abs(te - t).max() < 2e-3
+    # fewer than 4 points: no model; exactly 5: plain EPnP
+    assert not E.solve_pnp_ransac_epnp(pw[:3], uv[:3], K)[0]
+    R5, t5, pw5, uv5, _ = _case(rng, 5)
+    ok, Re, te, mask = E.solve_pnp_ransac_epnp(pw5, uv5, K)
+    assert ok and mask.all() and np.abs(te - t5).max() < 1e-4

@@ -1,0 +1,149 @@
+"""-m gpu: EPnP + RANSAC on the device (gdrnpp_epnp_ransac / gdrnpp_epnp_batched, row a7) against the NumPy oracle
+(oracle/epnp.py — LAPACK linear algebra, independent of the device's Jacobi / Householder code) with IDENTICAL draws:
+same hypotheses -> same inlier sets (bit-exact) -> poses within 1e-4 (north_star), measured ~1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from gdrnpp_bop2022_amd import synthetic as S
+from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+from gdrnpp_bop2022_amd.gdrn_modeling.engine import GdrnHipPost
+from oracle import epnp as E
+from oracle import postproc as P
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+K64 = S.YCBV_K.astype(np.float64)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _problem(rng, n, noise, outliers):
+    R = S.random_rotation(rng)
+    t = np.array([rng.uniform(-0.15, 0.15), rng.uniform(-0.15, 0.15), rng.uniform(0.5, 1.4)])
+    pw = rng.uniform(-0.1, 0.1, (n, 3)).astype(np.float32)
+    cam = pw.astype(np.float64) @ R.T + t
+    uv = cam[:, :2] / cam[:, 2:] * [K64[0, 0], K64[1, 1]] + [K64[0, 2], K64[1, 2]]
+    if noise:
+        uv = uv + rng.normal(0, noise, uv.shape)
+    bad = rng.uniform(0, 1, n) < outliers
+    uv[bad] += rng.uniform(20, 100, (int(bad.sum()), 2))
+    return R, t, pw, uv.astype(np.float32), bad
+
+
+def test_epnp_batched_recovers_exact_poses(hip):
+    rng = np.random.default_rng(0)
+    for n in (5, 6, 64, 700):
+        cases = [_problem(rng, n, 0.0, 0.0) for _ in range(6)]
+        R, t, st = hip.epnp_batched(T(np.stack([c[3] for c in cases])), T(np.stack([c[2] for c in cases])),
+                                    T(np.repeat(S.YCBV_K.reshape(1, 9), 6, 0)))
+        assert st.cpu().tolist() == [1] * 6
+        for i, c in enumerate(cases):
+            Ro, to = E.epnp(c[2], c[3], K64)
+            assert np.abs(R[i].cpu().numpy() - Ro).max() < 1e-5 and np.abs(t[i].cpu().numpy() - to).max() < 1e-5
+            assert np.abs(R[i].cpu().numpy() - c[0]).max() < 2e-4      # float32 image points limit the recovery
+
+
+@pytest.mark.parametrize("draw_source", ["cv_rng", "injected"])
+def test_ransac_matches_oracle_with_identical_draws(hip, draw_source):
+    """Ragged counts (0, 3, 4, 5, 6, hundreds, the full 4096 stride), noise + 30 % gross outliers."""
+    rng = np.random.default_rng(3)
+    stride, iters = 4096, 100
+    counts = [0, 3, 4, 5, 6, 40, 900, 4096, 1500, 2300]
+    b = len(counts)
+    img = np.zeros((b, stride, 2), np.float32)
+    mdl = np.zeros((b, stride, 3), np.float32)
+    truth = []
+    for i, n in enumerate(counts):
+        R, t, pw, uv, bad = _problem(rng, max(n, 1), 0.4, 0.3 if n > 20 else 0.0)
+        img[i, :n], mdl[i, :n] = uv[:n], pw[:n]
+        truth.append((R, t, bad[:n]))
+    words = None
+    if draw_source == "injected":
+        words = rng.integers(0, 2 ** 31 - 1, (b, iters * 8)).astype(np.int32)
+    R, t, n_inl, status, mask = hip.epnp_ransac(T(img), T(mdl), T(np.array(counts, np.int32)), T(np.repeat(S.YCBV_K.reshape(1, 9), b, 0)),
+                                                iters=iters, reproj_err=3.0, draws=T(words) if words is not None else None)
+    R, t, n_inl, status, mask = (x.cpu().numpy() for x in (R, t, n_inl, status, mask))
+    for i, n in enumerate(counts):
+        it = iter(words[i].astype(np.uint32).tolist()) if words is not None else None
+        ok, Ro, to, mo = E.solve_pnp_ransac_epnp(mdl[i, :n], img[i, :n], K64, 3.0, iters, 0.99,
+                                                 rng_next=(lambda it=it: next(it)) if it is not None else None)
+        assert bool(status[i]) == ok, (i, n)
+        assert np.array_equal(mask[i, :n].astype(bool), mo) and not mask[i, n:].any(), (i, n)     # inlier set: bit-exact
+        assert n_inl[i] == mo.sum()
+        if ok:
+            assert np.abs(R[i] - Ro).max() < 1e-4 and np.abs(t[i] - to).max() < 1e-4, (i, n)
+            if n > 20:
+                assert np.array_equal(mo, ~truth[i][2])                                             # exactly the clean points
+                assert np.abs(t[i] - truth[i][1]).max() < 5e-3
+        else:
+            assert np.array_equal(R[i], np.eye(3, dtype=np.float32)) and not t[i].any()
+
+
+def _maps_case(b, rng):
+    verts, faces, ext = S.make_models(5, rng, 3)
+    det = S.make_detections(b, 5, ext, rng)
+
+    def render_fn(obj, Kc, Rm, tv, res):
+        d, x = zip(*[P.render_depth(verts[obj[i]], faces[obj[i]], Kc[i], Rm[i], tv[i].astype(np.float64), res_w=res, want_xyz=True)
+                     for i in range(len(obj))])
+        return np.stack(d), np.stack(x)
+
+    maps = S.make_map_inputs(det, verts, faces, render_fn, rng)
+    return det, maps
+
+
+@pytest.mark.parametrize("pnp_type", ["ransac_pnp", "net_ransac_pnp", "net_ransac_pnp_rot"])
+def test_pnp_types_through_the_post_processing(hip, pnp_type):
+    """TEST.USE_PNP with the RANSAC variants through GdrnHipPost.process (gdrn_evaluator.py:165-176): maps -> decode ->
+    compaction -> RANSAC/EPnP, against the oracle chain on the same maps (ROI 1 has an empty mask: sentinel / net pose)."""
+    rng = np.random.default_rng(21)
+    b = 6
+    det, maps = _maps_case(b, rng)
+    maps["mask"][1] = -5.0 + 1e-3 * rng.standard_normal(maps["mask"][1].shape).astype(np.float32)   # no pixel above the threshold
+    maps["mask"][1, 0, 0, 0] = 50.0                                                                  # (L1 normalisation: one hot pixel)
+    cfg = get_cfg("ycbv_convnext_a6", ["TEST.USE_PNP=True", f"TEST.PNP_TYPE={pnp_type}"])
+    post = GdrnHipPost(cfg)
+    batch = dict(roi_cam=T(det["roi_cam"]), roi_coord_2d=T(maps["roi_coord_2d"]), roi_extent=T(det["roi_extent"]),
+                 im_W=T(det["im_W"]), im_H=T(det["im_H"]), roi_cls=T(det["roi_cls"]), score=T(det["score"]))
+    R_net = det["R_gt"].astype(np.float32)
+    t_net = (det["t_gt"] + rng.normal(0, 0.01, det["t_gt"].shape)).astype(np.float32)
+    out = dict(coor_x=T(maps["coor_x"]), coor_y=T(maps["coor_y"]), coor_z=T(maps["coor_z"]), mask=T(maps["mask"]),
+               rot=T(R_net), trans=T(t_net))
+    rec = post.process(batch, out, torch.arange(b, dtype=torch.int32, device=DEV)).cpu().numpy()
+    mask = P.get_out_mask(maps["mask"])
+    iters = 100 if pnp_type == "ransac_pnp" else 20
+    for i in range(b):
+        xyz = np.concatenate([maps["coor_x"][i], maps["coor_y"][i], maps["coor_z"][i]], 0).transpose(1, 2, 0).copy()
+        ip, mp = P.get_img_model_points_with_coords2d(mask[i, 0], xyz, maps["roi_coord_2d"][i].transpose(1, 2, 0), 480, 640,
+                                                      det["roi_extent"][i])
+        Rr, tr = rec[i, :9].reshape(3, 3), rec[i, 9:12]
+        if len(ip) < 4:
+            assert i == 1
+            if pnp_type == "ransac_pnp":
+                assert (rec[i, :12] == -100).all()
+            else:
+                assert np.array_equal(Rr, R_net[i]) and np.array_equal(tr, t_net[i])
+            continue
+        ok, Ro, to, _ = E.solve_pnp_ransac_epnp(mp, ip, det["roi_cam"][i].astype(np.float64), 3.0, iters)
+        assert ok
+        if pnp_type == "net_ransac_pnp_rot":
+            to = t_net[i]
+        elif pnp_type == "net_ransac_pnp" and np.linalg.norm(to - t_net[i]) > 1:
+            to = t_net[i]
+        assert np.abs(Rr - Ro).max() < 1e-4 and np.abs(tr - to).max() < 1e-4, i
+        assert np.abs(tr - det["t_gt"][i]).max() < 0.03                      # and it is a sensible pose
+
+
+def test_uncertainty_pnp_shim_initialises_with_device_epnp(hip):
+    """un_pnp_utils.uncertainty_pnp without init_rt (reference call signature, un_pnp_utils.py:11): EPnP on the four
+    best-weighted points seeds the LM."""
+    from gdrnpp_bop2022_amd.core.csrc.uncertainty_pnp.un_pnp_utils import uncertainty_pnp
+
+    rng = np.random.default_rng(9)
+    R, t, pw, uv, _ = _problem(rng, 9, 0.3, 0.0)
+    w = np.stack([rng.uniform(0.5, 1.5, 9), np.zeros(9), rng.uniform(0.5, 1.5, 9)], 1)
+    Rt = uncertainty_pnp(uv.astype(np.float64), w, pw.astype(np.float64), K64)
+    assert Rt.shape == (3, 4) and np.abs(Rt[:, :3] - R).max() < 2e-2 and np.abs(Rt[:, 3] - t).max() < 2e-2
