@@ -24,6 +24,8 @@ constexpr int kModelPts = 5;
 
 struct Cam { double fu, fv, uc, vc; };
 
+__device__ __forceinline__ bool is_finite(double v) { return fabs(v) <= 1.7976931348623157e308; }  // false for NaN / inf
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -183,7 +185,10 @@ struct Loop {
   int lane;
   __device__ int begin() const { return WAVE ? lane : 0; }
   __device__ int step() const { return WAVE ? 64 : 1; }
-  __device__ double sum(double v) const { return WAVE ? wave_sum(v) : v; }
+  __device__ double sum(double v) const {
+    if constexpr (WAVE) return wave_sum(v);
+    else return v;
+  }
 };
 
 template <bool WAVE>
@@ -224,7 +229,13 @@ __device__ bool epnp_solve(const PointSet& ps, const Cam cam, int lane, double* 
     jacobi_eigh<3>(a3, v3, w3);
     for (int i = 1; i < 4; ++i) {  // largest eigenvalue first, like the SVD order of the original
       const int c = 3 - i;
-      const double k = sqrt(fmax(w3[c], 0.0) / n);
+      double k = sqrt(fmax(w3[c], 0.0) / n);
+      // the sign of a principal axis is the eigen-solver's choice and would mirror the control point: fixed — the
+      // largest-magnitude component of the axis is positive
+      int big = 0;
+      for (int j = 1; j < 3; ++j)
+        if (fabs(v3[j * 3 + c]) > fabs(v3[big * 3 + c])) big = j;
+      if (v3[big * 3 + c] < 0.0) k = -k;
       for (int j = 0; j < 3; ++j) cws[i][j] = cws[0][j] + k * v3[j * 3 + c];
     }
   }
@@ -269,6 +280,40 @@ __device__ bool epnp_solve(const PointSet& ps, const Cam cam, int lane, double* 
     }
   double evec[144], eval[12];
   jacobi_eigh<12>(mtm, evec, eval);
+  {  // canonical basis of an exactly degenerate null space (4 or 5 points): project e_0, e_1, ... onto it and
+     // orthonormalise in that order — any basis is a valid set of "smallest eigenvectors", this one is unique
+    const double tol = 1e-9 * eval[11];
+    int d4 = 0, d = 0;
+    for (int i = 0; i < 4; ++i) d4 += eval[i] <= tol ? 1 : 0;
+    for (int i = 0; i < 12; ++i) d += eval[i] <= tol ? 1 : 0;
+    if (d4 >= 2) {
+      double* basis = mtm;  // MtM is dead: d x 12 scratch
+      int nb = 0;
+      for (int k = 0; k < 12 && nb < d; ++k) {
+        double c[12];
+        for (int r = 0; r < 12; ++r) {
+          double s = 0.0;
+          for (int j = 0; j < d; ++j) s += evec[r * 12 + j] * evec[k * 12 + j];
+          c[r] = s;
+        }
+        for (int j = 0; j < nb; ++j) {
+          double dot = 0.0;
+          for (int r = 0; r < 12; ++r) dot += basis[j * 12 + r] * c[r];
+          for (int r = 0; r < 12; ++r) c[r] -= dot * basis[j * 12 + r];
+        }
+        double nrm = 0.0;
+        for (int r = 0; r < 12; ++r) nrm += c[r] * c[r];
+        nrm = sqrt(nrm);
+        if (nrm > 1e-6) {
+          for (int r = 0; r < 12; ++r) basis[nb * 12 + r] = c[r] / nrm;
+          ++nb;
+        }
+      }
+      if (nb == d)
+        for (int j = 0; j < d; ++j)
+          for (int r = 0; r < 12; ++r) evec[r * 12 + j] = basis[j * 12 + r];
+    }
+  }
   auto V = [&](int i, int k) { return evec[k * 12 + i]; };  // i-th smallest eigenvector (ut[11 - i] of the original), component k
   // ---- the 6 x 10 distance system
   double L[6][10], rho[6];
@@ -311,7 +356,7 @@ __device__ bool epnp_solve(const PointSet& ps, const Cam cam, int lane, double* 
         betas[2] = cand == 2 ? x[3] / betas[0] : 0.0;
         betas[3] = 0.0;
       }
-      if (!(isfinite(betas[0]) && isfinite(betas[1]) && isfinite(betas[2]) && isfinite(betas[3]))) continue;
+      if (!(is_finite(betas[0]) && is_finite(betas[1]) && is_finite(betas[2]) && is_finite(betas[3]))) continue;
     }
     bool ok = true;
     for (int it = 0; it < 5 && ok; ++it) {  // gauss_newton
@@ -384,7 +429,7 @@ __device__ bool epnp_solve(const PointSet& ps, const Cam cam, int lane, double* 
         es += sqrt(du * du + dv2 * dv2);
       }
     const double err = lp.sum(es) / n;
-    if (isfinite(err) && err < best_err) {
+    if (is_finite(err) && err < best_err) {
       best_err = err;
       have = true;
       for (int k = 0; k < 9; ++k) R[k] = Rc[k];

@@ -64,7 +64,12 @@ def _control_points(pw):
     dc, uc = np.linalg.eigh(d.T @ d)               # ascending; epnp.cpp takes the SVD (descending) — order is immaterial
     cws = [c0]
     for i in (2, 1, 0):
-        cws.append(c0 + np.sqrt(max(dc[i], 0.0) / len(pw)) * uc[:, i])
+        axis = uc[:, i]
+        # the sign of a principal axis is the eigen-solver's choice and moves the control point to the mirrored position
+        # (the pose then differs at the noise level): fixed here — the largest-magnitude component is positive
+        if axis[int(np.argmax(np.abs(axis)))] < 0:
+            axis = -axis
+        cws.append(c0 + np.sqrt(max(dc[i], 0.0) / len(pw)) * axis)
     return np.array(cws)
 
 
@@ -95,7 +100,10 @@ def _gauss_newton(L, rho, betas, iters=5):
         res = rho - (L[:, 0] * b[0] ** 2 + L[:, 1] * b[0] * b[1] + L[:, 2] * b[1] ** 2 + L[:, 3] * b[0] * b[2]
                      + L[:, 4] * b[1] * b[2] + L[:, 5] * b[2] ** 2 + L[:, 6] * b[0] * b[3] + L[:, 7] * b[1] * b[3]
                      + L[:, 8] * b[2] * b[3] + L[:, 9] * b[3] ** 2)
-        b = b + np.linalg.lstsq(A, res, rcond=None)[0]
+        q, r = np.linalg.qr(A)                     # epnp.cpp qr_solve: Householder QR, no rank truncation
+        if np.any(np.diag(r) == 0):
+            return None
+        b = b + np.linalg.solve(r, q.T @ res)
     return b
 
 
@@ -143,6 +151,32 @@ def _pose_from_betas(v, betas, alphas, pw, uv, fu, fv, uc, vc):
     return R, t, err
 
 
+def canonical_null_basis(w, vec, rel_tol=1e-9):
+    """Four or five points leave MtM an exactly degenerate null space (12 - 2n dimensions): ANY orthonormal basis of it is a
+    valid set of "smallest eigenvectors", the three beta approximations start from whichever the eigen-solver returns and
+    five Gauss-Newton steps do not erase the choice (OpenCV's result depends on its SVD there).  To make the restatement
+    well defined, the degenerate block is replaced by the basis obtained by projecting e_0, e_1, ... onto the subspace and
+    orthonormalising in that order (unique for a given subspace, signs included).  Non-degenerate eigenvectors are kept."""
+    d = int((w[:4] <= rel_tol * w[-1]).sum())
+    if d < 2:
+        return vec
+    d = int((w <= rel_tol * w[-1]).sum())
+    Q = vec[:, :d]
+    basis = []
+    for k in range(12):
+        c = Q @ Q[k]                               # projection of e_k onto the subspace
+        for b in basis:
+            c = c - (b @ c) * b
+        nrm = np.linalg.norm(c)
+        if nrm > 1e-6:
+            basis.append(c / nrm)
+            if len(basis) == d:
+                break
+    out = vec.copy()
+    out[:, :d] = np.array(basis).T
+    return out
+
+
 def epnp(pw, uv, K):
     """pw f64[n,3], uv f64[n,2] (n >= 4), K 3x3 -> (R, t) of the best of the three beta approximations, or None when no
     candidate is finite (degenerate configuration)."""
@@ -158,6 +192,7 @@ def epnp(pw, uv, K):
         M[1::2, 3 * j + 1] = al[:, j] * fv
         M[1::2, 3 * j + 2] = al[:, j] * (vc - uv[:, 1])
     w, vec = np.linalg.eigh(M.T @ M)               # ascending: columns 0..3 are the null-space candidates
+    vec = canonical_null_basis(w, vec)
     v = [vec[:, i] for i in range(4)]              # epnp.cpp: ut[11], ut[10], ut[9], ut[8]
     L, rho = _L_rho(v, cws)
     best = None
@@ -165,6 +200,8 @@ def epnp(pw, uv, K):
         if not np.all(np.isfinite(b0)):
             continue
         betas = _gauss_newton(L, rho, b0)
+        if betas is None:
+            continue
         R, t, err = _pose_from_betas(v, betas, al, pw, uv, fu, fv, uc, vc)
         if np.isfinite(err) and (best is None or err < best[2]):
             best = (R, t, err)

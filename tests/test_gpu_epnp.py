@@ -117,7 +117,7 @@ def test_pnp_types_through_the_post_processing(hip, pnp_type):
     iters = 100 if pnp_type == "ransac_pnp" else 20
     for i in range(b):
         xyz = np.concatenate([maps["coor_x"][i], maps["coor_y"][i], maps["coor_z"][i]], 0).transpose(1, 2, 0).copy()
-        ip, mp = P.get_img_model_points_with_coords2d(mask[i, 0], xyz, maps["roi_coord_2d"][i].transpose(1, 2, 0), 480, 640,
+        ip, mp, _ = P.get_img_model_points_with_coords2d(mask[i, 0], xyz, maps["roi_coord_2d"][i].transpose(1, 2, 0), 480, 640,
                                                       det["roi_extent"][i])
         Rr, tr = rec[i, :9].reshape(3, 3), rec[i, 9:12]
         if len(ip) < 4:
