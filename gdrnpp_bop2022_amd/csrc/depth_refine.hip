@@ -6,22 +6,22 @@
 // cv2.resize 256->64 (INTER_LINEAR at exact scale 4 = mean of the 2x2 centre of each 4x4 block),
 // vispy render lib/render_vispy/renderer.py (see raster.hpp).
 //
-// Design: ONE workgroup of 1024 threads (16 waves) per ROI runs every refinement iteration
-// on chip — nothing but the final translation goes back to HBM:
-//   prologue  per-ROI mask min/max (shuffle + LDS reduce), per-pixel query base
-//             ||xyz||*mask and the 64x64 sensor-depth crop, all held in registers
-//             (4 pixels per thread, pixel p = k*1024 + tid -> coalesced 4 KiB rows);
-//   render    triangles are distributed over threads, transformed and set up in fp64,
-//             and resolved with ds_min_u32 on a 16 KiB LDS z-buffer holding float-Z bits
-//             (rounding to float is monotonic, so min-of-rounded == rounded-min); triangles
-//             with a large pixel bbox are queued in LDS and rasterised by the whole
-//             workgroup so one thread never serialises a big triangle;
-//   compare   q-map, fp64 block sum, fp32 normalise, block max, threshold, LDS compaction of
-//             the selected depth differences, bitonic sort in LDS, np.median semantics,
-//             fp64 weighted centroid, ray through K_crop^-1, t += ray * median.
-// HBM traffic per ROI is the algorithmic minimum except for the mesh, which is re-read per
-// iteration from L2 (all ROIs of a class share it): 4 maps x 16 KiB + the used quarter of the
-// 256x256 depth crop + I x (12 V + 12 F) mesh bytes.
+// Design: ONE workgroup of 512 threads (8 waves) per ROI runs every refinement iteration on chip — only the refined
+// translation / the finished pose record goes back to HBM:
+//   prologue  (optional) K_crop from the camera, ROI centre and scale (get_K_crop_resize fused); per-ROI mask min/max
+//             (shuffle + LDS reduce); the per-pixel query base ||xyz||*mask and the 64x64 sensor-depth crop go to LDS;
+//   stage     per iteration the V model points are transformed ONCE into homogeneous pixel space (fp64) and staged — in
+//             LDS (24 B/vertex, meshes up to 4096 vertices) or, for larger meshes, in a per-ROI slice of a global
+//             workspace (same kernel, template parameter);
+//   render    triangles -> threads, corners gathered from the stage, fp64 edge functions, ds_min_u32 on a 16 KiB LDS
+//             z-buffer of float-Z bits (rounding to float is monotonic, so min-of-rounded == rounded-min); triangles with a
+//             large pixel bbox are queued in LDS and rasterised by a whole wave each;
+//   compare   q-map, fp64 block sum, fp32 normalise, block max, threshold, np.median of the selected depth differences by
+//             a two-rank radix select (4 x 8-bit passes, LDS histograms), fp64 weighted centroid, ray through K_crop^-1,
+//             t += ray * median;
+//   epilogue  (optional) the f32[16] pose record R | t | score | obj | roi_id | valid (pack_pose_records fused).
+// HBM traffic per ROI is the algorithmic minimum except for the mesh, which is re-read per iteration from L2 (all ROIs of
+// a class share it): 4 maps x 16 KiB + the used quarter of the 256x256 depth crop + I x (12 V + 12 F) mesh bytes.
 #include "common.hpp"
 #include "raster.hpp"
 #include <cfloat>
@@ -30,12 +30,9 @@ namespace {
 
 using namespace gdrnpp;
 
-constexpr int kT = 512;           // threads per ROI workgroup (8 waves; 1024 spills under the 128-VGPR cap)
-constexpr int kWaves = kT / 64;
+constexpr int kT = 512;           // threads of a render workgroup
 constexpr int kMaxPix = 4096;     // res*res limit for the refine kernel (res <= 64)
-constexpr int kPPT = kMaxPix / kT;
 constexpr int kLargeArea = 32;    // bbox pixel centres above which a triangle is rasterised by its whole wave
-constexpr int kMaxLarge = 512;
 constexpr unsigned kInfBits = 0x7f800000u;
 
 struct MeshView {
@@ -63,248 +60,6 @@ __device__ __forceinline__ void face_setup(const MeshView& m, int f, const doubl
   setup_triangle(h0, h1, h2, res, res, z_near, z_far, s);
 }
 
-// rasterise the whole mesh into an LDS z-buffer of float-Z bits (must be pre-filled with kInfBits)
-__device__ void raster_mesh_u32(const MeshView& m, const double* K, const double* R, const double* t, int res,
-                                double z_near, double z_far, unsigned* zbuf, int* s_large, int* s_nlarge) {
-  __syncthreads();
-  for (int f0 = 0; f0 < m.nfaces; f0 += kT) {
-    const int f = f0 + (int)threadIdx.x;
-    TriSetup s;
-    s.i_lo = 1; s.i_hi = 0; s.j_lo = 1; s.j_hi = 0;
-    bool large = false;
-    if (f < m.nfaces) {
-      face_setup(m, f, K, R, t, res, z_near, z_far, s);
-      if (s.i_lo <= s.i_hi && s.j_lo <= s.j_hi) {
-        large = (s.i_hi - s.i_lo + 1) * (s.j_hi - s.j_lo + 1) > kLargeArea;
-        if (!large)
-          for (int j = s.j_lo; j <= s.j_hi; ++j)
-            for (int i = s.i_lo; i <= s.i_hi; ++i) {
-              double Z;
-              if (sample_triangle(s, i, j, z_near, z_far, Z, nullptr))
-                atomicMin(&zbuf[j * res + i], __float_as_uint((float)Z));
-            }
-      }
-    }
-    unsigned long long bal = __ballot(large);
-    const int lane = threadIdx.x & 63;
-    while (bal) {
-      const int src = __ffsll((long long)bal) - 1;
-      bal &= bal - 1;
-      const TriSetup s2 = shfl_setup(s, src);
-      const int bw = s2.i_hi - s2.i_lo + 1, bh = s2.j_hi - s2.j_lo + 1;
-      for (int p = lane; p < bw * bh; p += 64) {
-        const int j = s2.j_lo + p / bw, i = s2.i_lo + p % bw;
-        double Z;
-        if (sample_triangle(s2, i, j, z_near, z_far, Z, nullptr))
-          atomicMin(&zbuf[j * res + i], __float_as_uint((float)Z));
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// ---- block reductions over kT threads (results broadcast to every thread) -------------
-__device__ __forceinline__ double block_sum(double v, double* s_red) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) s_red[wave] = v;
-  __syncthreads();
-  double r = 0.0;
-  for (int w = 0; w < kWaves; ++w) r += s_red[w];
-  return r;
-}
-__device__ __forceinline__ float block_max(float v, float* s_red) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) s_red[wave] = v;
-  __syncthreads();
-  float r = -FLT_MAX;
-  for (int w = 0; w < kWaves; ++w) r = fmaxf(r, s_red[w]);
-  return r;
-}
-__device__ __forceinline__ float block_min(float v, float* s_red) { return -block_max(-v, s_red); }
-
-__global__ __launch_bounds__(kT) void depth_refine_kernel(
-    const float* __restrict__ verts, const int* __restrict__ faces, const int* __restrict__ vert_off,
-    const int* __restrict__ face_off, const int* __restrict__ obj, const float* __restrict__ coor_x,
-    const float* __restrict__ coor_y, const float* __restrict__ coor_z, const float* __restrict__ mask_raw,
-    const float* __restrict__ roi_depth, const float* __restrict__ K_crop, const float* __restrict__ Rin,
-    const float* __restrict__ t_in, double* __restrict__ t_out, float* __restrict__ debug_depth, int res, int iters,
-    float threshold, int mask_type, int use_coor_z, float z_near, float z_far) {
-  __shared__ unsigned zbuf[kMaxPix];
-  __shared__ float sortbuf[kMaxPix];
-  __shared__ int s_large[kMaxLarge];
-  __shared__ int s_nlarge, s_nsel;
-  __shared__ double s_redd[kWaves];
-  __shared__ float s_redf[kWaves];
-  __shared__ double s_t[3];
-
-  const int bi = blockIdx.x, tid = threadIdx.x;
-  const int hw = res * res;
-  const MeshView mesh = mesh_of(verts, faces, vert_off, face_off, obj[bi]);
-
-  double K[9], R[9], t[3];
-  float Rf[9];
-  for (int k = 0; k < 9; ++k) { K[k] = (double)K_crop[9 * (size_t)bi + k]; Rf[k] = Rin[9 * (size_t)bi + k]; R[k] = (double)Rf[k]; }
-  for (int k = 0; k < 3; ++k) t[k] = (double)t_in[3 * (size_t)bi + k];
-
-  // ---- prologue: mask normalisation, query base, sensor depth crop --------------------
-  const float* mk = mask_raw + (size_t)bi * hw;
-  float mraw[kPPT];
-  float lo = FLT_MAX, hi = -FLT_MAX;
-#pragma unroll
-  for (int k = 0; k < kPPT; ++k) {
-    const int p = k * kT + tid;
-    mraw[k] = (p < hw) ? mk[p] : 0.f;
-    if (p < hw) { lo = fminf(lo, mraw[k]); hi = fmaxf(hi, mraw[k]); }
-  }
-  float mmin = 0.f, mden = 1.f;
-  if (mask_type == 0) {
-    mmin = block_min(lo, s_redf);
-    const float mmax = block_max(hi, s_redf);
-    mden = mmax - mmin;  // no epsilon (engine_utils.py:325)
-  }
-  float qbase[kPPT], ds[kPPT];
-  const int in_w = 4 * res;
-  const float* dep = roi_depth + (size_t)bi * in_w * in_w;
-#pragma unroll
-  for (int k = 0; k < kPPT; ++k) {
-    const int p = k * kT + tid;
-    qbase[k] = 0.f; ds[k] = 0.f;
-    if (p < hw) {
-      float m = mraw[k];
-      if (mask_type == 0) m = (m - mmin) / mden;
-      else m = 1.f / (1.f + expf(-m));
-      const float x = coor_x[(size_t)bi * hw + p], y = coor_y[(size_t)bi * hw + p], z = coor_z[(size_t)bi * hw + p];
-      float qv;
-      if (use_coor_z) qv = (Rf[6] * x + Rf[7] * y) + Rf[8] * z;  // z component of R @ xyz (evaluator :528-535)
-      else qv = sqrtf((x * x + y * y) + z * z);                 // torch.norm(xyz, dim=-1) (:538-540)
-      qbase[k] = qv * m;
-      // cv2.resize(roi_depth, (res,res)) INTER_LINEAR, scale 4: source coordinate 4x+1.5
-      const int yy = p / res, xx = p - yy * res;
-      const float* r0 = dep + (size_t)(4 * yy + 1) * in_w + 4 * xx + 1;
-      const float* r1 = r0 + in_w;
-      const float h0 = r0[0] * 0.5f + r0[1] * 0.5f;
-      const float h1 = r1[0] * 0.5f + r1[1] * 0.5f;
-      ds[k] = h0 * 0.5f + h1 * 0.5f;
-    }
-  }
-
-  for (int it = 0; it < iters; ++it) {
-    // ---- render ------------------------------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-      const int p = k * kT + tid;
-      if (p < hw) zbuf[p] = kInfBits;
-    }
-    if (tid == 0) s_nsel = 0;
-    // the GL pipeline receives the pose as float32 uniforms
-    const double tr[3] = {(double)(float)t[0], (double)(float)t[1], (double)(float)t[2]};
-    raster_mesh_u32(mesh, K, R, tr, res, (double)z_near, (double)z_far, zbuf, s_large, &s_nlarge);
-
-    // ---- query map -----------------------------------------------------------------------
-    float ren[kPPT], q[kPPT];
-    double part = 0.0;
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-      const int p = k * kT + tid;
-      ren[k] = 0.f; q[k] = 0.f;
-      if (p < hw) {
-        const unsigned zb = zbuf[p];
-        ren[k] = (zb == kInfBits) ? 0.f : __uint_as_float(zb);
-        if (debug_depth) debug_depth[((size_t)bi * iters + it) * hw + p] = ren[k];
-        const float rm = ren[k] > 0.f ? 1.f : 0.f, dm = ds[k] > 0.f ? 1.f : 0.f;
-        q[k] = (qbase[k] * rm) * dm;
-        part += (double)q[k];
-      }
-    }
-    const float norm_sum = (float)block_sum(part, s_redd);
-    if (norm_sum == 0.f) continue;  // evaluator :542-544 (uniform across the workgroup)
-
-    float qm = -FLT_MAX;
-    double sy = 0.0, sx = 0.0;
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-      const int p = k * kT + tid;
-      if (p < hw) {
-        q[k] = q[k] / norm_sum;
-        qm = fmaxf(qm, q[k]);
-        const int yy = p / res, xx = p - yy * res;
-        sy += (double)yy * (double)q[k];  // int64 * float32 -> float64 (:553-555)
-        sx += (double)xx * (double)q[k];
-      }
-    }
-    const float qmax = block_max(qm, s_redf);
-    const float thr = qmax * threshold;
-    sy = block_sum(sy, s_redd);
-    sx = block_sum(sx, s_redd);
-
-    // ---- selected depth differences -> LDS, sort, median --------------------------------------
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-      const int p = k * kT + tid;
-      if (p < hw && q[k] > thr) {
-        const int slot = atomicAdd(&s_nsel, 1);
-        sortbuf[slot] = ds[k] - ren[k];
-      }
-    }
-    __syncthreads();
-    const int nsel = s_nsel;
-    if (nsel == 0) continue;
-    int M = 1;
-    while (M < nsel) M <<= 1;
-    for (int i = nsel + tid; i < M; i += kT) sortbuf[i] = INFINITY;
-    __syncthreads();
-    for (int k2 = 2; k2 <= M; k2 <<= 1)
-      for (int j = k2 >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < M; i += kT) {
-          const int ixj = i ^ j;
-          if (ixj > i) {
-            const float a = sortbuf[i], b = sortbuf[ixj];
-            const bool asc = (i & k2) == 0;
-            if ((a > b) == asc) { sortbuf[i] = b; sortbuf[ixj] = a; }
-          }
-        }
-        __syncthreads();
-      }
-    if (tid == 0) {
-      // np.median: odd -> middle; even -> float32 mean of the two middle elements
-      const float med = (nsel & 1) ? sortbuf[nsel >> 1] : (sortbuf[(nsel >> 1) - 1] + sortbuf[nsel >> 1]) / 2.f;
-      // ray = inv(K_crop) @ (x, y, 1); np.linalg.inv on float32 returns float32
-      const double a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i9 = K[8];
-      const double det = a * (e * i9 - f * h) - b * (d * i9 - f * g) + c * (d * h - e * g);
-      double Ki[9] = {(e * i9 - f * h) / det, (c * h - b * i9) / det, (b * f - c * e) / det,
-                      (f * g - d * i9) / det, (a * i9 - c * g) / det, (c * d - a * f) / det,
-                      (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
-      for (int k = 0; k < 9; ++k) Ki[k] = (double)(float)Ki[k];
-      double ray[3];
-      for (int r = 0; r < 3; ++r) ray[r] = (Ki[3 * r] * sx + Ki[3 * r + 1] * sy) + Ki[3 * r + 2] * 1.0;
-      const double rz = ray[2];
-      for (int r = 0; r < 3; ++r) s_t[r] = t[r] + (ray[r] / rz) * (double)med;
-    }
-    __syncthreads();
-    for (int r = 0; r < 3; ++r) t[r] = s_t[r];
-    __syncthreads();
-  }
-  if (tid == 0)
-    for (int r = 0; r < 3; ++r) t_out[3 * (size_t)bi + r] = t[r];
-}
-
-
-// ==================================================================================================
-// Staged variant (default whenever every mesh of the set has <= kMaxStagedVerts vertices):
-//   * 1024 threads per ROI; K, R, t live in LDS (wave-uniform doubles would otherwise cost 42 VGPRs/lane),
-//   * per iteration the V model points are transformed ONCE into homogeneous pixel space and staged in LDS
-//     (24 B/vertex, coalesced 12 B/vertex global reads) — triangles then gather their corners from LDS instead
-//     of re-transforming each vertex ~6x from dependent global loads,
-//   * np.median by a two-rank radix select over the selected differences kept in registers (4 x 8-bit passes,
-//     two 256-bin LDS histograms, 12 barriers) instead of a bitonic sort (up to 78 barrier stages).
-// Arithmetic (and therefore every rendered depth bit and the refined t) is identical to depth_refine_kernel.
-// ==================================================================================================
 // phase stamps of workgroup 0 (s_memtime cycles): [0] start [1] prologue done, then per iteration
 // [2+5i] staged [3+5i] rastered [4+5i] reduced [5+5i] median [6+5i] updated; read by gdrnpp_debug_refine_profile
 __device__ long long g_refine_prof[16];
@@ -397,14 +152,30 @@ __device__ void radix_select2(const unsigned* keys, const bool* sel, int nkeys, 
   out1 = pref1;
 }
 
-__global__ __launch_bounds__(kTS) void depth_refine_staged_kernel(
-    const float* __restrict__ verts, const int* __restrict__ faces, const int* __restrict__ vert_off,
-    const int* __restrict__ face_off, const int* __restrict__ obj, const float* __restrict__ coor_x,
-    const float* __restrict__ coor_y, const float* __restrict__ coor_z, const float* __restrict__ mask_raw,
-    const float* __restrict__ roi_depth, const float* __restrict__ K_crop, const float* __restrict__ Rin,
-    const float* __restrict__ t_in, double* __restrict__ t_out, float* __restrict__ debug_depth, int res, int iters,
-    float threshold, int mask_type, int use_coor_z, float z_near, float z_far) {
-  extern __shared__ double hv[];  // [V][3] homogeneous pixel-space vertices of the current iteration
+struct RefineArgs {
+  const float* verts; const int* faces; const int* vert_off; const int* face_off; int n_obj;
+  const int* obj;
+  const float *coor_x, *coor_y, *coor_z, *mask_raw, *roi_depth;
+  const float* K_crop;                                 // f32[b,9], or null: computed from cam / center / scale / out_res
+  const float *cam, *center, *scale; float out_res;    // get_K_crop_resize (camera_geometry.py:6-21) inputs
+  const float *R, *t_in;
+  double* t_out;                                       // f64[b,3] or null
+  float* debug_depth;                                  // f32[b,iters,res,res] or null
+  float* rec; const float* score; const int* roi_id;   // f32[b,16] pose records or null (score / roi_id nullable)
+  double* hv_global; int hv_stride;                    // vertex stage of meshes too large for LDS: [b][hv_stride][3]
+  int res, iters; float threshold; int mask_type, use_coor_z; float z_near, z_far;
+};
+
+// STAGED: the transformed vertices of the current iteration live in LDS; otherwise in this ROI's slice of a.hv_global
+template <bool STAGED>
+__global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
+  const float* __restrict__ coor_x = a.coor_x; const float* __restrict__ coor_y = a.coor_y; const float* __restrict__ coor_z = a.coor_z;
+  const float* __restrict__ mask_raw = a.mask_raw; const float* __restrict__ roi_depth = a.roi_depth;
+  const float* __restrict__ Rin = a.R; const float* __restrict__ t_in = a.t_in;
+  float* __restrict__ debug_depth = a.debug_depth;
+  const int res = a.res, iters = a.iters, mask_type = a.mask_type, use_coor_z = a.use_coor_z;
+  const float threshold = a.threshold, z_near = a.z_near, z_far = a.z_far;
+  extern __shared__ double hv_lds[];  // [V][3] homogeneous pixel-space vertices of the current iteration (STAGED)
   __shared__ unsigned zbuf[kMaxPix];
   __shared__ float s_qbase[kMaxPix], s_ds[kMaxPix];  // iteration-invariant per-pixel terms (kept out of the VGPRs)
   __shared__ unsigned hist[2][256];
@@ -418,18 +189,39 @@ __global__ __launch_bounds__(kTS) void depth_refine_staged_kernel(
 
   const int bi = blockIdx.x, tid = threadIdx.x;
   const int hw = res * res;
-  const int ob = obj[bi];
-  const float* mverts = verts + 3 * (size_t)vert_off[ob];
-  const int nverts = vert_off[ob + 1] - vert_off[ob];
-  const int* mfaces = faces + 3 * (size_t)face_off[ob];
-  const int nfaces = face_off[ob + 1] - face_off[ob];
+  const int ob = a.obj[bi];
+  // an object id outside the mesh set (a detector with another class map): the ROI keeps the network translation and
+  // its record is marked invalid — no out-of-bounds mesh offsets
+  const bool known = (unsigned)ob < (unsigned)a.n_obj;
+  const int obs = known ? ob : 0;
+  const float* mverts = a.verts + 3 * (size_t)a.vert_off[obs];
+  const int nverts = a.vert_off[obs + 1] - a.vert_off[obs];
+  const int* mfaces = a.faces + 3 * (size_t)a.face_off[obs];
+  const int nfaces = a.face_off[obs + 1] - a.face_off[obs];
   const double zn = (double)z_near, zf = (double)z_far;
+  double* hv;
+  if constexpr (STAGED) hv = hv_lds;
+  else hv = a.hv_global + (size_t)bi * a.hv_stride * 3;
+  const int n_it = known ? iters : 0;
 
   PROF_STAMP(0);
-  if (tid < 9) { s_K[tid] = (double)K_crop[9 * (size_t)bi + tid]; s_R[tid] = (double)Rin[9 * (size_t)bi + tid]; }
+  if (tid < 9) {
+    float kc;
+    if (a.K_crop) {
+      kc = a.K_crop[9 * (size_t)bi + tid];
+    } else {  // get_K_crop_resize: K' = diag(r, r, 1) (K - [0 0 x0; 0 0 y0; 0 0 0]), float32 like the torch ops
+      const float* k = a.cam + 9 * (size_t)bi;
+      const float sc = a.scale[bi];
+      const float x0 = a.center[2 * bi] - sc / 2, y0 = a.center[2 * bi + 1] - sc / 2;
+      const float r = a.out_res / sc;
+      kc = tid == 2 ? (k[2] - x0) * r : tid == 5 ? (k[5] - y0) * r : tid < 6 ? k[tid] * r : k[tid];
+    }
+    s_K[tid] = (double)kc;
+    s_R[tid] = (double)Rin[9 * (size_t)bi + tid];
+  }
   if (tid < 3) { s_t[tid] = (double)t_in[3 * (size_t)bi + tid]; s_Rf[tid] = Rin[9 * (size_t)bi + 6 + tid]; }
 
-  // ---- prologue (identical arithmetic to depth_refine_kernel) -----------------------------------------------
+  // ---- prologue: mask normalisation, query base, sensor depth crop ------------------------------------------
   const float* mk = mask_raw + (size_t)bi * hw;
   float mraw[kPPTS];
   float lo = FLT_MAX, hi = -FLT_MAX;
@@ -456,7 +248,7 @@ __global__ __launch_bounds__(kTS) void depth_refine_staged_kernel(
     if (p < hw) {
       float m = mraw[k];
       if (mask_type == 0) m = (m - mmin) / mden;
-      else m = 1.f / (1.f + expf(-m));
+      else if (mask_type == 1) m = 1.f / (1.f + expf(-m));  // 2: already a probability / label (CE argmax)
       const float x = coor_x[(size_t)bi * hw + p], y = coor_y[(size_t)bi * hw + p], z = coor_z[(size_t)bi * hw + p];
       float qv;
       if (use_coor_z) qv = (r20 * x + r21 * y) + r22 * z;
@@ -472,7 +264,7 @@ __global__ __launch_bounds__(kTS) void depth_refine_staged_kernel(
   }
 
   PROF_STAMP(1);
-  for (int it = 0; it < iters; ++it) {
+  for (int it = 0; it < n_it; ++it) {
     // ---- stage the transformed model points, clear the z-buffer ------------------------------------------------
     {
       double K[9], R[9], tr[3];
@@ -615,8 +407,18 @@ __global__ __launch_bounds__(kTS) void depth_refine_staged_kernel(
     __syncthreads();
     PROF_STAMP(6 + 5 * it);
   }
-  if (tid == 0)
-    for (int r = 0; r < 3; ++r) t_out[3 * (size_t)bi + r] = s_t[r];
+  __syncthreads();
+  if (tid < 3 && a.t_out) a.t_out[3 * (size_t)bi + tid] = s_t[tid];
+  if (a.rec && tid < 16) {  // pose_prediction_to_json's fields as one f32[16] record (gdrn_evaluator.py:636-665)
+    float v;
+    if (tid < 9) v = Rin[9 * (size_t)bi + tid];
+    else if (tid < 12) v = (float)s_t[tid - 9];
+    else if (tid == 12) v = a.score ? a.score[bi] : 1.f;
+    else if (tid == 13) v = (float)ob;
+    else if (tid == 14) v = a.roi_id ? (float)a.roi_id[bi] : (float)bi;
+    else v = known ? 1.f : 0.f;
+    a.rec[16 * (size_t)bi + tid] = v;
+  }
 }
 
 // ---- stand-alone render: depth (+ optional object-space xyz) -------------------------------
@@ -627,9 +429,16 @@ __global__ __launch_bounds__(kT) void render_depth_kernel(const float* __restric
                                                           const int* __restrict__ obj, const float* __restrict__ Kin,
                                                           const float* __restrict__ Rin, const float* __restrict__ tin,
                                                           float* __restrict__ depth, float* __restrict__ xyz, int res,
-                                                          float z_near, float z_far) {
+                                                          float z_near, float z_far, int n_obj) {
   extern __shared__ unsigned long long zkey[];  // (float Z bits << 32) | face id
   const int bi = blockIdx.x, tid = threadIdx.x, hw = res * res;
+  if ((unsigned)obj[bi] >= (unsigned)n_obj) {  // unknown object id: empty render
+    for (int p = tid; p < hw; p += kT) {
+      depth[(size_t)bi * hw + p] = 0.f;
+      if (xyz) { float* dst = xyz + ((size_t)bi * hw + p) * 3; dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f; }
+    }
+    return;
+  }
   const MeshView mesh = mesh_of(verts, faces, vert_off, face_off, obj[bi]);
   double K[9], R[9], t[3];
   for (int k = 0; k < 9; ++k) { K[k] = (double)Kin[9 * (size_t)bi + k]; R[k] = (double)Rin[9 * (size_t)bi + k]; }
@@ -707,6 +516,38 @@ int check_meshes(const gdrnpp_meshes* m, const char* who) {
   return 0;
 }
 
+// hipFuncSetAttribute is a per-device setting: done once per (kernel, device), not per launch
+template <typename F>
+int raise_dynamic_lds_once(F kernel, int bytes, bool* done /*[64]*/) {
+  int dev = 0;
+  GDRNPP_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || done[dev]) return 0;
+  GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done[dev] = true;
+  return 0;
+}
+
+int launch_refine(const gdrnpp_meshes* meshes, RefineArgs a, int b, void* workspace, size_t workspace_bytes, hipStream_t st,
+                  const char* who) {
+  a.verts = meshes->verts; a.faces = meshes->faces; a.vert_off = meshes->vert_off; a.face_off = meshes->face_off;
+  a.n_obj = meshes->n_obj;
+  if (meshes->max_verts > 0 && meshes->max_verts <= kMaxStagedVerts) {
+    static bool done[64];
+    if (int rc = raise_dynamic_lds_once(depth_refine_kernel<true>, 3 * (int)sizeof(double) * kMaxStagedVerts, done)) return rc;
+    a.hv_global = nullptr; a.hv_stride = 0;
+    hipLaunchKernelGGL(depth_refine_kernel<true>, dim3(b), dim3(kTS), 3 * (int)sizeof(double) * meshes->max_verts, st, a);
+  } else {
+    GDRNPP_REQUIRE(meshes->max_verts > 0, GDRNPP_EINVAL, "%s: gdrnpp_meshes.max_verts must be set", who);
+    const size_t need = (size_t)b * meshes->max_verts * 3 * sizeof(double);
+    GDRNPP_REQUIRE(workspace && workspace_bytes >= need, GDRNPP_EINVAL,
+                   "%s: meshes of up to %d vertices need a workspace of %zu bytes (gdrnpp_depth_refine_workspace_bytes)", who,
+                   meshes->max_verts, need);
+    a.hv_global = (double*)workspace; a.hv_stride = meshes->max_verts;
+    hipLaunchKernelGGL(depth_refine_kernel<false>, dim3(b), dim3(kTS), 0, st, a);
+  }
+  return gdrnpp::check_launch(who);
+}
+
 }  // namespace
 
 extern "C" {
@@ -719,41 +560,64 @@ int gdrnpp_render_depth(const gdrnpp_meshes* meshes, const int* obj, const float
   GDRNPP_REQUIRE(res <= 128, GDRNPP_ELIMIT, "gdrnpp_render_depth: res=%d > 128 (z-buffer lives in LDS)", res);
   const int lds = res * res * (int)sizeof(unsigned long long);
   if (lds > 48 * 1024) {
-    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)render_depth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       lds));
+    static bool done[64];
+    if (int rc = raise_dynamic_lds_once(render_depth_kernel, 128 * 128 * (int)sizeof(unsigned long long), done)) return rc;
   }
   hipLaunchKernelGGL(render_depth_kernel, dim3(b), dim3(kT), lds, (hipStream_t)stream, meshes->verts, meshes->faces,
-                     meshes->vert_off, meshes->face_off, obj, K, R, t, depth, xyz, res, z_near, z_far);
+                     meshes->vert_off, meshes->face_off, obj, K, R, t, depth, xyz, res, z_near, z_far, meshes->n_obj);
   return gdrnpp::check_launch("gdrnpp_render_depth");
+}
+
+size_t gdrnpp_depth_refine_workspace_bytes(const gdrnpp_meshes* meshes, int b) {
+  if (!meshes || b <= 0 || meshes->max_verts <= kMaxStagedVerts) return 0;
+  return (size_t)b * meshes->max_verts * 3 * sizeof(double);
 }
 
 int gdrnpp_depth_refine(const gdrnpp_meshes* meshes, const int* obj, const float* coor_x, const float* coor_y,
                         const float* coor_z, const float* mask_raw, const float* roi_depth, const float* K_crop,
-                        const float* R, const float* t_in, double* t_out, float* debug_depth, int b, int res,
+                        const float* R, const float* t_in, double* t_out, float* debug_depth, int b, int res, int in_res,
                         int iters, float threshold, int mask_type, int use_coor_z, float z_near, float z_far,
-                        void* stream) {
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (b == 0) return 0;
   if (int rc = check_meshes(meshes, "gdrnpp_depth_refine")) return rc;
   GDRNPP_REQUIRE(obj && coor_x && coor_y && coor_z && mask_raw && roi_depth && K_crop && R && t_in && t_out,
                  GDRNPP_EINVAL, "gdrnpp_depth_refine: null pointer");
   GDRNPP_REQUIRE(b > 0 && res > 0 && iters >= 0, GDRNPP_EINVAL, "gdrnpp_depth_refine: b=%d res=%d iters=%d", b, res,
                  iters);
   GDRNPP_REQUIRE(res * res <= kMaxPix, GDRNPP_ELIMIT, "gdrnpp_depth_refine: res=%d > 64", res);
-  GDRNPP_REQUIRE(mask_type == 0 || mask_type == 1, GDRNPP_EINVAL, "gdrnpp_depth_refine: mask_type=%d", mask_type);
-  hipStream_t st = (hipStream_t)stream;
-  if (meshes->max_verts > 0 && meshes->max_verts <= kMaxStagedVerts) {
-    const int lds = 3 * (int)sizeof(double) * meshes->max_verts;
-    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)depth_refine_staged_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       3 * (int)sizeof(double) * kMaxStagedVerts));  // per device, so per call
-    hipLaunchKernelGGL(depth_refine_staged_kernel, dim3(b), dim3(kTS), lds, st, meshes->verts, meshes->faces,
-                       meshes->vert_off, meshes->face_off, obj, coor_x, coor_y, coor_z, mask_raw, roi_depth, K_crop, R,
-                       t_in, t_out, debug_depth, res, iters, threshold, mask_type, use_coor_z, z_near, z_far);
-  } else {
-    hipLaunchKernelGGL(depth_refine_kernel, dim3(b), dim3(kT), 0, st, meshes->verts, meshes->faces, meshes->vert_off,
-                       meshes->face_off, obj, coor_x, coor_y, coor_z, mask_raw, roi_depth, K_crop, R, t_in, t_out,
-                       debug_depth, res, iters, threshold, mask_type, use_coor_z, z_near, z_far);
-  }
-  return gdrnpp::check_launch("gdrnpp_depth_refine");
+  GDRNPP_REQUIRE(in_res == 4 * res, GDRNPP_ELIMIT,
+                 "gdrnpp_depth_refine: roi_depth is %d x %d, the kernel reads the INPUT_RES = 4 x OUTPUT_RES crop (%d) the way "
+                 "cv2.resize does at scale 4", in_res, in_res, 4 * res);
+  GDRNPP_REQUIRE(mask_type >= 0 && mask_type <= 2, GDRNPP_EINVAL, "gdrnpp_depth_refine: mask_type=%d", mask_type);
+  RefineArgs a{};
+  a.obj = obj; a.coor_x = coor_x; a.coor_y = coor_y; a.coor_z = coor_z; a.mask_raw = mask_raw; a.roi_depth = roi_depth;
+  a.K_crop = K_crop; a.R = R; a.t_in = t_in; a.t_out = t_out; a.debug_depth = debug_depth;
+  a.res = res; a.iters = iters; a.threshold = threshold; a.mask_type = mask_type; a.use_coor_z = use_coor_z;
+  a.z_near = z_near; a.z_far = z_far;
+  return launch_refine(meshes, a, b, workspace, workspace_bytes, (hipStream_t)stream, "gdrnpp_depth_refine");
+}
+
+int gdrnpp_refine_to_records(const gdrnpp_meshes* meshes, const int* obj, const float* coor_x, const float* coor_y,
+                             const float* coor_z, const float* mask_raw, const float* roi_depth, const float* cam,
+                             const float* center, const float* scale, const float* R, const float* t_in,
+                             const float* score, const int* roi_id, float* rec, int b, int res, int in_res, int iters,
+                             float threshold, int mask_type, int use_coor_z, float z_near, float z_far, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (b == 0) return 0;
+  if (int rc = check_meshes(meshes, "gdrnpp_refine_to_records")) return rc;
+  GDRNPP_REQUIRE(obj && coor_x && coor_y && coor_z && mask_raw && roi_depth && cam && center && scale && R && t_in && rec,
+                 GDRNPP_EINVAL, "gdrnpp_refine_to_records: null pointer");
+  GDRNPP_REQUIRE(b > 0 && res > 0 && iters >= 0, GDRNPP_EINVAL, "gdrnpp_refine_to_records: b=%d res=%d iters=%d", b, res, iters);
+  GDRNPP_REQUIRE(res * res <= kMaxPix && in_res == 4 * res, GDRNPP_ELIMIT,
+                 "gdrnpp_refine_to_records: res=%d (<= 64) and in_res=%d (= 4 x res) required", res, in_res);
+  GDRNPP_REQUIRE(mask_type >= 0 && mask_type <= 2, GDRNPP_EINVAL, "gdrnpp_refine_to_records: mask_type=%d", mask_type);
+  RefineArgs a{};
+  a.obj = obj; a.coor_x = coor_x; a.coor_y = coor_y; a.coor_z = coor_z; a.mask_raw = mask_raw; a.roi_depth = roi_depth;
+  a.K_crop = nullptr; a.cam = cam; a.center = center; a.scale = scale; a.out_res = (float)res;
+  a.R = R; a.t_in = t_in; a.t_out = nullptr; a.debug_depth = nullptr; a.rec = rec; a.score = score; a.roi_id = roi_id;
+  a.res = res; a.iters = iters; a.threshold = threshold; a.mask_type = mask_type; a.use_coor_z = use_coor_z;
+  a.z_near = z_near; a.z_far = z_far;
+  return launch_refine(meshes, a, b, workspace, workspace_bytes, (hipStream_t)stream, "gdrnpp_refine_to_records");
 }
 
 /* debug: s_memtime stamps of workgroup 0 of the last staged refine launch (see g_refine_prof) */

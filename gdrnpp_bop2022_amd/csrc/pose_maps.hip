@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kThreads) void decode_corr_kernel(
     if (p < end) {
       float m = mk[p];
       if (mask_type == 0) m = (m - mmin) / mden;
-      else m = 1.f / (1.f + expf(-m));
+      else if (mask_type == 1) m = 1.f / (1.f + expf(-m));  // 2: already a probability / label (CE argmax)
       if (out_mask) out_mask[(size_t)bi * hw + p] = m;
       const float x = (cx[p] - 0.5f) * e0, y = (cy[p] - 0.5f) * e1, z = (cz[p] - 0.5f) * e2;
       sel = (m > mask_thr) && (fabsf(x) > t0) && (fabsf(y) > t1) && (fabsf(z) > t2);
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void decode_corr_kernel(
     if (p < end) {
       float m = mk[p];
       if (mask_type == 0) m = (m - mmin) / mden;
-      else m = 1.f / (1.f + expf(-m));
+      else if (mask_type == 1) m = 1.f / (1.f + expf(-m));  // 2: already a probability / label (CE argmax)
       x = (cx[p] - 0.5f) * e0; y = (cy[p] - 0.5f) * e1; z = (cz[p] - 0.5f) * e2;
       sel = (m > mask_thr) && (fabsf(x) > t0) && (fabsf(y) > t1) && (fabsf(z) > t2);
     }
@@ -127,31 +127,54 @@ __global__ __launch_bounds__(kThreads) void decode_corr_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ void pose_from_pred_kernel(const float* __restrict__ rot6d, const float* __restrict__ t_,
+// rot_mode: 0 = 6-d representation, 1 = quaternion (w,x,y,z), 2 = rotation matrix (row-major)
+// t_mode:   0 = centroid_z with relative z (SITE), 1 = centroid_z with absolute z, 2 = centroid_z_abs (absolute 2-d centre
+//           and z: pose_from_pred_centroid_z_abs.py:44-76), 3 = trans (the head's output IS the translation: pose_from_pred.py:25-27)
+__global__ void pose_from_pred_kernel(const float* __restrict__ rot_in, const float* __restrict__ t_,
                                       const float* __restrict__ cams, const float* __restrict__ centers,
                                       const float* __restrict__ whs, const float* __restrict__ resize_ratios,
-                                      float* __restrict__ rot, float* __restrict__ trans, int b, int z_type,
-                                      int is_allo) {
+                                      float* __restrict__ rot, float* __restrict__ trans, int b, int t_mode,
+                                      int is_allo, int rot_mode) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b) return;
-  // rot6d_to_mat_batch (rot_reps.py:34-55): x = normalize(a), z = normalize(x X b), y = z X x; columns (x,y,z)
-  const float* d6 = rot6d + 6 * (size_t)i;
-  float ax = d6[0], ay = d6[1], az = d6[2], bx = d6[3], by = d6[4], bz = d6[5];
-  float na = fmaxf(sqrtf((ax * ax + ay * ay) + az * az), 1e-12f);  // F.normalize eps
-  float x0 = ax / na, x1 = ay / na, x2 = az / na;
-  float z0 = x1 * bz - x2 * by, z1 = x2 * bx - x0 * bz, z2 = x0 * by - x1 * bx;
-  float nz = fmaxf(sqrtf((z0 * z0 + z1 * z1) + z2 * z2), 1e-12f);
-  z0 /= nz; z1 /= nz; z2 /= nz;
-  float y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0;
-  float Ra[9] = {x0, y0, z0, x1, y1, z1, x2, y2, z2};
+  float Ra[9];
+  if (rot_mode == 0) {
+    // rot6d_to_mat_batch (rot_reps.py:34-55): x = normalize(a), z = normalize(x X b), y = z X x; columns (x,y,z)
+    const float* d6 = rot_in + 6 * (size_t)i;
+    float ax = d6[0], ay = d6[1], az = d6[2], bx = d6[3], by = d6[4], bz = d6[5];
+    float na = fmaxf(sqrtf((ax * ax + ay * ay) + az * az), 1e-12f);  // F.normalize eps
+    float x0 = ax / na, x1 = ay / na, x2 = az / na;
+    float z0 = x1 * bz - x2 * by, z1 = x2 * bx - x0 * bz, z2 = x0 * by - x1 * bx;
+    float nz = fmaxf(sqrtf((z0 * z0 + z1 * z1) + z2 * z2), 1e-12f);
+    z0 /= nz; z1 /= nz; z2 /= nz;
+    float y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0;
+    Ra[0] = x0; Ra[1] = y0; Ra[2] = z0; Ra[3] = x1; Ra[4] = y1; Ra[5] = z1; Ra[6] = x2; Ra[7] = y2; Ra[8] = z2;
+  } else if (rot_mode == 1) {
+    // quat2mat_torch (core/utils/pose_utils.py:349-400, eps = 0): normalise, then the (w,x,y,z) -> matrix polynomial
+    const float* q = rot_in + 4 * (size_t)i;
+    const float nq = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+    const float qw = q[0] / nq, qx = q[1] / nq, qy = q[2] / nq, qz = q[3] / nq;
+    const float X = qx * 2.f, Y = qy * 2.f, Z = qz * 2.f;
+    const float wX = qw * X, wY = qw * Y, wZ = qw * Z, xX = qx * X, xY = qx * Y, xZ = qx * Z, yY = qy * Y, yZ = qy * Z, zZ = qz * Z;
+    Ra[0] = 1.f - (yY + zZ); Ra[1] = xY - wZ; Ra[2] = xZ + wY;
+    Ra[3] = xY + wZ; Ra[4] = 1.f - (xX + zZ); Ra[5] = yZ - wX;
+    Ra[6] = xZ - wY; Ra[7] = yZ + wX; Ra[8] = 1.f - (xX + yY);
+  } else {
+    for (int k = 0; k < 9; ++k) Ra[k] = rot_in[9 * (size_t)i + k];
+  }
 
-  // pose_from_predictions_test (pose_from_pred_centroid_z.py:73-110), fp32 like the torch ops
+  // pose_from_predictions_test (pose_from_pred_centroid_z.py:73-110 and its _abs / plain-translation siblings), fp32 like torch
   const float* K = cams + 9 * (size_t)i;
-  const float cxp = t_[3 * i] * whs[2 * i] + centers[2 * i];
-  const float cyp = t_[3 * i + 1] * whs[2 * i + 1] + centers[2 * i + 1];
-  const float z = (z_type == 0) ? t_[3 * i + 2] * resize_ratios[i] : t_[3 * i + 2];
-  const float tx = z * (cxp - K[2]) / K[0];
-  const float ty = z * (cyp - K[5]) / K[4];
+  float tx, ty, z;
+  if (t_mode == 3) {
+    tx = t_[3 * i]; ty = t_[3 * i + 1]; z = t_[3 * i + 2];
+  } else {
+    const float cxp = t_mode == 2 ? t_[3 * i] : t_[3 * i] * whs[2 * i] + centers[2 * i];
+    const float cyp = t_mode == 2 ? t_[3 * i + 1] : t_[3 * i + 1] * whs[2 * i + 1] + centers[2 * i + 1];
+    z = (t_mode == 0) ? t_[3 * i + 2] * resize_ratios[i] : t_[3 * i + 2];
+    tx = z * (cxp - K[2]) / K[0];
+    ty = z * (cyp - K[5]) / K[4];
+  }
   trans[3 * i] = tx; trans[3 * i + 1] = ty; trans[3 * i + 2] = z;
 
   float* Ro = rot + 9 * (size_t)i;
@@ -220,10 +243,11 @@ int gdrnpp_decode_correspondences(const float* coor_x, const float* coor_y, cons
                                   const float* mask_raw, const float* coord2d, const float* extent,
                                   const float* imwh, float* out_mask, int* count, int* sel_idx, float* img_pts,
                                   float* mdl_pts, int b, int hw, int mask_type, float mask_thr, void* stream) {
+  if (b == 0) return 0;  // an image / a rank without ROIs: nothing to launch
   GDRNPP_REQUIRE(coor_x && coor_y && coor_z && mask_raw && coord2d && extent && imwh && count && img_pts && mdl_pts,
                  GDRNPP_EINVAL, "gdrnpp_decode_correspondences: null pointer");
   GDRNPP_REQUIRE(b > 0 && hw > 0, GDRNPP_EINVAL, "gdrnpp_decode_correspondences: b=%d hw=%d", b, hw);
-  GDRNPP_REQUIRE(mask_type == 0 || mask_type == 1, GDRNPP_EINVAL, "gdrnpp_decode_correspondences: mask_type=%d",
+  GDRNPP_REQUIRE(mask_type >= 0 && mask_type <= 2, GDRNPP_EINVAL, "gdrnpp_decode_correspondences: mask_type=%d",
                  mask_type);
   hipLaunchKernelGGL(decode_corr_kernel, dim3(b), dim3(kThreads), 0, (hipStream_t)stream, coor_x, coor_y, coor_z,
                      mask_raw, coord2d, extent, imwh, out_mask, count, sel_idx, img_pts, mdl_pts, hw, mask_type,
@@ -239,12 +263,27 @@ int gdrnpp_pose_from_pred_centroid_z(const float* rot6d, const float* t_, const 
   GDRNPP_REQUIRE(b > 0 && (z_type == 0 || z_type == 1), GDRNPP_EINVAL,
                  "gdrnpp_pose_from_pred_centroid_z: b=%d z_type=%d", b, z_type);
   hipLaunchKernelGGL(pose_from_pred_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot6d, t_, cams,
-                     centers, whs, resize_ratios, rot, trans, b, z_type, is_allo);
+                     centers, whs, resize_ratios, rot, trans, b, z_type, is_allo, 0);
   return gdrnpp::check_launch("gdrnpp_pose_from_pred_centroid_z");
+}
+
+int gdrnpp_pose_from_pred(const float* rot_in, int rot_mode, const float* t_, int t_mode, const float* cams,
+                          const float* centers, const float* whs, const float* resize_ratios, float* rot, float* trans,
+                          int b, int is_allo, void* stream) {
+  if (b == 0) return 0;
+  GDRNPP_REQUIRE(rot_in && t_ && cams && rot && trans, GDRNPP_EINVAL, "gdrnpp_pose_from_pred: null pointer");
+  GDRNPP_REQUIRE(b > 0 && rot_mode >= 0 && rot_mode <= 2 && t_mode >= 0 && t_mode <= 3, GDRNPP_EINVAL,
+                 "gdrnpp_pose_from_pred: b=%d rot_mode=%d t_mode=%d", b, rot_mode, t_mode);
+  GDRNPP_REQUIRE(t_mode >= 2 || (centers && whs && (t_mode == 1 || resize_ratios)), GDRNPP_EINVAL,
+                 "gdrnpp_pose_from_pred: centroid_z needs centers, whs (and resize_ratios for relative z)");
+  hipLaunchKernelGGL(pose_from_pred_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot_in, t_, cams,
+                     centers, whs, resize_ratios, rot, trans, b, t_mode, is_allo, rot_mode);
+  return gdrnpp::check_launch("gdrnpp_pose_from_pred");
 }
 
 int gdrnpp_zoom_K(const float* K, const float* centers, const float* scales, float* K_crop, int b, float out_res,
                   void* stream) {
+  if (b == 0) return 0;
   GDRNPP_REQUIRE(K && centers && scales && K_crop && b > 0, GDRNPP_EINVAL, "gdrnpp_zoom_K: bad arguments");
   hipLaunchKernelGGL(zoom_K_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, K, centers, scales,
                      K_crop, b, out_res);
@@ -253,6 +292,7 @@ int gdrnpp_zoom_K(const float* K, const float* centers, const float* scales, flo
 
 int gdrnpp_pack_pose_records(const float* R, const double* t_refined, const float* t_net, const float* score,
                              const int* obj_id, const int* roi_id, float* rec, int b, void* stream) {
+  if (b == 0) return 0;
   GDRNPP_REQUIRE(R && rec && (t_refined || t_net) && b > 0, GDRNPP_EINVAL, "gdrnpp_pack_pose_records: bad arguments");
   hipLaunchKernelGGL(pack_records_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, R, t_refined, t_net,
                      score, obj_id, roi_id, rec, b);

@@ -174,15 +174,28 @@ class GDRN_DoubleMask(nn.Module):
         pred_rot_, pred_t_, maps = self.forward_maps(x, roi_classes, roi_coord_2d, roi_coord_2d_rel, roi_extents)
 
         # ---- rot6d -> R, centroid/z -> t, allo -> ego: one HIP kernel, no host sync --------------------------
-        rot_type = pnp_net_cfg.ROT_TYPE
-        if rot_type not in ("allo_rot6d", "ego_rot6d") or pnp_net_cfg.TRANS_TYPE != "centroid_z":
-            raise NotImplementedError(f"ROT_TYPE={rot_type} TRANS_TYPE={pnp_net_cfg.TRANS_TYPE}")
-        if pnp_net_cfg.Z_TYPE not in ("REL", "ABS"):
-            raise NotImplementedError(f"Z_TYPE={pnp_net_cfg.Z_TYPE}")
-        pred_ego_rot, pred_trans = hip_lib.pose_from_pred_centroid_z(
+        rot_type = pnp_net_cfg.ROT_TYPE          # get_rot_mat (model_utils.py:347-359) + the three TRANS_TYPE branches (:162-200)
+        if rot_type in ("allo_rot6d", "ego_rot6d"):
+            rot_mode = "rot6d"
+        elif rot_type in ("allo_quat", "ego_quat"):
+            rot_mode = "quat"
+        else:
+            raise NotImplementedError(f"ROT_TYPE={rot_type} (log-quaternion / Lie-vector heads are not used by the GDRNPP configs)")
+        trans_type = pnp_net_cfg.TRANS_TYPE
+        if trans_type == "centroid_z":
+            if pnp_net_cfg.Z_TYPE not in ("REL", "ABS"):
+                raise NotImplementedError(f"Z_TYPE={pnp_net_cfg.Z_TYPE}")
+            t_mode = "centroid_z_rel" if pnp_net_cfg.Z_TYPE == "REL" else "centroid_z_abs_z"
+        elif trans_type in ("centroid_z_abs", "trans"):
+            t_mode = trans_type
+        else:
+            raise ValueError(f"Unknown trans type: {trans_type}")
+        need_roi = trans_type == "centroid_z"
+        pred_ego_rot, pred_trans = hip_lib.pose_from_pred(
             pred_rot_.float().contiguous(), pred_t_.float().contiguous(), roi_cams.reshape(bs, 9).contiguous(),
-            roi_centers.contiguous(), roi_whs.contiguous(), resize_ratios.reshape(bs).contiguous(),
-            z_type=pnp_net_cfg.Z_TYPE, is_allo="allo" in rot_type)
+            roi_centers.contiguous() if need_roi else None, roi_whs.contiguous() if need_roi else None,
+            resize_ratios.reshape(bs).contiguous() if need_roi and t_mode == "centroid_z_rel" else None,
+            rot_mode=rot_mode, t_mode=t_mode, is_allo="allo" in rot_type)
 
         out_dict = {"rot": pred_ego_rot, "trans": pred_trans}
         if cfg.TEST.USE_PNP or cfg.TEST.SAVE_RESULTS_ONLY or cfg.TEST.USE_DEPTH_REFINE:

@@ -59,10 +59,20 @@ class GdrnHipPost:
             self.mask_type = 0
         elif mlt in ("BCE", "RW_BCE", "dice"):
             self.mask_type = 1
+        elif mlt == "CE":        # two logits per pixel: get_out_mask takes the argmax (engine_utils.py:329-330)
+            self.mask_type = 2
         else:
             raise NotImplementedError(f"MASK_LOSS_TYPE={mlt}")
         if cfg.TEST.USE_DEPTH_REFINE and meshes is None:
             raise ValueError("TEST.USE_DEPTH_REFINE needs the object meshes (gdrn_evaluator.py:64-84)")
+
+    def mask_plane(self, out_dict: dict) -> torch.Tensor:
+        """The mask map the kernels consume: raw logits for L1 / BCE (normalised / squashed inside the kernels), the argmax
+        label for the CE flavour (``get_out_mask``, engine_utils.py:315-333)."""
+        m = out_dict["mask"]
+        if self.mask_type == 2:
+            m = torch.argmax(m, dim=1, keepdim=True).to(torch.float32)
+        return m.contiguous()
 
     def process_depth_refine(self, batch: dict, out_dict: dict) -> torch.Tensor:
         """-> refined translation f64[b,3]; rotation is unchanged (gdrn_evaluator.py:559-561)."""
@@ -72,7 +82,7 @@ class GdrnHipPost:
                                 batch["scale"].reshape(b).contiguous(), self.out_res)
         cx, cy, cz = coor_planes(cfg, out_dict)
         return hip_lib.depth_refine(
-            self.meshes, batch["roi_cls"].to(torch.int32), cx, cy, cz, out_dict["mask"].contiguous(),
+            self.meshes, batch["roi_cls"].to(torch.int32), cx, cy, cz, self.mask_plane(out_dict),
             batch["roi_depth"].contiguous(), K_crop, out_dict["rot"].reshape(b, 9).contiguous(),
             out_dict["trans"].contiguous(), res=self.out_res, iters=cfg.TEST.DEPTH_REFINE_ITER,
             threshold=cfg.TEST.DEPTH_REFINE_THRESHOLD, mask_type=self.mask_type,
@@ -83,7 +93,7 @@ class GdrnHipPost:
         imwh = torch.stack([batch["im_W"], batch["im_H"]], 1).float().contiguous()
         cx, cy, cz = coor_planes(self.cfg, out_dict)
         return hip_lib.decode_correspondences(
-            cx, cy, cz, out_dict["mask"].contiguous(), batch["roi_coord_2d"].contiguous(), batch["roi_extent"].contiguous(), imwh,
+            cx, cy, cz, self.mask_plane(out_dict), batch["roi_coord_2d"].contiguous(), batch["roi_extent"].contiguous(), imwh,
             mask_type=self.mask_type, mask_thr=self.cfg.MODEL.POSE_NET.GEO_HEAD.MASK_THR_TEST)
 
     def process_net_and_pnp(self, batch: dict, out_dict: dict):
@@ -145,8 +155,20 @@ class GdrnHipPost:
                 R.reshape(b, 9).contiguous(), None, t.contiguous(),
                 batch["score"].float().contiguous() if "score" in batch else None,
                 batch["roi_cls"].to(torch.int32).contiguous(), roi_ids)
-        t_ref = self.process_depth_refine(batch, out_dict) if self.cfg.TEST.USE_DEPTH_REFINE else None
         b = out_dict["trans"].shape[0]
+        if self.cfg.TEST.USE_DEPTH_REFINE:
+            # zoom_K -> refine -> pack in ONE launch (the reference: batch_data_inference_roi + the per-ROI loop +
+            # pose_prediction_to_json, gdrn_evaluator.py:461-573)
+            cfg = self.cfg
+            cx, cy, cz = coor_planes(cfg, out_dict)
+            return hip_lib.refine_to_records(
+                self.meshes, batch["roi_cls"].to(torch.int32), cx, cy, cz, self.mask_plane(out_dict),
+                batch["roi_depth"].contiguous(), batch["roi_cam"].reshape(b, 9).contiguous(), batch["roi_center"].contiguous(),
+                batch["scale"].reshape(b).contiguous(), out_dict["rot"].reshape(b, 9).contiguous(), out_dict["trans"].contiguous(),
+                score=batch["score"].float().contiguous() if "score" in batch else None, roi_id=roi_ids, res=self.out_res,
+                iters=cfg.TEST.DEPTH_REFINE_ITER, threshold=cfg.TEST.DEPTH_REFINE_THRESHOLD, mask_type=self.mask_type,
+                use_coor_z=bool(cfg.TEST.USE_COOR_Z_REFINE), z_near=self.z_near, z_far=self.z_far)
+        t_ref = None
         return hip_lib.pack_pose_records(
             out_dict["rot"].reshape(b, 9).contiguous(), t_ref, out_dict["trans"].contiguous(),
             batch["score"].float().contiguous() if "score" in batch else None,

@@ -62,9 +62,14 @@ SIGNATURES = {
     "gdrnpp_zoom_K": (c_int, [_P, _P, _P, _P, c_int, c_float, _P]),
     "gdrnpp_render_depth": (
         c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "gdrnpp_depth_refine_workspace_bytes": (c_size_t, [POINTER(gdrnpp_meshes), c_int]),
     "gdrnpp_depth_refine": (
-        c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
-                c_int, c_int, c_float, c_float, _P]),
+        c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float,
+                c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
+    "gdrnpp_refine_to_records": (
+        c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
+                c_float, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
+    "gdrnpp_pose_from_pred": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "gdrnpp_debug_refine_profile": (c_int, [_P]),
     "gdrnpp_pack_weight_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -254,6 +259,23 @@ def pose_from_pred_centroid_z(rot6d, t_, cams, centers, whs, resize_ratios, z_ty
     return rot, trans
 
 
+def pose_from_pred(rot_in, t_, cams, centers=None, whs=None, resize_ratios=None, rot_mode: str = "rot6d",
+                   t_mode: str = "centroid_z_rel", is_allo: bool = True):
+    """``gdrnpp_pose_from_pred``: every ROT_TYPE (rot6d / quat / matrix) x TRANS_TYPE (centroid_z REL or ABS,
+    centroid_z_abs, trans) combination of GDRN_double_mask.py:162-200 -> (R_ego f32[b,3,3], t f32[b,3])."""
+    b = rot_in.shape[0]
+    rot = torch.empty((b, 3, 3), dtype=torch.float32, device=rot_in.device)
+    trans = torch.empty((b, 3), dtype=torch.float32, device=rot_in.device)
+    rm = {"rot6d": 0, "quat": 1, "mat": 2}[rot_mode]
+    tm = {"centroid_z_rel": 0, "centroid_z_abs_z": 1, "centroid_z_abs": 2, "trans": 3}[t_mode]
+    opt = lambda x, n: _dev(x, torch.float32, n) if x is not None else None  # noqa: E731
+    _check(load().gdrnpp_pose_from_pred(_dev(rot_in, torch.float32, "rot_in"), rm, _dev(t_, torch.float32, "t_"), tm,
+                                        _dev(cams, torch.float32, "cams"), opt(centers, "centers"), opt(whs, "whs"),
+                                        opt(resize_ratios, "resize_ratios"), rot.data_ptr(), trans.data_ptr(), b,
+                                        1 if is_allo else 0, _stream()), "gdrnpp_pose_from_pred")
+    return rot, trans
+
+
 def zoom_K(K, centers, scales, out_res: float):
     lib = load()
     b = K.shape[0]
@@ -277,6 +299,12 @@ def render_depth(meshes: MeshSet, obj, K, R, t, res: int, z_near: float = 0.1, z
     return (depth, xyz) if want_xyz else depth
 
 
+def _refine_workspace(meshes: MeshSet, b: int, device):
+    nbytes = load().gdrnpp_depth_refine_workspace_bytes(meshes.c, b)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
+    return ws, nbytes
+
+
 def depth_refine(meshes: MeshSet, obj, coor_x, coor_y, coor_z, mask_raw, roi_depth, K_crop, R, t, res: int = 64,
                  iters: int = 2, threshold: float = 0.8, mask_type: int = 0, use_coor_z: bool = False,
                  z_near: float = 0.1, z_far: float = 100.0, debug: bool = False, out: torch.Tensor | None = None):
@@ -285,9 +313,9 @@ def depth_refine(meshes: MeshSet, obj, coor_x, coor_y, coor_z, mask_raw, roi_dep
     b = obj.shape[0]
     t_out = out if out is not None else torch.empty((b, 3), dtype=torch.float64, device=obj.device)
     dbg = torch.zeros((b, iters, res, res), dtype=torch.float32, device=obj.device) if debug else None
-    if roi_depth.shape[-1] != 4 * res or roi_depth.shape[-2] != 4 * res:
-        raise RuntimeError(f"depth_refine: roi_depth is {tuple(roi_depth.shape[-2:])}, the kernel reads the INPUT_RES = 4 x "
-                           f"OUTPUT_RES crop ({4 * res} x {4 * res}) the way cv2.resize(..., ({res}, {res})) does")
+    if roi_depth.shape[-1] != roi_depth.shape[-2]:
+        raise RuntimeError(f"depth_refine: roi_depth must be square, got {tuple(roi_depth.shape[-2:])}")
+    ws, nbytes = _refine_workspace(meshes, b, obj.device)
     ev = None
     if _REFINE_EVENT_SINK is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -297,12 +325,42 @@ def depth_refine(meshes: MeshSet, obj, coor_x, coor_y, coor_z, mask_raw, roi_dep
         _dev(coor_y, torch.float32, "coor_y"), _dev(coor_z, torch.float32, "coor_z"),
         _dev(mask_raw, torch.float32, "mask"), _dev(roi_depth, torch.float32, "roi_depth"),
         _dev(K_crop, torch.float32, "K_crop"), _dev(R, torch.float32, "R"), _dev(t, torch.float32, "t"),
-        _dev(t_out, torch.float64, "t_out"), dbg.data_ptr() if debug else None, b, res, iters, float(threshold),
-        mask_type, 1 if use_coor_z else 0, z_near, z_far, _stream()), "gdrnpp_depth_refine")
+        _dev(t_out, torch.float64, "t_out"), dbg.data_ptr() if debug else None, b, res, int(roi_depth.shape[-1]), iters,
+        float(threshold), mask_type, 1 if use_coor_z else 0, z_near, z_far, ws.data_ptr() if ws is not None else None, nbytes,
+        _stream()), "gdrnpp_depth_refine")
     if ev is not None:
         ev[1].record()
         _REFINE_EVENT_SINK.append(ev)
     return (t_out, dbg) if debug else t_out
+
+
+def refine_to_records(meshes: MeshSet, obj, coor_x, coor_y, coor_z, mask_raw, roi_depth, cam, center, scale, R, t, score=None,
+                      roi_id=None, res: int = 64, iters: int = 2, threshold: float = 0.8, mask_type: int = 0,
+                      use_coor_z: bool = False, z_near: float = 0.1, z_far: float = 100.0):
+    """The refine configuration's post-processing tail in ONE launch (``gdrnpp_refine_to_records``): K_crop from cam /
+    center / scale, the depth refinement, and the f32[b,16] pose records."""
+    lib = load()
+    b = obj.shape[0]
+    rec = torch.empty((b, 16), dtype=torch.float32, device=obj.device)
+    if b == 0:
+        return rec
+    ws, nbytes = _refine_workspace(meshes, b, obj.device)
+    ev = None
+    if _REFINE_EVENT_SINK is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    _check(lib.gdrnpp_refine_to_records(
+        meshes.c, _dev(obj, torch.int32, "obj"), _dev(coor_x, torch.float32, "coor_x"), _dev(coor_y, torch.float32, "coor_y"),
+        _dev(coor_z, torch.float32, "coor_z"), _dev(mask_raw, torch.float32, "mask"), _dev(roi_depth, torch.float32, "roi_depth"),
+        _dev(cam, torch.float32, "cam"), _dev(center, torch.float32, "center"), _dev(scale, torch.float32, "scale"),
+        _dev(R, torch.float32, "R"), _dev(t, torch.float32, "t"), _dev(score, torch.float32, "score") if score is not None else None,
+        _dev(roi_id, torch.int32, "roi_id") if roi_id is not None else None, rec.data_ptr(), b, res, int(roi_depth.shape[-1]),
+        iters, float(threshold), mask_type, 1 if use_coor_z else 0, z_near, z_far, ws.data_ptr() if ws is not None else None,
+        nbytes, _stream()), "gdrnpp_refine_to_records")
+    if ev is not None:
+        ev[1].record()
+        _REFINE_EVENT_SINK.append(ev)
+    return rec
 
 
 _REFINE_EVENT_SINK = None
@@ -316,7 +374,7 @@ def set_refine_event_sink(sink):
 
 
 def refine_kernel_name() -> str:
-    return "depth_refine_staged_kernel"
+    return "depth_refine_kernel"
 
 
 def pack_pose_records(R, t_refined, t_net, score, obj_id, roi_id):

@@ -194,6 +194,15 @@ int gdrnpp_pose_from_pred_centroid_z(const float* rot6d, const float* t_,
                                      const float* whs, const float* resize_ratios,
                                      float* rot, float* trans, int b, int z_type,
                                      int is_allo, void* stream);
+/* the other ROT_TYPE / TRANS_TYPE variants of GDRN_double_mask.py:162-200 through the same kernel:
+ * rot_mode 0 = 6-d representation f32[b,6], 1 = quaternion (w,x,y,z) f32[b,4] (quat2mat_torch, pose_utils.py:349-400),
+ *          2 = rotation matrix f32[b,9];
+ * t_mode   0 = centroid_z with relative z, 1 = centroid_z with absolute z, 2 = centroid_z_abs (absolute 2-d centre and z,
+ *          pose_from_pred_centroid_z_abs.py:44-76; centers / whs / resize_ratios unused), 3 = trans (t_ is the translation,
+ *          pose_from_pred.py:25-27). */
+int gdrnpp_pose_from_pred(const float* rot_in, int rot_mode, const float* t_, int t_mode, const float* cams,
+                          const float* centers, const float* whs, const float* resize_ratios, float* rot, float* trans,
+                          int b, int is_allo, void* stream);
 
 /* ---- crop-resize intrinsics (a8.2) — camera_geometry.py:6-21 --------------
  * K f32[b,9], centers f32[b,2], scales f32[b] -> K_crop f32[b,9],
@@ -230,18 +239,32 @@ int gdrnpp_render_depth(const gdrnpp_meshes* meshes, const int* obj,
  * One workgroup per ROI runs all iterations (render -> query map -> threshold
  * -> median -> weighted centroid -> ray update) on chip.
  * coor_{x,y,z} f32[b,hw] normalised xyz maps; mask_raw f32[b,hw];
- * roi_depth f32[b,4*res,4*res] sensor depth crop (256x256 for res=64);
- * K_crop f32[b,9]; R f32[b,9]; t_in f32[b,3]; obj i32[b] -> t_out f64[b,3].
+ * roi_depth f32[b,in_res,in_res] sensor depth crop, in_res must be 4*res (256x256 for res=64: the kernel reads the 2x2
+ * centre of every 4x4 block like cv2.resize at scale 4; anything else is refused);
+ * K_crop f32[b,9]; R f32[b,9]; t_in f32[b,3]; obj i32[b] -> t_out f64[b,3].  An obj id outside [0, n_obj) leaves t = t_in.
  * mask_type as in gdrnpp_decode_correspondences; use_coor_z: TEST.USE_COOR_Z_REFINE.
- * debug_depth (f32[b,iters,hw]) receives each iteration's render or NULL. */
+ * debug_depth (f32[b,iters,hw]) receives each iteration's render or NULL.
+ * workspace: gdrnpp_depth_refine_workspace_bytes(meshes, b) — 0 unless a mesh has more than 4096 vertices (their
+ * transformed vertices are then staged in this workspace instead of LDS; same kernel, same arithmetic). */
+size_t gdrnpp_depth_refine_workspace_bytes(const gdrnpp_meshes* meshes, int b);
 int gdrnpp_depth_refine(const gdrnpp_meshes* meshes, const int* obj,
                         const float* coor_x, const float* coor_y,
                         const float* coor_z, const float* mask_raw,
                         const float* roi_depth, const float* K_crop,
                         const float* R, const float* t_in, double* t_out,
-                        float* debug_depth, int b, int res, int iters,
+                        float* debug_depth, int b, int res, int in_res, int iters,
                         float threshold, int mask_type, int use_coor_z,
-                        float z_near, float z_far, void* stream);
+                        float z_near, float z_far, void* workspace, size_t workspace_bytes, void* stream);
+/* The post-processing tail of the refine configuration in ONE launch: get_K_crop_resize (camera_geometry.py:6-21, from
+ * cam f32[b,9], center f32[b,2], scale f32[b] and OUTPUT_RES = res) -> the refinement above -> the f32[b,16] pose records
+ * R(9) | t(3, metres) | score | obj | roi_id | valid of gdrnpp_pack_pose_records (score / roi_id nullable; valid = 0 for
+ * an obj id outside the mesh set). */
+int gdrnpp_refine_to_records(const gdrnpp_meshes* meshes, const int* obj, const float* coor_x, const float* coor_y,
+                             const float* coor_z, const float* mask_raw, const float* roi_depth, const float* cam,
+                             const float* center, const float* scale, const float* R, const float* t_in,
+                             const float* score, const int* roi_id, float* rec, int b, int res, int in_res, int iters,
+                             float threshold, int mask_type, int use_coor_z, float z_near, float z_far, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* debug aid: PMC calibration stream — reads n floats with 4- or 16-byte lanes (a known byte count) */
 int gdrnpp_debug_stream_read(const float* p, size_t n, int lane_bytes, float* out_blocks,

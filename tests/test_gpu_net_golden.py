@@ -49,3 +49,34 @@ def test_hip_pose_matches_reference_forward(case):
     fx, out = case
     assert np.abs(out["rot"] - fx["rot"]).max() <= 1e-4
     assert np.abs(out["trans"] - fx["trans"]).max() <= 1e-4 * max(1.0, np.abs(fx["trans"]).max())
+
+
+def test_config_surface_variants_run_through_forward_and_post(hip):
+    """MASK_LOSS_TYPE="CE" (engine_utils.py:329-330), ROT_TYPE quaternion, TRANS_TYPE centroid_z_abs / trans
+    (GDRN_double_mask.py:162-200): build, forward, post-process — the decoded CE mask equals torch.argmax, poses are finite."""
+    from gdrnpp_bop2022_amd.gdrn_modeling.engine import GdrnHipPost
+
+    fx = NG.load_fixture("ycbv")
+    x = torch.from_numpy(NG.net_image()).cuda()
+    kw = NG.forward_kwargs(fx, "cuda")
+    for opts in (["MODEL.POSE_NET.LOSS_CFG.MASK_LOSS_TYPE=CE", "TEST.USE_PNP=True", "TEST.PNP_TYPE=net_iter_pnp"],
+                 ["MODEL.POSE_NET.PNP_NET.ROT_TYPE=ego_quat", "MODEL.POSE_NET.PNP_NET.TRANS_TYPE=trans"],
+                 ["MODEL.POSE_NET.PNP_NET.ROT_TYPE=allo_quat", "MODEL.POSE_NET.PNP_NET.TRANS_TYPE=centroid_z_abs"]):
+        cfg = get_cfg("ycbv_convnext_a6", opts=opts + ["TEST.SAVE_RESULTS_ONLY=True"])
+        torch.manual_seed(0)
+        model, _ = build_model_optimizer(cfg)
+        with torch.no_grad():
+            out = model(x, **kw)
+        assert torch.isfinite(out["rot"]).all() and torch.isfinite(out["trans"]).all()
+        R = out["rot"].double()
+        assert (R @ R.transpose(1, 2) - torch.eye(3, device="cuda", dtype=torch.float64)).abs().max().item() < 1e-5
+        if "CE" in opts[0]:
+            assert out["mask"].shape[1] == 2
+            post = GdrnHipPost(cfg)
+            batch = dict(roi_cam=kw["roi_cams"], roi_coord_2d=kw["roi_coord_2d"], roi_extent=kw["roi_extents"],
+                         im_W=torch.full((NG.B,), 640.0, device="cuda"), im_H=torch.full((NG.B,), 480.0, device="cuda"),
+                         roi_cls=kw["roi_classes"])
+            count, _, _, _, m = post.process_correspondences(batch, out)
+            assert torch.equal(m, torch.argmax(out["mask"], 1, keepdim=True).float())
+            rec = post.process(batch, out)
+            assert rec.shape == (NG.B, 16) and torch.isfinite(rec).all()

@@ -477,3 +477,77 @@ def test_paste_masks_rle_bit_exact(hip):
     rles = engine.mask_rles(cfg, batch, {"mask": raw})
     assert len(rles) == 4 and all(r["size"] == [H, W] and isinstance(r["counts"], str) for r in rles)
     assert 0 < M.rle_to_binary_mask(rles[0]).sum() < H * W
+
+
+def test_fused_tail_equals_the_three_launches(hip):
+    """gdrnpp_refine_to_records (K_crop + refinement + record packing in ONE launch) against zoom_K -> depth_refine ->
+    pack_pose_records: bitwise equal records; an object id outside the mesh set keeps the network translation and is
+    marked invalid instead of reading out of bounds."""
+    rng = np.random.default_rng(77)
+    verts, faces, ext = S.make_models(4, rng, 3)
+    b = 9
+    det = S.make_detections(b, 4, ext, rng)
+
+    def render_fn(obj, K, R, t, res):
+        d, x = zip(*[P.render_depth(verts[obj[i]], faces[obj[i]], K[i], R[i], t[i].astype(np.float64), res_w=res, want_xyz=True)
+                     for i in range(len(obj))])
+        return np.stack(d), np.stack(x)
+
+    maps = S.make_map_inputs(det, verts, faces, render_fn, rng)
+    meshes = hip.MeshSet(verts, faces)
+    obj = T(det["roi_cls"].astype(np.int32))
+    ids = torch.arange(100, 100 + b, dtype=torch.int32, device=DEV)
+    common = (T(maps["coor_x"]), T(maps["coor_y"]), T(maps["coor_z"]), T(maps["mask"]), T(maps["roi_depth"]))
+    K_crop = hip.zoom_K(T(det["roi_cam"]).reshape(b, 9), T(det["roi_center"]), T(det["scale"]), 64)
+    assert np.array_equal(K_crop.cpu().numpy().reshape(b, 3, 3), maps["K_crop"])
+    t_ref = hip.depth_refine(meshes, obj, *common, K_crop, T(det["R_gt"]).reshape(b, 9), T(maps["t_init"]))
+    rec3 = hip.pack_pose_records(T(det["R_gt"]).reshape(b, 9), t_ref, T(maps["t_init"]), T(det["score"]), obj, ids)
+    rec1 = hip.refine_to_records(meshes, obj, *common, T(det["roi_cam"]).reshape(b, 9), T(det["roi_center"]), T(det["scale"]),
+                                 T(det["R_gt"]).reshape(b, 9), T(maps["t_init"]), T(det["score"]), ids)
+    assert torch.equal(rec1, rec3)
+    bad = obj.clone()
+    bad[2] = 17
+    bad[5] = -1
+    rec_bad = hip.refine_to_records(meshes, bad, *common, T(det["roi_cam"]).reshape(b, 9), T(det["roi_center"]), T(det["scale"]),
+                                    T(det["R_gt"]).reshape(b, 9), T(maps["t_init"]), T(det["score"]), ids).cpu().numpy()
+    r1 = rec1.cpu().numpy()
+    for i in range(b):
+        if i in (2, 5):
+            assert rec_bad[i, 15] == 0 and np.array_equal(rec_bad[i, 9:12], maps["t_init"][i]) and rec_bad[i, 13] == bad[i].item()
+        else:
+            assert np.array_equal(rec_bad[i], r1[i])
+    with pytest.raises(RuntimeError, match="4 x"):
+        hip.depth_refine(meshes, obj, *common[:4], T(maps["roi_depth"][:, :, ::2, ::2].copy()), K_crop, T(det["R_gt"]).reshape(b, 9),
+                         T(maps["t_init"]))
+
+
+def test_pose_from_pred_variants(hip):
+    """ROT_TYPE quaternion and TRANS_TYPE centroid_z_abs / trans (GDRN_double_mask.py:162-200) through the one kernel, against
+    the reference's own formulas in torch: quat2mat_torch (pose_utils.py:349-400), pose_from_pred_centroid_z_abs.py:44-76,
+    pose_from_pred.py:25-27, with the allo -> ego step checked through the rot6d path (pinned by pyref_golden.npz)."""
+    torch.manual_seed(0)
+    b = 33
+    q = torch.randn(b, 4, device=DEV)
+    t_ = torch.randn(b, 3, device=DEV) * 0.3
+    t_[:, 2] = t_[:, 2].abs() + 0.5
+    cams = T(np.repeat(S.YCBV_K.reshape(1, 9), b, 0))
+    qn = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = qn.unbind(1)
+    Rq = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                      2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                      2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1).view(b, 3, 3)
+    R_ego, tr = hip.pose_from_pred(q, t_, cams, rot_mode="quat", t_mode="trans", is_allo=False)
+    assert torch.equal(tr, t_) and (R_ego - Rq).abs().max().item() < 2e-6
+    R_m, _ = hip.pose_from_pred(Rq.reshape(b, 9).contiguous(), t_, cams, rot_mode="mat", t_mode="trans", is_allo=False)
+    assert torch.equal(R_m, Rq)
+    # allocentric -> egocentric: the quaternion path and the matrix path agree with the rot6d path on the same rotation
+    d6 = torch.cat([Rq[:, :, 0], Rq[:, :, 1]], 1).contiguous()
+    Ra6, _ = hip.pose_from_pred(d6, t_, cams, rot_mode="rot6d", t_mode="trans", is_allo=True)
+    Raq, _ = hip.pose_from_pred(q, t_, cams, rot_mode="quat", t_mode="trans", is_allo=True)
+    assert (Ra6 - Raq).abs().max().item() < 5e-6
+    # centroid_z_abs: absolute centre (px) and depth
+    c = torch.rand(b, 3, device=DEV) * torch.tensor([640.0, 480.0, 1.0], device=DEV) + torch.tensor([0.0, 0.0, 0.4], device=DEV)
+    _, ta = hip.pose_from_pred(d6, c, cams, rot_mode="rot6d", t_mode="centroid_z_abs", is_allo=True)
+    K = cams.view(b, 3, 3)
+    want = torch.stack([c[:, 2] * (c[:, 0] - K[:, 0, 2]) / K[:, 0, 0], c[:, 2] * (c[:, 1] - K[:, 1, 2]) / K[:, 1, 1], c[:, 2]], 1)
+    assert torch.equal(ta, want)

@@ -1,14 +1,14 @@
 """Per-kernel time of the LAST timed bench step from a rocprofv3 --kernel-trace CSV (markdown on stdout).
 
 usage: step_breakdown.py <dir with *_kernel_trace.csv> [title]
-The last step is delimited by the last two depth_refine_staged_kernel launches (one per step)."""
+The last step is delimited by the last two depth_refine_kernel launches (one per step)."""
 import collections, csv, glob, sys
 
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "depth_refine_staged_kernel" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "depth_refine_kernel" in r["Kernel_Name"]]
 lo, hi = marks[-2] + 1, marks[-1] + 1
 step = rows[lo:hi]
 wall = (int(step[-1]["End_Timestamp"]) - int(rows[lo - 1]["End_Timestamp"])) / 1e6
@@ -24,5 +24,5 @@ print("| ms | calls | kernel |\n|---|---|---|")
 for k, (ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     if ms >= 0.05:
         print(f"| {ms:.3f} | {n} | `{k[:150]}` |")
-refine = [r for r in rows if "depth_refine_staged_kernel" in r["Kernel_Name"]]
-print("\ndepth_refine_staged_kernel launches (us):", [f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.1f}" for r in refine])
+refine = [r for r in rows if "depth_refine_kernel" in r["Kernel_Name"]]
+print("\ndepth_refine_kernel launches (us):", [f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.1f}" for r in refine])
