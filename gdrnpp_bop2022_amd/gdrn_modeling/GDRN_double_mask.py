@@ -94,9 +94,10 @@ class GDRN_DoubleMask(nn.Module):
         x = feat.reshape(bs, ch, h * wd)  # NCHW-logical [B,256,4096]; one copy if feat is channels-last
         out = torch.baddbmm(b[roi_classes].unsqueeze(-1), w[roi_classes], x)  # [B,70,4096]
         out = out.view(bs, -1, h, wd)
-        k = self.mask_out_dim
-        vis = out[:, 0:1]
-        full = out[:, 1:2] if k == 2 else None
+        k = self.mask_out_dim                      # channels of all masks of one class
+        m = k // 2 if self.double_mask else k      # channels per mask (2 for the CE flavour)
+        vis = out[:, 0:m]
+        full = out[:, m:2 * m] if self.double_mask else None
         return vis, full, out[:, k:k + 1], out[:, k + 1:k + 2], out[:, k + 2:k + 3], out[:, k + 3:]
 
     def forward_maps(self, x, roi_classes=None, roi_coord_2d=None, roi_coord_2d_rel=None, roi_extents=None):

@@ -176,16 +176,20 @@ class TopDownMaskXyzRegionHead(nn.Module):
 
     # ---- class-sliced output layer ------------------------------------
     def class_channel_index(self, num_classes: int) -> torch.Tensor:
-        """Rows of ``out_layer.weight`` that the class-aware gather of GDRN_double_mask.py:107-126
-        keeps for class c, in the order [vis, full, x, y, z, region(65)] -> i64[C, 70]."""
+        """Rows of ``out_layer.weight`` that the class-aware gather of GDRN_double_mask.py:107-126 keeps for class c, in the
+        order [vis(m), full(m), x, y, z, region(65)] -> i64[C, 2m + 3 + 65] (m = channels per mask: 1, or 2 for the CE
+        flavour; single-mask heads have no ``full`` block).  The reference views each block as (bs, C, k, h, w), i.e. class
+        c owns the k consecutive channels c*k .. c*k + k - 1 of its block; xyz is viewed (bs, 3, C, h, w) first."""
         C = num_classes
         assert self.xyz_out_dim == 3 and self.mask_num_classes == self.xyz_num_classes == self.region_num_classes == C
+        n_masks = 2 if self.double_mask else 1
+        m = self.mask_out_dim // n_masks
+        mask_dim = self.mask_out_dim * C
         rows = []
-        md = self.mask_out_dim  # 2 (double mask) or 1
         for c in range(C):
-            r = [k * C + c for k in range(md)]                       # vis (, full)
-            r += [md * C + k * C + c for k in range(3)]               # x, y, z
-            r += [md * C + 3 * C + c * self.region_out_dim + j for j in range(self.region_out_dim)]
+            r = [blk * m * C + c * m + j for blk in range(n_masks) for j in range(m)]     # vis (, full)
+            r += [mask_dim + k * C + c for k in range(3)]                                   # x, y, z
+            r += [mask_dim + 3 * C + c * self.region_out_dim + j for j in range(self.region_out_dim)]
             rows.append(r)
         return torch.tensor(rows, dtype=torch.long)
 

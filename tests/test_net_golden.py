@@ -157,3 +157,29 @@ def test_backbone_key_manifest_matches_published_timm_names(case):
     ds, fx, model, _ = case
     ours = {k[len("backbone."):]: tuple(v.shape) for k, v in model.state_dict().items() if k.startswith("backbone.")}
     assert ours == _timm067_convnext_keys()
+
+
+@pytest.mark.parametrize("name", ["GDRN_double_mask", "GDRN"])
+def test_class_sliced_output_layer_with_two_channel_ce_masks(name):
+    """MASK_LOSS_TYPE="CE" gives every mask two channels per class: the class-sliced output layer must pick the same
+    channels as the reference's view(bs, C, k, h, w)[arange, cls] gather (GDRN_double_mask.py:107-126)."""
+    hip_layers.set_enabled(False)
+    try:
+        torch.manual_seed(0)
+        cfg = get_cfg("icbin_convnext_a6", opts=["MODEL.DEVICE=cpu", "MODEL.POSE_NET.LOSS_CFG.MASK_LOSS_TYPE=CE", "TEST.USE_PNP=True",
+                                                 f"MODEL.POSE_NET.NAME={name}"] +
+                      (["MODEL.POSE_NET.GEO_HEAD.INIT_CFG.type=TopDownMaskXyzRegionHead"] if name == "GDRN" else []))
+        model, _ = build_model_optimizer(cfg)
+        torch.nn.init.normal_(model.geo_head_net.out_layer.weight, 0, 0.05)
+        torch.nn.init.normal_(model.geo_head_net.out_layer.bias, 0, 0.5)
+        x, cls = torch.rand(2, 3, 256, 256), torch.tensor([1, 0])
+        c2d, ext = torch.rand(2, 2, 64, 64), torch.rand(2, 3)
+        with torch.no_grad():
+            a = model.forward_maps(x, cls, c2d, None, ext)
+            model.exact_reference_order = True
+            b = model.forward_maps(x, cls, c2d, None, ext)
+        assert a[2]["mask"].shape == (2, 2, 64, 64) and set(a[2]) == set(b[2])
+        for k in a[2]:
+            assert (a[2][k] - b[2][k]).abs().max().item() <= 1e-5 * b[2][k].abs().max().item(), k
+    finally:
+        hip_layers.set_enabled(True)
