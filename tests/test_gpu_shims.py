@@ -23,7 +23,7 @@ def test_fps_utils_like_reference_call_site():
 
 
 def test_un_pnp_utils_like_pose_from_upnp():
-    """gdrn_evaluator.py:612-628 (pose_from_upnp) with the EPnP initialiser supplied by the caller."""
+    """gdrn_evaluator.py:612-628 (pose_from_upnp): caller-supplied initialiser and the default EPnP one."""
     from gdrnpp_bop2022_amd.core.csrc.uncertainty_pnp.un_pnp_utils import uncertainty_pnp, uncertainty_pnp_v2
 
     rng = np.random.default_rng(1)
@@ -49,8 +49,12 @@ def test_un_pnp_utils_like_pose_from_upnp():
     np.testing.assert_allclose(Rt[:, :3], R, atol=5e-2)
     Rt2 = uncertainty_pnp_v2(p2, cov, p3, K, init_rt=init)
     assert np.isfinite(Rt2).all()
-    with pytest.raises(RuntimeError, match="init_rt"):
-        uncertainty_pnp(p2, w, p3, K)  # cv2 absent: must not silently invent an initialiser
+    # reference call signature (no init_rt): EPnP on the four best-weighted points seeds the LM (un_pnp_utils.py:27-44) —
+    # the same optimum is reached from that start
+    Rt3 = uncertainty_pnp(p2, w, p3, K)
+    np.testing.assert_allclose(Rt3, Rt, atol=1e-5)
+    Rt4 = uncertainty_pnp_v2(p2, cov, p3, K)
+    np.testing.assert_allclose(Rt4, Rt2, atol=1e-5)
 
 
 def test_ransac_voting_layer_replays_reference_draw(golden_dir):
