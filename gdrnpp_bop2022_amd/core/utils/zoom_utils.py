@@ -13,25 +13,23 @@ def batch_crop_resize(x, rois, out_H, out_W, aligned=True, interpolation="biline
     return hip_lib.roi_align(x.contiguous(), rois.contiguous().float(), (out_H, out_W), 1.0, 0, aligned)
 
 
+_TO_CHW = {"HW": lambda a: a[None], "HWC": lambda a: np.moveaxis(a, 2, 0), "CHW": lambda a: a}
+
+
 def crop_resize_by_d2_roialign(img, center, scale, output_size, aligned=True, interpolation="bilinear",
                                in_format="HWC", out_format="HWC", dtype="float32", device="cuda"):
-    """img (np.ndarray) HWC/HW/CHW -> cropped + resized array (same conventions as the reference helper)."""
-    if isinstance(output_size, int):
-        output_size = (output_size, output_size)
-    output_size = (output_size[1], output_size[0])  # to (h, w)
-    assert in_format in ["HW", "HWC", "CHW"]
-    if in_format == "HW":
-        img = img[None]
-    elif in_format == "HWC":
-        img = img.transpose(2, 0, 1)
-    img_tensor = torch.as_tensor(np.ascontiguousarray(img[None]).astype("float32")).to(device)
-    cx, cy = center
-    if isinstance(scale, (int, float)):
-        scale = (scale, scale)
-    bw, bh = scale
-    rois = torch.as_tensor(np.array([0] + [cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], dtype="float32")[None])
-    result = batch_crop_resize(img_tensor, rois.to(device), output_size[0], output_size[1], aligned, interpolation)
-    result = result[0].cpu().numpy().astype(dtype)
-    if out_format == "HWC":
-        result = result.transpose(1, 2, 0)
-    return result
+    """Single-image convenience form of ``batch_crop_resize`` with the call surface of the reference helper
+    (core/utils/data_utils.py:65-112): a NumPy image in ``in_format``, a box given by its centre and (w, h) extent (a scalar
+    means a square), ``output_size`` an int or (w, h) -> the ROIAlign crop as a NumPy array in ``out_format``."""
+    out_w, out_h = (output_size, output_size) if np.isscalar(output_size) else output_size
+    box_w, box_h = (scale, scale) if np.isscalar(scale) else scale
+    if in_format not in _TO_CHW:
+        raise ValueError(f"in_format {in_format!r}: expected one of {sorted(_TO_CHW)}")
+    chw = np.ascontiguousarray(_TO_CHW[in_format](np.asarray(img)), np.float32)
+    half = 0.5 * np.array([box_w, box_h], np.float32)
+    c = np.asarray(center, np.float32)
+    roi = np.concatenate([[0.0], c - half, c + half]).astype(np.float32)[None]           # (image index, x1, y1, x2, y2)
+    crop = batch_crop_resize(torch.from_numpy(chw[None]).to(device), torch.from_numpy(roi).to(device), int(out_h), int(out_w),
+                             aligned, interpolation)[0]
+    out = crop.cpu().numpy().astype(dtype)
+    return np.moveaxis(out, 0, 2) if out_format == "HWC" else out

@@ -88,10 +88,23 @@ class GdrnHipPost:
             threshold=cfg.TEST.DEPTH_REFINE_THRESHOLD, mask_type=self.mask_type,
             use_coor_z=bool(cfg.TEST.USE_COOR_Z_REFINE), z_near=self.z_near, z_far=self.z_far)
 
-    def process_correspondences(self, batch: dict, out_dict: dict):
-        """2D-3D correspondences for the PnP variants (gdrn_evaluator.py:115-153,255-311), all ROIs at once."""
+    def process_correspondences(self, batch: dict, out_dict: dict, max_num_points: int = -1, generator=None):
+        """2D-3D correspondences for the PnP variants (gdrn_evaluator.py:115-153,255-311), all ROIs at once.
+        ``max_num_points >= 4`` keeps a uniformly random subset of that size per ROI, in random order (:146-152; the
+        reference shuffles with Python's unseeded ``random``, here a device permutation from ``generator``)."""
         imwh = torch.stack([batch["im_W"], batch["im_H"]], 1).float().contiguous()
         cx, cy, cz = coor_planes(self.cfg, out_dict)
+        if max_num_points >= 4:
+            count, sel_idx, img_pts, mdl_pts, m = self.process_correspondences(batch, out_dict)
+            b, hw = sel_idx.shape
+            keys = torch.rand((b, hw), device=count.device, generator=generator)
+            keys = torch.where(torch.arange(hw, device=count.device)[None] < count[:, None], keys, torch.full_like(keys, 2.0))
+            order = torch.argsort(keys, dim=1)[:, :max_num_points]                   # the first `count` entries are a permutation
+            take = lambda t: torch.gather(t, 1, order[..., None].expand(-1, -1, t.shape[2])).contiguous()  # noqa: E731
+            pad = hw - order.shape[1]
+            padded = lambda t: torch.cat([t, t.new_zeros((b, pad) + t.shape[2:])], 1).contiguous() if pad > 0 else t  # noqa: E731
+            return (torch.clamp(count, max=max_num_points), padded(torch.gather(sel_idx, 1, order)), padded(take(img_pts)),
+                    padded(take(mdl_pts)), m)
         return hip_lib.decode_correspondences(
             cx, cy, cz, self.mask_plane(out_dict), batch["roi_coord_2d"].contiguous(), batch["roi_extent"].contiguous(), imwh,
             mask_type=self.mask_type, mask_thr=self.cfg.MODEL.POSE_NET.GEO_HEAD.MASK_THR_TEST)
@@ -467,4 +480,8 @@ def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, dev
         im_H=torch.full((n,), float(H), device=dev), im_W=torch.full((n,), float(W), device=dev))
     if roi_depth is not None:
         batch["roi_depth"] = roi_depth
+    if net_cfg.PNP_NET.COORD_2D_TYPE == "rel":
+        # data_loader.py:799-804: (bbox_center - roi_coord_2d * (im_W, im_H)) / scale, float64 like NumPy, stored float32
+        wh = torch.tensor([float(W), float(H)], dtype=torch.float64, device=dev).view(1, 2, 1, 1)
+        batch["roi_coord_2d_rel"] = ((centers64.view(n, 2, 1, 1) - roi_c2d.double() * wh) / scales64.view(n, 1, 1, 1)).float()
     return batch

@@ -89,6 +89,43 @@ def test_batch_data_test_gpu_end_to_end(hip):
         assert np.array_equal(batch["roi_img"][i].cpu().numpy(), o_img)
         assert np.array_equal(batch["roi_depth"][i].cpu().numpy(), o_dep)
         assert np.array_equal(batch["roi_coord_2d"][i].cpu().numpy(), o_c2d)
+    # COORD_2D_TYPE = "rel" (data_loader.py:799-804): (bbox_center - roi_coord_2d * (W, H)) / scale in float64, stored float32
+    cfg_rel = get_cfg("ycbv_convnext_a6", ["MODEL.POSE_NET.PNP_NET.COORD_2D_TYPE=rel"])
+    b_rel = engine.batch_data_test_gpu(cfg_rel, torch.from_numpy(images).to(DEV), None, det)
+    for i in range(n):
+        want = ((r["bbox_center"][i].reshape(2, 1, 1) - batch["roi_coord_2d"][i].cpu().numpy() * np.array([640, 480]).reshape(2, 1, 1))
+                / r["scale"][i]).astype("float32")
+        assert np.array_equal(b_rel["roi_coord_2d_rel"][i].cpu().numpy(), want)
+
+
+def test_max_num_points_subsampling(hip):
+    """get_img_model_points_with_coords2d(max_num_points=k) (gdrn_evaluator.py:146-152): a random size-min(k, n) subset of
+    each ROI's correspondences, pairs kept together."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+
+    cfg = get_cfg("ycbv_convnext_a6")
+    post = engine.GdrnHipPost(cfg)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    b = 3
+    m = torch.full((b, 1, 64, 64), -1.0, device=DEV)
+    m[0, 0, 10:30, 10:30] = 1.0          # 400 points
+    m[1, 0, 5:7, 5:8] = 1.0              # 6 points
+    m[2, 0, 0, 0] = 1.0                  # 1 point
+    out = dict(coor_x=torch.rand(b, 1, 64, 64, device=DEV, generator=g) * 0.8 + 0.1, coor_y=torch.rand(b, 1, 64, 64, device=DEV, generator=g) * 0.8 + 0.1,
+               coor_z=torch.rand(b, 1, 64, 64, device=DEV, generator=g) * 0.3 + 0.6, mask=m)
+    batch = dict(roi_coord_2d=torch.rand(b, 2, 64, 64, device=DEV, generator=g), roi_extent=torch.full((b, 3), 0.1, device=DEV),
+                 im_W=torch.full((b,), 640.0, device=DEV), im_H=torch.full((b,), 480.0, device=DEV))
+    c0, s0, i0, m0, _ = post.process_correspondences(batch, out)
+    c1, s1, i1, m1, _ = post.process_correspondences(batch, out, max_num_points=50, generator=g)
+    assert c0.tolist() == [400, 6, 1] and c1.tolist() == [50, 6, 1]
+    for r_ in range(b):
+        full = {int(s): (i0[r_, k].tolist(), m0[r_, k].tolist()) for k, s in enumerate(s0[r_, :c0[r_]].tolist())}
+        picked = s1[r_, :c1[r_]].tolist()
+        assert len(set(picked)) == len(picked) and set(picked) <= set(full)
+        for k, s in enumerate(picked):
+            assert (i1[r_, k].tolist(), m1[r_, k].tolist()) == full[s]
+    assert s1[0, :50].tolist() != sorted(s1[0, :50].tolist())      # shuffled, not the first 50 in raster order
 
 
 def test_detector_output_to_pose_records_on_device(hip):
