@@ -46,6 +46,12 @@ int gdrnpp_debug_stream_read(const float* p, size_t n, int lane_bytes, float* ou
     hipLaunchKernelGGL(stream_read_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, out_blocks);
   return gdrnpp::check_launch("gdrnpp_debug_stream_read");
 }
+int gdrnpp_copy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+  if (bytes == 0) return 0;
+  GDRNPP_REQUIRE(dst && src, GDRNPP_EINVAL, "gdrnpp_copy_d2d: null pointer");
+  GDRNPP_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
 int gdrnpp_set_option(const char* name, int value) {
   GDRNPP_REQUIRE(name, GDRNPP_EINVAL, "gdrnpp_set_option: null name");
   if (!strcmp(name, "split_gemm_glds")) { gdrnpp::g_opt_glds = value != 0; return 0; }

@@ -37,6 +37,7 @@ _P = c_void_p
 SIGNATURES = {
     "gdrnpp_version": (c_int, []),
     "gdrnpp_set_option": (c_int, [ctypes.c_char_p, c_int]),
+    "gdrnpp_copy_d2d": (c_int, [_P, _P, c_size_t, _P]),
     "gdrnpp_epnp_ransac_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gdrnpp_epnp_ransac": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_int, ctypes.c_float, ctypes.c_double, _P, _P, _P, _P, _P,
                                    c_int, _P, c_size_t, _P]),
@@ -113,6 +114,14 @@ def load(path: str | None = None) -> ctypes.CDLL:
     if path is None:
         _lib = lib
     return lib
+
+
+def copy_d2d(dst_ptr: int, src: torch.Tensor) -> None:
+    """Copy a contiguous device tensor into a raw device pointer on the current stream (``gdrnpp_copy_d2d``)."""
+    if not src.is_cuda or not src.is_contiguous():
+        raise RuntimeError("copy_d2d: src must be a contiguous CUDA(HIP) tensor")
+    _check(load().gdrnpp_copy_d2d(c_void_p(int(dst_ptr)), src.data_ptr(), src.numel() * src.element_size(), _stream()),
+           "gdrnpp_copy_d2d")
 
 
 def set_option(name: str, value: int) -> None:

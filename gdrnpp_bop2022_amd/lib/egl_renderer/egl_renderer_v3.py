@@ -13,6 +13,10 @@ import torch
 
 from ... import hip_lib
 from ..pysixd.inout import load_ply
+from . import CppEGLRenderer
+
+# attachment numbering of the reference's framebuffer (egl_renderer_v3.py:205-262)
+COLOR_TEX, COLOR_TEX_2, COLOR_TEX_3, COLOR_TEX_4, COLOR_TEX_5 = 1, 2, 3, 4, 5
 
 
 class EGLRenderer:
@@ -25,6 +29,10 @@ class EGLRenderer:
         if height != width or height > 128:
             raise NotImplementedError("the LDS z-buffer rasteriser renders square maps up to 128x128 (GDRN uses 64x64)")
         self.device = torch.device(device if gpu_id is None else f"cuda:{gpu_id}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.r = CppEGLRenderer.CppEGLRenderer(int(width), int(height), self.device.index)      # egl_renderer_v3.py:93-94
+        self.r.init()
         self.meshes = hip_lib.MeshSet([np.asarray(m["pts"], np.float32) for m in models],
                                       [np.asarray(m["faces"], np.int32) for m in models], device=self.device)
         self.height = self.width = int(height)
@@ -52,21 +60,30 @@ class EGLRenderer:
         zmin, who = far.min(0)                       # nearest object per pixel
         hit = torch.isfinite(zmin)
         z = torch.where(hit, zmin, torch.zeros_like(zmin))
+        # the rasteriser fills the attachments; the caller's tensors receive them through the class boundary of the
+        # reference — map_tensor, then the row flip of egl_renderer_v3.py:1196-1225
+        hitf = hit.float()
         if pc_obj_tensor is not None:
             sel = xyz.gather(0, who[None, :, :, None].expand(1, res, res, 3))[0]
-            pc_obj_tensor[:, :, :3] = torch.where(hit[..., None], sel, torch.zeros_like(sel))
-            pc_obj_tensor[:, :, 3] = hit.float()
+            self.r.write_attachment(COLOR_TEX_4, torch.cat([torch.where(hit[..., None], sel, torch.zeros_like(sel)), hitf[..., None]], 2))
+            self.r.map_tensor(COLOR_TEX_4, self.width, self.height, pc_obj_tensor.data_ptr())
+            pc_obj_tensor.data = torch.flip(pc_obj_tensor, (0,))
         if pc_cam_tensor is not None:
             jj, ii = torch.meshgrid(torch.arange(res, device=dev, dtype=torch.float32),
                                     torch.arange(res, device=dev, dtype=torch.float32), indexing="ij")
-            pc_cam_tensor[:, :, 0] = (ii + 0.5 - float(K[0, 2])) / float(K[0, 0]) * z
-            pc_cam_tensor[:, :, 1] = (jj + 0.5 - float(K[1, 2])) / float(K[1, 1]) * z
-            pc_cam_tensor[:, :, 2] = z
-            pc_cam_tensor[:, :, 3] = hit.float()
+            cam = torch.stack([(ii + 0.5 - float(K[0, 2])) / float(K[0, 0]) * z, (jj + 0.5 - float(K[1, 2])) / float(K[1, 1]) * z,
+                               z, hitf], 2)
+            self.r.write_attachment(COLOR_TEX_5, cam)
+            self.r.map_tensor(COLOR_TEX_5, self.width, self.height, pc_cam_tensor.data_ptr())
+            pc_cam_tensor.data = torch.flip(pc_cam_tensor, (0,))
         if seg_tensor is not None:
             ids = torch.tensor(obj_ids, dtype=torch.float32, device=dev)[who] + 1
-            seg_tensor[:, :, 0] = torch.where(hit, ids, torch.zeros_like(ids))
+            seg = torch.zeros((res, res, 4), dtype=torch.float32, device=dev)
+            seg[:, :, 0] = torch.where(hit, ids, torch.zeros_like(ids))
+            self.r.write_attachment(COLOR_TEX_3, seg)
+            self.r.map_tensor(COLOR_TEX_3, self.width, self.height, seg_tensor.data_ptr())
+            seg_tensor.data = torch.flip(seg_tensor, (0,))
         return z
 
     def close(self):
-        pass
+        self.r.release()

@@ -266,6 +266,10 @@ int gdrnpp_refine_to_records(const gdrnpp_meshes* meshes, const int* obj, const 
                              float threshold, int mask_type, int use_coor_z, float z_near, float z_far, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* device-to-device copy into a raw device pointer on `stream` — the transfer CppEGLRenderer::map_tensor performs with
+ * cudaMemcpy2DFromArray in the reference (lib/egl_renderer/cpp/egl_renderer.cpp:262-298): attachment -> caller's tensor */
+int gdrnpp_copy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+
 /* debug aid: PMC calibration stream — reads n floats with 4- or 16-byte lanes (a known byte count) */
 int gdrnpp_debug_stream_read(const float* p, size_t n, int lane_bytes, float* out_blocks,
                              int blocks, void* stream);
