@@ -6,7 +6,7 @@ def collect(d, counter):
     vals = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "gemm_split_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if "gemm_split" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"]))
     return vals
 

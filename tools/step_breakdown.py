@@ -1,7 +1,8 @@
 """Per-kernel time of the LAST timed bench step from a rocprofv3 --kernel-trace CSV (markdown on stdout).
 
 usage: step_breakdown.py <dir with *_kernel_trace.csv> [title]
-The last step is delimited by the last two depth_refine_kernel launches (one per step)."""
+A step is delimited by two consecutive depth_refine_kernel launches (one per step); the last pair that encloses a full
+forward is taken (bench.py ends with a few post-processing-only timing launches, which enclose nothing)."""
 import collections, csv, glob, sys
 
 rows = []
@@ -9,7 +10,8 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "depth_refine_kernel" in r["Kernel_Name"]]
-lo, hi = marks[-2] + 1, marks[-1] + 1
+pair = max(range(len(marks) - 1), key=lambda i: (50 < marks[i + 1] - marks[i] < 400, i))   # last pair with ONE forward in between
+lo, hi = marks[pair] + 1, marks[pair + 1] + 1
 step = rows[lo:hi]
 wall = (int(step[-1]["End_Timestamp"]) - int(rows[lo - 1]["End_Timestamp"])) / 1e6
 agg = collections.defaultdict(lambda: [0.0, 0])
