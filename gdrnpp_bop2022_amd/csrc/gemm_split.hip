@@ -24,28 +24,15 @@
 //   LDS image per operand: [split][k-block of 8][row] 16-byte slots, plane pitch 132 slots: the 32 lanes of a
 //      ds_read_b128 lane group read 32 consecutive slots (conflict-free), a fragment is one ds_read_b128;
 //   per k-tile: 12 fragment reads (ds_read_b128) feed 24 MFMAs.
-#include "common.hpp"
+#include "gemm_split.hpp"
 
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-using f32x4v = __attribute__((ext_vector_type(4))) float;
-using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using namespace gdrnpp::splitgemm;
 
 #ifndef SPLIT_OCC
 #define SPLIT_OCC 2
 #endif
-
-constexpr int BM = 128, BN = 128, BK = 16, KB = BK / 8, PLANE = BM + 4;
-constexpr int OPER_SLOTS = 3 * KB * PLANE;  // uint4 slots per operand image
-constexpr int W_TILE_SLOTS = 3 * KB * BN;   // uint4 slots of one packed 128x16 weight tile
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_SCALE_RES = 2 };
-
-// exact-erf GELU (ocml erff).  A 23-instruction fitted erf was tried in its place: no measurable change end to end
-// (3071 vs 3077 ROIs/s on one box) — the epilogue's VALU work already overlaps other waves' MFMAs — so it was dropped.
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 // two fp32 -> three packed bf16 pairs with x = h + m + l exactly
 struct Split3 { unsigned h, m, l; };
@@ -76,12 +63,6 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, uint4* __restric
   img[(2 * KB + kb) * BN + row] = make_uint4(p0.l, p1.l, p2.l, p3.l);
 }
 
-// CONV: A is an NHWC image [.,H,W,Cin] and the GEMM row m = output pixel, k = (tap, channel) of a KHxKW convolution with
-// stride and symmetric zero padding (implicit im2col: the k-tile's 16 channels of one tap are 64 contiguous bytes per
-// pixel).  Every row keeps a pointer to its anchor input pixel (oy*stride, ox*stride), which is always inside the image.
-// H, W, C: input image; OH, OW: output image; KW x (K / (KW*C)) taps, stride, zero padding `pad` on every side.
-// nk_split > 0: split-K (linear only), blockIdx.y-th chunk of nk_split k-tiles -> partial C
-struct ConvGeom { int H, W, C, OH, OW, KW, stride, pad; int nk_split; };
 
 // MI = 32-row MFMA tiles per wave along M: 2 -> 128x128 block tile (three workgroups per CU), 4 -> 256x128 block tile
 // (each wave 128x64: 18 fragment reads feed 48 MFMAs per k-tile and per barrier, two workgroups per CU).
@@ -199,9 +180,9 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[s][j] = __builtin_bit_cast(bf16x8, b[s * KB * PLANE + j * 32]);
     }
-    // smallest partial products first; the accumulators rotate so no MFMA waits on its predecessor
-    constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+    // product order shared by all split-GEMM kernels (gemm_split.hpp); the accumulators rotate so no MFMA waits on
+    // its predecessor
+    GDRNPP_SPLIT_PRODUCT_ORDER
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
 #pragma unroll
@@ -395,8 +376,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_glds_kernel(const float* __
     for (int s = 0; s < 3; ++s)
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[s][j] = __builtin_bit_cast(bf16x8, b[s * KB * BN + j * 32]);
-    constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+    GDRNPP_SPLIT_PRODUCT_ORDER
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const Split3 p0 = split_pair(ra[i][0].x, ra[i][0].y), p1 = split_pair(ra[i][0].z, ra[i][0].w);
@@ -490,6 +470,10 @@ int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const f
   // 128x128 tiles at three workgroups per CU); gdrnpp_set_option("split_gemm_mi4", 0/1) forces the choice (A/B).
   const int force = gdrnpp::option_split_gemm_mi4();
   const bool big = force >= 0 ? force == 1 : tiles256 >= 512;
+  if (big && gdrnpp::option_split_gemm_pipe() && (!CONV || gdrnpp::option_split_gemm_pipe_conv())) {   // software-pipelined LDS-DMA kernel
+    const int rc = launch_split_pipe(A, Wp, bias, gamma, resid, C, M, N, K, EPI, CONV, cg, gdrnpp::option_split_gemm_pipe(), st, what);
+    if (rc >= 0) return rc;
+  }
   if (big && gdrnpp::option_split_gemm_glds()) {   // LDS-DMA kernel: any M, any of the three A forms
     if (CONV && fast3x3) hipLaunchKernelGGL((gemm_split_glds_kernel<EPI, CONV ? 1 : 0>), dim3((unsigned)tiles256), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
     else hipLaunchKernelGGL((gemm_split_glds_kernel<EPI, CONV ? 2 : 0>), dim3((unsigned)tiles256), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);

@@ -1,0 +1,373 @@
+// Software-pipelined LDS-DMA form of the split GEMM (gemm_split.hip explains the numerical scheme) — SURVEY.md §8 row a3.
+//
+// Same tile as gemm_split_glds_kernel: 256x128x16 block tile, 4 waves stacked along M (each 64 rows x 128 columns = 2 x 4
+// MFMA 32x32x16 tiles, 48 MFMAs per k-tile), fp32 A by LDS-DMA with the swizzled lane-linear image, pre-packed weights by
+// LDS-DMA, exact 3-way bf16 split of A at fragment-read time.  What changes is the instruction stream of one wave:
+//
+//   * register-level software pipeline: while the matrix pipe works on k-tile t (A fragments already split, in registers),
+//     the same wave reads the raw fp32 A of k-tile t+1 from LDS and splits it, two VALU operations per MFMA slot; the glds
+//     kernel splits a whole k-tile (72 VALU operations, v_pk_add_f32 among them) in front of its first MFMA;
+//   * the split subtracts with v_sub_f32 (this file is built with -fno-slp-vectorize): packed fp32 VALU beside MFMAs costs
+//     more than the two scalar operations it replaces (MI355X_MICROARCH.md, per-instruction constants);
+//   * weight fragments are read just in time, one split set (4 x ds_read_b128) ahead of the product group that uses it; the
+//     product order groups by weight split (gemm_split.hpp) so two sets (32 VGPRs) are live instead of three;
+//   * A stages are private to a wave (a wave stages exactly the rows it consumes), so with NA = 3 stages the A DMA runs two
+//     k-tiles ahead: the wait in front of the barrier is a counted vmcnt(4) that leaves the newest four A pieces in flight;
+//     weights (L2-resident) stay one k-tile ahead in two stages;
+//   * A is addressed as SGPR base + 32-bit lane offset (linear form): no per-lane pointer arithmetic in the loop;
+//   * the schedule is pinned slot by slot with sched_barrier(0): slot = one MFMA + its share of the other work.
+//
+// LDS: NA x 16 KB (A, fp32) + 2 x 12 KB (weights) = 56 / 72 KB dynamic, two workgroups per CU.
+// Results are bitwise equal to the other split-GEMM kernels (same products, same order per accumulator).
+#include "gemm_split.hpp"
+
+namespace {
+
+using namespace gdrnpp::splitgemm;
+
+constexpr int A_STAGE_B = 256 * BK * 4;       // fp32 A image of one k-tile: 16 KB
+constexpr int B_STAGE_B = W_TILE_SLOTS * 16;  // packed weight tile image: 12 KB
+
+__device__ __attribute__((aligned(64))) float g_pipe_zero_page[16];
+
+// LDS-DMA pieces (1 KiB per wave): M0 = LDS destination, written in the statement that uses it (cdna_hip_programming.md
+// §5.7).  hipcc does not count these loads: the kernel waits for them itself with counted vmcnt.
+// (No instruction offset: on an LDS-DMA load the immediate moves the LDS destination as well as the source address.)
+__device__ __forceinline__ void dma_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ void dma_v(const void* gsrc, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < E) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, E>(f);
+  }
+}
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// One half of a wave's A tile for one k-tile: 32 rows x 16 k, 8 consecutive k of one row per lane (two 16-byte chunks).
+// x = h + m + l exactly (h = rn(x), m = rn(x - h), l = x - h - m), produced in 22 steps of two VALU operations so that the
+// work can be spread over the MFMA slots of the previous k-tile.
+struct HalfSplit {
+  float x[8], r[8];
+  unsigned h[4], m[4], l[4];
+
+  template <int S>
+  __device__ __forceinline__ void step() {
+    if constexpr (S < 2) {
+      h[2 * S] = cvt_pk_bf16(x[4 * S], x[4 * S + 1]);
+      h[2 * S + 1] = cvt_pk_bf16(x[4 * S + 2], x[4 * S + 3]);
+    } else if constexpr (S < 10) {
+      constexpr int e = S - 2, p = e >> 1;
+      r[e] = x[e] - __uint_as_float((e & 1) ? (h[p] & 0xffff0000u) : (h[p] << 16));
+    } else if constexpr (S < 12) {
+      constexpr int q = S - 10;
+      m[2 * q] = cvt_pk_bf16(r[4 * q], r[4 * q + 1]);
+      m[2 * q + 1] = cvt_pk_bf16(r[4 * q + 2], r[4 * q + 3]);
+    } else if constexpr (S < 20) {
+      constexpr int e = S - 12, p = e >> 1;
+      r[e] = r[e] - __uint_as_float((e & 1) ? (m[p] & 0xffff0000u) : (m[p] << 16));
+    } else {
+      constexpr int q = S - 20;
+      l[2 * q] = cvt_pk_bf16(r[4 * q], r[4 * q + 1]);
+      l[2 * q + 1] = cvt_pk_bf16(r[4 * q + 2], r[4 * q + 3]);
+    }
+  }
+  __device__ __forceinline__ void load(const uint4* lds, int slot0, int slot1) {
+    const float4 a = __builtin_bit_cast(float4, lds[slot0]), b = __builtin_bit_cast(float4, lds[slot1]);
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+    x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+  }
+  template <int SPLIT>
+  __device__ __forceinline__ bf16x8 frag() const {
+    const unsigned* s = SPLIT == 0 ? h : SPLIT == 1 ? m : l;
+    return __builtin_bit_cast(bf16x8, make_uint4(s[0], s[1], s[2], s[3]));
+  }
+};
+
+// CONV: 0 = linear (A row-major [M,K]), 1 = 3x3 / stride 1 / pad 1 convolution over an NHWC image (implicit im2col)
+// NA: A stages (2: one k-tile ahead, 3: two k-tiles ahead)
+template <int EPI, int CONV, int NA>
+__global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __restrict__ A, const uint4* __restrict__ Wp,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ resid, float* __restrict__ C,
+                                                                 int M, int N, int K, ConvGeom cg) {
+  extern __shared__ uint4 smem[];  // the only LDS object: [NA][1024] A slots | [2][768] weight slots
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = N / BN;
+  // XCD-aware tile order, as in gemm_split.hip
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int tile_m = tile / ntn, tile_n = tile % ntn;
+  const int m0 = tile_m * 256, n0 = tile_n * BN;
+  const int nk = K / BK;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+
+  // ---- DMA lanes: piece c (0..3) of this wave fills A slots (wave*4 + c)*64 + lane = rows wave*64 + c*16 + lane/4, chunk
+  // q = (lane & 3) ^ ((row >> 2) & 3) of the row's 64-byte k segment (the swizzle is on the source address)
+  const int prow = lane >> 2, pq = lane & 3;
+  unsigned aoff[4];        // linear: byte offset of the lane's chunk from A + kt*64
+  const float* ap[4];      // conv: anchor pixel of the lane's row (+ chunk)
+  unsigned okmask[4];      // conv: bit tap = the tap lies inside the image
+  int cpt = 1;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int lrow = wave * 64 + c * 16 + prow;
+    const int q = pq ^ ((lrow >> 2) & 3);
+    const int arow = min(m0 + lrow, M - 1);
+    if constexpr (CONV) {
+      const int img = arow / (cg.H * cg.W), pp = arow - img * (cg.H * cg.W);
+      const int iy = pp / cg.W, ix = pp - iy * cg.W;
+      ap[c] = A + ((size_t)arow) * cg.C + q * 4;
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        if ((unsigned)(iy + dy) < (unsigned)cg.H && (unsigned)(ix + dx) < (unsigned)cg.W) mk |= 1u << t;
+      }
+      okmask[c] = mk;
+      aoff[c] = 0;
+    } else {
+      aoff[c] = (unsigned)arow * (unsigned)(K * 4) + (unsigned)(q * 16);
+      ap[c] = nullptr;
+      okmask[c] = 0;
+    }
+  }
+  if constexpr (CONV) cpt = cg.C / BK;
+  const unsigned boff = (unsigned)((wave * 3) * 64 + lane) * 16u;
+  const char* const wbase = reinterpret_cast<const char*>(Wp + (size_t)tile_n * nk * W_TILE_SLOTS);
+  const unsigned ldsA = lds0 + (unsigned)(wave * 4) * 1024u;
+  const unsigned ldsB = lds0 + (unsigned)(NA * A_STAGE_B) + (unsigned)(wave * 3) * 1024u;
+
+  // piece c of the A image of k-tile kt -> stage byte offset sb
+  auto dma_a = [&](int kt, unsigned sb, auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if constexpr (CONV) {
+      const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+      const int ky = tap / 3, dy = ky - 1, dx = tap - ky * 3 - 1;
+      const long off = ((long)dy * cg.W + dx) * cg.C + c0;
+      const bool ok = (okmask[c] >> tap) & 1u;
+      dma_v(ok ? (const void*)(ap[c] + off) : (const void*)g_pipe_zero_page, ldsA + sb + c * 1024u);
+    } else {
+      dma_s(aoff[c], reinterpret_cast<const char*>(A) + (size_t)kt * (BK * 4), ldsA + sb + c * 1024u);
+    }
+  };
+  auto dma_b = [&](int kt, unsigned sb, auto cc) {
+    constexpr int c = decltype(cc)::value;
+    dma_s(boff, wbase + ((size_t)kt * B_STAGE_B + c * 1024), ldsB + sb + c * 1024u);
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- fragment lanes: MFMA operand lane = row/column (lane & 31), k-block fk = lane >> 5
+  const int frow = lane & 31, fk = lane >> 5;
+  const int lrow0 = wave * 64 + frow, g0 = (lrow0 >> 2) & 3;  // rows +32 (second half) have the same swizzle
+  const int aslot0 = 4 * lrow0 + ((2 * fk) ^ g0), aslot1 = 4 * lrow0 + ((2 * fk + 1) ^ g0);
+  const uint4* const sA = smem;
+  const uint4* const sBf = smem + NA * (A_STAGE_B / 16) + fk * BN + frow;
+
+  auto load_half = [&](HalfSplit& hs, int stage, int half) {
+    hs.load(sA + stage * (A_STAGE_B / 16) + half * 128, aslot0, aslot1);
+  };
+
+  // One k-tile.  cur: split A fragments of k-tile kt (registers); nxt: receives the split of k-tile kt+1 (the raw first half
+  // is already in nxt[0].x).  fbX holds the weight split l of kt on entry, then its split h; fbY its split m, then the
+  // split l of kt+1 (the two sets swap roles from one k-tile to the next).  BS: weight stage of kt (compile-time parity).
+  // sa1 / sa2 / sa_wr: A stages of kt+1, of kt+2, and the one receiving kt+NA (= the stage kt has left).
+  // The wait + barrier that publishes k-tile kt+1 sits behind slot 39: the last eight MFMAs need no new data and run while
+  // the first fragments of kt+1 (weight split l, raw A of kt+2's first half) come out of LDS.
+  auto ktile = [&](int kt, HalfSplit (&cur)[2], HalfSplit (&nxt)[2], bf16x8 (&fbX)[4], bf16x8 (&fbY)[4], auto bs_, int sa1,
+                   int sa2, int sa_wr) {
+    constexpr int BS = decltype(bs_)::value;
+    const uint4* const b = sBf + BS * (B_STAGE_B / 16);
+    const uint4* const bn = sBf + (BS ^ 1) * (B_STAGE_B / 16);
+    const int kt_b = min(kt + 1, nk - 1), kt_a = min(kt + NA, nk - 1);
+    const unsigned sb_wr = (unsigned)((BS ^ 1) * B_STAGE_B), sa_wr_b = (unsigned)(sa_wr * A_STAGE_B);
+    static_for<0, 48>([&](auto s_) {
+      constexpr int S = decltype(s_)::value;
+      constexpr int G = S / 8, I = (S % 8) >> 2, J = S & 3;
+      GDRNPP_SPLIT_PRODUCT_ORDER
+      constexpr int SA_ = TA[G], SB_ = TB[G];
+      const bf16x8 fa = cur[I].template frag<SA_>();
+      const bf16x8 fb = (SB_ == 1) ? fbY[J] : fbX[J];
+      acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[I][J], 0, 0, 0);
+      // weight DMA of k-tile kt+1, then A DMA of k-tile kt+NA (the A pieces are the newest four loads at the wait)
+      if constexpr (S == 0) dma_b(kt_b, sb_wr, std::integral_constant<int, 0>{});
+      if constexpr (S == 2) dma_b(kt_b, sb_wr, std::integral_constant<int, 1>{});
+      if constexpr (S == 4) dma_b(kt_b, sb_wr, std::integral_constant<int, 2>{});
+      if constexpr (S == 6) dma_a(kt_a, sa_wr_b, std::integral_constant<int, 0>{});
+      if constexpr (S == 8) dma_a(kt_a, sa_wr_b, std::integral_constant<int, 1>{});
+      if constexpr (S == 10) dma_a(kt_a, sa_wr_b, std::integral_constant<int, 2>{});
+      if constexpr (S == 12) dma_a(kt_a, sa_wr_b, std::integral_constant<int, 3>{});
+      // weight split m for groups 1-2 (slots 8..23), weight split h for groups 3-5 (slots 24..47; reuses the l registers)
+      if constexpr (S == 1 || S == 3) {
+        constexpr int j0 = S - 1;
+        fbY[j0] = __builtin_bit_cast(bf16x8, b[1 * KB * BN + j0 * 32]);
+        fbY[j0 + 1] = __builtin_bit_cast(bf16x8, b[1 * KB * BN + (j0 + 1) * 32]);
+      }
+      if constexpr (S == 9 || S == 11) {
+        constexpr int j0 = S - 9;
+        fbX[j0] = __builtin_bit_cast(bf16x8, b[j0 * 32]);
+        fbX[j0 + 1] = __builtin_bit_cast(bf16x8, b[(j0 + 1) * 32]);
+      }
+      if constexpr (S == 19) load_half(nxt[1], sa1, 1);
+      // split of the next k-tile: first half in slots 4..25, second half in slots 26..47
+      if constexpr (S >= 4 && S < 26) nxt[0].template step<S - 4>();
+      if constexpr (S >= 26) nxt[1].template step<S - 26>();
+      if constexpr (S == 39) {
+        wait_vmcnt<NA == 3 ? 4 : 0>();
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): every LDS read of the stages about to be refilled has returned
+        __builtin_amdgcn_s_barrier();
+      }
+      // behind the barrier: first fragments of k-tile kt+1 (its weight split l; fbY's split m is dead since slot 23) and the
+      // raw first half of k-tile kt+2 (cur[0] is nxt[0] of the next k-tile; only cur[0].h is still in use)
+      if constexpr (S == 40 || S == 41) {
+        constexpr int j0 = 2 * (S - 40);
+        fbY[j0] = __builtin_bit_cast(bf16x8, bn[2 * KB * BN + j0 * 32]);
+        fbY[j0 + 1] = __builtin_bit_cast(bf16x8, bn[2 * KB * BN + (j0 + 1) * 32]);
+      }
+      if constexpr (S == 42) load_half(cur[0], sa2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // ---- prologue: k-tiles 0 .. NA-1 of A and k-tile 0 of the weights; split k-tile 0; first fragments of the loop
+  static_for<0, 4>([&](auto c) { dma_a(0, 0u, c); });
+  static_for<0, 3>([&](auto c) { dma_b(0, 0u, c); });
+  static_for<0, 4>([&](auto c) { dma_a(min(1, nk - 1), (unsigned)A_STAGE_B, c); });
+  if constexpr (NA == 3) static_for<0, 4>([&](auto c) { dma_a(min(2, nk - 1), 2u * A_STAGE_B, c); });
+  wait_vmcnt<NA == 3 ? 4 : 0>();
+  __builtin_amdgcn_s_barrier();
+  HalfSplit f0[2], f1[2];
+  bf16x8 fbA[4], fbB[4];
+  load_half(f0[0], 0, 0);
+  load_half(f0[1], 0, 1);
+  static_for<0, 22>([&](auto s) { f0[0].template step<decltype(s)::value>(); f0[1].template step<decltype(s)::value>(); });
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fbA[j] = __builtin_bit_cast(bf16x8, sBf[2 * KB * BN + j * 32]);
+  load_half(f1[0], 1, 0);
+
+  // ---- main loop, two k-tiles per trip (nk is even: K % 32 == 0)
+  int sa = 0;  // kt % NA
+  for (int kt = 0; kt < nk; kt += 2) {
+    const int sa1 = sa + 1 == NA ? 0 : sa + 1, sa2 = sa1 + 1 == NA ? 0 : sa1 + 1, sa3 = sa2 + 1 == NA ? 0 : sa2 + 1;
+    ktile(kt, f0, f1, fbA, fbB, std::integral_constant<int, 0>{}, sa1, sa2, sa);
+    ktile(kt + 1, f1, f0, fbB, fbA, std::integral_constant<int, 1>{}, sa2, sa3, sa1);
+    sa = sa2;
+  }
+  wait_vmcnt<0>();               // NA = 3: the clamped A pieces of the last trip are still in flight
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_s_barrier();  // every wave's stages are dead: the epilogue reuses them
+
+  // ---- epilogue: per wave one 16x64 slice at a time through LDS, written back row-wise as float4 (as in gemm_split.hip)
+  float* T = reinterpret_cast<float*>(smem) + wave * 16 * 65;
+  const int c4 = (lane & 15) * 4;
+#pragma unroll
+  for (int jh = 0; jh < 2; ++jh) {
+    const int nb = n0 + jh * 64 + c4;
+    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (EPI == EPI_SCALE_RES) gv = *reinterpret_cast<const float4*>(gamma + nb);
+#pragma unroll
+    for (int ih = 0; ih < 4; ++ih) {
+      const int i = ih >> 1, h = ih & 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 65 + j * 32 + (lane & 31)] = acc[i][jh * 2 + j][h * 8 + r];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = rr * 4 + (lane >> 4);
+        const float* t = T + row * 65 + c4;
+        float4 v = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
+        const int grow = m0 + wave * 64 + i * 32 + h * 16 + row;
+        if (grow >= M) continue;
+        const size_t off = (size_t)grow * N + nb;
+        if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        if (EPI == EPI_SCALE_RES) {
+          const float4 rs = *reinterpret_cast<const float4*>(resid + off);
+          v.x = rs.x + gv.x * v.x; v.y = rs.y + gv.y * v.y; v.z = rs.z + gv.z * v.z; v.w = rs.w + gv.w * v.w;
+        }
+        { const f32x4v t4 = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t4, reinterpret_cast<f32x4v*>(C + off)); }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+  }
+}
+
+// hipFuncSetAttribute is a per-device setting: done once per (kernel, device), not per launch
+template <int EPI, int CONV, int NA>
+int launch_one(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M,
+               int N, int K, ConvGeom cg, hipStream_t st, const char* what) {
+  constexpr int lds_bytes = NA * A_STAGE_B + 2 * B_STAGE_B;
+  static bool raised[64] = {};
+  int dev = 0;
+  GDRNPP_HIP_TRY(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && !raised[dev]) {
+    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_pipe_kernel<EPI, CONV, NA>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    raised[dev] = true;
+  }
+  const long tiles = (long)((M + 255) / 256) * (N / BN);
+  hipLaunchKernelGGL((gemm_split_pipe_kernel<EPI, CONV, NA>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, A, Wp, bias,
+                     gamma, resid, C, M, N, K, cg);
+  return gdrnpp::check_launch(what);
+}
+
+template <int EPI, int CONV>
+int launch_na(int a_stages, const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid,
+              float* C, int M, int N, int K, ConvGeom cg, hipStream_t st, const char* what) {
+  if (a_stages == 3) return launch_one<EPI, CONV, 3>(A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
+  return launch_one<EPI, CONV, 2>(A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
+}
+
+template <int CONV>
+int launch_epi(int epilogue, int a_stages, const float* A, const uint4* Wp, const float* bias, const float* gamma,
+               const float* resid, float* C, int M, int N, int K, ConvGeom cg, hipStream_t st, const char* what) {
+  if (epilogue == EPI_BIAS) return launch_na<EPI_BIAS, CONV>(a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
+  if (epilogue == EPI_GELU) return launch_na<EPI_GELU, CONV>(a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
+  return launch_na<EPI_SCALE_RES, CONV>(a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
+}
+
+}  // namespace
+
+namespace gdrnpp {
+namespace splitgemm {
+
+int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
+                      int M, int N, int K, int epilogue, bool conv, ConvGeom cg, int a_stages, hipStream_t st,
+                      const char* what) {
+  if (K % 32 || N % BN || M <= 0) return -1;
+  if (conv) {
+    if (!(cg.KW == 3 && cg.stride == 1 && cg.pad == 1 && K == 9 * cg.C && cg.C % BK == 0)) return -1;
+    return launch_epi<1>(epilogue, a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
+  }
+  if ((unsigned long long)M * (unsigned long long)K * 4ull >= (1ull << 32)) return -1;  // 32-bit lane offsets
+  return launch_epi<0>(epilogue, a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
+}
+
+}  // namespace splitgemm
+}  // namespace gdrnpp

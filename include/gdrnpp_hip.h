@@ -42,6 +42,9 @@ const char* gdrnpp_last_error(void);
 /* process-wide tuning switches, read on the launch path (no environment lookups there):
  *   "split_gemm_glds"  0 / 1   256-row tiles of the split GEMM / convolution use the register-staged kernel / the
  *                              LDS-DMA kernel (default 1; results are bitwise identical)
+ *   "split_gemm_pipe"  0 / 2 / 3   256-row tiles of the linear form use the software-pipelined LDS-DMA kernel with two /
+ *                              three A stages (default 3; bitwise identical to the other kernels); 0 = off
+ *   "split_gemm_pipe_conv"  0 / 1   the 3x3 / stride 1 / pad 1 convolution uses it too (default 0)
  *   "split_gemm_mi4"   -1 / 0 / 1   tile height by tile count (default) / force 128 rows / force 256 rows
  * unknown name -> GDRNPP_EINVAL. */
 int gdrnpp_set_option(const char* name, int value);

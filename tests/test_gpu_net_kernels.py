@@ -179,16 +179,20 @@ def test_layernorm_nhwc(hip, n, c, h, w):
     torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
 
 
-def test_split_gemm_lds_dma_kernel_is_bitwise_equal_to_register_staged(hip):
-    """The two 256-row kernels (register-staged A split before the LDS store vs LDS-DMA of fp32 A with the split at
-    fragment-read time) add the same six partial products per k-step in the same order: identical bits, for the linear,
-    3x3 and general convolution forms, ragged M included."""
-    torch.manual_seed(5)
+def test_split_gemm_kernels_are_bitwise_equal(hip):
+    """The 256-row kernels — register-staged (A split before the LDS store), LDS-DMA (fp32 A, split at fragment-read time)
+    and the software-pipelined LDS-DMA kernel with 2 and 3 A stages (split of k-tile t+1 inside the MFMA stream of k-tile t,
+    counted vmcnt) — add the same six partial products per k-step in the same order: identical bits, for the linear, 3x3
+    and general convolution forms, ragged M included (the general convolution stays on the first two kernels)."""
+    modes = [(0, 0), (1, 0), (1, 2), (1, 3)]   # (split_gemm_glds, split_gemm_pipe)
     try:
         hip.set_option("split_gemm_mi4", 1)            # force 256-row tiles at these small sizes
         outs = []
-        for glds in (0, 1):
+        for glds, pipe in modes:
+            torch.manual_seed(5)
             hip.set_option("split_gemm_glds", glds)
+            hip.set_option("split_gemm_pipe", pipe)
+            hip.set_option("split_gemm_pipe_conv", 1 if pipe else 0)
             m, k, n = 1024 + 37, 512, 256
             x = torch.randn(m, k, device=DEV)
             w = torch.randn(n, k, device=DEV) * (k ** -0.5)
@@ -199,17 +203,26 @@ def test_split_gemm_lds_dma_kernel_is_bitwise_equal_to_register_staged(hip):
             xc = torch.randn(3, 64, 16, 24, device=DEV).contiguous(memory_format=torch.channels_last)
             wc = torch.randn(128, 64, 3, 3, device=DEV) * 0.05
             wd = torch.randn(128, 64, 2, 2, device=DEV) * 0.05
+            xk = torch.randn(300, 32, device=DEV)          # shortest K (two k-tiles): prologue / clamp paths
+            wk = torch.randn(128, 32, device=DEV)
             outs.append((hip.linear_f32_split(x, pk, b, "gelu"), hip.linear_f32_split(x, pk, b, "scale_res", g, r),
+                         hip.linear_f32_split(x, pk, None, "none"),
                          hip.conv3x3_f32_split(xc, hip.pack_conv_weight_bf16x3(wc), None),
-                         hip.conv2d_f32_split(xc, hip.pack_conv_weight_bf16x3(wd), None, 2, 2, 2, 0)))
-            torch.manual_seed(5)
+                         hip.conv3x3_f32_split(xc, hip.pack_conv_weight_bf16x3(wc), b[:128].contiguous(), gelu=True),
+                         hip.conv2d_f32_split(xc, hip.pack_conv_weight_bf16x3(wd), None, 2, 2, 2, 0),
+                         hip.linear_f32_split(xk, hip.pack_weight_bf16x3(wk), None, "none")))
     finally:
         hip.set_option("split_gemm_mi4", -1)
         hip.set_option("split_gemm_glds", 1)
-    for a_, b_ in zip(*outs):
-        assert torch.equal(a_, b_)
+        hip.set_option("split_gemm_pipe", 3)
+        hip.set_option("split_gemm_pipe_conv", 0)
+    for other in outs[1:]:
+        for a_, b_ in zip(outs[0], other):
+            assert torch.equal(a_, b_)
     ref = F.conv2d(xc, wc, None, padding=1)
-    assert ((outs[1][2] - ref).abs().max() / ref.abs().max()).item() < 4e-6
+    assert ((outs[2][3] - ref).abs().max() / ref.abs().max()).item() < 4e-6
+    ref = x.double() @ w.double().T
+    assert ((outs[3][2].double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
 
 
 def test_split_gemm_gelu_epilogue_matches_fp64_gelu(hip):
