@@ -39,6 +39,27 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;  // CDNA4 wavefront
 
+// GELU(x) = x Phi(x), the erf form of torch.nn.GELU, branch-free:  x Phi(x) = max(x, 0) - u Phi(-u) with u = min(|x|, 5.9)
+// and Phi(-u) = exp2(q(u)), q the degree-8 fit of log2 Phi(-u) on [0, 5.9] that minimises the error of Phi (tools/fit_gelu_poly.py).
+// 13 instructions, one of them transcendental; ocml's erff is ~45 with divergent branches, which made the GELU epilogue a
+// quarter of an fc1 tile of the split GEMM.  Error against fp64 over [-9, 9] (emulated fp32, v_exp_f32 at 1 ulp): 2.7e-7
+// absolute, 8.9e-8 of max(|x|, 1) — below the 4.5e-7 / 1.0e-7 of the fp32 formula 0.5 x (1 + erf(x / sqrt 2)) evaluated with a
+// correctly rounded erf.  Below -5.9 the result is -1e-8 instead of -0 .. -1e-8; NaN propagates.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float u = fminf(fabsf(x), 5.9f);
+  float q = -2.7721912374545354e-06f;
+  q = fmaf(q, u, 3.862218727590516e-05f);
+  q = fmaf(q, u, -0.00018255332543049008f);
+  q = fmaf(q, u, -0.000145858692121692f);
+  q = fmaf(q, u, 0.007075459696352482f);
+  q = fmaf(q, u, -0.052505023777484894f);
+  q = fmaf(q, u, -0.45920491218566895f);
+  q = fmaf(q, u, -1.1511057615280151f);
+  q = fmaf(q, u, -1.0f);
+  const float r = fmaf(-u, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
+  return x != x ? x : r;
+}
+
 // process-wide tuning switches (gdrnpp_set_option): read on the launch path instead of getenv
 int option_split_gemm_glds();   // 1: 256-row split-GEMM tiles use the LDS-DMA kernel
 int option_split_gemm_mi4();    // -1: by tile count, 0 / 1: force 128- / 256-row tiles (A/B measurements)

@@ -32,9 +32,7 @@ enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_SCALE_RES = 2 };
 // nk_split > 0: split-K (linear only), blockIdx.y-th chunk of nk_split k-tiles -> partial C
 struct ConvGeom { int H, W, C, OH, OW, KW, stride, pad; int nk_split; };
 
-// exact-erf GELU (ocml erff).  A 23-instruction fitted erf was tried in its place: no measurable change end to end
-// (3071 vs 3077 ROIs/s on one box) — the epilogue's VALU work already overlaps other waves' MFMAs — so it was dropped.
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+using gdrnpp::gelu_erf;  // common.hpp
 
 // Software-pipelined LDS-DMA kernel (gemm_split_pipe.hip).  Handles the linear form and the 3x3/1/1 convolution with
 // M*K*4 (resp. the image bytes) below 4 GiB; returns -1 when the problem is outside its domain (the caller then uses the

@@ -23,7 +23,7 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+using gdrnpp::gelu_erf;  // common.hpp
 
 // --------------------------------------------------------------------------------------------------
 // depthwise 7x7 (pad 3, stride 1) + bias [+ LayerNorm over C], NHWC.
