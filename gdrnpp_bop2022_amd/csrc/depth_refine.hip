@@ -10,10 +10,12 @@
 // translation / the finished pose record goes back to HBM:
 //   prologue  (optional) K_crop from the camera, ROI centre and scale (get_K_crop_resize fused); per-ROI mask min/max
 //             (shuffle + LDS reduce); the per-pixel query base ||xyz||*mask and the 64x64 sensor-depth crop go to LDS;
-//   stage     per iteration the V model points are transformed ONCE into homogeneous pixel space (fp64) and staged — in
-//             LDS (24 B/vertex, meshes up to 4096 vertices) or, for larger meshes, in a per-ROI slice of a global
+//   stage     per iteration the V model points are transformed ONCE into homogeneous pixel space (fp64) and staged together
+//             with their projections u = h0/h2, v = h1/h2 (the bbox divisions, once per vertex instead of per corner) — in
+//             LDS (40 B/vertex, meshes up to 2688 vertices) or, for larger meshes, in a per-ROI slice of a global
 //             workspace (same kernel, template parameter);
-//   render    triangles -> threads, corners gathered from the stage, fp64 edge functions, ds_min_u32 on a 16 KiB LDS
+//   render    triangles -> threads; candidate pixels from the staged projections first (most sub-pixel triangles have none and
+//             stop there), corners gathered from the stage, fp64 edge functions, ds_min_u32 on a 16 KiB LDS
 //             z-buffer of float-Z bits (rounding to float is monotonic, so min-of-rounded == rounded-min); triangles with a
 //             large pixel bbox are queued in LDS and rasterised by a whole wave each;
 //   compare   q-map, fp64 block sum, fp32 normalise, block max, threshold, np.median of the selected depth differences by
@@ -68,8 +70,9 @@ __device__ long long g_refine_prof[16];
 constexpr int kTS = 512;
 constexpr int kWavesS = kTS / 64;
 constexpr int kPPTS = kMaxPix / kTS;
-constexpr int kMaxStagedVerts = 4096;  // 96 KiB of LDS
-constexpr int kMaxLargeS = 2048;       // queue of wave-rasterised triangles (overflow falls back to per-lane)
+constexpr int kStage = 5;              // doubles staged per vertex: homogeneous pixel-space h[3], u = h0/h2, v = h1/h2
+constexpr int kMaxStagedVerts = 2688;  // 105 KiB of LDS (with the 54 KiB of static LDS: the whole 160 KiB of a CU)
+constexpr int kMaxLargeS = 1024;       // queue of wave-rasterised triangles (overflow falls back to per-lane)
 
 __device__ __forceinline__ double block_sum_s(double v, double* s_red) {
 #pragma unroll
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
   __shared__ unsigned s_pref[4];
   __shared__ int s_large[kMaxLargeS];
   __shared__ int s_nsel, s_nlarge;
-  __shared__ double s_redd[kWavesS];
+  __shared__ double s_redd[kWavesS], s_redd2[kWavesS];
   __shared__ float s_redf[kWavesS];
   __shared__ double s_K[9], s_R[9], s_t[3];
   __shared__ float s_Rf[3];
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
   const double zn = (double)z_near, zf = (double)z_far;
   double* hv;
   if constexpr (STAGED) hv = hv_lds;
-  else hv = a.hv_global + (size_t)bi * a.hv_stride * 3;
+  else hv = a.hv_global + (size_t)bi * a.hv_stride * kStage;
   const int n_it = known ? iters : 0;
 
   PROF_STAMP(0);
@@ -222,15 +225,29 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
   if (tid < 3) { s_t[tid] = (double)t_in[3 * (size_t)bi + tid]; s_Rf[tid] = Rin[9 * (size_t)bi + 6 + tid]; }
 
   // ---- prologue: mask normalisation, query base, sensor depth crop ------------------------------------------
+  // every global load of the prologue is issued before the first barrier (the mask min / max reduction): loads do not move
+  // across __syncthreads, and 8 pixels x 8 loads in flight per thread hide the HBM latency that 24 k cycles were spent on
   const float* mk = mask_raw + (size_t)bi * hw;
-  float mraw[kPPTS];
+  const int in_w = 4 * res;
+  const float* dep = roi_depth + (size_t)bi * in_w * in_w;
+  float mraw[kPPTS], cx[kPPTS], cy[kPPTS], cz[kPPTS], d00[kPPTS], d01[kPPTS], d10[kPPTS], d11[kPPTS];
   float lo = FLT_MAX, hi = -FLT_MAX;
 #pragma unroll
   for (int k = 0; k < kPPTS; ++k) {
     const int p = k * kTS + tid;
-    mraw[k] = (p < hw) ? mk[p] : 0.f;
-    if (p < hw) { lo = fminf(lo, mraw[k]); hi = fmaxf(hi, mraw[k]); }
+    mraw[k] = 0.f; cx[k] = cy[k] = cz[k] = 0.f; d00[k] = d01[k] = d10[k] = d11[k] = 0.f;
+    if (p < hw) {
+      mraw[k] = mk[p];
+      cx[k] = coor_x[(size_t)bi * hw + p]; cy[k] = coor_y[(size_t)bi * hw + p]; cz[k] = coor_z[(size_t)bi * hw + p];
+      const int yy = p / res, xx = p - yy * res;
+      const float* r0 = dep + (size_t)(4 * yy + 1) * in_w + 4 * xx + 1;
+      const float* r1 = r0 + in_w;
+      d00[k] = r0[0]; d01[k] = r0[1]; d10[k] = r1[0]; d11[k] = r1[1];
+    }
   }
+#pragma unroll
+  for (int k = 0; k < kPPTS; ++k)
+    if (k * kTS + tid < hw) { lo = fminf(lo, mraw[k]); hi = fmaxf(hi, mraw[k]); }
   float mmin = 0.f, mden = 1.f;
   if (mask_type == 0) {
     mmin = -block_max_s(-lo, s_redf);
@@ -239,8 +256,6 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
   } else {
     __syncthreads();
   }
-  const int in_w = 4 * res;
-  const float* dep = roi_depth + (size_t)bi * in_w * in_w;
   const float r20 = s_Rf[0], r21 = s_Rf[1], r22 = s_Rf[2];
 #pragma unroll
   for (int k = 0; k < kPPTS; ++k) {
@@ -249,16 +264,13 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
       float m = mraw[k];
       if (mask_type == 0) m = (m - mmin) / mden;
       else if (mask_type == 1) m = 1.f / (1.f + expf(-m));  // 2: already a probability / label (CE argmax)
-      const float x = coor_x[(size_t)bi * hw + p], y = coor_y[(size_t)bi * hw + p], z = coor_z[(size_t)bi * hw + p];
+      const float x = cx[k], y = cy[k], z = cz[k];
       float qv;
       if (use_coor_z) qv = (r20 * x + r21 * y) + r22 * z;
       else qv = sqrtf((x * x + y * y) + z * z);
       s_qbase[p] = qv * m;
-      const int yy = p / res, xx = p - yy * res;
-      const float* r0 = dep + (size_t)(4 * yy + 1) * in_w + 4 * xx + 1;
-      const float* r1 = r0 + in_w;
-      const float h0 = r0[0] * 0.5f + r0[1] * 0.5f;
-      const float h1 = r1[0] * 0.5f + r1[1] * 0.5f;
+      const float h0 = d00[k] * 0.5f + d01[k] * 0.5f;
+      const float h1 = d10[k] * 0.5f + d11[k] * 0.5f;
       s_ds[p] = h0 * 0.5f + h1 * 0.5f;
     }
   }
@@ -275,7 +287,9 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
       for (int v = tid; v < nverts; v += kTS) {
         double h[3];
         project_vertex(mverts + 3 * (size_t)v, K, R, tr, h);
-        hv[3 * v] = h[0]; hv[3 * v + 1] = h[1]; hv[3 * v + 2] = h[2];
+        double* o = hv + kStage * (size_t)v;
+        o[0] = h[0]; o[1] = h[1]; o[2] = h[2];
+        o[3] = h[0] / h[2]; o[4] = h[1] / h[2];   // the per-triangle bbox divisions of setup_triangle, once per vertex
       }
     }
 #pragma unroll
@@ -290,14 +304,30 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
     // ---- rasterise: triangles -> threads, corners gathered from LDS.  A triangle whose bbox holds more than
     //      kLargeArea pixel centres is queued in LDS and rasterised by a whole wave (16 waves drain the queue in
     //      parallel), so one lane never serialises a big triangle --------------------------------------------------
-    for (int f = tid; f < nfaces; f += kTS) {
+    // candidates first (three z, then u, v of the staged vertices), edge planes only for triangles that have any: same
+    // TriSetup as setup_triangle
+    auto staged_setup = [&](int f, TriSetup& s) -> bool {
       const int i0 = mfaces[3 * f], i1 = mfaces[3 * f + 1], i2 = mfaces[3 * f + 2];
-      const double h0[3] = {hv[3 * i0], hv[3 * i0 + 1], hv[3 * i0 + 2]};
-      const double h1[3] = {hv[3 * i1], hv[3 * i1 + 1], hv[3 * i1 + 2]};
-      const double h2[3] = {hv[3 * i2], hv[3 * i2 + 1], hv[3 * i2 + 2]};
+      const double* p0 = hv + kStage * (size_t)i0;
+      const double* p1 = hv + kStage * (size_t)i1;
+      const double* p2 = hv + kStage * (size_t)i2;
+      double h0[3], h1[3], h2[3], uv0[2] = {0, 0}, uv1[2] = {0, 0}, uv2[2] = {0, 0};
+      h0[2] = p0[2]; h1[2] = p1[2]; h2[2] = p2[2];
+      const bool front = fmin(h0[2], fmin(h1[2], h2[2])) >= zn;
+      if (front) {
+        uv0[0] = p0[3]; uv0[1] = p0[4]; uv1[0] = p1[3]; uv1[1] = p1[4]; uv2[0] = p2[3]; uv2[1] = p2[4];
+        h0[0] = h0[1] = h1[0] = h1[1] = h2[0] = h2[1] = 0.0;
+      } else {
+        h0[0] = p0[0]; h0[1] = p0[1]; h1[0] = p1[0]; h1[1] = p1[1]; h2[0] = p2[0]; h2[1] = p2[1];
+      }
+      s.D = 0.0;
+      if (!triangle_bbox(h0, h1, h2, uv0, uv1, uv2, res, res, zn, zf, s)) return false;
+      if (front) { h0[0] = p0[0]; h0[1] = p0[1]; h1[0] = p1[0]; h1[1] = p1[1]; h2[0] = p2[0]; h2[1] = p2[1]; }
+      return triangle_edges(h0, h1, h2, s);
+    };
+    for (int f = tid; f < nfaces; f += kTS) {
       TriSetup s;
-      setup_triangle(h0, h1, h2, res, res, zn, zf, s);
-      if (s.i_lo > s.i_hi || s.j_lo > s.j_hi) continue;
+      if (!staged_setup(f, s)) continue;
       if ((s.i_hi - s.i_lo + 1) * (s.j_hi - s.j_lo + 1) > kLargeArea) {
         const int slot = atomicAdd(&s_nlarge, 1);
         if (slot < kMaxLargeS) { s_large[slot] = f; continue; }
@@ -314,12 +344,8 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
       const int lane = tid & 63;
       for (int qd = tid >> 6; qd < nl; qd += kWavesS) {
         const int f = s_large[qd];
-        const int i0 = mfaces[3 * f], i1 = mfaces[3 * f + 1], i2 = mfaces[3 * f + 2];
-        const double h0[3] = {hv[3 * i0], hv[3 * i0 + 1], hv[3 * i0 + 2]};
-        const double h1[3] = {hv[3 * i1], hv[3 * i1 + 1], hv[3 * i1 + 2]};
-        const double h2[3] = {hv[3 * i2], hv[3 * i2 + 1], hv[3 * i2 + 2]};
         TriSetup s;
-        setup_triangle(h0, h1, h2, res, res, zn, zf, s);
+        staged_setup(f, s);
         const int bw = s.i_hi - s.i_lo + 1, bh = s.j_hi - s.j_lo + 1;
         for (int p = lane; p < bw * bh; p += 64) {
           const int j = s.j_lo + p / bw, i = s.i_lo + p % bw;
@@ -329,6 +355,7 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
       }
     }
     __syncthreads();
+    PROF_STAMP(3 + 5 * it);
 
     // ---- query map -----------------------------------------------------------------------------------------------
     float ren[kPPTS], q[kPPTS], ds[kPPTS];
@@ -363,10 +390,23 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
         sx += (double)xx * (double)q[k];
       }
     }
-    const float qmax = block_max_s(qm, s_redf);
+    // qmax, sum y q, sum x q in ONE block reduction (wave shuffles, one LDS exchange, two barriers instead of six)
+    float qmax;
+    {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        qm = fmaxf(qm, __shfl_xor(qm, off, 64));
+        sy += __shfl_xor(sy, off, 64);
+        sx += __shfl_xor(sx, off, 64);
+      }
+      const int lane = tid & 63, wave = tid >> 6;
+      __syncthreads();
+      if (lane == 0) { s_redf[wave] = qm; s_redd[wave] = sy; s_redd2[wave] = sx; }
+      __syncthreads();
+      qmax = -FLT_MAX; sy = 0.0; sx = 0.0;
+      for (int w = 0; w < kWavesS; ++w) { qmax = fmaxf(qmax, s_redf[w]); sy += s_redd[w]; sx += s_redd2[w]; }
+    }
     const float thr = qmax * threshold;
-    sy = block_sum_s(sy, s_redd);
-    sx = block_sum_s(sx, s_redd);
 
     PROF_STAMP(4 + 5 * it);
     // ---- median of the selected depth differences: two-rank radix select --------------------------------------------
@@ -533,12 +573,12 @@ int launch_refine(const gdrnpp_meshes* meshes, RefineArgs a, int b, void* worksp
   a.n_obj = meshes->n_obj;
   if (meshes->max_verts > 0 && meshes->max_verts <= kMaxStagedVerts) {
     static bool done[64];
-    if (int rc = raise_dynamic_lds_once(depth_refine_kernel<true>, 3 * (int)sizeof(double) * kMaxStagedVerts, done)) return rc;
+    if (int rc = raise_dynamic_lds_once(depth_refine_kernel<true>, kStage * (int)sizeof(double) * kMaxStagedVerts, done)) return rc;
     a.hv_global = nullptr; a.hv_stride = 0;
-    hipLaunchKernelGGL(depth_refine_kernel<true>, dim3(b), dim3(kTS), 3 * (int)sizeof(double) * meshes->max_verts, st, a);
+    hipLaunchKernelGGL(depth_refine_kernel<true>, dim3(b), dim3(kTS), kStage * (int)sizeof(double) * meshes->max_verts, st, a);
   } else {
     GDRNPP_REQUIRE(meshes->max_verts > 0, GDRNPP_EINVAL, "%s: gdrnpp_meshes.max_verts must be set", who);
-    const size_t need = (size_t)b * meshes->max_verts * 3 * sizeof(double);
+    const size_t need = (size_t)b * meshes->max_verts * kStage * sizeof(double);
     GDRNPP_REQUIRE(workspace && workspace_bytes >= need, GDRNPP_EINVAL,
                    "%s: meshes of up to %d vertices need a workspace of %zu bytes (gdrnpp_depth_refine_workspace_bytes)", who,
                    meshes->max_verts, need);
@@ -570,7 +610,7 @@ int gdrnpp_render_depth(const gdrnpp_meshes* meshes, const int* obj, const float
 
 size_t gdrnpp_depth_refine_workspace_bytes(const gdrnpp_meshes* meshes, int b) {
   if (!meshes || b <= 0 || meshes->max_verts <= kMaxStagedVerts) return 0;
-  return (size_t)b * meshes->max_verts * 3 * sizeof(double);
+  return (size_t)b * meshes->max_verts * kStage * sizeof(double);
 }
 
 int gdrnpp_depth_refine(const gdrnpp_meshes* meshes, const int* obj, const float* coor_x, const float* coor_y,

@@ -50,25 +50,26 @@ __device__ __forceinline__ int clampi(double v, int lo, int hi) {
   return (int)v;
 }
 
-// Conservative pixel bbox of the part of the triangle with Z >= z_near (h[2] is the camera-space Z:
-// the last row of K is (0,0,1)).  Triangles entirely nearer than z_near or farther than z_far cannot
-// produce a fragment and are dropped; triangles crossing the near plane are clipped against it
-// (Sutherland-Hodgman on the 3 edges, in homogeneous pixel space where interpolation is linear) so that
-// objects straddling the camera plane do not degrade to a full-image bbox.  oracle/raster_oracle.c computes
-// the same bbox with the same expressions, so even degenerate slivers resolve identically on both sides.
-__device__ __forceinline__ void setup_triangle(const double* h0, const double* h1, const double* h2, int res_w,
-                                               int res_h, double z_near, double z_far, TriSetup& s) {
-  cross3(h1, h2, s.e0);
-  cross3(h2, h0, s.e1);
-  cross3(h0, h1, s.e2);
-  s.D = (h0[0] * s.e0[0] + h0[1] * s.e0[1]) + h0[2] * s.e0[2];
+// Candidate pixels of a triangle.  The conservative pixel bbox of the part of the triangle with Z >= z_near (h[2] is the
+// camera-space Z: the last row of K is (0,0,1)): triangles entirely nearer than z_near or farther than z_far cannot produce a
+// fragment and are dropped; triangles crossing the near plane are clipped against it (Sutherland-Hodgman on the 3 edges, in
+// homogeneous pixel space where interpolation is linear) so that objects straddling the camera plane do not degrade to a
+// full-image bbox.  oracle/raster_oracle.c computes the same bbox with the same expressions.
+// The bbox rounds OUTWARDS (floor / ceil), so a sub-pixel triangle with no pixel centre inside still names up to 2x2
+// candidates.  Coverage is decided by the edge functions alone; a covered centre lies inside [umin, umax] x [vmin, vmax] up
+// to the rounding of fp64 (~1e-13 px), so the candidates are intersected with the centres inside that box widened by 1e-6 px:
+// the rendered maps are unchanged, and most triangles of a 64x64 render of a 5k-face mesh (0.5 px each) leave before any
+// cross product is formed.
+// uv0..2: u = h[0] / h[2], v = h[1] / h[2] of the vertices, read only when all three z >= z_near (else h x, y are read).
+// Returns false when the triangle has no candidate pixel.
+__device__ __forceinline__ bool triangle_bbox(const double* h0, const double* h1, const double* h2, const double* uv0,
+                                              const double* uv1, const double* uv2, int res_w, int res_h, double z_near,
+                                              double z_far, TriSetup& s) {
   const double zmin = fmin(h0[2], fmin(h1[2], h2[2])), zmax = fmax(h0[2], fmax(h1[2], h2[2]));
   double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
   if (zmin >= z_near) {
-    const double u0 = h0[0] / h0[2], u1 = h1[0] / h1[2], u2 = h2[0] / h2[2];
-    const double v0 = h0[1] / h0[2], v1 = h1[1] / h1[2], v2 = h2[1] / h2[2];
-    umin = fmin(u0, fmin(u1, u2)); umax = fmax(u0, fmax(u1, u2));
-    vmin = fmin(v0, fmin(v1, v2)); vmax = fmax(v0, fmax(v1, v2));
+    umin = fmin(uv0[0], fmin(uv1[0], uv2[0])); umax = fmax(uv0[0], fmax(uv1[0], uv2[0]));
+    vmin = fmin(uv0[1], fmin(uv1[1], uv2[1])); vmax = fmax(uv0[1], fmax(uv1[1], uv2[1]));
   } else {
     const double* hv[3] = {h0, h1, h2};
 #pragma unroll
@@ -87,12 +88,37 @@ __device__ __forceinline__ void setup_triangle(const double* h0, const double* h
       }
     }
   }
-  // pixel centre i+0.5 in [umin,umax]  =>  i in [umin-0.5, umax-0.5]; floor/ceil round outwards
-  s.i_lo = clampi(floor(umin - 0.5), 0, res_w);  // res_w => empty after the hi clamp
-  s.i_hi = clampi(ceil(umax - 0.5), -1, res_w - 1);
-  s.j_lo = clampi(floor(vmin - 0.5), 0, res_h);
-  s.j_hi = clampi(ceil(vmax - 0.5), -1, res_h - 1);
-  if (!(s.D != 0.0) || zmax < z_near || zmin > z_far || !(umin <= umax)) { s.i_lo = 1; s.i_hi = 0; }
+  if (zmax < z_near || zmin > z_far || !(umin <= umax)) { s.i_lo = 1; s.i_hi = 0; return false; }
+  // pixel centre i+0.5 in [umin,umax]  =>  i in [umin-0.5, umax-0.5].  The oracle rounds this range outwards (floor / ceil);
+  // the centres inside the box widened by 1e-6 px are a subset of that (ceil(x - 1e-6) >= floor(x), floor(x + 1e-6) <=
+  // ceil(x)) and contain every centre the edge functions can accept: candidates only, see above
+  s.i_lo = clampi(ceil(umin - 0.5 - 1e-6), 0, res_w);   // res_w => empty after the hi clamp
+  s.i_hi = clampi(floor(umax - 0.5 + 1e-6), -1, res_w - 1);
+  s.j_lo = clampi(ceil(vmin - 0.5 - 1e-6), 0, res_h);
+  s.j_hi = clampi(floor(vmax - 0.5 + 1e-6), -1, res_h - 1);
+  return s.i_lo <= s.i_hi && s.j_lo <= s.j_hi;
+}
+
+// edge planes and determinant; false for a degenerate triangle (no fragment)
+__device__ __forceinline__ bool triangle_edges(const double* h0, const double* h1, const double* h2, TriSetup& s) {
+  cross3(h1, h2, s.e0);
+  cross3(h2, h0, s.e1);
+  cross3(h0, h1, s.e2);
+  s.D = (h0[0] * s.e0[0] + h0[1] * s.e0[1]) + h0[2] * s.e0[2];
+  if (!(s.D != 0.0)) { s.i_lo = 1; s.i_hi = 0; return false; }
+  return true;
+}
+
+__device__ __forceinline__ void setup_triangle(const double* h0, const double* h1, const double* h2, int res_w,
+                                               int res_h, double z_near, double z_far, TriSetup& s) {
+  double uv0[2] = {0, 0}, uv1[2] = {0, 0}, uv2[2] = {0, 0};
+  if (fmin(h0[2], fmin(h1[2], h2[2])) >= z_near) {
+    uv0[0] = h0[0] / h0[2]; uv1[0] = h1[0] / h1[2]; uv2[0] = h2[0] / h2[2];
+    uv0[1] = h0[1] / h0[2]; uv1[1] = h1[1] / h1[2]; uv2[1] = h2[1] / h2[2];
+  }
+  s.D = 0.0;
+  if (!triangle_bbox(h0, h1, h2, uv0, uv1, uv2, res_w, res_h, z_near, z_far, s)) { s.i_lo = 1; s.i_hi = 0; return; }
+  triangle_edges(h0, h1, h2, s);
 }
 
 // depth of the triangle at pixel (i,j); returns false when the pixel centre is not covered
