@@ -115,6 +115,17 @@ struct StreamK {
   unsigned epoch;           // > 0, unique per launch
 };
 
+// Grouped launch (linear form): rows [g*rows_per_group, (g+1)*rows_per_group) use weight / bias slice sel[g] of a stack of
+// equally shaped packed weights — the class-sliced 1x1 output layer of the geometry head (every ROI = 4096 rows selects the
+// 70 output channels of its class).  rows_per_group is a multiple of the 256-row tile.  Columns >= n_store are not written.
+struct Grouped {
+  const int* sel;          // null = plain launch
+  int rows_per_group;
+  long w_stride;           // uint4 slots between consecutive weight slices
+  int bias_stride;         // floats between consecutive bias slices
+  int n_store;
+};
+
 // CONV: 0 = linear (A row-major [M,K]), 1 = 3x3 / stride 1 / pad 1 convolution over an NHWC image (implicit im2col)
 // NA: A stages (2: one k-tile ahead, 3: two k-tiles ahead).  SK: stream-K schedule (linear form), else one tile per workgroup.
 template <int EPI, int CONV, int NA, bool SK>
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
                                                                  const float* __restrict__ bias,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ resid, float* __restrict__ C,
-                                                                 int M, int N, int K, ConvGeom cg, StreamK sk) {
+                                                                 int M, int N, int K, ConvGeom cg, StreamK sk, Grouped grp) {
   extern __shared__ uint4 smem[];  // the only LDS object: [NA][1024] A slots | [2][768] weight slots
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
   const int cpt = CONV ? cg.C / BK : 1;
   const unsigned boff = (unsigned)((wave * 3) * 64 + lane) * 16u;
   const char* wbase = nullptr;
+  const float* bias_t = nullptr;   // bias slice of the current tile
   const unsigned ldsA = lds0 + (unsigned)(wave * 4) * 1024u;
   const unsigned ldsB = lds0 + (unsigned)(NA * A_STAGE_B) + (unsigned)(wave * 3) * 1024u;
 
@@ -158,7 +170,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
   auto setup_tile = [&](long tile) {
     const int tile_m = (int)(tile / ntn), tile_n = (int)(tile - (long)tile_m * ntn);
     m0 = tile_m * 256; n0 = tile_n * BN;
-    wbase = reinterpret_cast<const char*>(Wp + (size_t)tile_n * nk * W_TILE_SLOTS);
+    const int g = grp.sel ? grp.sel[m0 / grp.rows_per_group] : 0;
+    wbase = reinterpret_cast<const char*>(Wp + (size_t)g * grp.w_stride + (size_t)tile_n * nk * W_TILE_SLOTS);
+    bias_t = bias ? bias + (size_t)g * grp.bias_stride : nullptr;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int lrow = wave * 64 + c * 16 + prow;
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
 #pragma unroll
     for (int jh = 0; jh < 2; ++jh) {
       const int nb = n0 + jh * 64 + c4;
-      const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 bv = bias_t ? *reinterpret_cast<const float4*>(bias_t + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
       if (EPI == EPI_SCALE_RES) gv = *reinterpret_cast<const float4*>(gamma + nb);
 #pragma unroll
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
           const float* t = T + row * 65 + c4;
           float4 v = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
           const int grow = m0 + wave * 64 + i * 32 + h * 16 + row;
-          if (grow >= M) continue;
+          if (grow >= M || nb >= grp.n_store) continue;
           const size_t off = (size_t)grow * N + nb;
           if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
           if (EPI == EPI_SCALE_RES) {
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
 // hipFuncSetAttribute is a per-device setting: done once per (kernel, device), not per launch
 template <int EPI, int CONV, int NA, bool SK>
 int launch_one(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M,
-               int N, int K, ConvGeom cg, StreamK sk, int grid, hipStream_t st, const char* what) {
+               int N, int K, ConvGeom cg, StreamK sk, Grouped grp, int grid, hipStream_t st, const char* what) {
   constexpr int lds_bytes = NA * A_STAGE_B + 2 * B_STAGE_B;
   static bool raised[64] = {};
   int dev = 0;
@@ -433,31 +447,31 @@ int launch_one(const float* A, const uint4* Wp, const float* bias, const float* 
     raised[dev] = true;
   }
   hipLaunchKernelGGL((gemm_split_pipe_kernel<EPI, CONV, NA, SK>), dim3((unsigned)grid), dim3(256), lds_bytes, st, A, Wp, bias,
-                     gamma, resid, C, M, N, K, cg, sk);
+                     gamma, resid, C, M, N, K, cg, sk, grp);
   return gdrnpp::check_launch(what);
 }
 
 template <int EPI, int CONV>
 int launch_na(int a_stages, bool use_sk, const float* A, const uint4* Wp, const float* bias, const float* gamma,
-              const float* resid, float* C, int M, int N, int K, ConvGeom cg, StreamK sk, int grid, hipStream_t st,
+              const float* resid, float* C, int M, int N, int K, ConvGeom cg, StreamK sk, Grouped grp, int grid, hipStream_t st,
               const char* what) {
   if constexpr (CONV == 0) {
     if (use_sk) {
-      if (a_stages == 3) return launch_one<EPI, 0, 3, true>(A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grid, st, what);
-      return launch_one<EPI, 0, 2, true>(A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grid, st, what);
+      if (a_stages == 3) return launch_one<EPI, 0, 3, true>(A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
+      return launch_one<EPI, 0, 2, true>(A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
     }
   }
-  if (a_stages == 3) return launch_one<EPI, CONV, 3, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grid, st, what);
-  return launch_one<EPI, CONV, 2, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grid, st, what);
+  if (a_stages == 3) return launch_one<EPI, CONV, 3, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
+  return launch_one<EPI, CONV, 2, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
 }
 
 template <int CONV>
 int launch_epi(int epilogue, int a_stages, bool use_sk, const float* A, const uint4* Wp, const float* bias, const float* gamma,
-               const float* resid, float* C, int M, int N, int K, ConvGeom cg, StreamK sk, int grid, hipStream_t st,
+               const float* resid, float* C, int M, int N, int K, ConvGeom cg, StreamK sk, Grouped grp, int grid, hipStream_t st,
                const char* what) {
-  if (epilogue == EPI_BIAS) return launch_na<EPI_BIAS, CONV>(a_stages, use_sk, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grid, st, what);
-  if (epilogue == EPI_GELU) return launch_na<EPI_GELU, CONV>(a_stages, use_sk, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grid, st, what);
-  return launch_na<EPI_SCALE_RES, CONV>(a_stages, use_sk, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grid, st, what);
+  if (epilogue == EPI_BIAS) return launch_na<EPI_BIAS, CONV>(a_stages, use_sk, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
+  if (epilogue == EPI_GELU) return launch_na<EPI_GELU, CONV>(a_stages, use_sk, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
+  return launch_na<EPI_SCALE_RES, CONV>(a_stages, use_sk, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
 }
 
 // resident capacity of the pipelined kernel: two workgroups per CU (72 KB of LDS, 235 VGPRs)
@@ -488,10 +502,11 @@ int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const 
   const long tiles = (long)((M + 255) / 256) * (N / BN);
   if (tiles >= (1l << 30)) return -1;
   StreamK sk{nullptr, nullptr, 0};
+  const Grouped grp{nullptr, 1, 0, 0, N};
   if (conv) {
     if (allow_small) return -1;
     if (!(cg.KW == 3 && cg.stride == 1 && cg.pad == 1 && K == 9 * cg.C && cg.C % BK == 0)) return -1;
-    return launch_epi<1>(epilogue, a_stages, false, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, (int)tiles, st, what);
+    return launch_epi<1>(epilogue, a_stages, false, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, (int)tiles, st, what);
   }
   if ((unsigned long long)M * (unsigned long long)K * 4ull >= (1ull << 32)) return -1;  // 32-bit lane offsets
   // stream-K when one-tile-per-workgroup scheduling would leave more than a tenth of the resident slots idle on average
@@ -508,11 +523,31 @@ int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const 
     sk.flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sk_workspace) + (size_t)G * (256 * 128 * sizeof(float)));
     sk.epoch = ++g_sk_epoch;
     if (sk.epoch == 0) sk.epoch = ++g_sk_epoch;
-    return launch_epi<0>(epilogue, a_stages, true, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, G, st, what);
+    return launch_epi<0>(epilogue, a_stages, true, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, G, st, what);
   }
   if (allow_small) return -1;
-  return launch_epi<0>(epilogue, a_stages, false, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, (int)tiles, st, what);
+  return launch_epi<0>(epilogue, a_stages, false, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, (int)tiles, st, what);
 }
 
 }  // namespace splitgemm
 }  // namespace gdrnpp
+
+extern "C" int gdrnpp_linear_f32_split_grouped(const float* A, const void* W_packed_stack, const float* bias_stack,
+                                               const int* group_sel, int rows_per_group, float* C, int M, int N, int K,
+                                               int n_store, void* stream) {
+  using namespace gdrnpp::splitgemm;
+  GDRNPP_REQUIRE(A && W_packed_stack && group_sel && C, GDRNPP_EINVAL, "gdrnpp_linear_f32_split_grouped: null pointer");
+  GDRNPP_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % 32 == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_linear_f32_split_grouped: N=%d K=%d must be multiples of %d/32", N, K, BN);
+  GDRNPP_REQUIRE(rows_per_group > 0 && rows_per_group % 256 == 0 && M % rows_per_group == 0, GDRNPP_EINVAL,
+                 "gdrnpp_linear_f32_split_grouped: rows_per_group=%d must be a multiple of 256 that divides M=%d", rows_per_group, M);
+  GDRNPP_REQUIRE(n_store > 0 && n_store <= N && n_store % 4 == 0, GDRNPP_EINVAL, "gdrnpp_linear_f32_split_grouped: n_store=%d", n_store);
+  GDRNPP_REQUIRE((unsigned long long)M * (unsigned long long)K * 4ull < (1ull << 32), GDRNPP_ELIMIT,
+                 "gdrnpp_linear_f32_split_grouped: M*K*4 must stay below 4 GiB");
+  const long tiles = (long)(M / 256) * (N / BN);
+  GDRNPP_REQUIRE(tiles < (1l << 30), GDRNPP_ELIMIT, "gdrnpp_linear_f32_split_grouped: grid too large");
+  const Grouped grp{group_sel, rows_per_group, (long)(N / BN) * (K / BK) * W_TILE_SLOTS, N, n_store};
+  return launch_epi<0>(EPI_BIAS, gdrnpp::option_split_gemm_pipe() == 2 ? 2 : 3, false, A, (const uint4*)W_packed_stack, bias_stack,
+                       nullptr, nullptr, C, M, N, K, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0}, StreamK{nullptr, nullptr, 0}, grp, (int)tiles,
+                       (hipStream_t)stream, "gdrnpp_linear_f32_split_grouped");
+}

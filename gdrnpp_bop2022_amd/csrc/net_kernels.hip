@@ -409,7 +409,68 @@ __global__ __launch_bounds__(256) void layernorm_nhwc_kernel(const float* __rest
   }
 }
 
+// --------------------------------------------------------------------------------------------------
+// Tail of the geometry head (GDRN_double_mask.py:128-160 + conv_pnp_net.py:120-134) on the NHWC result of the class-sliced
+// output layer.  in: f32[B*HW][pitch], channels [vis | full (double mask) | x | y | z | region 0..R] (R = 64 regions + bg).
+//   pnp_in f32[B*HW][96] = [(x-0.5) ex, (y-0.5) ey, (z-0.5) ez | coord2d u, v | softmax(region[1..64]) | 27 zeros]
+//       (ConvPnPNet's in-place de-normalisation by the object extent, its torch.cat with the region softmax, Cin padded to the
+//        next multiple of 32 for the implicit-GEMM convolution)
+//   planes f32[n_planes][B*HW]: vis, (full,) x, y, z as they appear in out_dict (normalised xyz)
+// One workgroup of 256 threads = 64 pixels; 4 lanes per pixel share the 64-way softmax (16 logits each, quad shuffles).
+// --------------------------------------------------------------------------------------------------
+constexpr int kTailPix = 64, kTailIn = 72, kTailOut = 96;
+__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ in, int pitch, const float* __restrict__ coord2d,
+                                                        const float* __restrict__ extents, float* __restrict__ pnp_in,
+                                                        float* __restrict__ planes, int hw, long n_pix, int double_mask) {
+  __shared__ float T[kTailPix][kTailIn + 1];
+  __shared__ float O[kTailPix][kTailOut + 4];
+  const int tid = threadIdx.x;
+  const long p0 = (long)blockIdx.x * kTailPix;
+  for (int idx = tid; idx < kTailPix * (kTailIn / 4); idx += 256) {
+    const int row = idx / (kTailIn / 4), c4 = idx - row * (kTailIn / 4);
+    const float4 v = ld4(in + (size_t)(p0 + row) * pitch + 4 * c4);
+    T[row][4 * c4] = v.x; T[row][4 * c4 + 1] = v.y; T[row][4 * c4 + 2] = v.z; T[row][4 * c4 + 3] = v.w;
+  }
+  __syncthreads();
+  const int p = tid >> 2, part = tid & 3;
+  const long pix = p0 + p;
+  const int b = (int)(pix / hw), q = (int)(pix - (long)b * hw);
+  const int kx = double_mask ? 2 : 1, kr = kx + 3;   // first xyz channel, region background channel
+  // softmax over region[1..64] (the background channel kr is dropped, GDRN_double_mask.py:148)
+  float e[16];
+  float m = -3.402823466e38f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { e[i] = T[p][kr + 1 + part * 16 + i]; m = fmaxf(m, e[i]); }
+  m = fmaxf(m, __shfl_xor(m, 1, 64));
+  m = fmaxf(m, __shfl_xor(m, 2, 64));
+  float ssum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { e[i] = expf(e[i] - m); ssum += e[i]; }
+  ssum += __shfl_xor(ssum, 1, 64);
+  ssum += __shfl_xor(ssum, 2, 64);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) O[p][5 + part * 16 + i] = e[i] / ssum;
+  if (part == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) O[p][c] = (T[p][kx + c] - 0.5f) * extents[3 * (size_t)b + c];
+    O[p][3] = coord2d[((size_t)b * 2) * hw + q];
+    O[p][4] = coord2d[((size_t)b * 2 + 1) * hw + q];
+    const int n_planes = kx + 3;
+    for (int k = 0; k < n_planes; ++k) planes[(size_t)k * n_pix + pix] = T[p][k];
+  } else {
+    // 27 padding channels, 9 per lane
+#pragma unroll
+    for (int i = 0; i < 9; ++i) O[p][69 + (part - 1) * 9 + i] = 0.f;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < kTailPix * (kTailOut / 4); idx += 256) {
+    const int row = idx / (kTailOut / 4), c4 = idx - row * (kTailOut / 4);
+    st4(pnp_in + (size_t)(p0 + row) * kTailOut + 4 * c4, make_float4(O[row][4 * c4], O[row][4 * c4 + 1], O[row][4 * c4 + 2], O[row][4 * c4 + 3]));
+  }
+}
+
 }  // namespace
+
 
 extern "C" {
 
@@ -518,6 +579,18 @@ int gdrnpp_groupnorm_act_nhwc(const float* x, const float* gamma, const float* b
     hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)bx, N), dim3(256), 0, st, x, (const double*)workspace,
                        gamma, beta, y, HW, C, G, P, eps);
   return gdrnpp::check_launch("gdrnpp_groupnorm_act_nhwc");
+}
+
+int gdrnpp_head_tail_nhwc(const float* out_nhwc, int pitch, const float* coord2d, const float* extents, float* pnp_in,
+                          float* planes, int b, int hw, int double_mask, void* stream) {
+  if (b == 0) return 0;
+  GDRNPP_REQUIRE(out_nhwc && coord2d && extents && pnp_in && planes, GDRNPP_EINVAL, "gdrnpp_head_tail_nhwc: null pointer");
+  GDRNPP_REQUIRE(b > 0 && hw > 0 && hw % kTailPix == 0 && pitch >= kTailIn && pitch % 4 == 0, GDRNPP_EINVAL,
+                 "gdrnpp_head_tail_nhwc: b=%d hw=%d (multiple of %d) pitch=%d (>= %d, multiple of 4)", b, hw, kTailPix, pitch, kTailIn);
+  const long n_pix = (long)b * hw;
+  hipLaunchKernelGGL(head_tail_kernel, dim3((unsigned)(n_pix / kTailPix)), dim3(256), 0, (hipStream_t)stream, out_nhwc, pitch,
+                     coord2d, extents, pnp_in, planes, hw, n_pix, double_mask ? 1 : 0);
+  return gdrnpp::check_launch("gdrnpp_head_tail_nhwc");
 }
 
 }  // extern "C"

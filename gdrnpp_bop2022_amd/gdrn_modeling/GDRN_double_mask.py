@@ -79,6 +79,8 @@ class GDRN_DoubleMask(nn.Module):
             self.register_buffer("_cls_rows", geo_head_net.class_channel_index(cfg.MODEL.POSE_NET.NUM_CLASSES),
                                  persistent=False)
         self._sliced_w = None  # cache of (weight[C,70,256], bias[C,70]) for eval
+        self._sliced_pk = None  # cache of the packed, 128-row padded slices for the grouped split GEMM
+        self.fused_head_tail = True   # all-NHWC head tail on the HIP path (False: baddbmm + torch ops, for A/B)
 
     # ------------------------------------------------------------------------------------------
     def _sliced_out_layer(self, feat, roi_classes):
@@ -100,6 +102,52 @@ class GDRN_DoubleMask(nn.Module):
         full = out[:, m:2 * m] if self.double_mask else None
         return vis, full, out[:, k:k + 1], out[:, k + 1:k + 2], out[:, k + 2:k + 3], out[:, k + 3:]
 
+    def _fused_tail_ok(self, x, feat, roi_classes, coord2d, roi_extents) -> bool:
+        """The all-NHWC head tail (grouped class-sliced GEMM -> head_tail kernel -> Patch-PnP on the split convolution) covers
+        the GDRNPP BOP configuration: regression xyz, 64 regions, coord2d + region attention into Patch-PnP, no mask attention."""
+        net_cfg = self.cfg.MODEL.POSE_NET
+        pn = net_cfg.PNP_NET
+        return (hip_layers.enabled_for(x) and hip_layers.mlp_gemm() == "split" and self.fused_head_tail
+                and self.class_aware and self.xyz_out_dim == 3 and not self.exact_reference_order and not self.training
+                and self.region_out_dim == 65 and self.mask_out_dim == (2 if self.double_mask else 1)
+                and pn.WITH_2D_COORD and pn.REGION_ATTENTION and pn.MASK_ATTENTION == "none"
+                and roi_classes is not None and coord2d is not None and roi_extents is not None
+                and self.pnp_net is not None and hasattr(self.pnp_net, "accepts_prepared_input") and self.pnp_net.accepts_prepared_input()
+                and feat.shape[1] % 32 == 0 and (feat.shape[2] * feat.shape[3]) % 256 == 0
+                and feat.shape[0] * feat.shape[2] * feat.shape[3] * feat.shape[1] * 4 < (1 << 32))
+
+    def _fused_tail(self, feat, roi_classes, coord2d, roi_extents):
+        """feat [B,256,64,64] (channels_last) -> Patch-PnP outputs and the maps of out_dict, without leaving NHWC:
+        one grouped GEMM launch (each ROI's 4096 rows against the 70-channel weight slice of its class, padded to one 128-wide
+        tile), one kernel for [xyz * extent | coord2d | region softmax] + the map planes, Patch-PnP's first convolution with
+        Cin padded 69 -> 96 on the implicit-GEMM kernel.  Same arithmetic as the module path (fp32-accurate GEMMs)."""
+        ol = self.geo_head_net.out_layer
+        tag = hip_layers.weight_tag(ol.weight, ol.bias)
+        if self._sliced_pk is None or self._sliced_pk[0] != tag:
+            w = ol.weight.detach().view(ol.out_channels, -1)[self._cls_rows]    # [C,70,256]
+            b = ol.bias.detach()[self._cls_rows]                                  # [C,70]
+            C, n70, k = w.shape
+            w128 = torch.zeros((C, 128, k), dtype=w.dtype, device=w.device)
+            w128[:, :n70] = w
+            b128 = torch.zeros((C, 128), dtype=b.dtype, device=b.device)
+            b128[:, :n70] = b
+            self._sliced_pk = (tag, hip_lib.pack_weight_bf16x3(w128.view(C * 128, k).contiguous()), b128.contiguous(), n70)
+        _, w_pk, b128, n70 = self._sliced_pk
+        bs, ch, h, wd = feat.shape
+        feat = feat.contiguous(memory_format=torch.channels_last)
+        x2d = feat.permute(0, 2, 3, 1).reshape(bs * h * wd, ch)     # a view of the NHWC memory
+        out = hip_lib.linear_f32_split_grouped(x2d, w_pk, b128, roi_classes.to(torch.int32), h * wd, n_store=(n70 + 3) // 4 * 4)
+        pnp_in, planes = hip_lib.head_tail_nhwc(out, coord2d.contiguous(), roi_extents.contiguous().float(), self.double_mask)
+        x96 = pnp_in.view(bs, h, wd, 96).permute(0, 3, 1, 2)        # [B,96,H,W] channels_last view
+        pred_rot_, pred_t_ = self.pnp_net.forward_prepared(x96)
+        planes = planes.view(planes.shape[0], bs, 1, h, wd)
+        k = 2 if self.double_mask else 1
+        maps = {"mask": planes[0], "coor_x": planes[k], "coor_y": planes[k + 1], "coor_z": planes[k + 2],
+                "region": out.view(bs, h, wd, out.shape[1])[..., k + 3:n70].permute(0, 3, 1, 2)}
+        if self.double_mask:
+            maps["full_mask"] = planes[1]
+        return pred_rot_, pred_t_, maps
+
     def forward_maps(self, x, roi_classes=None, roi_coord_2d=None, roi_coord_2d_rel=None, roi_extents=None):
         """Everything of ``forward`` up to the Patch-PnP outputs: pure PyTorch (also runs on CPU)."""
         cfg = self.cfg
@@ -118,6 +166,9 @@ class GDRN_DoubleMask(nn.Module):
         if self.class_aware and self.xyz_out_dim == 3 and not self.exact_reference_order:
             assert roi_classes is not None
             feat = self.geo_head_net.trunk(conv_feat)
+            coord2d = roi_coord_2d_rel if pnp_net_cfg.WITH_2D_COORD and pnp_net_cfg.COORD_2D_TYPE == "rel" else roi_coord_2d
+            if self._fused_tail_ok(x, feat, roi_classes, coord2d, roi_extents):
+                return self._fused_tail(feat, roi_classes, coord2d, roi_extents)
             vis_mask, full_mask, coor_x, coor_y, coor_z, region = self._sliced_out_layer(feat, roi_classes)
         else:
             outs = self.geo_head_net(conv_feat)

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import hip_layers
+from .. import hip_lib
 
 
 def get_nn_act_func(act: str):
@@ -246,10 +247,39 @@ class ConvPnPNet(nn.Module):
         elif self.mask_attention_type == "concat":
             x = torch.cat([x, mask_attention], dim=1)
         x = run_features(self.features, x)
+        return self._fc_tail(x)
+
+    def _fc_tail(self, x):
         x = x.flatten(2).flatten(1)  # NCHW order, like the reference (weights of fc1 depend on it)
         x = self.act(hip_layers.linear(self.fc1, x))
         x = self.act(hip_layers.linear(self.fc2, x))
         return self.fc_r(x), self.fc_t(x)
+
+    # ---- NHWC entry used by the fused head tail (hip_lib.head_tail_nhwc) ------------------------------------------------
+    def accepts_prepared_input(self) -> bool:
+        """The prepared [xyz * extent | coord2d | region softmax | zero pad] NHWC input replaces ``forward``'s own de-normalisation
+        and concatenation: only for the plain configuration (69 input channels, no mask attention)."""
+        c0 = self.features[0] if len(self.features) else None
+        return (isinstance(c0, nn.Conv2d) and c0.in_channels == 69 and c0.out_channels % 128 == 0 and c0.kernel_size == (3, 3)
+                and c0.stride == (2, 2) and c0.padding == (1, 1) and c0.bias is None and self.mask_attention_type == "none"
+                and self.denormalize_by_extent)
+
+    def forward_prepared(self, x96_cl):
+        """``x96_cl``: [B, 96, H, W] channels_last, channels 69..95 zero.  First convolution with its weight zero-padded to 96
+        input channels on the implicit-GEMM split kernel, the rest as ``forward``."""
+        c0 = self.features[0]
+        cache = c0.__dict__.setdefault("_gdrnpp_cache", {})
+        tag = hip_layers.weight_tag(c0.weight)
+        hit = cache.get("w96_pk")
+        if hit is None or hit[0] != tag:
+            w = c0.weight.detach()
+            w96 = torch.zeros((w.shape[0], 96, 3, 3), dtype=w.dtype, device=w.device)
+            w96[:, :69] = w
+            hit = (tag, hip_lib.pack_conv_weight_bf16x3(w96))
+            cache["w96_pk"] = hit
+        x = hip_lib.conv2d_f32_split(x96_cl, hit[1], None, 3, 3, 2, 1)
+        x = run_features(self.features[1:], x)
+        return self._fc_tail(x)
 
 
 HEADS = {

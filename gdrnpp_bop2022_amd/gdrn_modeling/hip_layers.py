@@ -97,6 +97,11 @@ def set_mlp_gemm(mode: str) -> None:
     _MLP_GEMM = mode
 
 
+def mlp_gemm() -> str:
+    """Current GEMM engine of the network layers: "split" (HIP, bf16x6) or "torch" (hipBLASLt / MIOpen)."""
+    return _MLP_GEMM
+
+
 def set_library_below_tiles(n: int) -> None:
     """ConvNeXt blocks whose fc2 result has fewer than ``n`` 128x128 tiles run on hipBLASLt + elementwise kernels instead
     of the split GEMM (one image's worth of ROIs leaves the deep stages with a handful of tiles)."""

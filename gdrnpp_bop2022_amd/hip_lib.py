@@ -74,6 +74,8 @@ SIGNATURES = {
     "gdrnpp_debug_refine_profile": (c_int, [_P]),
     "gdrnpp_pack_weight_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_linear_f32_split_grouped": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_head_tail_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split_workspace_bytes": (c_size_t, []),
     "gdrnpp_linear_f32_split_ws": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "gdrnpp_linear_f32_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -631,6 +633,40 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
     nbytes = 4.0 * m * k + 6.0 * n * k + 4.0 * m * n * (2 if epilogue == "scale_res" else 1)
     _check(_timed("linear", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split_ws(*args), nbytes), "gdrnpp_linear_f32_split")
     return out
+
+
+def linear_f32_split_grouped(x2d, weight_packed_stack, bias_stack, group_sel, rows_per_group: int, n_store: int | None = None):
+    """out[m] = x2d[m] @ W[sel[m // rows_per_group]]^T + bias[sel[...]]: the class-sliced output layer of the geometry head.
+    ``weight_packed_stack`` = pack_weight_bf16x3 of the slices stacked along N ([groups * N, K]), ``bias_stack`` f32[groups, N],
+    ``group_sel`` i32[M / rows_per_group].  Returns f32[M, N]; columns >= n_store are left unwritten."""
+    m, k = x2d.shape
+    n = bias_stack.shape[1]
+    if weight_packed_stack.dtype != torch.bfloat16 or weight_packed_stack.dim() != 6 or weight_packed_stack.shape[1] * 16 != k \
+            or (weight_packed_stack.shape[0] * 128) % n:
+        raise ValueError("weight_packed_stack must come from pack_weight_bf16x3 of the stacked [groups*N, K] weight")
+    out = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
+    args = (_dev(x2d, torch.float32, "x"), weight_packed_stack.data_ptr(), _dev(bias_stack, torch.float32, "bias_stack"),
+            _dev(group_sel, torch.int32, "group_sel"), int(rows_per_group), out.data_ptr(), m, n, k,
+            int(n_store if n_store is not None else n), _stream())
+    nbytes = 4.0 * m * k + 6.0 * n * k * group_sel.numel() + 4.0 * m * (n_store or n)
+    _check(_timed("linear_grouped", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split_grouped(*args), nbytes),
+           "gdrnpp_linear_f32_split_grouped")
+    return out
+
+
+def head_tail_nhwc(out_nhwc, coord2d, extents, double_mask: bool):
+    """Tail of the geometry head on the NHWC result [B*HW, pitch] of the class-sliced output layer: returns
+    (pnp_in f32[B, HW, 96] — Patch-PnP's input, NHWC with Cin padded to 96 — and planes f32[P, B, HW]: vis, (full,) x, y, z)."""
+    b = coord2d.shape[0]
+    hw = coord2d.shape[2] * coord2d.shape[3]
+    pitch = out_nhwc.shape[1]
+    n_planes = 5 if double_mask else 4
+    pnp_in = torch.empty((b, hw, 96), dtype=torch.float32, device=out_nhwc.device)
+    planes = torch.empty((n_planes, b, hw), dtype=torch.float32, device=out_nhwc.device)
+    _check(load().gdrnpp_head_tail_nhwc(_dev(out_nhwc, torch.float32, "out_nhwc"), pitch, _dev(coord2d, torch.float32, "coord2d"),
+                                        _dev(extents, torch.float32, "extents"), pnp_in.data_ptr(), planes.data_ptr(), b, hw,
+                                        1 if double_mask else 0, _stream()), "gdrnpp_head_tail_nhwc")
+    return pnp_in, planes
 
 
 def linear_f32_splitk(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None):

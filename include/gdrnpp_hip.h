@@ -366,6 +366,19 @@ int gdrnpp_linear_f32_split_ws(const float* A, const void* W_packed, const float
                                const float* resid, float* C, int M, int N, int K, int epilogue, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* Grouped form for the class-sliced 1x1 output layer of the geometry head (GDRN_double_mask.py:107-126 folded into the
+ * weights): W_packed_stack holds one gdrnpp_pack_weight_bf16x3 image per group (all [N,K]), bias_stack f32[groups][N];
+ * rows [g*rows_per_group, (g+1)*rows_per_group) of A use slice group_sel[g] (device i32[M / rows_per_group]); rows_per_group a
+ * multiple of 256 dividing M.  C is f32[M][N]; columns >= n_store (multiple of 4) are not written.  Bias epilogue only. */
+int gdrnpp_linear_f32_split_grouped(const float* A, const void* W_packed_stack, const float* bias_stack, const int* group_sel,
+                                    int rows_per_group, float* C, int M, int N, int K, int n_store, void* stream);
+/* Tail of the geometry head on that NHWC result (GDRN_double_mask.py:128-160, conv_pnp_net.py:120-134): out_nhwc
+ * f32[b*hw][pitch] with channels [vis | full (double_mask) | x | y | z | region bg, 1..64] ->
+ *   pnp_in f32[b*hw][96] = [(xyz - 0.5) * extent | coord2d (f32[b,2,hw]) | softmax(region[1..64]) | 27 zeros]  (Patch-PnP input, NHWC,
+ *          Cin padded to a multiple of 32), planes f32[3 + (double_mask ? 2 : 1)][b*hw] = vis, (full,) x, y, z of out_dict. */
+int gdrnpp_head_tail_nhwc(const float* out_nhwc, int pitch, const float* coord2d, const float* extents, float* pnp_in,
+                          float* planes, int b, int hw, int double_mask, void* stream);
+
 /* 3x3 / stride 1 / zero-pad 1 convolution of the geometry head (a3) as an implicit GEMM on the same kernel:
  * x f32 NHWC [n_img,H,W,Cin] -> y f32 NHWC [n_img,H,W,Cout]; W_packed = gdrnpp_pack_weight_bf16x3 of the weight
  * reordered to [Cout][ky][kx][Cin] (N = Cout, K = 9*Cin); bias may be NULL; epilogue 0 = none, 1 = GELU.

@@ -80,3 +80,28 @@ def test_config_surface_variants_run_through_forward_and_post(hip):
             assert torch.equal(m, torch.argmax(out["mask"], 1, keepdim=True).float())
             rec = post.process(batch, out)
             assert rec.shape == (NG.B, 16) and torch.isfinite(rec).all()
+
+
+@pytest.mark.parametrize("ds", ["ycbv", "tless"])
+def test_fused_head_tail_matches_module_path(hip, ds):
+    """The all-NHWC head tail (grouped class-sliced GEMM, head_tail kernel, Patch-PnP's first convolution with Cin padded to 96)
+    against the module path (baddbmm + torch softmax / cat + MIOpen / CK convolution) on the same weights: maps and Patch-PnP
+    outputs agree to fp32 rounding; the fused path is really the one taken by default."""
+    fx = NG.load_fixture(ds)
+    cfg = get_cfg(f"{ds}_convnext_a6", opts=["TEST.USE_DEPTH_REFINE=True"])
+    model, _ = build_model_optimizer(cfg)
+    model.load_state_dict(NG.seeded_reference_state_dict(model, fx), strict=True)
+    x = torch.from_numpy(NG.net_image()).cuda()
+    kw = NG.forward_kwargs(fx, "cuda")
+    with torch.no_grad():
+        assert model.fused_head_tail
+        fused = model(x, **kw)
+        model.fused_head_tail = False
+        plain = model(x, **kw)
+    assert not fused["region"].is_contiguous() and plain["region"].shape == fused["region"].shape   # NHWC view vs NCHW tensor
+    for k in ("mask", "full_mask", "coor_x", "coor_y", "coor_z", "region"):
+        a, b = fused[k].float(), plain[k].float()
+        assert a.shape == b.shape
+        assert ((a - b).abs().max() / b.abs().max()).item() < 2e-5, k
+    assert (fused["rot"] - plain["rot"]).abs().max().item() < 2e-5
+    assert (fused["trans"] - plain["trans"]).abs().max().item() < 2e-5 * max(1.0, plain["trans"].abs().max().item())
