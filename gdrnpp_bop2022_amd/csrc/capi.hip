@@ -10,6 +10,21 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+void* shim_scratch(size_t bytes) {
+  static thread_local void* block = nullptr;
+  static thread_local size_t cap = 0;
+  static thread_local int block_dev = -1;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { set_error("hipGetDevice: %s", hipGetErrorString(e)); return nullptr; }
+  if (block && block_dev == dev && cap >= bytes) return block;
+  if (block) { (void)hipFree(block); block = nullptr; cap = 0; }
+  const size_t want = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes + (bytes >> 2);
+  e = hipMalloc(&block, want);
+  if (e != hipSuccess) { block = nullptr; set_error("hipMalloc(%zu): %s", want, hipGetErrorString(e)); return nullptr; }
+  cap = want; block_dev = dev;
+  return block;
+}
 static int g_opt_glds = 1, g_opt_mi4 = -1, g_opt_pipe = 3, g_opt_pipe_conv = 0, g_opt_sk = 0;
 int option_split_gemm_glds() { return g_opt_glds; }
 int option_split_gemm_pipe() { return g_opt_pipe; }

@@ -60,6 +60,11 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return x != x ? x : r;
 }
 
+// Device scratch of the host-pointer shims of the reference ABI (farthest_point_sampling, uncertainty_pnp): grow-only, one
+// block per host thread, re-allocated when the thread switches device; kept for the life of the process (no hipMalloc /
+// hipFree per call).  Returns nullptr with the error text set when the allocation fails.
+void* shim_scratch(size_t bytes);
+
 // process-wide tuning switches (gdrnpp_set_option): read on the launch path instead of getenv
 int option_split_gemm_glds();   // 1: 256-row split-GEMM tiles use the LDS-DMA kernel
 int option_split_gemm_mi4();    // -1: by tile count, 0 / 1: force 128- / 256-row tiles (A/B measurements)

@@ -252,39 +252,36 @@ __global__ __launch_bounds__(kThreads) void fps_global_kernel(const float* __res
 }
 
 void host_fps(float* pts, int* idxs, int pn, int sn, int mode, int start) {
+  auto fail = [&](const char* what, const char* why) {
+    gdrnpp::set_error("farthest_point_sampling: %s: %s", what, why);
+    fprintf(stderr, "[gdrnpp_hip] %s\n", gdrnpp_last_error());
+    if (idxs) for (int i = 0; i < sn; ++i) idxs[i] = -1;  // loud: -1 is never a valid index
+  };
   if (!pts || !idxs || pn <= 0 || sn <= 0) {
     gdrnpp::set_error("farthest_point_sampling: bad arguments pn=%d sn=%d", pn, sn);
     fprintf(stderr, "[gdrnpp_hip] %s\n", gdrnpp_last_error());
     return;
   }
-  float* d_pts = nullptr;
-  int* d_idx = nullptr;
-  int* d_start = nullptr;
-  void* d_ws = nullptr;
-  size_t ws = gdrnpp_fps_workspace_bytes(1, pn);
-  int rc = 0;
-  auto fail = [&](const char* what, hipError_t e) {
-    gdrnpp::set_error("farthest_point_sampling: %s: %s", what, hipGetErrorString(e));
-    fprintf(stderr, "[gdrnpp_hip] %s\n", gdrnpp_last_error());
-    for (int i = 0; i < sn; ++i) idxs[i] = -1;  // loud: -1 is never a valid index
-  };
+  // one scratch block (kept per host thread): points | indices | start | workspace, 256-byte aligned pieces
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t n_pts = al(sizeof(float) * 3 * (size_t)pn), n_idx = al(sizeof(int) * (size_t)sn), n_start = 256;
+  const size_t ws = gdrnpp_fps_workspace_bytes(1, pn);
+  char* d = (char*)gdrnpp::shim_scratch(n_pts + n_idx + n_start + ws);
+  if (!d) return fail("scratch", gdrnpp_last_error());
+  float* d_pts = (float*)d;
+  int* d_idx = (int*)(d + n_pts);
+  int* d_start = (int*)(d + n_pts + n_idx);
+  void* d_ws = ws ? (void*)(d + n_pts + n_idx + n_start) : nullptr;
   hipError_t e;
-  if ((e = hipMalloc(&d_pts, sizeof(float) * 3 * (size_t)pn)) != hipSuccess) return fail("hipMalloc", e);
-  if ((e = hipMalloc(&d_idx, sizeof(int) * (size_t)sn)) != hipSuccess) { hipFree(d_pts); return fail("hipMalloc", e); }
-  hipMalloc(&d_start, sizeof(int));
-  if (ws) hipMalloc(&d_ws, ws);
-  hipMemcpy(d_pts, pts, sizeof(float) * 3 * (size_t)pn, hipMemcpyHostToDevice);
-  hipMemcpy(d_start, &start, sizeof(int), hipMemcpyHostToDevice);
-  rc = gdrnpp_fps(d_pts, d_idx, d_start, 1, pn, sn, mode, d_ws, nullptr);
-  if (rc == 0) {
-    e = hipMemcpy(idxs, d_idx, sizeof(int) * (size_t)sn, hipMemcpyDeviceToHost);  // syncs
-    if (e != hipSuccess) fail("hipMemcpy D2H", e);
-  } else {
+  if ((e = hipMemcpy(d_pts, pts, sizeof(float) * 3 * (size_t)pn, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy H2D", hipGetErrorString(e));
+  if ((e = hipMemcpy(d_start, &start, sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy H2D", hipGetErrorString(e));
+  const int rc = gdrnpp_fps(d_pts, d_idx, d_start, 1, pn, sn, mode, d_ws, nullptr);
+  if (rc != 0) {
     fprintf(stderr, "[gdrnpp_hip] farthest_point_sampling failed (%d): %s\n", rc, gdrnpp_last_error());
     for (int i = 0; i < sn; ++i) idxs[i] = -1;
+    return;
   }
-  hipFree(d_pts); hipFree(d_idx); hipFree(d_start);
-  if (d_ws) hipFree(d_ws);
+  if ((e = hipMemcpy(idxs, d_idx, sizeof(int) * (size_t)sn, hipMemcpyDeviceToHost)) != hipSuccess) fail("hipMemcpy D2H", hipGetErrorString(e));  // syncs
 }
 
 }  // namespace

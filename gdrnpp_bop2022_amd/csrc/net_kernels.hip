@@ -410,6 +410,62 @@ __global__ __launch_bounds__(256) void layernorm_nhwc_kernel(const float* __rest
 }
 
 // --------------------------------------------------------------------------------------------------
+// ConvNeXt stem: Conv2d(3 -> 128, 4x4, stride 4) + bias + LayerNorm2d in one pass, NCHW image in, NHWC features out
+// (timm convnext stem_0 / stem_1).  MIOpen ran the convolution (0.11-0.23 ms at 128 ROIs), ATen added the bias (0.08 ms),
+// a layout copy and a LayerNorm launch followed.  One wave = the 64 channel pairs of a pixel: the 2 x 48 weights of a lane
+// live in registers for the whole kernel, the 4 x 256 x 3 input floats of an output row are staged in LDS and read back as
+// broadcast float4s, LayerNorm over the 128 channels is a wave reduction (DPP).  fp32 fma chain in (ci, ky, kx) order.
+// --------------------------------------------------------------------------------------------------
+constexpr int kStemC = 128, kStemK = 48;
+__global__ __launch_bounds__(256) void stem_conv_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, const float* __restrict__ ln_w,
+                                                           const float* __restrict__ ln_b, float* __restrict__ y, int N, int H,
+                                                           int W, float eps) {
+  extern __shared__ float4 stem_rows[];   // [3][4][W/4] float4: the four image rows of one output row, per input channel
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int OH = H >> 2, OW = W >> 2, W4 = W >> 2;
+  float wr[2][kStemK];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int k4 = 0; k4 < kStemK / 4; ++k4) {
+      const float4 v = ld4(w + (size_t)(2 * lane + c) * kStemK + 4 * k4);
+      wr[c][4 * k4] = v.x; wr[c][4 * k4 + 1] = v.y; wr[c][4 * k4 + 2] = v.z; wr[c][4 * k4 + 3] = v.w;
+    }
+  const float b0 = bias ? bias[2 * lane] : 0.f, b1 = bias ? bias[2 * lane + 1] : 0.f;
+  const float g0 = ln_w[2 * lane], g1 = ln_w[2 * lane + 1], be0 = ln_b[2 * lane], be1 = ln_b[2 * lane + 1];
+  const long n_rows = (long)N * OH;
+  for (long row = blockIdx.x; row < n_rows; row += gridDim.x) {
+    const int n = (int)(row / OH), oy = (int)(row - (long)n * OH);
+    __syncthreads();   // the previous row's reads are done
+    for (int i = tid; i < 12 * W4; i += 256) {
+      const int r = i / W4, c4 = i - r * W4, ci = r >> 2, ky = r & 3;
+      stem_rows[i] = ld4(x + (((size_t)n * 3 + ci) * H + 4 * oy + ky) * W + 4 * c4);
+    }
+    __syncthreads();
+    for (int ox = wave; ox < OW; ox += 4) {
+      float a0 = b0, a1 = b1;
+#pragma unroll
+      for (int r = 0; r < 12; ++r) {
+        const float4 v = stem_rows[r * W4 + ox];   // same address in every lane: LDS broadcast
+        a0 = fmaf(v.x, wr[0][4 * r], a0); a1 = fmaf(v.x, wr[1][4 * r], a1);
+        a0 = fmaf(v.y, wr[0][4 * r + 1], a0); a1 = fmaf(v.y, wr[1][4 * r + 1], a1);
+        a0 = fmaf(v.z, wr[0][4 * r + 2], a0); a1 = fmaf(v.z, wr[1][4 * r + 2], a1);
+        a0 = fmaf(v.w, wr[0][4 * r + 3], a0); a1 = fmaf(v.w, wr[1][4 * r + 3], a1);
+      }
+      // LayerNorm2d over the 128 channels of the pixel (two passes, biased variance, eps inside the sqrt: as layernorm_nhwc_kernel)
+      const float mean = group_sum_dpp(a0 + a1, 64, lane) * (1.f / (float)kStemC);
+      a0 -= mean; a1 -= mean;
+      const float rstd = rsqrtf(group_sum_dpp(a0 * a0 + a1 * a1, 64, lane) * (1.f / (float)kStemC) + eps);
+      float2 o;
+      o.x = a0 * rstd * g0 + be0;
+      o.y = a1 * rstd * g1 + be1;
+      *reinterpret_cast<float2*>(y + (((size_t)n * OH + oy) * OW + ox) * kStemC + 2 * lane) = o;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
 // Tail of the geometry head (GDRN_double_mask.py:128-160 + conv_pnp_net.py:120-134) on the NHWC result of the class-sliced
 // output layer.  in: f32[B*HW][pitch], channels [vis | full (double mask) | x | y | z | region 0..R] (R = 64 regions + bg).
 //   pnp_in f32[B*HW][96] = [(x-0.5) ex, (y-0.5) ey, (z-0.5) ez | coord2d u, v | softmax(region[1..64]) | 27 zeros]
@@ -591,6 +647,19 @@ int gdrnpp_head_tail_nhwc(const float* out_nhwc, int pitch, const float* coord2d
   hipLaunchKernelGGL(head_tail_kernel, dim3((unsigned)(n_pix / kTailPix)), dim3(256), 0, (hipStream_t)stream, out_nhwc, pitch,
                      coord2d, extents, pnp_in, planes, hw, n_pix, double_mask ? 1 : 0);
   return gdrnpp::check_launch("gdrnpp_head_tail_nhwc");
+}
+
+int gdrnpp_stem_conv4x4_ln(const float* x_nchw, const float* weight, const float* bias, const float* ln_weight,
+                           const float* ln_bias, float* y_nhwc, int N, int H, int W, int Cout, float eps, void* stream) {
+  if (N == 0) return 0;
+  GDRNPP_REQUIRE(x_nchw && weight && ln_weight && ln_bias && y_nhwc, GDRNPP_EINVAL, "gdrnpp_stem_conv4x4_ln: null pointer");
+  GDRNPP_REQUIRE(N > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 16 == 0 && W <= 1024 && Cout == kStemC, GDRNPP_ELIMIT,
+                 "gdrnpp_stem_conv4x4_ln: N=%d H=%d W=%d Cout=%d (H %% 4, W %% 16, W <= 1024, Cout = %d)", N, H, W, Cout, kStemC);
+  const long n_rows = (long)N * (H / 4);
+  const long blocks = n_rows < 256 * 8 ? n_rows : 256 * 8;
+  hipLaunchKernelGGL(stem_conv_ln_kernel, dim3((unsigned)blocks), dim3(256), 12 * (W / 4) * sizeof(float4), (hipStream_t)stream, x_nchw,
+                     weight, bias, ln_weight, ln_bias, y_nhwc, N, H, W, eps);
+  return gdrnpp::check_launch("gdrnpp_stem_conv4x4_ln");
 }
 
 }  // extern "C"

@@ -378,20 +378,18 @@ void uncertainty_pnp(double* pts2d, double* pts3d, double* wgt2d, double* K, dou
   }
   const size_t n2 = sizeof(double) * 2 * (size_t)pn, n3 = sizeof(double) * 3 * (size_t)pn;
   const size_t total = n2 + 2 * n3 + sizeof(double) * (9 + 6 + 6);
-  char* d = nullptr;
-  hipError_t e = hipMalloc((void**)&d, total);
-  if (e != hipSuccess) { gdrnpp::set_error("%s", hipGetErrorString(e)); return fail("hipMalloc"); }
+  char* d = (char*)gdrnpp::shim_scratch(total);   // kept per host thread: no hipMalloc / hipFree per call
+  if (!d) return fail("scratch");
   double* d2 = (double*)d;
   double* d3 = (double*)(d + n2);
   double* dw = (double*)(d + n2 + n3);
   double* dK = (double*)(d + n2 + 2 * n3);
   double* di = dK + 9;
   double* dr = di + 6;
-  (void)hipMemcpy(d2, pts2d, n2, hipMemcpyHostToDevice);
-  (void)hipMemcpy(d3, pts3d, n3, hipMemcpyHostToDevice);
-  (void)hipMemcpy(dw, wgt2d, n3, hipMemcpyHostToDevice);
-  (void)hipMemcpy(dK, K, sizeof(double) * 9, hipMemcpyHostToDevice);
-  (void)hipMemcpy(di, init_rt, sizeof(double) * 6, hipMemcpyHostToDevice);
+  hipError_t e = hipSuccess;
+  auto up = [&](void* dst, const void* src, size_t n) { if (e == hipSuccess) e = hipMemcpy(dst, src, n, hipMemcpyHostToDevice); };
+  up(d2, pts2d, n2); up(d3, pts3d, n3); up(dw, wgt2d, n3); up(dK, K, sizeof(double) * 9); up(di, init_rt, sizeof(double) * 6);
+  if (e != hipSuccess) { gdrnpp::set_error("%s", hipGetErrorString(e)); return fail("hipMemcpy H2D"); }
   int rc = gdrnpp_uncertainty_pnp_batched(d2, d3, dw, dK, di, dr, nullptr, 1, pn, nullptr);
   if (rc == 0) {
     e = hipMemcpy(result_rt, dr, sizeof(double) * 6, hipMemcpyDeviceToHost);
@@ -399,7 +397,6 @@ void uncertainty_pnp(double* pts2d, double* pts3d, double* wgt2d, double* K, dou
   } else {
     fail("launch");
   }
-  (void)hipFree(d);
 }
 
 }  // extern "C"

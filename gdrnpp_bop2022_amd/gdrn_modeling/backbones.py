@@ -91,8 +91,7 @@ class ConvNeXtFeatures(nn.Module):
         self.num_features = prev
 
     def forward(self, x):
-        x = x.contiguous(memory_format=torch.channels_last)
-        x = self.stem_1(self.stem_0(x))
+        x = hip_layers.stem(self.stem_0, self.stem_1, x)   # fused conv + bias + LayerNorm2d on the GPU
         feats = []
         for i in range(max(self.out_indices) + 1):
             x = getattr(self, f"stages_{i}")(x)

@@ -64,6 +64,23 @@ def layernorm2d(ln: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
     return y.permute(0, 3, 1, 2)
 
 
+def stem(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+    """ConvNeXt stem: 4x4 / stride 4 convolution from 3 channels + LayerNorm2d.  One fused HIP kernel for the ConvNeXt-B shape
+    (NCHW-contiguous fp32 image, 128 output channels), else the module path."""
+    if (enabled_for(x) and _MLP_GEMM == "split" and x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+            and conv.in_channels == 3 and conv.out_channels == 128 and conv.kernel_size == (4, 4) and conv.stride == (4, 4)
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and ln.elementwise_affine
+            and x.shape[2] % 4 == 0 and x.shape[3] % 16 == 0 and x.shape[3] <= 1024):
+        cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
+        tag = weight_tag(conv.weight)
+        hit = cache.get("w_oihw")
+        if hit is None or hit[0] != tag:   # the kernel reads [co][ci][ky][kx]; the module may hold the weight channels_last
+            hit = (tag, conv.weight.detach().contiguous(memory_format=torch.contiguous_format).clone())
+            cache["w_oihw"] = hit
+        return hip_lib.stem_conv4x4_ln(x, hit[1], conv.bias, ln.weight, ln.bias, ln.eps)
+    return ln(conv(x.contiguous(memory_format=torch.channels_last)))
+
+
 def dwconv_ln(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor, cache: dict) -> torch.Tensor:
     """ConvNeXt block head: depthwise 7x7 then LayerNorm over C.  Returns the NHWC *view* [N,H,W,C]."""
     c = conv.in_channels

@@ -75,6 +75,7 @@ SIGNATURES = {
     "gdrnpp_pack_weight_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split_grouped": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_stem_conv4x4_ln": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "gdrnpp_head_tail_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split_workspace_bytes": (c_size_t, []),
     "gdrnpp_linear_f32_split_ws": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
@@ -651,6 +652,18 @@ def linear_f32_split_grouped(x2d, weight_packed_stack, bias_stack, group_sel, ro
     nbytes = 4.0 * m * k + 6.0 * n * k * group_sel.numel() + 4.0 * m * (n_store or n)
     _check(_timed("linear_grouped", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split_grouped(*args), nbytes),
            "gdrnpp_linear_f32_split_grouped")
+    return out
+
+
+def stem_conv4x4_ln(x_nchw, weight, bias, ln_weight, ln_bias, eps: float):
+    """ConvNeXt stem in one kernel: Conv2d(3 -> 128, 4x4/4) + bias + LayerNorm2d; NCHW image in, channels_last [N,128,H/4,W/4] out."""
+    n, cin, h, w = x_nchw.shape
+    cout = weight.shape[0]
+    out = torch.empty((n, cout, h // 4, w // 4), dtype=torch.float32, device=x_nchw.device, memory_format=torch.channels_last)
+    _check(load().gdrnpp_stem_conv4x4_ln(_dev(x_nchw, torch.float32, "x"), _dev(weight, torch.float32, "weight"),
+                                         _dev(bias, torch.float32, "bias") if bias is not None else None,
+                                         _dev(ln_weight, torch.float32, "ln_weight"), _dev(ln_bias, torch.float32, "ln_bias"),
+                                         out.data_ptr(), n, h, w, cout, float(eps), _stream()), "gdrnpp_stem_conv4x4_ln")
     return out
 
 

@@ -366,6 +366,11 @@ int gdrnpp_linear_f32_split_ws(const float* A, const void* W_packed, const float
                                const float* resid, float* C, int M, int N, int K, int epilogue, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* ConvNeXt stem (timm stem_0 + stem_1): Conv2d(3 -> 128, kernel 4, stride 4) + bias + LayerNorm2d over the channels in one
+ * pass.  x f32 NCHW [N,3,H,W] (H % 4 == 0, W % 16 == 0, W <= 1024), weight f32[128,3,4,4], bias f32[128] or NULL ->
+ * y f32 NHWC [N,H/4,W/4,128].  fp32 fma chain in (ci, ky, kx) order; LayerNorm as gdrnpp_layernorm_nhwc. */
+int gdrnpp_stem_conv4x4_ln(const float* x_nchw, const float* weight, const float* bias, const float* ln_weight,
+                           const float* ln_bias, float* y_nhwc, int N, int H, int W, int Cout, float eps, void* stream);
 /* Grouped form for the class-sliced 1x1 output layer of the geometry head (GDRN_double_mask.py:107-126 folded into the
  * weights): W_packed_stack holds one gdrnpp_pack_weight_bf16x3 image per group (all [N,K]), bias_stack f32[groups][N];
  * rows [g*rows_per_group, (g+1)*rows_per_group) of A use slice group_sel[g] (device i32[M / rows_per_group]); rows_per_group a

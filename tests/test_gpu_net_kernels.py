@@ -399,3 +399,24 @@ def test_conv2d_f32_split_general(hip, n, cin, cout, h, w, k, stride, pad):
     e_split = (out.double() - ref64).abs().max().item() / scale
     e_f32 = (ref32.double() - ref64).abs().max().item() / scale
     assert e_split <= max(1.5 * e_f32 + 1.5e-7, 4e-8 * (k * k * cin) ** 0.5), (e_split, e_f32)
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 256, 256), (2, 64, 96)])
+def test_stem_conv_ln_fused_vs_torch(hip, n, h, w):
+    """Fused ConvNeXt stem (4x4/4 convolution from 3 channels + bias + LayerNorm2d, NCHW in / NHWC out) against
+    F.conv2d + F.layer_norm in fp64."""
+    torch.manual_seed(7)
+    x = torch.rand(n, 3, h, w, device=DEV)
+    wt = torch.randn(128, 3, 4, 4, device=DEV) * 0.2
+    b = torch.randn(128, device=DEV) * 0.1
+    g = torch.rand(128, device=DEV) + 0.5
+    be = torch.randn(128, device=DEV) * 0.1
+    y = hip.stem_conv4x4_ln(x, wt, b, g, be, 1e-6)
+    assert y.shape == (n, 128, h // 4, w // 4) and y.is_contiguous(memory_format=torch.channels_last)
+    c = F.conv2d(x.double(), wt.double(), b.double(), stride=4)
+    ref = F.layer_norm(c.permute(0, 2, 3, 1), (128,), g.double(), be.double(), 1e-6).permute(0, 3, 1, 2)
+    assert (y.double() - ref).abs().max().item() < 2e-5
+    y0 = hip.stem_conv4x4_ln(x, wt, None, g, be, 1e-6)
+    c0 = F.conv2d(x.double(), wt.double(), None, stride=4)
+    ref0 = F.layer_norm(c0.permute(0, 2, 3, 1), (128,), g.double(), be.double(), 1e-6).permute(0, 3, 1, 2)
+    assert (y0.double() - ref0).abs().max().item() < 2e-5
