@@ -208,8 +208,8 @@ def inference_step_streams(model, post: GdrnHipPost, batch: dict, roi_ids: torch
                            n_streams: int = 2) -> torch.Tensor:
     """``inference_step`` with the ROIs cut into ``n_streams`` contiguous sub-batches that run on separate HIP streams (ROIs
     are independent).  Kernels of different sub-batches overlap on the chip: where one launch leaves workgroup slots idle —
-    the tile counts of the ConvNeXt GEMMs do not fill the 2 x 256 slots evenly, DESIGN.md §5 — the other stream's launch
-    fills them.  Same records, in ROI order."""
+    e.g. GEMM tile counts that do not fill the 2 x 256 slots evenly, DESIGN.md §5 — the other stream's launch
+    fills them (measured slower on the headline workload, whose shapes do divide evenly).  Same records, in ROI order."""
     b = batch["roi_img"].shape[0]
     if n_streams <= 1 or b < 2 * n_streams:
         return inference_step(model, post, batch, roi_ids)

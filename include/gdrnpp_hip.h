@@ -353,7 +353,7 @@ int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* b
                             void* stream);
 /* Same GEMM with a stream-K workspace (gdrnpp_linear_f32_split_workspace_bytes(); zero it ONCE when it is allocated; one
  * stream at a time).  When one 256x128 tile per workgroup would leave resident workgroup slots idle — the tile count is not a
- * multiple of the 2 x CU capacity, e.g. 392 tiles for the stage-2 fc2 of ConvNeXt-B at 128 ROIs — the launch is persistent
+ * multiple of the 2 x CU capacity, e.g. 392 tiles for the stage-2 fc2 of ConvNeXt-B at 128 ROIs of 224 x 224 crops — the launch is persistent
  * and every workgroup gets an equal contiguous range of (tile, k-pair) units; tiles shared by several workgroups are summed
  * from fp32 partials in ascending k order by the workgroup that holds their k = 0 (deterministic for given shapes; differs
  * from the one-tile-per-workgroup result by fp32 rounding of that sum).  workspace NULL = gdrnpp_linear_f32_split.

@@ -1,4 +1,5 @@
-"""Tile-count quantisation of the split GEMM at the real row counts of the 128-ROI step (GPU box)."""
+"""Tile-count quantisation of the split GEMM: row counts of 224x224 crops (56/28/14/7-pixel stages, uneven tile counts) against the
+next evenly dividing ones (the 256x256 headline workload has 64/32/16/8-pixel stages and divides evenly).  GPU box."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
