@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DW_WPE))) v
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ ln_w,
                                                          const float* __restrict__ ln_b, float* __restrict__ y, int N,
-                                                         int H, int W, int C, float eps) {
+                                                         int H, int W, int C, float eps, int buf_rows) {
   __shared__ float red[TH * TW * 8];  // FUSE_LN: per-wave partials when a pixel spans several waves
   extern __shared__ float4 wlds[];    // LDS_W: [49][C/4]
   const f4* wldsv = reinterpret_cast<const f4*>(wlds);
@@ -125,7 +125,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DW_WPE))) v
 #pragma unroll
     for (int j = 0; j < TW; ++j) acc[i][j] = b4;
 
-  if (active) {
+  if (active && buf_rows) {
+    // Input rows through buffer loads (rocprofv3 SQ counters: the kernel is VALU-bound and only 37 % of its VALU instructions
+    // were the pk_fma's — the rest was 64-bit address arithmetic per load and the compare + 4 v_cndmask that zero the columns
+    // outside the image).  One buffer descriptor per image row (base uniform in the wave, num_records = the row's bytes): a
+    // column offset outside [0, W*C*4) — negative ones wrap to huge unsigned values — makes the hardware return 0, and the
+    // TW+6 column offsets are constants of the tile, so a row costs its loads and nothing else.
+    using u4 = __attribute__((ext_vector_type(4))) unsigned;
+    const int n_u = __builtin_amdgcn_readfirstlane(n), ty_u = __builtin_amdgcn_readfirstlane(ty0);
+    int coff[TW + 6];
+#pragma unroll
+    for (int c = 0; c < TW + 6; ++c) coff[c] = ((tx0 + c - 3) * C + 4 * q) * 4;
+    const int row_bytes = W * C * 4;
+#pragma unroll 1
+    for (int r = 0; r < TH + 6; ++r) {
+      const int iy = ty_u + r - 3;
+      if (iy < 0 || iy >= H) continue;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(x) + ((size_t)n_u * H + iy) * W * C, 0, row_bytes, 0x00020000);
+      f4 row[TW + 6];
+#pragma unroll
+      for (int c = 0; c < TW + 6; ++c) row[c] = __builtin_bit_cast(f4, (u4)__builtin_amdgcn_raw_buffer_load_b128(rs, coff[c], 0, 0));
+#pragma unroll
+      for (int i = 0; i < TH; ++i) {
+        const int ky = r - i;
+        if (ky < 0 || ky > 6) continue;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const f4 wv = LDS_W ? wldsv[(ky * 7 + kx) * Q + q] : ld4v(w49c + (size_t)(ky * 7 + kx) * C + 4 * q);
+#pragma unroll
+          for (int j = 0; j < TW; ++j) acc[i][j] = DW_FMA(row[j + kx], wv, acc[i][j]);
+        }
+      }
+    }
+  } else if (active) {
     const float* xn = x + (size_t)n * H * W * C + 4 * q;
 #pragma unroll 1
     for (int r = 0; r < TH + 6; ++r) {
@@ -540,6 +573,10 @@ int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bia
   const int Q = C / 4;
   const long n_tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
   hipStream_t st = (hipStream_t)stream;
+  // buffer-load rows need the image (n) and tile row of a wave to be uniform: one tile per wave or more (Q >= 64), or the
+  // 64 / Q tiles of a wave side by side in one tile row; the row must fit a 32-bit buffer range
+  const int tiles_x = (W + TW - 1) / TW;
+  const int buf_rows = ((Q >= 64) || (tiles_x % (64 / Q) == 0)) && (long)W * C * 4 < (1l << 31) ? 1 : 0;
   const size_t wbytes = (size_t)49 * C * sizeof(float);
   const bool fuse = ln_w && ln_b;
   if (wbytes <= 112 * 1024) {
@@ -561,10 +598,10 @@ int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bia
     if (blocks > n_groups) blocks = n_groups;
     if (fuse) {
       hipLaunchKernelGGL((dwconv7_ln_kernel<true, true>), dim3((unsigned)blocks), dim3(threads), wbytes, st, x, w49c, bias,
-                         ln_w, ln_b, y, N, H, W, C, eps);
+                         ln_w, ln_b, y, N, H, W, C, eps, buf_rows);
     } else {
       hipLaunchKernelGGL((dwconv7_ln_kernel<false, true>), dim3((unsigned)blocks), dim3(threads), wbytes, st, x, w49c, bias,
-                         nullptr, nullptr, y, N, H, W, C, eps);
+                         nullptr, nullptr, y, N, H, W, C, eps, buf_rows);
     }
   } else {
     const int tiles_per_block = 256 / Q;
@@ -572,10 +609,10 @@ int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bia
     GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "gdrnpp_dwconv7x7_ln_nhwc: grid too large");
     if (fuse) {
       hipLaunchKernelGGL((dwconv7_ln_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias, ln_w,
-                         ln_b, y, N, H, W, C, eps);
+                         ln_b, y, N, H, W, C, eps, buf_rows);
     } else {
       hipLaunchKernelGGL((dwconv7_ln_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias,
-                         nullptr, nullptr, y, N, H, W, C, eps);
+                         nullptr, nullptr, y, N, H, W, C, eps, buf_rows);
     }
   }
   return gdrnpp::check_launch("gdrnpp_dwconv7x7_ln_nhwc");
