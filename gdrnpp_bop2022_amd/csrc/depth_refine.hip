@@ -11,8 +11,8 @@
 //   prologue  (optional) K_crop from the camera, ROI centre and scale (get_K_crop_resize fused); per-ROI mask min/max
 //             (shuffle + LDS reduce); the per-pixel query base ||xyz||*mask and the 64x64 sensor-depth crop go to LDS;
 //   stage     per iteration the V model points are transformed ONCE into homogeneous pixel space (fp64) and staged together
-//             with their projections u = h0/h2, v = h1/h2 (the bbox divisions, once per vertex instead of per corner) — in
-//             LDS (40 B/vertex, meshes up to 2688 vertices) or, for larger meshes, in a per-ROI slice of a global
+//             with their projections u = h0/h2, v = h1/h2 (fp32 {u, v, z} for the candidate test, once per vertex instead of fp64 divisions per
+//             corner) — in LDS (40 B/vertex, meshes up to 2688 vertices) or, for larger meshes, in a per-ROI slice of a global
 //             workspace (same kernel, template parameter);
 //   render    triangles -> threads; candidate pixels from the staged projections first (most sub-pixel triangles have none and
 //             stop there), corners gathered from the stage, fp64 edge functions, ds_min_u32 on a 16 KiB LDS
@@ -70,7 +70,7 @@ __device__ long long g_refine_prof[16];
 constexpr int kTS = 512;
 constexpr int kWavesS = kTS / 64;
 constexpr int kPPTS = kMaxPix / kTS;
-constexpr int kStage = 5;              // doubles staged per vertex: homogeneous pixel-space h[3], u = h0/h2, v = h1/h2
+constexpr int kStageBytes = 40;        // staged per vertex: homogeneous pixel-space h[3] (fp64) + {u = h0/h2, v = h1/h2, z} as one fp32 float4
 constexpr int kMaxStagedVerts = 2688;  // 105 KiB of LDS (with the 54 KiB of static LDS: the whole 160 KiB of a CU)
 constexpr int kMaxLargeS = 1024;       // queue of wave-rasterised triangles (overflow falls back to per-lane)
 
@@ -165,7 +165,8 @@ struct RefineArgs {
   double* t_out;                                       // f64[b,3] or null
   float* debug_depth;                                  // f32[b,iters,res,res] or null
   float* rec; const float* score; const int* roi_id;   // f32[b,16] pose records or null (score / roi_id nullable)
-  double* hv_global; int hv_stride;                    // vertex stage of meshes too large for LDS: [b][hv_stride][3]
+  double* hv_global; int hv_stride;                    // vertex stage of meshes too large for LDS: [b] x (hv_stride x 40 bytes)
+  int max_verts;                                       // of the mesh set (LDS stage layout)
   int res, iters; float threshold; int mask_type, use_coor_z; float z_near, z_far;
 };
 
@@ -204,7 +205,10 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
   const double zn = (double)z_near, zf = (double)z_far;
   double* hv;
   if constexpr (STAGED) hv = hv_lds;
-  else hv = a.hv_global + (size_t)bi * a.hv_stride * kStage;
+  else hv = a.hv_global + (size_t)bi * a.hv_stride * (kStageBytes / 8);
+  // staged projections behind the fp64 vertices (vertex count rounded up to even keeps the float4s 16-byte aligned)
+  const int vpad = STAGED ? ((a.max_verts + 1) & ~1) : a.hv_stride;
+  float4* const uvz = reinterpret_cast<float4*>(hv + 3 * (size_t)vpad);
   const int n_it = known ? iters : 0;
 
   PROF_STAMP(0);
@@ -287,9 +291,12 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
       for (int v = tid; v < nverts; v += kTS) {
         double h[3];
         project_vertex(mverts + 3 * (size_t)v, K, R, tr, h);
-        double* o = hv + kStage * (size_t)v;
+        double* o = hv + 3 * (size_t)v;
         o[0] = h[0]; o[1] = h[1]; o[2] = h[2];
-        o[3] = h[0] / h[2]; o[4] = h[1] / h[2];   // the per-triangle bbox divisions of setup_triangle, once per vertex
+        // projections for the candidate test, once per vertex, in single precision (the test carries a 1e-3 px margin): one
+        // 16-byte gather per corner instead of three 8-byte ones — the rasteriser is bound by these LDS gathers
+        const float hz = (float)h[2];
+        uvz[v] = make_float4((float)h[0] / hz, (float)h[1] / hz, hz, 0.f);
       }
     }
 #pragma unroll
@@ -308,21 +315,21 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
     // TriSetup as setup_triangle
     auto staged_setup = [&](int f, TriSetup& s) -> bool {
       const int i0 = mfaces[3 * f], i1 = mfaces[3 * f + 1], i2 = mfaces[3 * f + 2];
-      const double* p0 = hv + kStage * (size_t)i0;
-      const double* p1 = hv + kStage * (size_t)i1;
-      const double* p2 = hv + kStage * (size_t)i2;
-      double h0[3], h1[3], h2[3], uv0[2] = {0, 0}, uv1[2] = {0, 0}, uv2[2] = {0, 0};
-      h0[2] = p0[2]; h1[2] = p1[2]; h2[2] = p2[2];
-      const bool front = fmin(h0[2], fmin(h1[2], h2[2])) >= zn;
-      if (front) {
-        uv0[0] = p0[3]; uv0[1] = p0[4]; uv1[0] = p1[3]; uv1[1] = p1[4]; uv2[0] = p2[3]; uv2[1] = p2[4];
-        h0[0] = h0[1] = h1[0] = h1[1] = h2[0] = h2[1] = 0.0;
-      } else {
-        h0[0] = p0[0]; h0[1] = p0[1]; h1[0] = p1[0]; h1[1] = p1[1]; h2[0] = p2[0]; h2[1] = p2[1];
-      }
       s.D = 0.0;
-      if (!triangle_bbox(h0, h1, h2, uv0, uv1, uv2, res, res, zn, zf, s)) return false;
-      if (front) { h0[0] = p0[0]; h0[1] = p0[1]; h1[0] = p1[0]; h1[1] = p1[1]; h2[0] = p2[0]; h2[1] = p2[1]; }
+      const int cand = triangle_bbox_f32(uvz[i0], uvz[i1], uvz[i2], res, res, z_near, z_far, s);
+      if (cand == 0) return false;
+      const double* p0 = hv + 3 * (size_t)i0;
+      const double* p1 = hv + 3 * (size_t)i1;
+      const double* p2 = hv + 3 * (size_t)i2;
+      const double h0[3] = {p0[0], p0[1], p0[2]}, h1[3] = {p1[0], p1[1], p1[2]}, h2[3] = {p2[0], p2[1], p2[2]};
+      if (cand == 2) {   // near-plane clipping / non-finite projections: the exact fp64 candidate box
+        double uv0[2] = {0, 0}, uv1[2] = {0, 0}, uv2[2] = {0, 0};
+        if (fmin(h0[2], fmin(h1[2], h2[2])) >= zn) {
+          uv0[0] = h0[0] / h0[2]; uv0[1] = h0[1] / h0[2]; uv1[0] = h1[0] / h1[2]; uv1[1] = h1[1] / h1[2];
+          uv2[0] = h2[0] / h2[2]; uv2[1] = h2[1] / h2[2];
+        }
+        if (!triangle_bbox(h0, h1, h2, uv0, uv1, uv2, res, res, zn, zf, s)) return false;
+      }
       return triangle_edges(h0, h1, h2, s);
     };
     for (int f = tid; f < nfaces; f += kTS) {
@@ -573,16 +580,17 @@ int launch_refine(const gdrnpp_meshes* meshes, RefineArgs a, int b, void* worksp
   a.n_obj = meshes->n_obj;
   if (meshes->max_verts > 0 && meshes->max_verts <= kMaxStagedVerts) {
     static bool done[64];
-    if (int rc = raise_dynamic_lds_once(depth_refine_kernel<true>, kStage * (int)sizeof(double) * kMaxStagedVerts, done)) return rc;
-    a.hv_global = nullptr; a.hv_stride = 0;
-    hipLaunchKernelGGL(depth_refine_kernel<true>, dim3(b), dim3(kTS), kStage * (int)sizeof(double) * meshes->max_verts, st, a);
+    if (int rc = raise_dynamic_lds_once(depth_refine_kernel<true>, kStageBytes * kMaxStagedVerts, done)) return rc;
+    a.hv_global = nullptr; a.hv_stride = 0; a.max_verts = meshes->max_verts;
+    hipLaunchKernelGGL(depth_refine_kernel<true>, dim3(b), dim3(kTS), kStageBytes * ((meshes->max_verts + 1) & ~1), st, a);
   } else {
     GDRNPP_REQUIRE(meshes->max_verts > 0, GDRNPP_EINVAL, "%s: gdrnpp_meshes.max_verts must be set", who);
-    const size_t need = (size_t)b * meshes->max_verts * kStage * sizeof(double);
+    const int vp = (meshes->max_verts + 1) & ~1;
+    const size_t need = (size_t)b * vp * kStageBytes;
     GDRNPP_REQUIRE(workspace && workspace_bytes >= need, GDRNPP_EINVAL,
                    "%s: meshes of up to %d vertices need a workspace of %zu bytes (gdrnpp_depth_refine_workspace_bytes)", who,
                    meshes->max_verts, need);
-    a.hv_global = (double*)workspace; a.hv_stride = meshes->max_verts;
+    a.hv_global = (double*)workspace; a.hv_stride = vp; a.max_verts = meshes->max_verts;
     hipLaunchKernelGGL(depth_refine_kernel<false>, dim3(b), dim3(kTS), 0, st, a);
   }
   return gdrnpp::check_launch(who);
@@ -610,7 +618,7 @@ int gdrnpp_render_depth(const gdrnpp_meshes* meshes, const int* obj, const float
 
 size_t gdrnpp_depth_refine_workspace_bytes(const gdrnpp_meshes* meshes, int b) {
   if (!meshes || b <= 0 || meshes->max_verts <= kMaxStagedVerts) return 0;
-  return (size_t)b * meshes->max_verts * kStage * sizeof(double);
+  return (size_t)b * ((meshes->max_verts + 1) & ~1) * kStageBytes;
 }
 
 int gdrnpp_depth_refine(const gdrnpp_meshes* meshes, const int* obj, const float* coor_x, const float* coor_y,

@@ -99,6 +99,26 @@ __device__ __forceinline__ bool triangle_bbox(const double* h0, const double* h1
   return s.i_lo <= s.i_hi && s.j_lo <= s.j_hi;
 }
 
+// Candidate pixels from single-precision projections (uvz = {u, v, z, -} of each vertex, relative error <= 3e-7): the same
+// box as triangle_bbox's all-in-front branch, widened by 1e-3 px instead of 1e-6 — still a superset of every centre the fp64
+// edge functions can accept, so the rendered maps do not change.  Returns 0 = no candidate, 1 = candidates in s, 2 = the
+// triangle is not safely in front of the near plane (or not finite): the caller must take the fp64 path.
+__device__ __forceinline__ int triangle_bbox_f32(const float4 a, const float4 b, const float4 c, int res_w, int res_h,
+                                                 float z_near, float z_far, TriSetup& s) {
+  const float zmin = fminf(a.z, fminf(b.z, c.z)), zmax = fmaxf(a.z, fmaxf(b.z, c.z));
+  if (!(zmin >= z_near * 1.00001f)) return 2;          // near-plane clipping (or NaN): exact path
+  if (zmin > z_far * 1.00001f) return 0;               // entirely beyond the far plane (zmax >= zmin >= z_near here)
+  const float umin = fminf(a.x, fminf(b.x, c.x)), umax = fmaxf(a.x, fmaxf(b.x, c.x));
+  const float vmin = fminf(a.y, fminf(b.y, c.y)), vmax = fmaxf(a.y, fmaxf(b.y, c.y));
+  if (!(umin <= umax) || !(vmin <= vmax)) return 2;    // NaN / inf projections: exact path decides
+  const float lo_u = fmaxf(ceilf(umin - 0.501f), 0.f), hi_u = fminf(floorf(umax - 0.499f), (float)(res_w - 1));
+  const float lo_v = fmaxf(ceilf(vmin - 0.501f), 0.f), hi_v = fminf(floorf(vmax - 0.499f), (float)(res_h - 1));
+  if (!(lo_u <= hi_u && lo_v <= hi_v)) return 0;
+  s.i_lo = (int)lo_u; s.i_hi = (int)hi_u; s.j_lo = (int)lo_v; s.j_hi = (int)hi_v;
+  (void)zmax;
+  return 1;
+}
+
 // edge planes and determinant; false for a degenerate triangle (no fragment)
 __device__ __forceinline__ bool triangle_edges(const double* h0, const double* h1, const double* h2, TriSetup& s) {
   cross3(h1, h2, s.e0);
