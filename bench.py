@@ -73,8 +73,6 @@ def parse(argv=None):
                    help="auto = refine (BASELINE configs[2]) below 8 GPUs, tless (config 4: 1024 ROIs over 8 ranks) at 8")
     p.add_argument("--batch", type=int, default=0, help="ROIs per GPU per step (0 = the workload's batch)")
     p.add_argument("--graph", action="store_true", help="replay the whole step from a captured hipGraph")
-    p.add_argument("--streams", type=int, default=1,
-                   help="run the step as this many ROI sub-batches on separate HIP streams (engine.inference_step_streams)")
     p.add_argument("--with-crop", action="store_true",
                    help="start each step from full images: GPU ROI crop-resize (row a1) feeds the forward")
     p.add_argument("--subdiv", type=int, default=4, help="icosphere subdivision of the synthetic meshes (4 = 2562V/5120F)")
@@ -238,7 +236,7 @@ def worker(args):
             "config": {
                 "workload": f"{label}, batch={b} ROIs/GPU" + (f", {n_global} ROIs per iteration over {world} ranks" if world > 1 else ""),
                 "baseline_config_index": cfg_no, "workload_key": wname, "global_batch": n_global, "rois_per_gpu": b,
-                "roi_prep_on_gpu": bool(args.with_crop), "hipgraph": bool(args.graph), "roi_streams": int(args.streams), "input_res": 256, "output_res": 64,
+                "roi_prep_on_gpu": bool(args.with_crop), "hipgraph": bool(args.graph), "input_res": 256, "output_res": 64,
                 "parallelism": f"roi-shard x{world}", "collective": "all_gather f32[n,16] pose records" if world > 1 else None,
                 "class_sliced_out_layer": not args.exact_reference_order, "hip_network_layers": not args.no_hip_layers,
                 "mlp_gemm": args.mlp_gemm, "library_options": args.opt, "timed_entry_point": "engine.inference_step + engine.gather_records",
@@ -258,7 +256,7 @@ def worker(args):
 def build_state(args, cfg_names, refine, wname, b, rank, dev, roi_ids):
     from gdrnpp_bop2022_amd import hip_lib
     from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
-    from gdrnpp_bop2022_amd.gdrn_modeling.engine import GdrnHipPost, GraphedInference, inference_step, inference_step_streams
+    from gdrnpp_bop2022_amd.gdrn_modeling.engine import GdrnHipPost, GraphedInference, inference_step
     from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
 
     hip_lib.load()
@@ -360,10 +358,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, roi_ids):
                 m["graphs"][k] = GraphedInference(m["model"], m["post"], m["batches"][k], roi_ids)
             m["graphs"][k].graph.replay()   # inputs already live in the graph's static buffers (resident in HBM)
             return m["graphs"][k].records
-        if args.streams > 1:
-            rec = inference_step_streams(m["model"], m["post"], prepared(m, k), roi_ids, args.streams)
-        else:
-            rec = inference_step(m["model"], m["post"], prepared(m, k), roi_ids)
+        rec = inference_step(m["model"], m["post"], prepared(m, k), roi_ids)
         if upnp is not None:
             u = upnp[k]
             rt = hip_lib.uncertainty_pnp_batched(u["p2"], u["p3"], u["w"], u["K"], u["init"])

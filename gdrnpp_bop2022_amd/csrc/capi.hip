@@ -25,11 +25,10 @@ void* shim_scratch(size_t bytes) {
   cap = want; block_dev = dev;
   return block;
 }
-static int g_opt_glds = 1, g_opt_mi4 = -1, g_opt_pipe = 3, g_opt_pipe_conv = 0, g_opt_sk = 0;
+static int g_opt_glds = 1, g_opt_mi4 = -1, g_opt_pipe = 3, g_opt_pipe_conv = 0;
 int option_split_gemm_glds() { return g_opt_glds; }
 int option_split_gemm_pipe() { return g_opt_pipe; }
 int option_split_gemm_pipe_conv() { return g_opt_pipe_conv; }
-int option_split_gemm_sk() { return g_opt_sk; }
 int option_split_gemm_mi4() { return g_opt_mi4; }
 }  // namespace gdrnpp
 
@@ -73,7 +72,6 @@ int gdrnpp_copy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
 int gdrnpp_set_option(const char* name, int value) {
   GDRNPP_REQUIRE(name, GDRNPP_EINVAL, "gdrnpp_set_option: null name");
   if (!strcmp(name, "split_gemm_glds")) { gdrnpp::g_opt_glds = value != 0; return 0; }
-  if (!strcmp(name, "split_gemm_sk")) { gdrnpp::g_opt_sk = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   if (!strcmp(name, "split_gemm_pipe_conv")) { gdrnpp::g_opt_pipe_conv = value != 0; return 0; }
   if (!strcmp(name, "split_gemm_pipe")) { gdrnpp::g_opt_pipe = value == 3 ? 3 : (value != 0 ? 2 : 0); return 0; }
   if (!strcmp(name, "split_gemm_mi4")) { gdrnpp::g_opt_mi4 = value < 0 ? -1 : (value != 0); return 0; }

@@ -462,7 +462,7 @@ namespace {
 
 template <int EPI, bool CONV>
 int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
-                     int M, int N, int K, ConvGeom cg, void* ws, size_t ws_bytes, hipStream_t st, const char* what) {
+                     int M, int N, int K, ConvGeom cg, hipStream_t st, const char* what) {
   const bool fast3x3 = CONV && cg.KW == 3 && cg.stride == 1 && cg.pad == 1 && K == 9 * cg.C;
   const long tiles256 = (long)((M + 255) / 256) * (N / BN);
   GDRNPP_REQUIRE(tiles256 < (1l << 30), GDRNPP_ELIMIT, "%s: grid too large", what);
@@ -470,10 +470,8 @@ int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const f
   // 128x128 tiles at three workgroups per CU); gdrnpp_set_option("split_gemm_mi4", 0/1) forces the choice (A/B).
   const int force = gdrnpp::option_split_gemm_mi4();
   const bool big = force >= 0 ? force == 1 : tiles256 >= 512;
-  if (gdrnpp::option_split_gemm_pipe() && force != 0 && (!CONV || gdrnpp::option_split_gemm_pipe_conv()) && (big || (!CONV && ws))) {
-    // software-pipelined LDS-DMA kernel; below one round of 256-row tiles only as a stream-K schedule
-    const int rc = launch_split_pipe(A, Wp, bias, gamma, resid, C, M, N, K, EPI, CONV, cg, gdrnpp::option_split_gemm_pipe(), ws,
-                                     ws_bytes, !big, st, what);
+  if (big && gdrnpp::option_split_gemm_pipe() && (!CONV || gdrnpp::option_split_gemm_pipe_conv())) {   // software-pipelined LDS-DMA kernel
+    const int rc = launch_split_pipe(A, Wp, bias, gamma, resid, C, M, N, K, EPI, CONV, cg, gdrnpp::option_split_gemm_pipe(), st, what);
     if (rc >= 0) return rc;
   }
   if (big && gdrnpp::option_split_gemm_glds()) {   // LDS-DMA kernel: any M, any of the three A forms
@@ -496,10 +494,10 @@ int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const f
 
 template <bool CONV>
 int launch_split(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
-                 int M, int N, int K, int epilogue, ConvGeom cg, void* ws, size_t ws_bytes, hipStream_t st, const char* what) {
-  if (epilogue == EPI_BIAS) return launch_split_epi<EPI_BIAS, CONV>(A, Wp, bias, gamma, resid, C, M, N, K, cg, ws, ws_bytes, st, what);
-  if (epilogue == EPI_GELU) return launch_split_epi<EPI_GELU, CONV>(A, Wp, bias, gamma, resid, C, M, N, K, cg, ws, ws_bytes, st, what);
-  return launch_split_epi<EPI_SCALE_RES, CONV>(A, Wp, bias, gamma, resid, C, M, N, K, cg, ws, ws_bytes, st, what);
+                 int M, int N, int K, int epilogue, ConvGeom cg, hipStream_t st, const char* what) {
+  if (epilogue == EPI_BIAS) return launch_split_epi<EPI_BIAS, CONV>(A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
+  if (epilogue == EPI_GELU) return launch_split_epi<EPI_GELU, CONV>(A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
+  return launch_split_epi<EPI_SCALE_RES, CONV>(A, Wp, bias, gamma, resid, C, M, N, K, cg, st, what);
 }
 
 }  // namespace
@@ -571,11 +569,9 @@ extern "C" int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, co
   return gdrnpp::check_launch("gdrnpp_linear_f32_splitk");
 }
 
-extern "C" size_t gdrnpp_linear_f32_split_workspace_bytes(void) { return split_sk_workspace_bytes(); }
-
-extern "C" int gdrnpp_linear_f32_split_ws(const float* A, const void* W_packed, const float* bias, const float* gamma,
-                                          const float* resid, float* C, int M, int N, int K, int epilogue, void* workspace,
-                                          size_t workspace_bytes, void* stream) {
+extern "C" int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* bias, const float* gamma,
+                                       const float* resid, float* C, int M, int N, int K, int epilogue,
+                                       void* stream) {
   GDRNPP_REQUIRE(A && W_packed && C, GDRNPP_EINVAL, "gdrnpp_linear_f32_split: null pointer");
   GDRNPP_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % 32 == 0, GDRNPP_ELIMIT,
                  "gdrnpp_linear_f32_split: N=%d K=%d must be multiples of %d/32 (M=%d is free)", N, K, BN, M);
@@ -583,13 +579,7 @@ extern "C" int gdrnpp_linear_f32_split_ws(const float* A, const void* W_packed, 
   GDRNPP_REQUIRE(epilogue != EPI_SCALE_RES || (gamma && resid), GDRNPP_EINVAL,
                  "gdrnpp_linear_f32_split: scale+residual epilogue needs gamma and resid");
   return launch_split<false>(A, (const uint4*)W_packed, bias, gamma, resid, C, M, N, K, epilogue, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0},
-                             workspace, workspace ? workspace_bytes : 0, (hipStream_t)stream, "gdrnpp_linear_f32_split");
-}
-
-extern "C" int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* bias, const float* gamma,
-                                       const float* resid, float* C, int M, int N, int K, int epilogue,
-                                       void* stream) {
-  return gdrnpp_linear_f32_split_ws(A, W_packed, bias, gamma, resid, C, M, N, K, epilogue, nullptr, 0, stream);
+                             (hipStream_t)stream, "gdrnpp_linear_f32_split");
 }
 
 extern "C" int gdrnpp_conv2d_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
@@ -607,7 +597,7 @@ extern "C" int gdrnpp_conv2d_f32_split(const float* x_nhwc, const void* W_packed
                  "gdrnpp_conv2d_f32_split: Cout=%d Cin=%d must be multiples of %d/32 (pixels=%ld is free)", Cout, Cin, BN, M);
   GDRNPP_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_GELU, GDRNPP_EINVAL, "gdrnpp_conv2d_f32_split: epilogue=%d", epilogue);
   return launch_split<true>(x_nhwc, (const uint4*)W_packed, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, KH * KW * Cin, epilogue,
-                            ConvGeom{H, W, Cin, OH, OW, KW, stride, pad, 0}, nullptr, 0, (hipStream_t)stream, "gdrnpp_conv2d_f32_split");
+                            ConvGeom{H, W, Cin, OH, OW, KW, stride, pad, 0}, (hipStream_t)stream, "gdrnpp_conv2d_f32_split");
 }
 
 extern "C" int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,

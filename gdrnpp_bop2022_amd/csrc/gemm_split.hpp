@@ -36,18 +36,13 @@ using gdrnpp::gelu_erf;  // common.hpp
 
 // Software-pipelined LDS-DMA kernel (gemm_split_pipe.hip).  Handles the linear form and the 3x3/1/1 convolution with
 // M*K*4 (resp. the image bytes) below 4 GiB; returns -1 when the problem is outside its domain (the caller then uses the
-// kernels of gemm_split.hip), else the launch status.  With a stream-K workspace (split_sk_workspace_bytes(), zeroed once by
-// its owner, used by one stream at a time) the linear form is scheduled stream-K when one tile per workgroup would leave
-// resident slots idle; allow_small: accept problems with fewer tiles than resident slots (stream-K only).
-size_t split_sk_workspace_bytes();
+// kernels of gemm_split.hip), else the launch status.
 int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
-                      int M, int N, int K, int epilogue, bool conv, ConvGeom cg, int a_stages, void* sk_workspace,
-                      size_t sk_workspace_bytes, bool allow_small, hipStream_t st, const char* what);
+                      int M, int N, int K, int epilogue, bool conv, ConvGeom cg, int a_stages, hipStream_t st, const char* what);
 
 }  // namespace splitgemm
 
 int option_split_gemm_pipe();       // 0: off, 2 / 3 (default): pipelined kernel with that many A stages for 256-row tiles (linear form)
-int option_split_gemm_sk();         // 0 (default): never, 1: stream-K when tiles do not fill the resident slots evenly, 2: always
 int option_split_gemm_pipe_conv();  // 1: the 3x3/1/1 convolution uses it too (default 0: measured 1 % slower than the LDS-DMA kernel)
 
 }  // namespace gdrnpp

@@ -20,7 +20,6 @@
 // LDS: NA x 16 KB (A, fp32) + 2 x 12 KB (weights) = 56 / 72 KB dynamic, two workgroups per CU.
 // Results are bitwise equal to the other split-GEMM kernels (same products, same order per accumulator).
 #include "gemm_split.hpp"
-#include <atomic>
 
 namespace {
 
@@ -99,22 +98,6 @@ struct HalfSplit {
   }
 };
 
-// Stream-K bookkeeping (SK kernels): the grid is persistent (G workgroups = the resident capacity), split into G / ntn teams of
-// ntn = N/128 workgroups; team t owns the contiguous range [tot*t/teams, tot*(t+1)/teams) of (m-tile, k-pair) units, tot =
-// m-tiles * nk/2, and its workgroup j computes n-tile j of those units.  A workgroup therefore runs: the END of one tile (its first piece, if its range starts inside a tile), whole tiles, and the
-// BEGINNING of a last tile.  Pieces that do not start at k = 0 store their fp32 accumulators as a partial (slot = workgroup id,
-// register-major, 128 KB) and publish a flag; the piece that holds k = 0 of a tile is processed LAST by its workgroup and
-// finishes the tile: it waits for the flags of the same-column workgroups of the following teams that hold the rest of that tile (they computed it
-// first, long ago), adds their partials in ascending k order and runs the epilogue.  No workgroup ever waits before it has
-// published its own partial, so there is no cyclic dependency whatever the dispatch order; spins are bounded all the same.
-// The consumer clears the flag it waited for, so every launch (and every hipGraph replay of it) starts from clear flags.
-// Partials cross XCDs (per-XCD L2s are not coherent) as sc1 stores / sc1 loads behind a relaxed agent-scope flag.
-struct StreamK {
-  float* partials;          // [G][256*128] fp32
-  unsigned* flags;          // [G], holds the epoch of the launch that last published the slot
-  unsigned epoch;           // > 0, unique per launch
-};
-
 // Grouped launch (linear form): rows [g*rows_per_group, (g+1)*rows_per_group) use weight / bias slice sel[g] of a stack of
 // equally shaped packed weights — the class-sliced 1x1 output layer of the geometry head (every ROI = 4096 rows selects the
 // 70 output channels of its class).  rows_per_group is a multiple of the 256-row tile.  Columns >= n_store are not written.
@@ -127,73 +110,62 @@ struct Grouped {
 };
 
 // CONV: 0 = linear (A row-major [M,K]), 1 = 3x3 / stride 1 / pad 1 convolution over an NHWC image (implicit im2col)
-// NA: A stages (2: one k-tile ahead, 3: two k-tiles ahead).  SK: stream-K schedule (linear form), else one tile per workgroup.
-template <int EPI, int CONV, int NA, bool SK>
+// NA: A stages (2: one k-tile ahead, 3: two k-tiles ahead)
+template <int EPI, int CONV, int NA>
 __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __restrict__ A, const uint4* __restrict__ Wp,
                                                                  const float* __restrict__ bias,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ resid, float* __restrict__ C,
-                                                                 int M, int N, int K, ConvGeom cg, StreamK sk, Grouped grp) {
+                                                                 int M, int N, int K, ConvGeom cg, Grouped grp) {
   extern __shared__ uint4 smem[];  // the only LDS object: [NA][1024] A slots | [2][768] weight slots
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntn = N / BN;
-  // XCD-aware order of workgroups (hardware deals consecutive ids round-robin to the 8 XCDs): logical neighbours share an L2
+  // XCD-aware tile order, as in gemm_split.hip
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int lw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-  const int nk = K / BK, U = nk >> 1;  // k-tiles, k-pairs per tile
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int tile_m = tile / ntn, tile_n = tile % ntn;
+  const int m0 = tile_m * 256, n0 = tile_n * BN;
+  const int nk = K / BK;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
-  // stream-K: the ntn workgroups of a TEAM (consecutive logical ids, one XCD) take the same contiguous range of
-  // (m-tile, k-pair) units and differ only in the n-tile, so they walk through the same A rows at the same time and share them
-  // through L2 exactly as the n-tiles of an m-tile do in the one-tile-per-workgroup schedule (a partition that gave
-  // neighbouring workgroups different k offsets of the same rows re-fetched A ntn times and was slower than no stream-K)
-  const int ntm = (M + 255) / 256;
-  const int teams = SK ? nwg / ntn : 1, team = SK ? lw / ntn : 0, tj = SK ? lw - team * ntn : 0;
-  const long tot = (long)ntm * U;   // units of one n-tile column
-  auto range_lo = [&](int t) -> long { return tot * t / teams; };
 
-  // ---- per-piece state (a piece = k-tiles [k0, k1) of one output tile)
-  int m0 = 0, n0 = 0, k_last = 0;
+  // ---- DMA lanes: piece c (0..3) of this wave fills A slots (wave*4 + c)*64 + lane = rows wave*64 + c*16 + lane/4, chunk
+  // q = (lane & 3) ^ ((row >> 2) & 3) of the row's 64-byte k segment (the swizzle is on the source address)
   const int prow = lane >> 2, pq = lane & 3;
-  unsigned aoff[4] = {0, 0, 0, 0};                       // linear: byte offset of the lane's chunk from A + kt*64
-  const float* ap[4] = {nullptr, nullptr, nullptr, nullptr};  // conv: anchor pixel of the lane's row (+ chunk)
-  unsigned okmask[4] = {0, 0, 0, 0};                     // conv: bit tap = the tap lies inside the image
-  const int cpt = CONV ? cg.C / BK : 1;
+  unsigned aoff[4];        // linear: byte offset of the lane's chunk from A + kt*64
+  const float* ap[4];      // conv: anchor pixel of the lane's row (+ chunk)
+  unsigned okmask[4];      // conv: bit tap = the tap lies inside the image
+  int cpt = 1;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int lrow = wave * 64 + c * 16 + prow;
+    const int q = pq ^ ((lrow >> 2) & 3);
+    const int arow = min(m0 + lrow, M - 1);
+    if constexpr (CONV) {
+      const int img = arow / (cg.H * cg.W), pp = arow - img * (cg.H * cg.W);
+      const int iy = pp / cg.W, ix = pp - iy * cg.W;
+      ap[c] = A + ((size_t)arow) * cg.C + q * 4;
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        if ((unsigned)(iy + dy) < (unsigned)cg.H && (unsigned)(ix + dx) < (unsigned)cg.W) mk |= 1u << t;
+      }
+      okmask[c] = mk;
+      aoff[c] = 0;
+    } else {
+      aoff[c] = (unsigned)arow * (unsigned)(K * 4) + (unsigned)(q * 16);
+      ap[c] = nullptr;
+      okmask[c] = 0;
+    }
+  }
+  if constexpr (CONV) cpt = cg.C / BK;
   const unsigned boff = (unsigned)((wave * 3) * 64 + lane) * 16u;
-  const char* wbase = nullptr;
-  const float* bias_t = nullptr;   // bias slice of the current tile
+  const int grp_i = grp.sel ? grp.sel[m0 / grp.rows_per_group] : 0;   // weight / bias slice of this tile's rows
+  const char* const wbase = reinterpret_cast<const char*>(Wp + (size_t)grp_i * grp.w_stride + (size_t)tile_n * nk * W_TILE_SLOTS);
+  const float* const bias_t = bias ? bias + (size_t)grp_i * grp.bias_stride : nullptr;
   const unsigned ldsA = lds0 + (unsigned)(wave * 4) * 1024u;
   const unsigned ldsB = lds0 + (unsigned)(NA * A_STAGE_B) + (unsigned)(wave * 3) * 1024u;
-
-  // DMA lanes: piece c (0..3) of this wave fills A slots (wave*4 + c)*64 + lane = rows wave*64 + c*16 + lane/4, chunk
-  // q = (lane & 3) ^ ((row >> 2) & 3) of the row's 64-byte k segment (the swizzle is on the source address)
-  auto setup_tile = [&](long tile) {
-    const int tile_m = (int)(tile / ntn), tile_n = (int)(tile - (long)tile_m * ntn);
-    m0 = tile_m * 256; n0 = tile_n * BN;
-    const int g = grp.sel ? grp.sel[m0 / grp.rows_per_group] : 0;
-    wbase = reinterpret_cast<const char*>(Wp + (size_t)g * grp.w_stride + (size_t)tile_n * nk * W_TILE_SLOTS);
-    bias_t = bias ? bias + (size_t)g * grp.bias_stride : nullptr;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int lrow = wave * 64 + c * 16 + prow;
-      const int q = pq ^ ((lrow >> 2) & 3);
-      const int arow = min(m0 + lrow, M - 1);
-      if constexpr (CONV) {
-        const int img = arow / (cg.H * cg.W), pp = arow - img * (cg.H * cg.W);
-        const int iy = pp / cg.W, ix = pp - iy * cg.W;
-        ap[c] = A + ((size_t)arow) * cg.C + q * 4;
-        unsigned mk = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int dy = t / 3 - 1, dx = t % 3 - 1;
-          if ((unsigned)(iy + dy) < (unsigned)cg.H && (unsigned)(ix + dx) < (unsigned)cg.W) mk |= 1u << t;
-        }
-        okmask[c] = mk;
-      } else {
-        aoff[c] = (unsigned)arow * (unsigned)(K * 4) + (unsigned)(q * 16);
-      }
-    }
-  };
 
   // piece c of the A image of k-tile kt -> stage byte offset sb
   auto dma_a = [&](int kt, unsigned sb, auto cc) {
@@ -214,6 +186,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
   };
 
   f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // ---- fragment lanes: MFMA operand lane = row/column (lane & 31), k-block fk = lane >> 5
   const int frow = lane & 31, fk = lane >> 5;
@@ -237,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
     constexpr int BS = decltype(bs_)::value;
     const uint4* const b = sBf + BS * (B_STAGE_B / 16);
     const uint4* const bn = sBf + (BS ^ 1) * (B_STAGE_B / 16);
-    const int kt_b = min(kt + 1, k_last), kt_a = min(kt + NA, k_last);
+    const int kt_b = min(kt + 1, nk - 1), kt_a = min(kt + NA, nk - 1);
     const unsigned sb_wr = (unsigned)((BS ^ 1) * B_STAGE_B), sa_wr_b = (unsigned)(sa_wr * A_STAGE_B);
     static_for<0, 48>([&](auto s_) {
       constexpr int S = decltype(s_)::value;
@@ -287,246 +265,122 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
     });
   };
 
-  // k-tiles [k0, k1) of the current tile accumulated into acc (k1 - k0 even).  On return every DMA has landed and every wave
-  // has passed a barrier: the LDS stages are free.
-  auto run_piece = [&](int k0, int k1) {
-    k_last = k1 - 1;
+  // ---- prologue: k-tiles 0 .. NA-1 of A and k-tile 0 of the weights; split k-tile 0; first fragments of the loop
+  static_for<0, 4>([&](auto c) { dma_a(0, 0u, c); });
+  static_for<0, 3>([&](auto c) { dma_b(0, 0u, c); });
+  static_for<0, 4>([&](auto c) { dma_a(min(1, nk - 1), (unsigned)A_STAGE_B, c); });
+  if constexpr (NA == 3) static_for<0, 4>([&](auto c) { dma_a(min(2, nk - 1), 2u * A_STAGE_B, c); });
+  wait_vmcnt<NA == 3 ? 4 : 0>();
+  __builtin_amdgcn_s_barrier();
+  HalfSplit f0[2], f1[2];
+  bf16x8 fbA[4], fbB[4];
+  load_half(f0[0], 0, 0);
+  load_half(f0[1], 0, 1);
+  static_for<0, 22>([&](auto s) { f0[0].template step<decltype(s)::value>(); f0[1].template step<decltype(s)::value>(); });
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // prologue: k-tiles k0 .. k0+NA-1 of A and k-tile k0 of the weights; split k-tile k0; first fragments of the loop
-    static_for<0, 4>([&](auto c) { dma_a(k0, 0u, c); });
-    static_for<0, 3>([&](auto c) { dma_b(k0, 0u, c); });
-    static_for<0, 4>([&](auto c) { dma_a(min(k0 + 1, k_last), (unsigned)A_STAGE_B, c); });
-    if constexpr (NA == 3) static_for<0, 4>([&](auto c) { dma_a(min(k0 + 2, k_last), 2u * A_STAGE_B, c); });
-    wait_vmcnt<NA == 3 ? 4 : 0>();
-    __builtin_amdgcn_s_barrier();
-    HalfSplit f0[2], f1[2];
-    bf16x8 fbA[4], fbB[4];
-    load_half(f0[0], 0, 0);
-    load_half(f0[1], 0, 1);
-    static_for<0, 22>([&](auto s) { f0[0].template step<decltype(s)::value>(); f0[1].template step<decltype(s)::value>(); });
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fbA[j] = __builtin_bit_cast(bf16x8, sBf[2 * KB * BN + j * 32]);
-    load_half(f1[0], 1, 0);
-    int sa = 0;  // (kt - k0) % NA
-    for (int kt = k0; kt < k1; kt += 2) {
-      const int sa1 = sa + 1 == NA ? 0 : sa + 1, sa2 = sa1 + 1 == NA ? 0 : sa1 + 1, sa3 = sa2 + 1 == NA ? 0 : sa2 + 1;
-      ktile(kt, f0, f1, fbA, fbB, std::integral_constant<int, 0>{}, sa1, sa2, sa);
-      ktile(kt + 1, f1, f0, fbB, fbA, std::integral_constant<int, 1>{}, sa2, sa3, sa1);
-      sa = sa2;
-    }
-    wait_vmcnt<0>();               // NA = 3: the clamped A pieces of the last trip are still in flight
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();  // every wave's stages are dead: the epilogue / the next piece reuses them
-  };
+  for (int j = 0; j < 4; ++j) fbA[j] = __builtin_bit_cast(bf16x8, sBf[2 * KB * BN + j * 32]);
+  load_half(f1[0], 1, 0);
 
-  // epilogue: per wave one 16x64 slice at a time through LDS, written back row-wise as float4 (as in gemm_split.hip)
-  auto epilogue = [&]() {
-    float* T = reinterpret_cast<float*>(smem) + wave * 16 * 65;
-    const int c4 = (lane & 15) * 4;
-#pragma unroll
-    for (int jh = 0; jh < 2; ++jh) {
-      const int nb = n0 + jh * 64 + c4;
-      const float4 bv = bias_t ? *reinterpret_cast<const float4*>(bias_t + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (EPI == EPI_SCALE_RES) gv = *reinterpret_cast<const float4*>(gamma + nb);
-#pragma unroll
-      for (int ih = 0; ih < 4; ++ih) {
-        const int i = ih >> 1, h = ih & 1;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 8; ++r)
-            T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 65 + j * 32 + (lane & 31)] = acc[i][jh * 2 + j][h * 8 + r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int row = rr * 4 + (lane >> 4);
-          const float* t = T + row * 65 + c4;
-          float4 v = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
-          const int grow = m0 + wave * 64 + i * 32 + h * 16 + row;
-          if (grow >= M || nb >= grp.n_store) continue;
-          const size_t off = (size_t)grow * N + nb;
-          if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-          if (EPI == EPI_SCALE_RES) {
-            const float4 rs = *reinterpret_cast<const float4*>(resid + off);
-            v.x = rs.x + gv.x * v.x; v.y = rs.y + gv.y * v.y; v.z = rs.z + gv.z * v.z; v.w = rs.w + gv.w * v.w;
-          }
-          { const f32x4v t4 = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t4, reinterpret_cast<f32x4v*>(C + off)); }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-      }
-    }
-  };
+  // ---- main loop, two k-tiles per trip (nk is even: K % 32 == 0)
+  int sa = 0;  // kt % NA
+  for (int kt = 0; kt < nk; kt += 2) {
+    const int sa1 = sa + 1 == NA ? 0 : sa + 1, sa2 = sa1 + 1 == NA ? 0 : sa1 + 1, sa3 = sa2 + 1 == NA ? 0 : sa2 + 1;
+    ktile(kt, f0, f1, fbA, fbB, std::integral_constant<int, 0>{}, sa1, sa2, sa);
+    ktile(kt + 1, f1, f0, fbB, fbA, std::integral_constant<int, 1>{}, sa2, sa3, sa1);
+    sa = sa2;
+  }
+  wait_vmcnt<0>();               // NA = 3: the clamped A pieces of the last trip are still in flight
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_s_barrier();  // every wave's stages are dead: the epilogue reuses them
 
-  if constexpr (!SK) {
-    setup_tile(lw);   // tiles in the XCD-aware order, n fastest
-    run_piece(0, nk);
-    epilogue();
-  } else {
-    // partial accumulators, register-major: float4 index ((wave*32 + q)*64 + lane), q = (i*4 + j)*4 + r/4.  They travel as
-    // write-through (sc1) stores and sc1 loads, which is all the cross-XCD hand-off needs (cdna_hip_programming.md §6 G16): an
-    // agent-scope release / acquire pair per workgroup writes back and invalidates a whole L2 — the one that holds the weights
-    // — and made this schedule slower than the one it replaces.
-    using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
-    auto part_rsrc = [&](int w) {
-      return __builtin_amdgcn_make_buffer_rsrc(sk.partials + (size_t)w * (256 * 128), 0, 256 * 128 * 4, 0x00020000);
-    };
-    const int part_off = ((wave * 32) * 64 + lane) * 16;
-    const long lo = range_lo(team), hi = range_lo(team + 1);
-    for (long it = lo; it < hi;) {
-      const long mt = it / U;
-      const int kb = (int)(it - mt * U), ke = (int)min((long)U, kb + (hi - it));
-      setup_tile(mt * ntn + tj);
-      run_piece(2 * kb, 2 * ke);
-      if (kb > 0) {
-        // tail / middle segment of a tile (always the first piece of this workgroup): publish the partial
-        const __amdgpu_buffer_rsrc_t rs = part_rsrc(lw);
+  // ---- epilogue: per wave one 16x64 slice at a time through LDS, written back row-wise as float4 (as in gemm_split.hip)
+  float* T = reinterpret_cast<float*>(smem) + wave * 16 * 65;
+  const int c4 = (lane & 15) * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+  for (int jh = 0; jh < 2; ++jh) {
+    const int nb = n0 + jh * 64 + c4;
+    const float4 bv = bias_t ? *reinterpret_cast<const float4*>(bias_t + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (EPI == EPI_SCALE_RES) gv = *reinterpret_cast<const float4*>(gamma + nb);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+    for (int ih = 0; ih < 4; ++ih) {
+      const int i = ih >> 1, h = ih & 1;
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-              const f32x4v v = {acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), rs, part_off + ((i * 4 + j) * 4 + r4) * 1024, 0, 16);
-            }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(sk.flags + lw, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        if (ke < U) {
-          // this workgroup holds k = 0 of the tile: add the partials of the workgroups that hold the rest, in k order
-          const long tile_end = (mt + 1) * U;
-          for (int pt = team + 1; pt < teams && range_lo(pt) < tile_end; ++pt) {
-            const int p = pt * ntn + tj;   // same n-tile column of the following teams
-            if (tid == 0) {
-              unsigned spins = 0;
-              while (__hip_atomic_load(sk.flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch && ++spins < (1u << 24))
-                __builtin_amdgcn_s_sleep(8);
-              // each published partial has exactly one consumer: hand the flag back, so that a replay of this very launch
-              // (hipGraph: same arguments, same epoch) starts from clear flags
-              __hip_atomic_store(sk.flags + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            const __amdgpu_buffer_rsrc_t rs = part_rsrc(p);
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int r = 0; r < 8; ++r)
+          T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 65 + j * 32 + (lane & 31)] = acc[i][jh * 2 + j][h * 8 + r];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
-              for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                  const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, part_off + ((i * 4 + j) * 4 + r4) * 1024, 0, 16));
-                  acc[i][j][4 * r4] += v.x; acc[i][j][4 * r4 + 1] += v.y; acc[i][j][4 * r4 + 2] += v.z; acc[i][j][4 * r4 + 3] += v.w;
-                }
-          }
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = rr * 4 + (lane >> 4);
+        const float* t = T + row * 65 + c4;
+        float4 v = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
+        const int grow = m0 + wave * 64 + i * 32 + h * 16 + row;
+        if (grow >= M || nb >= grp.n_store) continue;
+        const size_t off = (size_t)grow * N + nb;
+        if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        if (EPI == EPI_SCALE_RES) {
+          const float4 rs = *reinterpret_cast<const float4*>(resid + off);
+          v.x = rs.x + gv.x * v.x; v.y = rs.y + gv.y * v.y; v.z = rs.z + gv.z * v.z; v.w = rs.w + gv.w * v.w;
         }
-        epilogue();
-        __syncthreads();  // the epilogue's LDS staging is read before the next piece's DMA refills the stages
+        { const f32x4v t4 = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t4, reinterpret_cast<f32x4v*>(C + off)); }
       }
-      it += ke - kb;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
     }
   }
 }
 
 // hipFuncSetAttribute is a per-device setting: done once per (kernel, device), not per launch
-template <int EPI, int CONV, int NA, bool SK>
+template <int EPI, int CONV, int NA>
 int launch_one(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M,
-               int N, int K, ConvGeom cg, StreamK sk, Grouped grp, int grid, hipStream_t st, const char* what) {
+               int N, int K, ConvGeom cg, Grouped grp, hipStream_t st, const char* what) {
   constexpr int lds_bytes = NA * A_STAGE_B + 2 * B_STAGE_B;
   static bool raised[64] = {};
   int dev = 0;
   GDRNPP_HIP_TRY(hipGetDevice(&dev));
   if (dev >= 0 && dev < 64 && !raised[dev]) {
-    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_pipe_kernel<EPI, CONV, NA, SK>,
+    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_pipe_kernel<EPI, CONV, NA>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     raised[dev] = true;
   }
-  hipLaunchKernelGGL((gemm_split_pipe_kernel<EPI, CONV, NA, SK>), dim3((unsigned)grid), dim3(256), lds_bytes, st, A, Wp, bias,
-                     gamma, resid, C, M, N, K, cg, sk, grp);
+  const long tiles = (long)((M + 255) / 256) * (N / BN);
+  hipLaunchKernelGGL((gemm_split_pipe_kernel<EPI, CONV, NA>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, A, Wp, bias,
+                     gamma, resid, C, M, N, K, cg, grp);
   return gdrnpp::check_launch(what);
 }
 
 template <int EPI, int CONV>
-int launch_na(int a_stages, bool use_sk, const float* A, const uint4* Wp, const float* bias, const float* gamma,
-              const float* resid, float* C, int M, int N, int K, ConvGeom cg, StreamK sk, Grouped grp, int grid, hipStream_t st,
-              const char* what) {
-  if constexpr (CONV == 0) {
-    if (use_sk) {
-      if (a_stages == 3) return launch_one<EPI, 0, 3, true>(A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
-      return launch_one<EPI, 0, 2, true>(A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
-    }
-  }
-  if (a_stages == 3) return launch_one<EPI, CONV, 3, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
-  return launch_one<EPI, CONV, 2, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
+int launch_na(int a_stages, const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid,
+              float* C, int M, int N, int K, ConvGeom cg, Grouped grp, hipStream_t st, const char* what) {
+  if (a_stages == 3) return launch_one<EPI, CONV, 3>(A, Wp, bias, gamma, resid, C, M, N, K, cg, grp, st, what);
+  return launch_one<EPI, CONV, 2>(A, Wp, bias, gamma, resid, C, M, N, K, cg, grp, st, what);
 }
 
 template <int CONV>
-int launch_epi(int epilogue, int a_stages, bool use_sk, const float* A, const uint4* Wp, const float* bias, const float* gamma,
-               const float* resid, float* C, int M, int N, int K, ConvGeom cg, StreamK sk, Grouped grp, int grid, hipStream_t st,
-               const char* what) {
-  if (epilogue == EPI_BIAS) return launch_na<EPI_BIAS, CONV>(a_stages, use_sk, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
-  if (epilogue == EPI_GELU) return launch_na<EPI_GELU, CONV>(a_stages, use_sk, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
-  return launch_na<EPI_SCALE_RES, CONV>(a_stages, use_sk, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, grid, st, what);
+int launch_epi(int epilogue, int a_stages, const float* A, const uint4* Wp, const float* bias, const float* gamma,
+               const float* resid, float* C, int M, int N, int K, ConvGeom cg, Grouped grp, hipStream_t st, const char* what) {
+  if (epilogue == EPI_BIAS) return launch_na<EPI_BIAS, CONV>(a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, grp, st, what);
+  if (epilogue == EPI_GELU) return launch_na<EPI_GELU, CONV>(a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, grp, st, what);
+  return launch_na<EPI_SCALE_RES, CONV>(a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, grp, st, what);
 }
-
-// resident capacity of the pipelined kernel: two workgroups per CU (72 KB of LDS, 235 VGPRs)
-int sk_grid() {
-  static int grid[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 512;
-  if (!grid[dev]) {
-    hipDeviceProp_t prop;
-    grid[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? 2 * prop.multiProcessorCount : 512;
-  }
-  return grid[dev];
-}
-
-std::atomic<unsigned> g_sk_epoch{0};
 
 }  // namespace
 
 namespace gdrnpp {
 namespace splitgemm {
 
-size_t split_sk_workspace_bytes() { return (size_t)sk_grid() * (256 * 128 * sizeof(float)) + (size_t)sk_grid() * sizeof(unsigned); }
-
 int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
-                      int M, int N, int K, int epilogue, bool conv, ConvGeom cg, int a_stages, void* sk_workspace,
-                      size_t sk_workspace_bytes, bool allow_small, hipStream_t st, const char* what) {
+                      int M, int N, int K, int epilogue, bool conv, ConvGeom cg, int a_stages, hipStream_t st,
+                      const char* what) {
   if (K % 32 || N % BN || M <= 0) return -1;
-  const long tiles = (long)((M + 255) / 256) * (N / BN);
-  if (tiles >= (1l << 30)) return -1;
-  StreamK sk{nullptr, nullptr, 0};
   const Grouped grp{nullptr, 1, 0, 0, N};
   if (conv) {
-    if (allow_small) return -1;
     if (!(cg.KW == 3 && cg.stride == 1 && cg.pad == 1 && K == 9 * cg.C && cg.C % BK == 0)) return -1;
-    return launch_epi<1>(epilogue, a_stages, false, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, (int)tiles, st, what);
+    return launch_epi<1>(epilogue, a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, grp, st, what);
   }
   if ((unsigned long long)M * (unsigned long long)K * 4ull >= (1ull << 32)) return -1;  // 32-bit lane offsets
-  // stream-K when one-tile-per-workgroup scheduling would leave more than a tenth of the resident slots idle on average
-  // (tiles not a multiple of the capacity) and a workspace was handed in
-  const int G = sk_grid();
-  const long rounds = (tiles + G - 1) / G;
-  const bool wasteful = tiles * 10 < rounds * G * 9;
-  const int want = gdrnpp::option_split_gemm_sk();
-  // (at least 16 k-pairs per workgroup, else prologue / partial traffic outweigh the balance)
-  const int ntn = N / BN;
-  if (sk_workspace && sk_workspace_bytes >= split_sk_workspace_bytes() && want != 0 && (want == 2 || wasteful) &&
-      tiles * (K / 32) >= 16l * G && ntn <= G && G % ntn == 0) {
-    sk.partials = reinterpret_cast<float*>(sk_workspace);
-    sk.flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sk_workspace) + (size_t)G * (256 * 128 * sizeof(float)));
-    sk.epoch = ++g_sk_epoch;
-    if (sk.epoch == 0) sk.epoch = ++g_sk_epoch;
-    return launch_epi<0>(epilogue, a_stages, true, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, G, st, what);
-  }
-  if (allow_small) return -1;
-  return launch_epi<0>(epilogue, a_stages, false, A, Wp, bias, gamma, resid, C, M, N, K, cg, sk, grp, (int)tiles, st, what);
+  return launch_epi<0>(epilogue, a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, grp, st, what);
 }
 
 }  // namespace splitgemm
@@ -544,10 +398,8 @@ extern "C" int gdrnpp_linear_f32_split_grouped(const float* A, const void* W_pac
   GDRNPP_REQUIRE(n_store > 0 && n_store <= N && n_store % 4 == 0, GDRNPP_EINVAL, "gdrnpp_linear_f32_split_grouped: n_store=%d", n_store);
   GDRNPP_REQUIRE((unsigned long long)M * (unsigned long long)K * 4ull < (1ull << 32), GDRNPP_ELIMIT,
                  "gdrnpp_linear_f32_split_grouped: M*K*4 must stay below 4 GiB");
-  const long tiles = (long)(M / 256) * (N / BN);
-  GDRNPP_REQUIRE(tiles < (1l << 30), GDRNPP_ELIMIT, "gdrnpp_linear_f32_split_grouped: grid too large");
+  GDRNPP_REQUIRE((long)(M / 256) * (N / BN) < (1l << 30), GDRNPP_ELIMIT, "gdrnpp_linear_f32_split_grouped: grid too large");
   const Grouped grp{group_sel, rows_per_group, (long)(N / BN) * (K / BK) * W_TILE_SLOTS, N, n_store};
-  return launch_epi<0>(EPI_BIAS, gdrnpp::option_split_gemm_pipe() == 2 ? 2 : 3, false, A, (const uint4*)W_packed_stack, bias_stack,
-                       nullptr, nullptr, C, M, N, K, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0}, StreamK{nullptr, nullptr, 0}, grp, (int)tiles,
-                       (hipStream_t)stream, "gdrnpp_linear_f32_split_grouped");
+  return launch_epi<0>(EPI_BIAS, gdrnpp::option_split_gemm_pipe() == 2 ? 2 : 3, A, (const uint4*)W_packed_stack, bias_stack, nullptr,
+                       nullptr, C, M, N, K, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0}, grp, (hipStream_t)stream, "gdrnpp_linear_f32_split_grouped");
 }

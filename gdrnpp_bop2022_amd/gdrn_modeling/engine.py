@@ -201,39 +201,6 @@ def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor 
     return post.process(batch, out_dict, roi_ids)
 
 
-_SIDE_STREAMS = {}
-
-
-def inference_step_streams(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor | None = None,
-                           n_streams: int = 2) -> torch.Tensor:
-    """``inference_step`` with the ROIs cut into ``n_streams`` contiguous sub-batches that run on separate HIP streams (ROIs
-    are independent).  Kernels of different sub-batches overlap on the chip: where one launch leaves workgroup slots idle —
-    e.g. GEMM tile counts that do not fill the 2 x 256 slots evenly, DESIGN.md §5 — the other stream's launch
-    fills them (measured slower on the headline workload, whose shapes do divide evenly).  Same records, in ROI order."""
-    b = batch["roi_img"].shape[0]
-    if n_streams <= 1 or b < 2 * n_streams:
-        return inference_step(model, post, batch, roi_ids)
-    dev = batch["roi_img"].device
-    key = (dev.index, n_streams)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-    cur = torch.cuda.current_stream(dev)
-    if roi_ids is None:
-        roi_ids = torch.arange(b, device=dev, dtype=torch.int32)
-    bounds = [b * i // n_streams for i in range(n_streams + 1)]
-    recs = []
-    for st, lo, hi in zip(_SIDE_STREAMS[key], bounds[:-1], bounds[1:]):
-        st.wait_stream(cur)
-        with torch.cuda.stream(st):
-            sub = {k: (v[lo:hi] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == b else v) for k, v in batch.items()}
-            rec = inference_step(model, post, sub, roi_ids[lo:hi])
-            rec.record_stream(cur)
-            recs.append(rec)
-    for st in _SIDE_STREAMS[key]:
-        cur.wait_stream(st)
-    return torch.cat(recs, 0)
-
-
 def gather_records(rec: torch.Tensor, n_local_max: int, group=None) -> torch.Tensor:
     """The one collective of the inference path (gdrn_evaluator.py:575-585 / my_comm.py:70-171): instead of
     pickling Python dicts into byte tensors (size all-gather + padded byte all-gather), every rank contributes a

@@ -77,8 +77,6 @@ SIGNATURES = {
     "gdrnpp_linear_f32_split_grouped": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_stem_conv4x4_ln": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "gdrnpp_head_tail_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    "gdrnpp_linear_f32_split_workspace_bytes": (c_size_t, []),
-    "gdrnpp_linear_f32_split_ws": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "gdrnpp_linear_f32_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gdrnpp_linear_f32_splitk": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "gdrnpp_conv2d_f32_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -129,13 +127,9 @@ def copy_d2d(dst_ptr: int, src: torch.Tensor) -> None:
            "gdrnpp_copy_d2d")
 
 
-_OPTIONS = {}
-
-
 def set_option(name: str, value: int) -> None:
     """Process-wide tuning switch of the library (``gdrnpp_set_option``)."""
     _check(load().gdrnpp_set_option(name.encode(), int(value)), "gdrnpp_set_option")
-    _OPTIONS[name] = int(value)
 
 
 def _check(rc: int, what: str) -> None:
@@ -600,39 +594,22 @@ def unpack_weight_bf16x3(packed):
     return packed.permute(2, 0, 4, 1, 3, 5).reshape(3, tn * 128, tk * 16)
 
 
-_SK_WORKSPACES = {}
-
-
-def _stream_k_workspace(device):
-    """Stream-K scratch of gdrnpp_linear_f32_split_ws: one zero-initialised buffer per (device, stream), kept for the
-    process (partials of at most 2 x CUs workgroups + their flags: 64 MiB on an MI355X)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream() or 0)
-    ws = _SK_WORKSPACES.get(key)
-    if ws is None:
-        ws = torch.zeros((load().gdrnpp_linear_f32_split_workspace_bytes(),), dtype=torch.uint8, device=device)
-        _SK_WORKSPACES[key] = ws
-    return ws
-
-
 def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None):
     """out = epilogue(x2d @ W^T + bias) with the weight given as pack_weight_bf16x3(weight); runs on the bf16 matrix cores
-    with six partial products per fp32 product (fp32-accurate, see csrc/gemm_split.hip).  The library picks the schedule
-    (one tile per workgroup, or stream-K when that would leave workgroup slots idle)."""
+    with six partial products per fp32 product (fp32-accurate, see csrc/gemm_split.hip)."""
     m, k = x2d.shape
     if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or not weight_packed.is_contiguous() \
             or weight_packed.shape[1] * 16 != k:
         raise ValueError("weight_packed must be the contiguous bf16 tensor from pack_weight_bf16x3 with matching K")
     n = weight_packed.shape[0] * 128
     out = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
-    ws = _stream_k_workspace(x2d.device) if _OPTIONS.get("split_gemm_sk", 0) else None   # stream-K is opt-in
     args = (_dev(x2d, torch.float32, "x"), weight_packed.data_ptr(),
             _dev(bias, torch.float32, "bias") if bias is not None else None,
             _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
             _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
-            {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], ws.data_ptr() if ws is not None else None,
-            ws.numel() if ws is not None else 0, _stream())
+            {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream())
     nbytes = 4.0 * m * k + 6.0 * n * k + 4.0 * m * n * (2 if epilogue == "scale_res" else 1)
-    _check(_timed("linear", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split_ws(*args), nbytes), "gdrnpp_linear_f32_split")
+    _check(_timed("linear", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split(*args), nbytes), "gdrnpp_linear_f32_split")
     return out
 
 

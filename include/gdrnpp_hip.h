@@ -45,8 +45,6 @@ const char* gdrnpp_last_error(void);
  *   "split_gemm_pipe"  0 / 2 / 3   256-row tiles of the linear form use the software-pipelined LDS-DMA kernel with two /
  *                              three A stages (default 3; bitwise identical to the other kernels); 0 = off
  *   "split_gemm_pipe_conv"  0 / 1   the 3x3 / stride 1 / pad 1 convolution uses it too (default 0)
- *   "split_gemm_sk"    0 / 1 / 2   stream-K schedule of gdrnpp_linear_f32_split_ws: never (default) / when tiles do not fill
- *                              the resident workgroup slots evenly / always
  *   "split_gemm_mi4"   -1 / 0 / 1   tile height by tile count (default) / force 128 rows / force 256 rows
  * unknown name -> GDRNPP_EINVAL. */
 int gdrnpp_set_option(const char* name, int value);
@@ -351,21 +349,6 @@ int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, const float* 
 int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* bias, const float* gamma,
                             const float* resid, float* C, int M, int N, int K, int epilogue,
                             void* stream);
-/* Same GEMM with a stream-K workspace (gdrnpp_linear_f32_split_workspace_bytes(); zero it ONCE when it is allocated; one
- * stream at a time).  When one 256x128 tile per workgroup would leave resident workgroup slots idle — the tile count is not a
- * multiple of the 2 x CU capacity, e.g. 392 tiles for the stage-2 fc2 of ConvNeXt-B at 128 ROIs of 224 x 224 crops — the launch is persistent
- * and every workgroup gets an equal contiguous range of (tile, k-pair) units; tiles shared by several workgroups are summed
- * from fp32 partials in ascending k order by the workgroup that holds their k = 0 (deterministic for given shapes; differs
- * from the one-tile-per-workgroup result by fp32 rounding of that sum).  workspace NULL = gdrnpp_linear_f32_split.
- * gdrnpp_set_option("split_gemm_sk", 0 / 1 / 2): never (default) / when the tile count is uneven / always.  Measured on the
- * ConvNeXt-B shapes at 128 ROIs it wins only where the epilogue is light or the problem small (stage 3: +11 %): equal work per
- * workgroup makes every workgroup reach its epilogue at the same moment, so the epilogue's HBM burst is exposed at the end of
- * the launch instead of overlapping other workgroups' main loops. */
-size_t gdrnpp_linear_f32_split_workspace_bytes(void);
-int gdrnpp_linear_f32_split_ws(const float* A, const void* W_packed, const float* bias, const float* gamma,
-                               const float* resid, float* C, int M, int N, int K, int epilogue, void* workspace,
-                               size_t workspace_bytes, void* stream);
-
 /* ConvNeXt stem (timm stem_0 + stem_1): Conv2d(3 -> 128, kernel 4, stride 4) + bias + LayerNorm2d over the channels in one
  * pass.  x f32 NCHW [N,3,H,W] (H % 4 == 0, W % 16 == 0, W <= 1024), weight f32[128,3,4,4], bias f32[128] or NULL ->
  * y f32 NHWC [N,H/4,W/4,128].  fp32 fma chain in (ci, ky, kx) order; LayerNorm as gdrnpp_layernorm_nhwc. */
