@@ -389,3 +389,35 @@ def test_stem_conv_ln_fused_vs_torch(hip, n, h, w):
     c0 = F.conv2d(x.double(), wt.double(), None, stride=4)
     ref0 = F.layer_norm(c0.permute(0, 2, 3, 1), (128,), g.double(), be.double(), 1e-6).permute(0, 3, 1, 2)
     assert (y0.double() - ref0).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("b", [1, 17])
+def test_model_forward_more_roi_counts(hip, b):
+    """Whole forward (fused stem, pipelined / small-tile GEMMs, grouped output layer, head tail, Patch-PnP) on the HIP path
+    against the PyTorch-operator path at ROI counts that leave ragged row tiles everywhere (1 ROI: 64 rows at stage 3)."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+    from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+
+    cfg = get_cfg("tless_convnext_a6", ["TEST.USE_DEPTH_REFINE=True"])
+    torch.manual_seed(2)
+    model, _ = build_model_optimizer(cfg)
+    with torch.no_grad():
+        model.pnp_net.fc_t.bias.copy_(torch.tensor([0.0, 0.0, 4.0]))
+    x = torch.rand(b, 3, 256, 256, device=DEV)
+    K = torch.tensor([[1075.65, 0, 360.0], [0, 1073.9, 270.0], [0, 0, 1]], device=DEV).repeat(b, 1, 1)
+    args = dict(roi_classes=torch.randint(0, 30, (b,), device=DEV), roi_cams=K, roi_whs=torch.full((b, 2), 110.0, device=DEV),
+                roi_centers=torch.full((b, 2), 300.0, device=DEV), resize_ratios=torch.full((b,), 64 / 165.0, device=DEV),
+                roi_coord_2d=torch.rand(b, 2, 64, 64, device=DEV), roi_extents=torch.rand(b, 3, device=DEV) * 0.2 + 0.05)
+    with torch.no_grad():
+        o1 = model(x, **args)
+        hip_layers.set_enabled(False)
+        try:
+            o2 = model(x, **args)
+        finally:
+            hip_layers.set_enabled(True)
+    for key in ("mask", "full_mask", "coor_x", "coor_y", "coor_z", "region"):
+        assert o1[key].shape == o2[key].shape
+        assert (o1[key] - o2[key]).abs().max().item() <= 1e-4 * max(o2[key].abs().max().item(), 1.0), key
+    torch.testing.assert_close(o1["rot"], o2["rot"], rtol=0, atol=1e-4)
+    torch.testing.assert_close(o1["trans"], o2["trans"], rtol=0, atol=1e-4)
