@@ -116,14 +116,17 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
     }
   }
   if (CONV) cpt = cg.C / BK;
+  const int ntaps = CONV ? nk_total / cpt : 1;  // conv_ktile() below
   const uint4* Wg = Wp + ((size_t)tile_n * nk_total + kt0) * W_TILE_SLOTS + tid;
   struct Stage { float4 a[MI]; uint4 b0, b1, b2; };
   auto gload = [&](int kt) {
     Stage r;
+    int wkt = kt;
     if (CONV) {
       // the loads are unconditional (address clamped to the centre pixel, value zeroed afterwards): a predicated load
       // would make the outstanding-load count unknown to the compiler and collapse the software pipeline
-      const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+      const int chunk = kt / ntaps, tap = kt - chunk * ntaps, c0 = chunk * BK;
+      wkt = tap * cpt + chunk;
       const int KW = CONV == 1 ? 3 : cg.KW, pad = CONV == 1 ? 1 : cg.pad;
       const int ky = tap / KW, dy = ky - pad, dx = tap - ky * KW - pad;
       const int off = (dy * cg.W + dx) * cg.C;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
 #pragma unroll
       for (int p = 0; p < MI; ++p) r.a[p] = *reinterpret_cast<const float4*>(ap[p] + (kt0 + kt) * BK);
     }
-    const uint4* w = Wg + (size_t)kt * W_TILE_SLOTS;
+    const uint4* w = Wg + (size_t)wkt * W_TILE_SLOTS;
     r.b0 = w[0]; r.b1 = w[256]; r.b2 = w[512];
     return r;
   };
@@ -320,14 +323,17 @@ __global__ __launch_bounds__(256, 2) void gemm_split_glds_kernel(const float* __
     }
   }
   if (CONV) cpt = cg.C / BK;
+  const int ntaps = CONV ? nk / cpt : 1;
   const uint4* Wg = Wp + (size_t)tile_n * nk * W_TILE_SLOTS + (wave * 3) * 64 + lane;
   const unsigned ldsA = lds_addr(sA) + (unsigned)(wave * 4) * 1024u;
   const unsigned ldsB = lds_addr(sB) + (unsigned)(wave * 3) * 1024u;
 
   auto issue = [&](int kt, int stage) {
     const unsigned da = ldsA + (unsigned)stage * (GA_SLOTS * 16u), db = ldsB + (unsigned)stage * (GB_SLOTS * 16u);
+    int wkt = kt;
     if (CONV) {
-      const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+      const int chunk = kt / ntaps, tap = kt - chunk * ntaps, c0 = chunk * BK;
+      wkt = tap * cpt + chunk;
       const int KW = CONV == 1 ? 3 : cg.KW, pad = CONV == 1 ? 1 : cg.pad;
       const int ky = tap / KW, dy = ky - pad, dx = tap - ky * KW - pad;
       const int off = (dy * cg.W + dx) * cg.C + c0;
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_glds_kernel(const float* __
 #pragma unroll
       for (int c = 0; c < 4; ++c) glds16(ap[c] + kt * BK, da + c * 1024u);
     }
-    const uint4* w = Wg + (size_t)kt * W_TILE_SLOTS;
+    const uint4* w = Wg + (size_t)wkt * W_TILE_SLOTS;
 #pragma unroll
     for (int c = 0; c < 3; ++c) glds16(w + c * 64, db + c * 1024u);
   };

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
   auto dma_a = [&](int kt, unsigned sb, auto cc) {
     constexpr int c = decltype(cc)::value;
     if constexpr (CONV) {
-      const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+      const int chunk = kt / 9, tap = kt - chunk * 9, c0 = chunk * BK;  // conv k order: gemm_split.hpp
       const int ky = tap / 3, dy = ky - 1, dx = tap - ky * 3 - 1;
       const long off = ((long)dy * cg.W + dx) * cg.C + c0;
       const bool ok = (okmask[c] >> tap) & 1u;
@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
   };
   auto dma_b = [&](int kt, unsigned sb, auto cc) {
     constexpr int c = decltype(cc)::value;
-    dma_s(boff, wbase + ((size_t)kt * B_STAGE_B + c * 1024), ldsB + sb + c * 1024u);
+    int wkt = kt;
+    if constexpr (CONV) { const int chunk = kt / 9; wkt = (kt - chunk * 9) * cpt + chunk; }
+    dma_s(boff, wbase + ((size_t)wkt * B_STAGE_B + c * 1024), ldsB + sb + c * 1024u);
   };
 
   f32x16 acc[2][4];
