@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
     }
   }
   if (CONV) cpt = cg.C / BK;
-  const int ntaps = CONV ? nk_total / cpt : 1;  // conv_ktile() below
+  const int ntaps = CONV ? nk_total / cpt : 1, cps = (cpt & 1) ? 1 : 2;  // conv k-tile order: gemm_split.hpp
   const uint4* Wg = Wp + ((size_t)tile_n * nk_total + kt0) * W_TILE_SLOTS + tid;
   struct Stage { float4 a[MI]; uint4 b0, b1, b2; };
   auto gload = [&](int kt) {
@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
     if (CONV) {
       // the loads are unconditional (address clamped to the centre pixel, value zeroed afterwards): a predicated load
       // would make the outstanding-load count unknown to the compiler and collapse the software pipeline
-      const int chunk = kt / ntaps, tap = kt - chunk * ntaps, c0 = chunk * BK;
+      const int sup = kt / (ntaps * cps), rem = kt - sup * (ntaps * cps), tap = rem / cps;
+      const int chunk = sup * cps + (rem - tap * cps), c0 = chunk * BK;
       wkt = tap * cpt + chunk;
       const int KW = CONV == 1 ? 3 : cg.KW, pad = CONV == 1 ? 1 : cg.pad;
       const int ky = tap / KW, dy = ky - pad, dx = tap - ky * KW - pad;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_glds_kernel(const float* __
     }
   }
   if (CONV) cpt = cg.C / BK;
-  const int ntaps = CONV ? nk / cpt : 1;
+  const int ntaps = CONV ? nk / cpt : 1, cps = (cpt & 1) ? 1 : 2;  // conv k-tile order: gemm_split.hpp
   const uint4* Wg = Wp + (size_t)tile_n * nk * W_TILE_SLOTS + (wave * 3) * 64 + lane;
   const unsigned ldsA = lds_addr(sA) + (unsigned)(wave * 4) * 1024u;
   const unsigned ldsB = lds_addr(sB) + (unsigned)(wave * 3) * 1024u;
@@ -332,7 +333,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_glds_kernel(const float* __
     const unsigned da = ldsA + (unsigned)stage * (GA_SLOTS * 16u), db = ldsB + (unsigned)stage * (GB_SLOTS * 16u);
     int wkt = kt;
     if (CONV) {
-      const int chunk = kt / ntaps, tap = kt - chunk * ntaps, c0 = chunk * BK;
+      const int sup = kt / (ntaps * cps), rem = kt - sup * (ntaps * cps), tap = rem / cps;
+      const int chunk = sup * cps + (rem - tap * cps), c0 = chunk * BK;
       wkt = tap * cpt + chunk;
       const int KW = CONV == 1 ? 3 : cg.KW, pad = CONV == 1 ? 1 : cg.pad;
       const int ky = tap / KW, dy = ky - pad, dx = tap - ky * KW - pad;

@@ -28,10 +28,11 @@ enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_SCALE_RES = 2 };
 // CONV: A is an NHWC image [.,H,W,Cin] and the GEMM row m = output pixel, k = (tap, channel) of a KHxKW convolution with
 // stride and symmetric zero padding (implicit im2col: the k-tile's 16 channels of one tap are 64 contiguous bytes per
 // pixel).  Every row keeps a pointer to its anchor input pixel (oy*stride, ox*stride), which is always inside the image.
-// The k-tiles of a convolution run channel-chunk outer, tap inner (k-tile t = taps * chunk + tap reads weight tile
-// tap * (C/16) + chunk of the (tap, channel)-ordered packed weight): the KH*KW taps of one 16-channel chunk re-read the
-// same 64-byte pixel segments back to back, so the tap overlap is served by L2 (tap-outer order puts a whole pass over
-// the tile's channels, 16 MB per XCD at 64x64x256, between two reads of a pixel and fetched the image 12x).
+// The k-tiles of a convolution run 32-channel group outer, tap, then the group's two 16-channel chunks (one 128-byte line
+// of a pixel; a single chunk per group when C/16 is odd); k-tile (group g, tap, half h) reads weight tile
+// tap * (C/16) + 2g + h of the (tap, channel)-ordered packed weight.  The KH*KW taps of a group re-read the same lines
+// back to back, so the tap overlap is served by L2 (tap-outer order puts a whole pass over the tile's channels, 16 MB
+// per XCD at 64x64x256, between two reads of a pixel and fetched the image 12x).
 // H, W, C: input image; OH, OW: output image; KW x (K / (KW*C)) taps, stride, zero padding `pad` on every side.
 // nk_split > 0: split-K (linear only), blockIdx.y-th chunk of nk_split k-tiles -> partial C
 struct ConvGeom { int H, W, C, OH, OW, KW, stride, pad; int nk_split; };
@@ -47,6 +48,7 @@ int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const 
 }  // namespace splitgemm
 
 int option_split_gemm_pipe();       // 0: off, 2 / 3 (default): pipelined kernel with that many A stages for 256-row tiles (linear form)
+int option_split_gemm_panel();      // row blocks per tile panel of wide layers in the pipelined kernel (default 4; 0: row-major)
 int option_split_gemm_pipe_conv();  // 1: the 3x3/1/1 convolution uses it too (default 0: measured 1 % slower than the LDS-DMA kernel)
 
 }  // namespace gdrnpp

@@ -107,6 +107,7 @@ struct Grouped {
   long w_stride;           // uint4 slots between consecutive weight slices
   int bias_stride;         // floats between consecutive bias slices
   int n_store;
+  int panel;               // > 1: tiles are walked in panels of that many row blocks, column tile outer (launch_split_pipe)
 };
 
 // CONV: 0 = linear (A row-major [M,K]), 1 = 3x3 / stride 1 / pad 1 convolution over an NHWC image (implicit im2col)
@@ -124,7 +125,16 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
   // XCD-aware tile order, as in gemm_split.hip
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-  const int tile_m = tile / ntn, tile_n = tile % ntn;
+  int tile_m, tile_n;
+  if (grp.panel > 1) {  // panel order for wide layers, see launch_split_pipe
+    const int ntm = (M + 255) >> 8, per = grp.panel * ntn, p = tile / per, w = tile - p * per;
+    const int rows = min(grp.panel, ntm - p * grp.panel);
+    tile_n = w / rows;
+    tile_m = p * grp.panel + (w - tile_n * rows);
+  } else {
+    tile_m = tile / ntn;
+    tile_n = tile - tile_m * ntn;
+  }
   const int m0 = tile_m * 256, n0 = tile_n * BN;
   const int nk = K / BK;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
@@ -171,7 +181,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
   auto dma_a = [&](int kt, unsigned sb, auto cc) {
     constexpr int c = decltype(cc)::value;
     if constexpr (CONV) {
-      const int chunk = kt / 9, tap = kt - chunk * 9, c0 = chunk * BK;  // conv k order: gemm_split.hpp
+      const int cps = (cpt & 1) ? 1 : 2, sup = kt / (9 * cps), rem = kt - sup * (9 * cps), tap = rem / cps;  // gemm_split.hpp
+      const int c0 = (sup * cps + (rem - tap * cps)) * BK;
       const int ky = tap / 3, dy = ky - 1, dx = tap - ky * 3 - 1;
       const long off = ((long)dy * cg.W + dx) * cg.C + c0;
       const bool ok = (okmask[c] >> tap) & 1u;
@@ -183,7 +194,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
   auto dma_b = [&](int kt, unsigned sb, auto cc) {
     constexpr int c = decltype(cc)::value;
     int wkt = kt;
-    if constexpr (CONV) { const int chunk = kt / 9; wkt = (kt - chunk * 9) * cpt + chunk; }
+    if constexpr (CONV) {
+      const int cps = (cpt & 1) ? 1 : 2, sup = kt / (9 * cps), rem = kt - sup * (9 * cps), tap = rem / cps;
+      wkt = tap * cpt + sup * cps + (rem - tap * cps);
+    }
     dma_s(boff, wbase + ((size_t)wkt * B_STAGE_B + c * 1024), ldsB + sb + c * 1024u);
   };
 
@@ -376,7 +390,15 @@ int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const 
                       int M, int N, int K, int epilogue, bool conv, ConvGeom cg, int a_stages, hipStream_t st,
                       const char* what) {
   if (K % 32 || N % BN || M <= 0) return -1;
-  const Grouped grp{nullptr, 1, 0, 0, N};
+  // Wide layers (packed weight beyond an XCD's L2: N*K*6 bytes > 2 MB, at least 8 column tiles) walk the tiles in panels of
+  // option split_gemm_panel (4) row blocks, column tile outer: workgroups that start back to back then share the weight tile
+  // and meet the same row blocks again `panel` starts later, so both operands are re-read while still in the XCD's L2.
+  // Row-major order (narrow layers) shares the row block between neighbours and the weight tile only N/128 starts apart.
+  // Measured fetch of the 32768x512 -> 2048 layer per launch: row-major 464 MB, panels of 2/3/4/5/6/8/16: 464/415/317/376/
+  // 348/357/575 MB (profiles/r02l_gemm_traffic_by_shape.md); launch time unchanged (the operands come from the memory-side
+  // cache either way).
+  const int panel = (!conv && N / BN >= 8 && (long)N * K * 6 > (2l << 20)) ? gdrnpp::option_split_gemm_panel() : 0;
+  const Grouped grp{nullptr, 1, 0, 0, N, panel};
   if (conv) {
     if (!(cg.KW == 3 && cg.stride == 1 && cg.pad == 1 && K == 9 * cg.C && cg.C % BK == 0)) return -1;
     return launch_epi<1>(epilogue, a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, grp, st, what);
@@ -401,7 +423,7 @@ extern "C" int gdrnpp_linear_f32_split_grouped(const float* A, const void* W_pac
   GDRNPP_REQUIRE((unsigned long long)M * (unsigned long long)K * 4ull < (1ull << 32), GDRNPP_ELIMIT,
                  "gdrnpp_linear_f32_split_grouped: M*K*4 must stay below 4 GiB");
   GDRNPP_REQUIRE((long)(M / 256) * (N / BN) < (1l << 30), GDRNPP_ELIMIT, "gdrnpp_linear_f32_split_grouped: grid too large");
-  const Grouped grp{group_sel, rows_per_group, (long)(N / BN) * (K / BK) * W_TILE_SLOTS, N, n_store};
+  const Grouped grp{group_sel, rows_per_group, (long)(N / BN) * (K / BK) * W_TILE_SLOTS, N, n_store, 0};
   return launch_epi<0>(EPI_BIAS, gdrnpp::option_split_gemm_pipe() == 2 ? 2 : 3, A, (const uint4*)W_packed_stack, bias_stack, nullptr,
                        nullptr, C, M, N, K, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0}, grp, (hipStream_t)stream, "gdrnpp_linear_f32_split_grouped");
 }
