@@ -25,27 +25,48 @@ constexpr int AB_BITS = 10, AB_SCALE = 1 << AB_BITS, INTER_BITS = 5, INTER_TAB_S
 __device__ __forceinline__ int cv_round(double v) { return __double2int_rn(v); }
 __device__ __forceinline__ int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 
-// cv::LUImpl, 6x6, one right-hand side (getAffineTransform)
-__device__ bool lu_solve6(double* A, double* b) {
-  const int m = 6;
+// cv::LUImpl, 6x6, one right-hand side (getAffineTransform).  Every index is a compile-time constant after unrolling (the
+// pivot row is applied as a chain of predicated swaps), so the system lives in registers: with a run-time row index the
+// arrays went to scratch memory and the solve took 20 us on the one lane that does it.  Same operations in the same order
+// as the loop form (first maximal pivot, `>` comparison).
+__device__ __forceinline__ bool lu_solve6(double (&A)[36], double (&b)[6]) {
+  constexpr int m = 6;
+#pragma unroll
   for (int i = 0; i < m; i++) {
     int k = i;
-    for (int j = i + 1; j < m; j++)
-      if (fabs(A[j * m + i]) > fabs(A[k * m + i])) k = j;
-    if (fabs(A[k * m + i]) < 2.220446049250313e-16 * 100) return false;
-    if (k != i) {
-      for (int j = i; j < m; j++) { double t = A[i * m + j]; A[i * m + j] = A[k * m + j]; A[k * m + j] = t; }
-      double t = b[i]; b[i] = b[k]; b[k] = t;
+    double best = fabs(A[i * m + i]);
+#pragma unroll
+    for (int j = i + 1; j < m; j++) {
+      const double v = fabs(A[j * m + i]);
+      if (v > best) { best = v; k = j; }
+    }
+    if (best < 2.220446049250313e-16 * 100) return false;
+#pragma unroll
+    for (int r = i + 1; r < m; r++) {
+      const bool sw = k == r;
+#pragma unroll
+      for (int j = i; j < m; j++) {
+        const double ai = A[i * m + j], ar = A[r * m + j];
+        A[i * m + j] = sw ? ar : ai;
+        A[r * m + j] = sw ? ai : ar;
+      }
+      const double bi = b[i], br = b[r];
+      b[i] = sw ? br : bi;
+      b[r] = sw ? bi : br;
     }
     const double d = -1 / A[i * m + i];
+#pragma unroll
     for (int j = i + 1; j < m; j++) {
       const double alpha = A[j * m + i] * d;
+#pragma unroll
       for (int kk = i + 1; kk < m; kk++) A[j * m + kk] += alpha * A[i * m + kk];
       b[j] += alpha * b[i];
     }
   }
+#pragma unroll
   for (int i = m - 1; i >= 0; i--) {
     double s = b[i];
+#pragma unroll
     for (int k = i + 1; k < m; k++) s -= A[i * m + k] * b[k];
     b[i] = s / A[i * m + i];
   }
@@ -66,6 +87,7 @@ __device__ void inverse_affine(double cx, double cy, double scale, int out, doub
   dx = dst[0][0] - dst[1][0]; dy = dst[0][1] - dst[1][1];
   dst[2][0] = dst[1][0] + (-dy); dst[2][1] = dst[1][1] + dx;
   double a[36], b[6];
+#pragma unroll
   for (int i = 0; i < 3; i++) {
     const int j = i * 12, k = i * 12 + 6;
     a[j] = a[k + 3] = src[i][0];
@@ -76,8 +98,11 @@ __device__ void inverse_affine(double cx, double cy, double scale, int out, doub
     b[i * 2] = dst[i][0];
     b[i * 2 + 1] = dst[i][1];
   }
-  if (!lu_solve6(a, b))
+  if (!lu_solve6(a, b)) {
+#pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = 0.0;
+  }
+#pragma unroll
   for (int i = 0; i < 6; ++i) M[i] = b[i];
   double D = M[0] * M[4] - M[1] * M[3];
   D = D != 0 ? 1. / D : 0;
@@ -159,19 +184,9 @@ __global__ __launch_bounds__(256) void crop_img_depth_kernel(const unsigned char
   }
 }
 
-// roi_coord_2d: bilinear (float weights) of the analytic coord_2d map, CHW output
-__global__ __launch_bounds__(256) void crop_coord2d_kernel(int H, int W, const double* __restrict__ centers,
-                                                           const double* __restrict__ scales,
-                                                           float* __restrict__ roi_coord2d, int out) {
-  __shared__ double sM[6];
-  const int bi = blockIdx.y;
-  if (threadIdx.x == 0) inverse_affine(centers[2 * bi], centers[2 * bi + 1], scales[bi], out, sM);
-  __syncthreads();
-  double M[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) M[k] = sM[k];
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= out * out) return;
+// one output pixel of roi_coord_2d: bilinear (float weights) of the analytic coord_2d map, CHW output
+__device__ __forceinline__ void coord2d_pixel(const double* M, int H, int W, int p, int out, int bi,
+                                              float* __restrict__ roi_coord2d) {
   const int y = p / out, x = p - y * out;
   int sx, sy, alpha;
   src_coord(M, x, y, false, sx, sy, alpha);
@@ -193,6 +208,110 @@ __global__ __launch_bounds__(256) void crop_coord2d_kernel(int H, int W, const d
   roi_coord2d[(((size_t)bi * 2 + 1) * out + y) * out + x] = ((b00 * w0 + b01 * w1) + b10 * w2) + b11 * w3;
 }
 
+// The same two maps for out == 256 (the configured INPUT_RES): thread = output column, workgroup = 16 output rows, so
+// the column terms of the fixed-point source coordinate are per-thread constants and the row terms are uniform; the
+// float64 normalisation ((s - mean) / std -> float32) has only 256 possible inputs per channel and comes from a table in
+// LDS (768 double divisions per workgroup instead of 12 288); the 2 x 2 x 3 source bytes of an interior pixel are two
+// unaligned 8-byte loads instead of twelve byte loads.  Same integer arithmetic and the same table values as the generic
+// kernel above: bit-identical output.
+typedef unsigned long long __attribute__((aligned(1))) u64_unaligned;
+
+__global__ __launch_bounds__(256) void crop_img_depth_256_kernel(const unsigned char* __restrict__ images,
+                                                                 const float* __restrict__ depths, int H, int W,
+                                                                 const int* __restrict__ im_idx,
+                                                                 const double* __restrict__ centers,
+                                                                 const double* __restrict__ scales,
+                                                                 float* __restrict__ roi_img, float* __restrict__ roi_depth,
+                                                                 float* __restrict__ roi_coord2d, int out_small, Norm3 nrm) {
+  constexpr int out = 256;
+  __shared__ double sM[6];
+  __shared__ float lut[3][256];
+  const int bi = blockIdx.y, x = threadIdx.x;
+  if (blockIdx.x >= out / kPixPerThread) {  // the extra workgroup of the ROI: its roi_coord_2d map (own affine map)
+    if (threadIdx.x == 0) inverse_affine(centers[2 * bi], centers[2 * bi + 1], scales[bi], out_small, sM);
+    __syncthreads();
+    double Ms[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Ms[k] = sM[k];
+    for (int p = threadIdx.x; p < out_small * out_small; p += 256) coord2d_pixel(Ms, H, W, p, out_small, bi, roi_coord2d);
+    return;
+  }
+  if (threadIdx.x == 0) inverse_affine(centers[2 * bi], centers[2 * bi + 1], scales[bi], out, sM);
+  if (roi_img) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lut[k][x] = (float)(((double)x - nrm.mean[k]) / nrm.stdv[k]);
+  }
+  __syncthreads();
+  double M[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) M[k] = sM[k];
+  const size_t im = (size_t)(im_idx ? im_idx[bi] : 0);
+  const int adelta = cv_round(M[0] * x * AB_SCALE), bdelta = cv_round(M[3] * x * AB_SCALE);
+  const unsigned char* const src = images + im * H * W * 3;
+  const float* const dsrc = depths ? depths + im * H * W : nullptr;
+  const bool want_depth = roi_depth && depths;
+#pragma unroll 4
+  for (int it = 0; it < kPixPerThread; ++it) {
+    const int y = blockIdx.x * kPixPerThread + it;
+    const int X00 = cv_round((M[1] * y + M[2]) * AB_SCALE), Y00 = cv_round((M[4] * y + M[5]) * AB_SCALE);
+    if (roi_img) {
+      const int X0 = X00 + AB_SCALE / INTER_TAB_SIZE / 2, Y0 = Y00 + AB_SCALE / INTER_TAB_SIZE / 2;
+      const int X = (X0 + adelta) >> (AB_BITS - INTER_BITS), Y = (Y0 + bdelta) >> (AB_BITS - INTER_BITS);
+      const int sx = sat_short(X >> INTER_BITS), sy = sat_short(Y >> INTER_BITS);
+      const int fy = Y & (INTER_TAB_SIZE - 1), fx = X & (INTER_TAB_SIZE - 1);
+      int w0 = (32 - fy) * (32 - fx) * 32, w1 = (32 - fy) * fx * 32, w2 = fy * (32 - fx) * 32, w3 = fy * fx * 32;
+      if ((fy | fx) == 0) { w0 = 32767; w3 = 1; }  // saturate_cast<short>(32768) + the table's sum fix-up
+      int v00[3], v01[3], v10[3], v11[3];
+      if (sx >= 0 && sx + 2 < W && sy >= 0 && sy + 1 < H) {  // interior: 8 bytes per source row hold both pixels
+        const unsigned char* r0 = src + ((size_t)sy * W + sx) * 3;
+        const unsigned long long a = *reinterpret_cast<const u64_unaligned*>(r0);
+        const unsigned long long b = *reinterpret_cast<const u64_unaligned*>(r0 + (size_t)W * 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          v00[k] = (int)((a >> (8 * k)) & 0xff); v01[k] = (int)((a >> (8 * (k + 3))) & 0xff);
+          v10[k] = (int)((b >> (8 * k)) & 0xff); v11[k] = (int)((b >> (8 * (k + 3))) & 0xff);
+        }
+      } else {
+        const bool x0 = sx >= 0 && sx < W, x1 = sx + 1 >= 0 && sx + 1 < W, y0 = sy >= 0 && sy < H,
+                   y1 = sy + 1 >= 0 && sy + 1 < H;
+        const long base = ((long)sy * W + sx) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          v00[k] = (x0 && y0) ? src[base + k] : 0; v01[k] = (x1 && y0) ? src[base + 3 + k] : 0;
+          v10[k] = (x0 && y1) ? src[base + (long)W * 3 + k] : 0; v11[k] = (x1 && y1) ? src[base + (long)W * 3 + 3 + k] : 0;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        int sv = (v00[k] * w0 + v01[k] * w1 + v10[k] * w2 + v11[k] * w3 + (1 << 14)) >> 15;
+        sv = sv < 0 ? 0 : (sv > 255 ? 255 : sv);
+        __builtin_nontemporal_store(lut[k][sv], roi_img + (((size_t)bi * 3 + k) * out + y) * out + x);
+      }
+    }
+    if (want_depth) {
+      const int sx = sat_short((X00 + AB_SCALE / 2 + adelta) >> AB_BITS), sy = sat_short((Y00 + AB_SCALE / 2 + bdelta) >> AB_BITS);
+      __builtin_nontemporal_store((sx >= 0 && sx < W && sy >= 0 && sy < H) ? dsrc[(size_t)sy * W + sx] : 0.f,
+                                  roi_depth + ((size_t)bi * out + y) * out + x);
+    }
+  }
+}
+
+// roi_coord_2d: bilinear (float weights) of the analytic coord_2d map, CHW output
+__global__ __launch_bounds__(256) void crop_coord2d_kernel(int H, int W, const double* __restrict__ centers,
+                                                           const double* __restrict__ scales,
+                                                           float* __restrict__ roi_coord2d, int out) {
+  __shared__ double sM[6];
+  const int bi = blockIdx.y;
+  if (threadIdx.x == 0) inverse_affine(centers[2 * bi], centers[2 * bi + 1], scales[bi], out, sM);
+  __syncthreads();
+  double M[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) M[k] = sM[k];
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= out * out) return;
+  coord2d_pixel(M, H, W, p, out, bi, roi_coord2d);
+}
+
 }  // namespace
 
 extern "C" {
@@ -208,14 +327,22 @@ int gdrnpp_crop_resize_roi(const unsigned char* images, const float* depths, int
                  "gdrnpp_crop_resize_roi: roi_img requested without images / mean / std");
   GDRNPP_REQUIRE(W < 32767 && H < 32767, GDRNPP_ELIMIT, "gdrnpp_crop_resize_roi: image larger than SHRT_MAX");
   hipStream_t st = (hipStream_t)stream;
+  bool coord_done = false;
   if ((roi_img || (roi_depth && depths)) && out_res > 0) {
     Norm3 nrm;
     for (int k = 0; k < 3; ++k) { nrm.mean[k] = h_mean3 ? h_mean3[k] : 0.0; nrm.stdv[k] = h_std3 ? h_std3[k] : 1.0; }
     dim3 grid((out_res * out_res + 256 * kPixPerThread - 1) / (256 * kPixPerThread), b);
-    hipLaunchKernelGGL(crop_img_depth_kernel, grid, dim3(256), 0, st, images, depths, H, W, im_idx, centers, scales,
-                       roi_img, roi_depth, out_res, nrm);
+    if (out_res == 256) {
+      const bool with_coord = roi_coord2d && out_res_small > 0;   // one more workgroup per ROI writes roi_coord_2d
+      if (with_coord) { grid.x += 1; coord_done = true; }
+      hipLaunchKernelGGL(crop_img_depth_256_kernel, grid, dim3(256), 0, st, images, depths, H, W, im_idx, centers, scales,
+                         roi_img, roi_depth, with_coord ? roi_coord2d : nullptr, out_res_small, nrm);
+    } else {
+      hipLaunchKernelGGL(crop_img_depth_kernel, grid, dim3(256), 0, st, images, depths, H, W, im_idx, centers, scales,
+                         roi_img, roi_depth, out_res, nrm);
+    }
   }
-  if (roi_coord2d && out_res_small > 0) {
+  if (roi_coord2d && out_res_small > 0 && !coord_done) {
     dim3 grid((out_res_small * out_res_small + 255) / 256, b);
     hipLaunchKernelGGL(crop_coord2d_kernel, grid, dim3(256), 0, st, H, W, centers, scales, roi_coord2d, out_res_small);
   }

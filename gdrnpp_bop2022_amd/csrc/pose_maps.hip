@@ -127,6 +127,111 @@ __global__ __launch_bounds__(kThreads) void decode_corr_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// The same decode for maps of at most 4096 pixels (OUTPUT_RES 64): 16 waves per ROI, every pixel's inputs are loaded
+// once, all loads of a lane in flight together, and stay in registers from the mask normalisation to the scatter; two
+// barriers instead of three passes over the maps.  Pixel ranges per wave, ballot ranks and arithmetic as above, so the
+// selection, its order and the values are identical.
+// ---------------------------------------------------------------------------------------
+constexpr int kRegThreads = 1024, kRegWaves = kRegThreads / 64, kRegIt = 4, kRegMaxHw = kRegThreads * kRegIt;
+
+__global__ __launch_bounds__(kRegThreads) void decode_corr_reg_kernel(
+    const float* __restrict__ coor_x, const float* __restrict__ coor_y, const float* __restrict__ coor_z,
+    const float* __restrict__ mask_raw, const float* __restrict__ coord2d, const float* __restrict__ extent,
+    const float* __restrict__ imwh, float* __restrict__ out_mask, int* __restrict__ count,
+    int* __restrict__ sel_idx, float* __restrict__ img_pts, float* __restrict__ mdl_pts, int hw, int mask_type,
+    float mask_thr) {
+  __shared__ float s_min[kRegWaves], s_max[kRegWaves];
+  __shared__ int s_cnt[kRegWaves];
+  const int bi = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* cx = coor_x + (size_t)bi * hw;
+  const float* cy = coor_y + (size_t)bi * hw;
+  const float* cz = coor_z + (size_t)bi * hw;
+  const float* mk = mask_raw + (size_t)bi * hw;
+  const float* c2 = coord2d + (size_t)bi * 2 * hw;
+  const int chunk = ((hw + kRegThreads - 1) / kRegThreads) * 64;  // pixels per wave, multiple of 64, <= 64 * kRegIt
+  const int begin = wave * chunk, end = min(hw, begin + chunk);
+
+  float mv[kRegIt], xv[kRegIt], yv[kRegIt], zv[kRegIt], ux[kRegIt], uy[kRegIt];
+  bool in[kRegIt];
+#pragma unroll
+  for (int j = 0; j < kRegIt; ++j) {
+    const int p = begin + 64 * j + lane;
+    in[j] = p < end;
+    const int q = in[j] ? p : 0;
+    mv[j] = mk[q]; xv[j] = cx[q]; yv[j] = cy[q]; zv[j] = cz[q]; ux[j] = c2[q]; uy[j] = c2[hw + q];
+  }
+  const float e0 = extent[bi * 3], e1 = extent[bi * 3 + 1], e2 = extent[bi * 3 + 2];
+  const float imW = imwh[bi * 2], imH = imwh[bi * 2 + 1];
+
+  float mmin = 0.f, mden = 1.f;
+  if (mask_type == 0) {
+    float lo = FLT_MAX, hi = -FLT_MAX;
+    bool has_nan = false;
+#pragma unroll
+    for (int j = 0; j < kRegIt; ++j)
+      if (in[j]) {
+        has_nan |= (mv[j] != mv[j]);
+        lo = fminf(lo, mv[j]);
+        hi = fmaxf(hi, mv[j]);
+      }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo = fminf(lo, __shfl_xor(lo, off, 64));
+      hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    }
+    const bool any_nan = __any(has_nan);
+    if (lane == 0) { s_min[wave] = any_nan ? NAN : lo; s_max[wave] = any_nan ? NAN : hi; }
+    __syncthreads();
+    lo = s_min[0]; hi = s_max[0];
+    for (int w = 1; w < kRegWaves; ++w) {  // torch.max/min propagate NaN
+      lo = (s_min[w] != s_min[w] || lo != lo) ? NAN : fminf(lo, s_min[w]);
+      hi = (s_max[w] != s_max[w] || hi != hi) ? NAN : fmaxf(hi, s_max[w]);
+    }
+    mmin = lo;
+    mden = hi - lo;
+  }
+
+  const float t0 = 0.0001f * e0, t1 = 0.0001f * e1, t2 = 0.0001f * e2;
+  unsigned long long bal[kRegIt];
+  int my_cnt = 0;
+#pragma unroll
+  for (int j = 0; j < kRegIt; ++j) {
+    bool sel = false;
+    if (in[j]) {
+      float m = mv[j];
+      if (mask_type == 0) m = (m - mmin) / mden;
+      else if (mask_type == 1) m = 1.f / (1.f + expf(-m));
+      if (out_mask) out_mask[(size_t)bi * hw + begin + 64 * j + lane] = m;
+      xv[j] = (xv[j] - 0.5f) * e0; yv[j] = (yv[j] - 0.5f) * e1; zv[j] = (zv[j] - 0.5f) * e2;
+      sel = (m > mask_thr) && (fabsf(xv[j]) > t0) && (fabsf(yv[j]) > t1) && (fabsf(zv[j]) > t2);
+    }
+    bal[j] = __ballot(sel);
+    my_cnt += __popcll(bal[j]);
+  }
+  if (lane == 0) s_cnt[wave] = my_cnt;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < kRegWaves; ++w) {
+    if (w < wave) base += s_cnt[w];
+    total += s_cnt[w];
+  }
+  if (threadIdx.x == 0) count[bi] = total;
+#pragma unroll
+  for (int j = 0; j < kRegIt; ++j) {
+    if ((bal[j] >> lane) & 1ull) {
+      const int r = base + __popcll(bal[j] & ((1ull << lane) - 1ull));
+      const size_t o = (size_t)bi * hw + r;
+      if (sel_idx) sel_idx[o] = begin + 64 * j + lane;
+      img_pts[o * 2] = ux[j] * imW;
+      img_pts[o * 2 + 1] = uy[j] * imH;
+      mdl_pts[o * 3] = xv[j]; mdl_pts[o * 3 + 1] = yv[j]; mdl_pts[o * 3 + 2] = zv[j];
+    }
+    base += __popcll(bal[j]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // rot_mode: 0 = 6-d representation, 1 = quaternion (w,x,y,z), 2 = rotation matrix (row-major)
 // t_mode:   0 = centroid_z with relative z (SITE), 1 = centroid_z with absolute z, 2 = centroid_z_abs (absolute 2-d centre
 //           and z: pose_from_pred_centroid_z_abs.py:44-76), 3 = trans (the head's output IS the translation: pose_from_pred.py:25-27)
@@ -249,9 +354,14 @@ int gdrnpp_decode_correspondences(const float* coor_x, const float* coor_y, cons
   GDRNPP_REQUIRE(b > 0 && hw > 0, GDRNPP_EINVAL, "gdrnpp_decode_correspondences: b=%d hw=%d", b, hw);
   GDRNPP_REQUIRE(mask_type >= 0 && mask_type <= 2, GDRNPP_EINVAL, "gdrnpp_decode_correspondences: mask_type=%d",
                  mask_type);
-  hipLaunchKernelGGL(decode_corr_kernel, dim3(b), dim3(kThreads), 0, (hipStream_t)stream, coor_x, coor_y, coor_z,
-                     mask_raw, coord2d, extent, imwh, out_mask, count, sel_idx, img_pts, mdl_pts, hw, mask_type,
-                     mask_thr);
+  if (hw <= kRegMaxHw)
+    hipLaunchKernelGGL(decode_corr_reg_kernel, dim3(b), dim3(kRegThreads), 0, (hipStream_t)stream, coor_x, coor_y, coor_z,
+                       mask_raw, coord2d, extent, imwh, out_mask, count, sel_idx, img_pts, mdl_pts, hw, mask_type,
+                       mask_thr);
+  else
+    hipLaunchKernelGGL(decode_corr_kernel, dim3(b), dim3(kThreads), 0, (hipStream_t)stream, coor_x, coor_y, coor_z,
+                       mask_raw, coord2d, extent, imwh, out_mask, count, sel_idx, img_pts, mdl_pts, hw, mask_type,
+                       mask_thr);
   return gdrnpp::check_launch("gdrnpp_decode_correspondences");
 }
 

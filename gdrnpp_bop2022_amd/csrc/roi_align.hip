@@ -8,57 +8,98 @@
 // bilinear_interpolate with the (-1, size) validity window and clamping at the far border, mean over the grid.
 // fp32, accumulation order iy-major / ix-minor, val = w1*v1 + w2*v2 + w3*v3 + w4*v4 left to right, no FMA.
 //
-// One thread per output element, pw fastest (coalesced stores); taps are gathers inside one [H,W] channel plane
+// pw fastest (coalesced stores), grid (plane tiles, channel, ROI); taps are gathers inside one [H,W] channel plane
 // (L2-resident for image-sized inputs).  Write-bound: 4 B per output element.
 #include "common.hpp"
 
 namespace {
 
-__device__ __forceinline__ float bilinear_interpolate(const float* __restrict__ data, int height, int width, float y,
-                                                      float x) {
-  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) return 0.f;
-  if (y <= 0) y = 0;
-  if (x <= 0) x = 0;
-  int y_low = (int)y, x_low = (int)x, y_high, x_high;
-  if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else { y_high = y_low + 1; }
-  if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else { x_high = x_low + 1; }
-  const float ly = y - y_low, lx = x - x_low, hy = 1.f - ly, hx = 1.f - lx;
-  const float v1 = data[y_low * width + x_low], v2 = data[y_low * width + x_high];
-  const float v3 = data[y_high * width + x_low], v4 = data[y_high * width + x_high];
-  const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-  return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+struct __attribute__((aligned(4))) float2_u { float x, y; };
+
+// One axis of detectron2's bilinear_interpolate: validity window (-1, size), clamp at 0, far-border clamp.
+struct AxisTap {
+  bool valid;
+  int low, high;
+  float l, h;  // weight of `high`, weight of `low`
+};
+__device__ __forceinline__ AxisTap axis_tap(float v, int size) {
+  AxisTap t;
+  t.valid = !(v < -1.0f || v > (float)size);
+  if (v <= 0) v = 0;
+  t.low = (int)v;
+  if (t.low >= size - 1) { t.high = t.low = size - 1; v = (float)t.low; } else { t.high = t.low + 1; }
+  if (!t.valid) t.low = t.high = 0;  // any in-range address: the value is discarded
+  t.l = v - t.low;
+  t.h = 1.f - t.l;
+  return t;
 }
 
-__global__ void roi_align_kernel(const float* __restrict__ x, const float* __restrict__ rois, float* __restrict__ out,
-                                 long total, int C, int H, int W, int PH, int PW, float spatial_scale,
-                                 int sampling_ratio, int aligned) {
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int pw = (int)(idx % PW);
-    const int ph = (int)((idx / PW) % PH);
-    const int c = (int)((idx / ((long)PW * PH)) % C);
-    const int n = (int)(idx / ((long)PW * PH * C));
-    const float* r = rois + 5 * (size_t)n;
-    const int bi = (int)r[0];
-    const float offset = aligned ? 0.5f : 0.f;
-    const float sw = r[1] * spatial_scale - offset, sh = r[2] * spatial_scale - offset;
-    const float ew = r[3] * spatial_scale - offset, eh = r[4] * spatial_scale - offset;
-    float rw = ew - sw, rh = eh - sh;
-    if (!aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
-    const float bin_h = rh / (float)PH, bin_w = rw / (float)PW;
-    const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
-    const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
-    const float count = fmaxf((float)(gh * gw), 1.f);
-    const float* data = x + ((size_t)bi * C + c) * H * W;
-    float acc = 0.f;
-    for (int iy = 0; iy < gh; ++iy) {
-      const float y = sh + ph * bin_h + (iy + .5f) * bin_h / (float)gh;
-      for (int ix = 0; ix < gw; ++ix) {
-        const float xx = sw + pw * bin_w + (ix + .5f) * bin_w / (float)gw;
-        acc += bilinear_interpolate(data, H, W, y, xx);
+// grid (tiles of row groups x PW, channel, ROI).  A thread owns kRows consecutive output rows of one column: the x taps of
+// a sample column are shared by its rows, and the 2 * kRows row loads of a sample are issued together (a workgroup lives
+// for a few dependent memory round trips, so the kernel's time is rounds x latency: more loads in flight per thread and
+// kRows times fewer workgroups is what it needs).  Per output the samples are still added iy-major, ix-minor, each as
+// w1*v1 + w2*v2 + w3*v3 + w4*v4 left to right.
+constexpr int kRows = 8;
+
+template <bool kAligned>
+__global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict__ x, const float* __restrict__ rois,
+                                                        float* __restrict__ out, int C, int H, int W, int PH, int PW,
+                                                        float spatial_scale, int sampling_ratio) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int groups = (PH + kRows - 1) / kRows;
+  if (p >= groups * PW) return;
+  const int g = p / PW, pw = p - g * PW, ph0 = g * kRows;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float* r = rois + 5 * (size_t)n;
+  const int bi = (int)r[0];
+  const float offset = kAligned ? 0.5f : 0.f;
+  const float sw = r[1] * spatial_scale - offset, sh = r[2] * spatial_scale - offset;
+  const float ew = r[3] * spatial_scale - offset, eh = r[4] * spatial_scale - offset;
+  float rw = ew - sw, rh = eh - sh;
+  if (!kAligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+  const float bin_h = rh / (float)PH, bin_w = rw / (float)PW;
+  const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+  const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+  const float count = fmaxf((float)(gh * gw), 1.f);
+  const float* data = x + ((size_t)bi * C + c) * H * W;
+  const float x0 = sw + pw * bin_w;
+  float acc[kRows];
+#pragma unroll
+  for (int k = 0; k < kRows; ++k) acc[k] = 0.f;
+  for (int iy = 0; iy < gh; ++iy) {
+    const float dy = (iy + .5f) * bin_h / (float)gh;
+    AxisTap ty[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) ty[k] = axis_tap(sh + (ph0 + k) * bin_h + dy, H);
+    for (int ix = 0; ix < gw; ++ix) {
+      const AxisTap tx = axis_tap(x0 + (ix + .5f) * bin_w / (float)gw, W);
+      // high is low + 1 or (clamped at the right border) low: both taps of a row come from one 8-byte load at
+      // min(low, W - 2) (4-byte alignment is enough for global_load_dwordx2); W == 1 has a single column
+      const int xb = W >= 2 ? min(tx.low, W - 2) : 0;
+      float2_u r0[kRows], r1[kRows];
+#pragma unroll
+      for (int k = 0; k < kRows; ++k) {
+        if (W >= 2) {
+          r0[k] = *reinterpret_cast<const float2_u*>(data + ty[k].low * W + xb);
+          r1[k] = *reinterpret_cast<const float2_u*>(data + ty[k].high * W + xb);
+        } else {
+          r0[k].x = r0[k].y = data[ty[k].low * W];
+          r1[k].x = r1[k].y = data[ty[k].high * W];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kRows; ++k) {
+        const float v1 = tx.low == xb ? r0[k].x : r0[k].y, v2 = tx.high == xb ? r0[k].x : r0[k].y;
+        const float v3 = tx.low == xb ? r1[k].x : r1[k].y, v4 = tx.high == xb ? r1[k].x : r1[k].y;
+        const float w1 = ty[k].h * tx.h, w2 = ty[k].h * tx.l, w3 = ty[k].l * tx.h, w4 = ty[k].l * tx.l;
+        const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+        acc[k] += (ty[k].valid && tx.valid) ? val : 0.f;
       }
     }
-    out[idx] = acc / count;
   }
+#pragma unroll
+  for (int k = 0; k < kRows; ++k)
+    if (ph0 + k < PH) __builtin_nontemporal_store(acc[k] / count, out + (((size_t)n * C + c) * PH + ph0 + k) * PW + pw);
 }
 
 }  // namespace
@@ -69,10 +110,14 @@ extern "C" int gdrnpp_roi_align(const float* x, const float* rois, float* out, i
   GDRNPP_REQUIRE(x && rois && out, GDRNPP_EINVAL, "gdrnpp_roi_align: null pointer");
   GDRNPP_REQUIRE(n_rois > 0 && C > 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0 && sampling_ratio >= 0,
                  GDRNPP_EINVAL, "gdrnpp_roi_align: bad sizes");
-  const long total = (long)n_rois * C * pooled_h * pooled_w;
-  long blocks = (total + 255) / 256;
-  if (blocks > 256 * 64) blocks = 256 * 64;
-  hipLaunchKernelGGL(roi_align_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, rois, out, total, C,
-                     H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned);
+  GDRNPP_REQUIRE(n_rois <= 65535 && C <= 65535 && (long)pooled_h * pooled_w < (1l << 30), GDRNPP_ELIMIT,
+                 "gdrnpp_roi_align: n_rois=%d / C=%d above 65535 or output plane too large", n_rois, C);
+  const dim3 grid((unsigned)((((pooled_h + kRows - 1) / kRows) * pooled_w + 255) / 256), (unsigned)C, (unsigned)n_rois);
+  if (aligned)
+    hipLaunchKernelGGL(roi_align_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, rois, out, C, H, W, pooled_h,
+                       pooled_w, spatial_scale, sampling_ratio);
+  else
+    hipLaunchKernelGGL(roi_align_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, rois, out, C, H, W, pooled_h,
+                       pooled_w, spatial_scale, sampling_ratio);
   return gdrnpp::check_launch("gdrnpp_roi_align");
 }

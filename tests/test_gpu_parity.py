@@ -197,6 +197,38 @@ def test_decode_correspondences_bit_exact(hip, seed):
     assert cnt[3] == 0 and cnt.sum() > 100
 
 
+@pytest.mark.parametrize("res", [8, 32, 48, 64, 80])
+def test_decode_correspondences_other_map_sizes(hip, res):
+    """OUTPUT_RES other than 64: up to 64 x 64 the register-resident kernel (ragged last wave at 48 x 48, a single
+    partial wave at 8 x 8), above it the looping kernel; random maps, one constant mask, one mask with a NaN."""
+    rng = np.random.default_rng(res)
+    b = 5
+    cx, cy, cz = (rng.random((b, 1, res, res), dtype=np.float32) for _ in range(3))
+    cx[rng.random(cx.shape) < 0.2] = 0.5                     # |x| <= 1e-4 * extent -> rejected
+    mask = rng.standard_normal((b, 1, res, res)).astype(np.float32)
+    mask[1] = 0.25
+    mask[2, 0, res // 2, 1] = np.nan
+    c2 = rng.random((b, 2, res, res), dtype=np.float32)
+    ext = rng.uniform(0.05, 0.3, (b, 3)).astype(np.float32)
+    imwh = np.tile(np.array([[640.0, 480.0]], np.float32), (b, 1))
+    cnt, sel, ip, mp, om = hip.decode_correspondences(T(cx), T(cy), T(cz), T(mask), T(c2), T(ext), T(imwh))
+    cnt, sel, ip, mp, om = (x.cpu().numpy() for x in (cnt, sel, ip, mp, om))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        omask = P.get_out_mask(mask)
+    assert np.array_equal(om.view(np.uint32)[[0, 3, 4]], omask.view(np.uint32)[[0, 3, 4]])
+    assert np.isnan(om[1]).all() and np.isnan(om[2]).all()    # 0/0 and NaN min/max: nothing selected
+    for i in range(b):
+        xyz = np.concatenate([cx[i], cy[i], cz[i]], 0).transpose(1, 2, 0)
+        with np.errstate(invalid="ignore"):
+            oip, omp, osel = P.get_img_model_points_with_coords2d(omask[i, 0], xyz, c2[i].transpose(1, 2, 0), 480, 640, ext[i])
+        n = len(oip)
+        assert cnt[i] == n
+        assert np.array_equal(sel[i, :n], np.flatnonzero(osel.reshape(-1)))
+        assert np.array_equal(ip[i, :n].view(np.uint32), oip.view(np.uint32))
+        assert np.array_equal(mp[i, :n].view(np.uint32), omp.view(np.uint32))
+    assert cnt[1] == 0 and cnt[2] == 0 and cnt[0] > 0
+
+
 def test_pose_from_pred_and_zoom_K(hip):
     rng = np.random.default_rng(3)
     b = 64
