@@ -474,10 +474,11 @@ int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const f
   const bool fast3x3 = CONV && cg.KW == 3 && cg.stride == 1 && cg.pad == 1 && K == 9 * cg.C;
   const long tiles256 = (long)((M + 255) / 256) * (N / BN);
   GDRNPP_REQUIRE(tiles256 < (1l << 30), GDRNPP_ELIMIT, "%s: grid too large", what);
-  // 256-row tiles when they still give every CU its two workgroups (measured +3 % / +7 % on the stage-2 MLP shapes over
-  // 128x128 tiles at three workgroups per CU); gdrnpp_set_option("split_gemm_mi4", 0/1) forces the choice (A/B).
+  // 256-row tiles when they still give every CU a workgroup (option split_gemm_big_tiles, 256; measured +3 % / +7 % on the
+  // stage-2 MLP shapes over 128x128 tiles at three workgroups per CU; end to end against a threshold of 512: +0.4 % at 128
+  // ROIs, +2.2 % at 64, +0.1 % at 32; 128: -0.5 % at 32, -0.9 % at 16); gdrnpp_set_option("split_gemm_mi4", 0/1) forces the choice.
   const int force = gdrnpp::option_split_gemm_mi4();
-  const bool big = force >= 0 ? force == 1 : tiles256 >= 512;
+  const bool big = force >= 0 ? force == 1 : tiles256 >= gdrnpp::option_split_gemm_big_tiles();
   if (big && gdrnpp::option_split_gemm_pipe() && (!CONV || gdrnpp::option_split_gemm_pipe_conv())) {   // software-pipelined LDS-DMA kernel
     const int rc = launch_split_pipe(A, Wp, bias, gamma, resid, C, M, N, K, EPI, CONV, cg, gdrnpp::option_split_gemm_pipe(), st, what);
     if (rc >= 0) return rc;

@@ -49,6 +49,7 @@ int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const 
 
 int option_split_gemm_pipe();       // 0: off, 2 / 3 (default): pipelined kernel with that many A stages for 256-row tiles (linear form)
 int option_split_gemm_panel();      // row blocks per tile panel of wide layers in the pipelined kernel (default 4; 0: row-major)
+int option_split_gemm_big_tiles();  // 256x128 tiles (pipelined / LDS-DMA kernels) from this many of them on
 int option_split_gemm_pipe_conv();  // 1: the 3x3/1/1 convolution uses it too (default 0: measured 1 % slower than the LDS-DMA kernel)
 
 }  // namespace gdrnpp

@@ -45,6 +45,8 @@ const char* gdrnpp_last_error(void);
  *   "split_gemm_pipe"  0 / 2 / 3   256-row tiles of the linear form use the software-pipelined LDS-DMA kernel with two /
  *                              three A stages (default 3; bitwise identical to the other kernels); 0 = off
  *   "split_gemm_pipe_conv"  0 / 1   the 3x3 / stride 1 / pad 1 convolution uses it too (default 0)
+ *   "split_gemm_big_tiles"  >= 1    256x128 output tiles (pipelined / LDS-DMA kernels) when the problem has at least this many
+ *                                   of them (default 256 = one per CU), 128x128 tiles below
  *   "split_gemm_panel"      0, 2..64  wide layers (packed weight > 2 MB, N >= 1024) walk their tiles in panels of that many
  *                                   256-row blocks, column tile outer, for L2 reuse of both operands (default 4; 0: row-major)
  *   "split_gemm_mi4"   -1 / 0 / 1   tile height by tile count (default) / force 128 rows / force 256 rows
