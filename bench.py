@@ -82,6 +82,7 @@ def parse(argv=None):
     p.add_argument("--exact-reference-order", action="store_true",
                    help="run the reference's full 1470-channel output layer + gather instead of the class-sliced one")
     p.add_argument("--no-hip-layers", action="store_true", help="A/B: run the memory-bound network layers with PyTorch ops")
+    p.add_argument("--no-conv-gn-fusion", action="store_true", help="A/B: GroupNorm statistics in their own pass instead of the conv epilogue")
     p.add_argument("--mlp-gemm", choices=["split", "torch"], default="split",
                    help="GEMM engine of the ConvNeXt MLPs / head convolutions: split = exact 3-way bf16 operand split on the "
                         "bf16 matrix cores (fp32-accurate); torch = hipBLASLt / MIOpen fp32 + separate elementwise kernels")
@@ -265,6 +266,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, roi_ids):
         hip_lib.set_option(k_, int(v_))
     torch.backends.cudnn.benchmark = True  # MIOpen find mode during warm-up
     hip_layers.set_enabled(not args.no_hip_layers)
+    hip_layers.set_conv_gn_fused(not args.no_conv_gn_fusion)
     hip_layers.set_mlp_gemm(args.mlp_gemm)
     opts = ["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"] if refine else []
 

@@ -286,12 +286,18 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 constexpr int GA_SLOTS = 256 * 4;   // fp32 A image of one stage: 256 rows x 4 chunks of 16 B
 constexpr int GB_SLOTS = 3 * KB * BN;  // packed weight tile image
 
-template <int EPI, int CONV>
+// GroupNorm statistics of the result, taken in the epilogue of the convolution that produces it (GNS): every wave writes
+// the fp64 (sum, sum of squares) of its 64 rows x 8-channel groups to part[image][P][G][2], P = 4 * (256-row tiles per
+// image), slot 4 * tile + wave — the layout gn_apply_kernel (net_kernels.hip) reduces, so the separate statistics pass over
+// the stored tensor is not needed.  Requires 8 channels per group and images of a multiple of 256 pixels.
+struct GnStats { double* part; int G; int tiles_per_img; };
+
+template <int EPI, int CONV, bool GNS = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_glds_kernel(const float* __restrict__ A, const uint4* __restrict__ Wp,
                                                                  const float* __restrict__ bias,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ resid, float* __restrict__ C,
-                                                                 int M, int N, int K, ConvGeom cg) {
+                                                                 int M, int N, int K, ConvGeom cg, GnStats gn) {
   __shared__ uint4 sA[2 * GA_SLOTS];
   __shared__ uint4 sB[2 * GB_SLOTS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -425,6 +431,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_glds_kernel(const float* __
     const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
     if (EPI == EPI_SCALE_RES) gv = *reinterpret_cast<const float4*>(gamma + nb);
+    double gs = 0.0, gss = 0.0;  // GNS: this lane's four columns over its 16 rows
 #pragma unroll
     for (int ih = 0; ih < 4; ++ih) {
       const int i = ih >> 1, h = ih & 1;
@@ -442,6 +449,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_glds_kernel(const float* __
         const int grow = m0 + wave * 64 + i * 32 + h * 16 + row;
         if (grow >= M) continue;
         const size_t off = (size_t)grow * N + nb;
+        if (GNS) {
+          gs += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+          gss += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+        }
         if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
         if (EPI == EPI_SCALE_RES) {
           const float4 rs = *reinterpret_cast<const float4*>(resid + off);
@@ -450,6 +461,19 @@ __global__ __launch_bounds__(256, 2) void gemm_split_glds_kernel(const float* __
         { const f32x4v t4 = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t4, reinterpret_cast<f32x4v*>(C + off)); }
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+    if (GNS) {
+      // a group's 8 channels are the column quads of lanes 2k, 2k+1; its 64 rows sit in the four 16-lane row groups
+      gs += __shfl_xor(gs, 1, 64);   gss += __shfl_xor(gss, 1, 64);
+      gs += __shfl_xor(gs, 16, 64);  gss += __shfl_xor(gss, 16, 64);
+      gs += __shfl_xor(gs, 32, 64);  gss += __shfl_xor(gss, 32, 64);
+      if ((lane & 0x31) == 0) {
+        const int hw = cg.H * cg.W, img = m0 / hw, mt = (m0 - img * hw) >> 8;
+        const int g = ((n0 + jh * 64) >> 3) + (lane >> 1);
+        double* o = gn.part + (((size_t)img * (4 * gn.tiles_per_img) + 4 * mt + wave) * gn.G + g) * 2;
+        o[0] = gs;
+        o[1] = gss;
+      }
     }
   }
 }
@@ -484,8 +508,8 @@ int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const f
     if (rc >= 0) return rc;
   }
   if (big && gdrnpp::option_split_gemm_glds()) {   // LDS-DMA kernel: any M, any of the three A forms
-    if (CONV && fast3x3) hipLaunchKernelGGL((gemm_split_glds_kernel<EPI, CONV ? 1 : 0>), dim3((unsigned)tiles256), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
-    else hipLaunchKernelGGL((gemm_split_glds_kernel<EPI, CONV ? 2 : 0>), dim3((unsigned)tiles256), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
+    if (CONV && fast3x3) hipLaunchKernelGGL((gemm_split_glds_kernel<EPI, CONV ? 1 : 0>), dim3((unsigned)tiles256), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg, GnStats{nullptr, 0, 0});
+    else hipLaunchKernelGGL((gemm_split_glds_kernel<EPI, CONV ? 2 : 0>), dim3((unsigned)tiles256), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg, GnStats{nullptr, 0, 0});
     return gdrnpp::check_launch(what);
   }
   // (the general convolution form needs a few more registers than 256x128 tiles leave: it stays on 128x128 tiles)
@@ -612,4 +636,26 @@ extern "C" int gdrnpp_conv2d_f32_split(const float* x_nhwc, const void* W_packed
 extern "C" int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                                         int n_img, int H, int W, int Cin, int Cout, int epilogue, void* stream) {
   return gdrnpp_conv2d_f32_split(x_nhwc, W_packed, bias, y_nhwc, n_img, H, W, Cin, Cout, 3, 3, 1, 1, epilogue, stream);
+}
+
+extern "C" int gdrnpp_conv3x3_gnstats_partials(int H, int W) { return (H * W) % 256 == 0 ? 4 * ((H * W) / 256) : 0; }
+
+extern "C" int gdrnpp_conv3x3_f32_split_gnstats(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
+                                                double* gn_partials, int n_img, int H, int W, int Cin, int Cout, int groups,
+                                                void* stream) {
+  GDRNPP_REQUIRE(x_nhwc && W_packed && y_nhwc && gn_partials, GDRNPP_EINVAL, "gdrnpp_conv3x3_f32_split_gnstats: null pointer");
+  GDRNPP_REQUIRE(n_img > 0 && H > 0 && W > 0 && H < 32768 && W < 32768 && Cin > 0 && Cout > 0 && groups > 0, GDRNPP_EINVAL,
+                 "gdrnpp_conv3x3_f32_split_gnstats: bad shape");
+  const long M = (long)n_img * H * W;
+  GDRNPP_REQUIRE(M < (1l << 31) && Cout % BN == 0 && Cin % 32 == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_conv3x3_f32_split_gnstats: Cout=%d Cin=%d must be multiples of %d/32", Cout, Cin, BN);
+  GDRNPP_REQUIRE((H * W) % 256 == 0 && Cout == 8 * groups, GDRNPP_ELIMIT,
+                 "gdrnpp_conv3x3_f32_split_gnstats: needs H*W %% 256 == 0 and 8 channels per group (H*W=%d Cout=%d groups=%d)",
+                 H * W, Cout, groups);
+  const long tiles = (M / 256) * (Cout / BN);
+  GDRNPP_REQUIRE(tiles < (1l << 30), GDRNPP_ELIMIT, "gdrnpp_conv3x3_f32_split_gnstats: grid too large");
+  hipLaunchKernelGGL((gemm_split_glds_kernel<EPI_BIAS, 1, true>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x_nhwc,
+                     (const uint4*)W_packed, bias, (const float*)nullptr, (const float*)nullptr, y_nhwc, (int)M, Cout, 9 * Cin,
+                     ConvGeom{H, W, Cin, H, W, 3, 1, 1, 0}, GnStats{gn_partials, groups, (H * W) / 256});
+  return gdrnpp::check_launch("gdrnpp_conv3x3_f32_split_gnstats");
 }

@@ -674,6 +674,26 @@ int gdrnpp_groupnorm_act_nhwc(const float* x, const float* gamma, const float* b
   return gdrnpp::check_launch("gdrnpp_groupnorm_act_nhwc");
 }
 
+int gdrnpp_groupnorm_apply_nhwc(const float* x, const double* partials, int P, const float* gamma, const float* beta,
+                                float* y, int N, int HW, int C, int G, float eps, int act_gelu, void* stream) {
+  GDRNPP_REQUIRE(x && partials && gamma && beta && y, GDRNPP_EINVAL, "gdrnpp_groupnorm_apply_nhwc: null pointer");
+  GDRNPP_REQUIRE(N > 0 && HW > 0 && C > 0 && G > 0 && P > 0 && C % G == 0, GDRNPP_EINVAL,
+                 "gdrnpp_groupnorm_apply_nhwc: N=%d HW=%d C=%d G=%d P=%d", N, HW, C, G, P);
+  const int cpg = C / G, Q = C / 4;
+  GDRNPP_REQUIRE(C % 4 == 0 && cpg % 4 == 0 && Q <= 256 && 256 % Q == 0 && G <= 64 && N <= 65535, GDRNPP_ELIMIT,
+                 "gdrnpp_groupnorm_apply_nhwc: unsupported shape C=%d G=%d N=%d", C, G, N);
+  const long total = (long)HW * Q;
+  long bx = (total + 256 * 16 - 1) / (256 * 16);
+  if (bx > 64) bx = 64;
+  if (bx < 1) bx = 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (act_gelu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)bx, N), dim3(256), 0, st, x, partials, gamma, beta, y, HW, C, G, P, eps);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)bx, N), dim3(256), 0, st, x, partials, gamma, beta, y, HW, C, G, P, eps);
+  return gdrnpp::check_launch("gdrnpp_groupnorm_apply_nhwc");
+}
+
 int gdrnpp_head_tail_nhwc(const float* out_nhwc, int pitch, const float* coord2d, const float* extents, float* pnp_in,
                           float* planes, int b, int hw, int double_mask, void* stream) {
   if (b == 0) return 0;

@@ -59,6 +59,10 @@ class ConvModule(nn.Module):
         nn.init.kaiming_normal_(self.conv.weight, a=0, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x):
+        if self.norm_name == "gn":   # conv3x3 -> GN (-> GELU): GroupNorm statistics from the convolution's epilogue
+            y = hip_layers.conv3x3_groupnorm_act(self.conv, getattr(self, "gn"), self.activate, x)
+            if y is not None:
+                return y
         x = hip_layers.conv2d(self.conv, x)
         if self.norm_name == "gn":
             return hip_layers.groupnorm_act(getattr(self, "gn"), self.activate, x)  # fused GN(+GELU) on the GPU
@@ -96,6 +100,15 @@ def run_features(features, x):
         elif isinstance(layer, nn.UpsamplingBilinear2d) and layer.scale_factor in (2, 2.0):
             x = hip_layers.upsample2x(layer, x)
         elif isinstance(layer, nn.Conv2d):
+            gn = features[i + 1] if i + 1 < n else None
+            if isinstance(gn, nn.GroupNorm):   # conv -> GN (-> exact GELU): statistics in the convolution's epilogue
+                nxt = features[i + 2] if i + 2 < n else None
+                gelu = nxt if isinstance(nxt, nn.GELU) and getattr(nxt, "approximate", "none") == "none" else None
+                y = hip_layers.conv3x3_groupnorm_act(layer, gn, gelu, x)
+                if y is not None:
+                    x = y
+                    i += 3 if gelu is not None else 2
+                    continue
             x = hip_layers.conv2d(layer, x)
         else:
             x = layer(x)

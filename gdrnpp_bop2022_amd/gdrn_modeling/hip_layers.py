@@ -192,6 +192,35 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     return conv(x)
 
 
+_CONV_GN_FUSED = True
+
+
+def set_conv_gn_fused(flag: bool) -> None:
+    """A/B switch: False runs conv3x3 and GroupNorm as two layers (statistics pass + apply pass) again."""
+    global _CONV_GN_FUSED
+    _CONV_GN_FUSED = bool(flag)
+
+
+def conv3x3_groupnorm_act(conv: nn.Conv2d, gn: nn.GroupNorm, act: nn.Module | None, x: torch.Tensor):
+    """The head's [Conv2d 3x3/1/1, GroupNorm(, GELU)] triple with the GroupNorm statistics taken in the convolution's
+    epilogue (``hip_lib.conv3x3_groupnorm_act``).  Returns None when the layers or the shape are outside that form; the
+    caller then runs them one by one."""
+    if not (_CONV_GN_FUSED and _CONV_SPLIT and _MLP_GEMM == "split" and enabled_for(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
+            and conv.in_channels % 32 == 0 and conv.out_channels % 128 == 0 and gn.affine
+            and gn.num_channels == conv.out_channels and conv.out_channels == 8 * gn.num_groups
+            and (act is None or (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none"))):
+        return None
+    cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
+    tag = weight_tag(conv.weight)
+    hit = cache.get("w_pk")
+    if hit is None or hit[0] != tag:
+        hit = (tag, hip_lib.pack_conv_weight_bf16x3(conv.weight.detach()))
+        cache["w_pk"] = hit
+    return hip_lib.conv3x3_groupnorm_act(_cl(x), hit[1], conv.bias, gn.weight, gn.bias, gn.num_groups, gn.eps,
+                                         gelu=act is not None)
+
+
 def linear(fc: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     """nn.Linear on a [M, K] activation with few rows and a long K (Patch-PnP fc1: 8192 -> 1024 on one row per ROI):
     hipBLASLt picks a 256x16 macro-tile for it and streams the 33 MB weight at ~70 GB/s (0.49 ms at 128 ROIs); the split-K

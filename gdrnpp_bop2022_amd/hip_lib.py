@@ -95,6 +95,9 @@ SIGNATURES = {
     "gdrnpp_upsample_bilinear2x_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_groupnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gdrnpp_groupnorm_act_nhwc": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "gdrnpp_conv3x3_gnstats_partials": (c_int, [c_int, c_int]),
+    "gdrnpp_conv3x3_f32_split_gnstats": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_groupnorm_apply_nhwc": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
 }
 
 
@@ -726,6 +729,34 @@ def conv3x3_f32_split(x_cl, weight_packed, bias, gelu: bool = False):
     nbytes = 4.0 * n * h * w * (cin + cout) + 6.0 * cout * 9 * cin
     _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split(*args), nbytes),
            "gdrnpp_conv3x3_f32_split")
+    return out
+
+
+def conv3x3_groupnorm_act(x_cl, weight_packed, bias, gamma, beta, groups: int, eps: float = 1e-5, gelu: bool = False):
+    """conv3x3 (stride 1, pad 1) -> GroupNorm(groups) [-> GELU] of a channels_last tensor: the convolution's epilogue
+    leaves the GroupNorm partial sums, the norm is one more pass (``gdrnpp_conv3x3_f32_split_gnstats`` +
+    ``gdrnpp_groupnorm_apply_nhwc``).  Returns None when the shape is outside the fused form (H*W % 256, 8 channels
+    per group): the caller then runs the two layers separately."""
+    n, cin, h, w = x_cl.shape
+    if not x_cl.is_contiguous(memory_format=torch.channels_last) or x_cl.dtype != torch.float32 or not x_cl.is_cuda:
+        raise ValueError("conv3x3_groupnorm_act expects a float32 channels_last device tensor")
+    if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or weight_packed.shape[1] * 16 != 9 * cin:
+        raise ValueError("weight_packed must come from pack_conv3x3_weight_bf16x3 with matching Cin")
+    cout = weight_packed.shape[0] * 128
+    P = load().gdrnpp_conv3x3_gnstats_partials(h, w)
+    if P <= 0 or cout != 8 * groups or n * h * w < 256 * 256:
+        return None
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
+    part = torch.empty((n, P, groups, 2), dtype=torch.float64, device=x_cl.device)
+    args = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
+            y.data_ptr(), part.data_ptr(), n, h, w, cin, cout, groups, _stream())
+    nbytes = 4.0 * n * h * w * (cin + cout) + 6.0 * cout * 9 * cin
+    _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split_gnstats(*args), nbytes),
+           "gdrnpp_conv3x3_f32_split_gnstats")
+    out = torch.empty_like(y)
+    _check(load().gdrnpp_groupnorm_apply_nhwc(
+        y.data_ptr(), part.data_ptr(), P, _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"),
+        out.data_ptr(), n, h * w, cout, groups, float(eps), 1 if gelu else 0, _stream()), "gdrnpp_groupnorm_apply_nhwc")
     return out
 
 

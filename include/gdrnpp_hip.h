@@ -383,6 +383,18 @@ int gdrnpp_conv2d_f32_split(const float* x_nhwc, const void* W_packed, const flo
                             int epilogue, void* stream);
 int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                              int n_img, int H, int W, int Cin, int Cout, int epilogue, void* stream);
+/* The ConvModule pair conv3x3 -> GroupNorm of the geometry head (lib/torch_utils/layers/conv_module.py:222-236,
+ * top_down_doublemask_xyz_region_head.py:84-107) with the GroupNorm statistics taken in the convolution's epilogue:
+ * gn_partials f64[n_img, P, groups, 2] (sum, sum of squares; P = gdrnpp_conv3x3_gnstats_partials(H, W), 0 = shape not
+ * supported) is fully written; gdrnpp_groupnorm_apply_nhwc then normalises y (+ affine, optional GELU) from them, the
+ * same second pass gdrnpp_groupnorm_act_nhwc runs after its own statistics pass.  Needs H*W % 256 == 0 and
+ * Cout == 8 * groups; no activation between convolution and norm. */
+int gdrnpp_conv3x3_gnstats_partials(int H, int W);
+int gdrnpp_conv3x3_f32_split_gnstats(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
+                                     double* gn_partials, int n_img, int H, int W, int Cin, int Cout, int groups,
+                                     void* stream);
+int gdrnpp_groupnorm_apply_nhwc(const float* x, const double* partials, int P, const float* gamma, const float* beta,
+                                float* y, int N, int HW, int C, int G, float eps, int act_gelu, void* stream);
 
 /* ---- depth-to-flow (SURVEY §8b boundary "flow") — replaces the flow_cuda torch extension,
  * core/csrc/flow/src/flow_cuda.cpp:30-47 (kernel flow_cuda_kernel.cu:33-64).

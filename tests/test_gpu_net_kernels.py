@@ -391,6 +391,31 @@ def test_stem_conv_ln_fused_vs_torch(hip, n, h, w):
     assert (y0.double() - ref0).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("n,h,w,gelu,bias", [(16, 64, 64, True, False), (64, 32, 32, False, True), (65, 32, 32, True, True)])
+def test_conv3x3_groupnorm_fused_vs_torch(hip, n, h, w, gelu, bias):
+    """conv3x3 -> GroupNorm(32) (-> GELU) with the statistics from the convolution's epilogue: against F.conv2d +
+    F.group_norm (+ gelu) in fp64, and bit-for-bit conv output / 1e-6 norm output against the two separate HIP layers."""
+    torch.manual_seed(n + h)
+    x = _cl(torch.randn(n, 256, h, w, device=DEV))
+    wt = torch.randn(256, 256, 3, 3, device=DEV) * 0.03
+    b = torch.randn(256, device=DEV) * 0.1 if bias else None
+    g = torch.rand(256, device=DEV) + 0.5
+    be = torch.randn(256, device=DEV) * 0.1
+    pk = hip.pack_conv_weight_bf16x3(wt)
+    y = hip.conv3x3_groupnorm_act(x, pk, b, g, be, 32, 1e-5, gelu=gelu)
+    assert y is not None and y.shape == (n, 256, h, w) and y.is_contiguous(memory_format=torch.channels_last)
+    c = F.conv2d(x.double(), wt.double(), None if b is None else b.double(), padding=1)
+    ref = F.group_norm(c, 32, g.double(), be.double(), 1e-5)
+    if gelu:
+        ref = F.gelu(ref)
+    assert (y.double() - ref).abs().max().item() < 3e-5
+    two = hip.groupnorm_act(hip.conv3x3_f32_split(x, pk, b), g, be, 32, 1e-5, gelu=gelu)
+    assert (y - two).abs().max().item() < 1e-6
+    # shapes outside the fused form are declined, not mis-computed
+    assert hip.conv3x3_groupnorm_act(_cl(torch.randn(2, 256, 8, 8, device=DEV)), pk, b, g, be, 32) is None
+    assert hip.conv3x3_groupnorm_act(x, pk, b, g[:64].repeat(4), be, 16) is None
+
+
 @pytest.mark.parametrize("b", [1, 17])
 def test_model_forward_more_roi_counts(hip, b):
     """Whole forward (fused stem, pipelined / small-tile GEMMs, grouped output layer, head tail, Patch-PnP) on the HIP path
