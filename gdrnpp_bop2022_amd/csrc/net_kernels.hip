@@ -293,6 +293,43 @@ __global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict
 }
 
 // --------------------------------------------------------------------------------------------------
+// Transposed convolution (nn.ConvTranspose2d, square kernel / stride / padding) as a GEMM plus this gather: the GEMM
+// cols[n, iy, ix, (ky, kx, co)] = sum_ci x[n, iy, ix, ci] * w[ci, co, ky, kx] does exactly the useful multiplies (a
+// zero-stuffed convolution would do stride^2 times as many); output pixel (oy, ox) then sums the taps whose input
+// position (oy + pad - ky) / stride, (ox + pad - kx) / stride is integral and inside the image — at most
+// ceil(KS / stride)^2 of them, added in (ky, kx) order, so the result is deterministic.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void deconv_col2im_kernel(const float* __restrict__ cols, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int H, int W, int C, int KS, int stride,
+                                                            int pad, int OH, int OW, long total) {
+  const int Q = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    long p = i / Q;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const long n = p / OH;
+    float4 a = bias ? ld4(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < KS; ++ky) {
+      const int ty = oy + pad - ky;
+      if (ty < 0 || ty % stride) continue;
+      const int iy = ty / stride;
+      if (iy >= H) continue;
+      for (int kx = 0; kx < KS; ++kx) {
+        const int tx = ox + pad - kx;
+        if (tx < 0 || tx % stride) continue;
+        const int ix = tx / stride;
+        if (ix >= W) continue;
+        const float4 v = ld4(cols + (((size_t)n * H + iy) * W + ix) * ((size_t)KS * KS * C) + (size_t)(ky * KS + kx) * C + 4 * q);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    }
+    st4(y + (((size_t)n * OH + oy) * OW + ox) * C + 4 * q, a);
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
 // GroupNorm (+ optional exact GELU), NHWC.  Pass A: per (sample, pixel chunk) fp64 partial sums per group,
 // written to a workspace [N, P, G, 2] (no atomics -> deterministic).  Pass B: every thread rebuilds mean/rstd of
 // its quad's group from the P partials and applies (x-mean)*rstd*gamma+beta, then GELU.
@@ -672,6 +709,21 @@ int gdrnpp_groupnorm_act_nhwc(const float* x, const float* gamma, const float* b
     hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)bx, N), dim3(256), 0, st, x, (const double*)workspace,
                        gamma, beta, y, HW, C, G, P, eps);
   return gdrnpp::check_launch("gdrnpp_groupnorm_act_nhwc");
+}
+
+int gdrnpp_deconv_col2im_nhwc(const float* cols, const float* bias, float* y, int N, int H, int W, int C, int KS, int stride,
+                              int pad, int out_pad, void* stream) {
+  GDRNPP_REQUIRE(cols && y, GDRNPP_EINVAL, "gdrnpp_deconv_col2im_nhwc: null pointer");
+  GDRNPP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && KS > 0 && stride > 0 && pad >= 0 && out_pad >= 0 &&
+                     out_pad < stride,
+                 GDRNPP_EINVAL, "gdrnpp_deconv_col2im_nhwc: bad shape");
+  const int OH = (H - 1) * stride - 2 * pad + KS + out_pad, OW = (W - 1) * stride - 2 * pad + KS + out_pad;
+  GDRNPP_REQUIRE(OH > 0 && OW > 0, GDRNPP_EINVAL, "gdrnpp_deconv_col2im_nhwc: empty output");
+  const long total = (long)N * OH * OW * (C / 4);
+  const long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(deconv_col2im_kernel, dim3((unsigned)(blocks < 65536 * 8 ? blocks : 65536 * 8)), dim3(256), 0,
+                     (hipStream_t)stream, cols, bias, y, H, W, C, KS, stride, pad, OH, OW, total);
+  return gdrnpp::check_launch("gdrnpp_deconv_col2im_nhwc");
 }
 
 int gdrnpp_groupnorm_apply_nhwc(const float* x, const double* partials, int P, const float* gamma, const float* beta,

@@ -110,6 +110,8 @@ def run_features(features, x):
                     i += 3 if gelu is not None else 2
                     continue
             x = hip_layers.conv2d(layer, x)
+        elif isinstance(layer, nn.ConvTranspose2d):
+            x = hip_layers.conv_transpose2d(layer, x)
         else:
             x = layer(x)
         i += 1

@@ -192,6 +192,26 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     return conv(x)
 
 
+def conv_transpose2d(deconv: nn.ConvTranspose2d, x: torch.Tensor) -> torch.Tensor:
+    """nn.ConvTranspose2d forward; the head's square-kernel / stride-2 form with Cin % 32 == 0 and KS*KS*Cout % 128 == 0
+    runs as split GEMM + col2im gather (``hip_lib.conv_transpose2d_f32_split``), everything else in MIOpen."""
+    ks = deconv.kernel_size[0]
+    if (_CONV_SPLIT and _MLP_GEMM == "split" and enabled_for(x) and deconv.kernel_size[0] == deconv.kernel_size[1]
+            and deconv.stride[0] == deconv.stride[1] and deconv.padding[0] == deconv.padding[1]
+            and deconv.output_padding[0] == deconv.output_padding[1] and deconv.output_padding[0] < deconv.stride[0]
+            and deconv.dilation == (1, 1) and deconv.groups == 1 and deconv.in_channels % 32 == 0
+            and deconv.out_channels % 4 == 0 and (ks * ks * deconv.out_channels) % 128 == 0):
+        cache = deconv.__dict__.setdefault("_gdrnpp_cache", {})
+        tag = weight_tag(deconv.weight)
+        hit = cache.get("w_pk")
+        if hit is None or hit[0] != tag:
+            hit = (tag, hip_lib.pack_deconv_weight_bf16x3(deconv.weight))
+            cache["w_pk"] = hit
+        return hip_lib.conv_transpose2d_f32_split(_cl(x), hit[1], deconv.bias, ks, deconv.stride[0], deconv.padding[0],
+                                                  deconv.output_padding[0])
+    return deconv(x)
+
+
 _CONV_GN_FUSED = True
 
 

@@ -95,6 +95,7 @@ SIGNATURES = {
     "gdrnpp_upsample_bilinear2x_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_groupnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gdrnpp_groupnorm_act_nhwc": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "gdrnpp_deconv_col2im_nhwc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_conv3x3_gnstats_partials": (c_int, [c_int, c_int]),
     "gdrnpp_conv3x3_f32_split_gnstats": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_groupnorm_apply_nhwc": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
@@ -597,7 +598,7 @@ def unpack_weight_bf16x3(packed):
     return packed.permute(2, 0, 4, 1, 3, 5).reshape(3, tn * 128, tk * 16)
 
 
-def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None):
+def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None, _kind: str = "linear"):
     """out = epilogue(x2d @ W^T + bias) with the weight given as pack_weight_bf16x3(weight); runs on the bf16 matrix cores
     with six partial products per fp32 product (fp32-accurate, see csrc/gemm_split.hip)."""
     m, k = x2d.shape
@@ -612,7 +613,7 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
             _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
             {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream())
     nbytes = 4.0 * m * k + 6.0 * n * k + 4.0 * m * n * (2 if epilogue == "scale_res" else 1)
-    _check(_timed("linear", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split(*args), nbytes), "gdrnpp_linear_f32_split")
+    _check(_timed(_kind, 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split(*args), nbytes), "gdrnpp_linear_f32_split")
     return out
 
 
@@ -730,6 +731,28 @@ def conv3x3_f32_split(x_cl, weight_packed, bias, gelu: bool = False):
     _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split(*args), nbytes),
            "gdrnpp_conv3x3_f32_split")
     return out
+
+
+def pack_deconv_weight_bf16x3(weight):
+    """nn.ConvTranspose2d weight [Cin, Cout, KS, KS] -> packed GEMM weight with rows (ky, kx, co), K = Cin."""
+    cin, cout, kh, kw = weight.shape
+    return pack_weight_bf16x3(weight.detach().permute(2, 3, 1, 0).reshape(kh * kw * cout, cin).contiguous())
+
+
+def conv_transpose2d_f32_split(x_cl, weight_packed, bias, ks: int, stride: int, pad: int, out_pad: int):
+    """nn.ConvTranspose2d of a channels_last tensor [N,Cin,H,W] as split GEMM + col2im gather -> channels_last
+    [N,Cout,OH,OW] (``weight_packed`` from pack_deconv_weight_bf16x3)."""
+    n, cin, h, w = x_cl.shape
+    if not x_cl.is_contiguous(memory_format=torch.channels_last) or x_cl.dtype != torch.float32 or not x_cl.is_cuda:
+        raise ValueError("conv_transpose2d_f32_split expects a float32 channels_last device tensor")
+    cout = weight_packed.shape[0] * 128 // (ks * ks)
+    cols = linear_f32_split(x_cl.permute(0, 2, 3, 1).reshape(n * h * w, cin), weight_packed, None, _kind="deconv")
+    oh, ow = (h - 1) * stride - 2 * pad + ks + out_pad, (w - 1) * stride - 2 * pad + ks + out_pad
+    y = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
+    _check(load().gdrnpp_deconv_col2im_nhwc(cols.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
+                                            y.data_ptr(), n, h, w, cout, ks, stride, pad, out_pad, _stream()),
+           "gdrnpp_deconv_col2im_nhwc")
+    return y
 
 
 def conv3x3_groupnorm_act(x_cl, weight_packed, bias, gamma, beta, groups: int, eps: float = 1e-5, gelu: bool = False):

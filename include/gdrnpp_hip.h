@@ -389,6 +389,13 @@ int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const fl
  * supported) is fully written; gdrnpp_groupnorm_apply_nhwc then normalises y (+ affine, optional GELU) from them, the
  * same second pass gdrnpp_groupnorm_act_nhwc runs after its own statistics pass.  Needs H*W % 256 == 0 and
  * Cout == 8 * groups; no activation between convolution and norm. */
+/* nn.ConvTranspose2d (the head's first upsampling step, top_down_doublemask_xyz_region_head.py:62-78) = one
+ * gdrnpp_linear_f32_split of the NHWC input [n*H*W, Cin] with the weight reordered to [(ky, kx, co), ci]
+ * (N = KS*KS*Cout columns) -> cols f32[n, H, W, KS*KS, Cout], then this gather: y f32 NHWC [n, OH, OW, Cout],
+ * OH = (H-1)*stride - 2*pad + KS + out_pad; every output pixel adds its <= ceil(KS/stride)^2 taps in (ky, kx) order
+ * (+ bias, may be NULL).  Cout % 4 == 0. */
+int gdrnpp_deconv_col2im_nhwc(const float* cols, const float* bias, float* y, int N, int H, int W, int C, int KS,
+                              int stride, int pad, int out_pad, void* stream);
 int gdrnpp_conv3x3_gnstats_partials(int H, int W);
 int gdrnpp_conv3x3_f32_split_gnstats(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                                      double* gn_partials, int n_img, int H, int W, int Cin, int Cout, int groups,

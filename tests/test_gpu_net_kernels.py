@@ -416,6 +416,21 @@ def test_conv3x3_groupnorm_fused_vs_torch(hip, n, h, w, gelu, bias):
     assert hip.conv3x3_groupnorm_act(x, pk, b, g[:64].repeat(4), be, 16) is None
 
 
+@pytest.mark.parametrize("ks,pad,out_pad", [(3, 1, 1), (4, 1, 0), (2, 0, 0)])
+@pytest.mark.parametrize("n,h,w,cin,cout,bias", [(5, 8, 8, 1024, 256, False), (2, 5, 7, 64, 128, True)])
+def test_conv_transpose2d_split_vs_torch(hip, ks, pad, out_pad, n, h, w, cin, cout, bias):
+    """ConvTranspose2d (stride 2; the three kernel sizes of the head's deconv table) as split GEMM + col2im gather against
+    F.conv_transpose2d in fp64."""
+    torch.manual_seed(ks + n)
+    x = _cl(torch.randn(n, cin, h, w, device=DEV))
+    wt = torch.randn(cin, cout, ks, ks, device=DEV) * 0.03
+    b = torch.randn(cout, device=DEV) * 0.1 if bias else None
+    y = hip.conv_transpose2d_f32_split(x, hip.pack_deconv_weight_bf16x3(wt), b, ks, 2, pad, out_pad)
+    ref = F.conv_transpose2d(x.double(), wt.double(), None if b is None else b.double(), stride=2, padding=pad, output_padding=out_pad)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert (y.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("b", [1, 17])
 def test_model_forward_more_roi_counts(hip, b):
     """Whole forward (fused stem, pipelined / small-tile GEMMs, grouped output layer, head tail, Patch-PnP) on the HIP path
