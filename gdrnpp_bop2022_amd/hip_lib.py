@@ -767,7 +767,7 @@ def conv3x3_groupnorm_act(x_cl, weight_packed, bias, gamma, beta, groups: int, e
         raise ValueError("weight_packed must come from pack_conv3x3_weight_bf16x3 with matching Cin")
     cout = weight_packed.shape[0] * 128
     P = load().gdrnpp_conv3x3_gnstats_partials(h, w)
-    if P <= 0 or cout != 8 * groups or n * h * w < 256 * 256:
+    if P <= 0 or cout != 8 * groups or (n * h * w // 256) * (cout // 128) < 256:   # below: the 128x128-tile kernels are faster
         return None
     y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
     part = torch.empty((n, P, groups, 2), dtype=torch.float64, device=x_cl.device)
