@@ -1,6 +1,7 @@
 // libgdrnpp_hip.so — library-level entry points (version, last error).
 #include "gemm_split.hpp"
 #include <cstring>
+#include <mutex>
 
 namespace gdrnpp {
 static thread_local char g_err[512] = "";
@@ -24,6 +25,23 @@ void* shim_scratch(size_t bytes) {
   if (e != hipSuccess) { block = nullptr; set_error("hipMalloc(%zu): %s", want, hipGetErrorString(e)); return nullptr; }
   cap = want; block_dev = dev;
   return block;
+}
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+  struct Entry { const void* fn; int dev, bytes; };
+  static std::mutex mu;
+  static Entry table[128];
+  static int n = 0;
+  int dev = 0;
+  GDRNPP_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  Entry* e = nullptr;
+  for (int i = 0; i < n; ++i)
+    if (table[i].fn == kernel && table[i].dev == dev) e = &table[i];
+  if (e && e->bytes >= bytes) return 0;
+  GDRNPP_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (e) e->bytes = bytes;
+  else if (n < 128) table[n++] = Entry{kernel, dev, bytes};
+  return 0;
 }
 static int g_opt_glds = 1, g_opt_mi4 = -1, g_opt_pipe = 3, g_opt_pipe_conv = 0, g_opt_panel = 4, g_opt_big_tiles = 256;
 int option_split_gemm_glds() { return g_opt_glds; }

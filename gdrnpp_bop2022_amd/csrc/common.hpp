@@ -64,6 +64,9 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // block per host thread, re-allocated when the thread switches device; kept for the life of the process (no hipMalloc /
 // hipFree per call).  Returns nullptr with the error text set when the allocation fails.
 void* shim_scratch(size_t bytes);
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-(kernel, device) setting: raised when `bytes` exceeds what this process
+// has already set for the pair on the current device, not on every launch.  Returns 0 or a GDRNPP_* code (error text set).
+int ensure_dynamic_lds(const void* kernel, int bytes);
 
 // process-wide tuning switches (gdrnpp_set_option): read on the launch path instead of getenv
 int option_split_gemm_glds();   // 1: 256-row split-GEMM tiles use the LDS-DMA kernel

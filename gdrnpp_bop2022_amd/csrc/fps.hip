@@ -301,8 +301,7 @@ int gdrnpp_fps(const float* pts, int* idxs, const int* start_idx, int b, int pn,
   hipStream_t st = (hipStream_t)stream;
   if (pn <= kLdsPts) {
     const int lds_bytes = 3 * kLdsPts * (int)sizeof(float);
-    // per call: the attribute is per device, and a process may drive several devices
-    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)fps_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    if (int rc = gdrnpp::ensure_dynamic_lds((const void*)fps_lds_kernel, lds_bytes)) return rc;
     hipLaunchKernelGGL(fps_lds_kernel, dim3(b), dim3(kThreads), lds_bytes, st, pts, idxs, start_idx, pn, sn, mode);
   } else {
     GDRNPP_REQUIRE(workspace, GDRNPP_EINVAL, "gdrnpp_fps: pn=%d needs a workspace of %zu bytes", pn,

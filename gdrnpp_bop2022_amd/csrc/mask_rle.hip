@@ -119,7 +119,7 @@ extern "C" int gdrnpp_paste_masks_rle(const float* mask_probs, const float* boxe
   GDRNPP_REQUIRE((long)im_H * im_W < (1l << 31) && mask_h * mask_w * 4 <= 128 * 1024, GDRNPP_ELIMIT,
                  "gdrnpp_paste_masks_rle: image %dx%d or mask %dx%d too large", im_H, im_W, mask_h, mask_w);
   const int lds = mask_h * mask_w * (int)sizeof(float);
-  GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)paste_rle_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  if (int rc = gdrnpp::ensure_dynamic_lds((const void*)paste_rle_kernel, lds)) return rc;
   hipLaunchKernelGGL(paste_rle_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, mask_probs, boxes_xyxy, mask_h, mask_w,
                      im_H, im_W, threshold, counts, n_runs, max_runs);
   return gdrnpp::check_launch("gdrnpp_paste_masks_rle");

@@ -13,6 +13,7 @@
 // fp32 math as the PyTorch operators (exact erf GELU, biased variance, eps inside the sqrt); summation
 // order differs, so parity is a tolerance (1e-5 rel, tests/test_gpu_net_kernels.py), not bit equality.
 #include "common.hpp"
+#include <mutex>
 
 namespace {
 
@@ -620,17 +621,31 @@ int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bia
     // weights in LDS, persistent workgroups: 512 threads when the weight set allows only one workgroup per CU
     const int threads = wbytes > 52 * 1024 ? 512 : 256;
     const long n_groups = (n_tiles + threads / Q - 1) / (threads / Q);
-    static int n_cu = 0;
-    if (!n_cu) {
-      int dev = 0;
-      GDRNPP_HIP_TRY(hipGetDevice(&dev));
-      GDRNPP_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    // CU count, LDS attribute and occupancy are per (device, kernel, launch shape): looked up once, not per launch
+    struct Cfg { int dev; bool fuse; int threads; size_t wbytes; int n_cu, per_cu; };
+    static std::mutex mu;
+    static Cfg cache[16];
+    static int n_cached = 0;
+    int dev = 0, n_cu = 0, per_cu = 1;
+    GDRNPP_HIP_TRY(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      const Cfg* hit = nullptr;
+      for (int i = 0; i < n_cached; ++i)
+        if (cache[i].dev == dev && cache[i].fuse == fuse && cache[i].threads == threads && cache[i].wbytes == wbytes) hit = &cache[i];
+      if (!hit) {
+        Cfg c{dev, fuse, threads, wbytes, 0, 1};
+        GDRNPP_HIP_TRY(hipDeviceGetAttribute(&c.n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        const void* fn = fuse ? (const void*)dwconv7_ln_kernel<true, true> : (const void*)dwconv7_ln_kernel<false, true>;
+        if (int rc = gdrnpp::ensure_dynamic_lds(fn, 112 * 1024)) return rc;
+        GDRNPP_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.per_cu, fn, threads, wbytes));
+        if (c.per_cu < 1) c.per_cu = 1;
+        cache[n_cached < 16 ? n_cached++ : 15] = c;
+        hit = &cache[n_cached - 1 < 15 ? n_cached - 1 : 15];
+      }
+      n_cu = hit->n_cu;
+      per_cu = hit->per_cu;
     }
-    const void* fn = fuse ? (const void*)dwconv7_ln_kernel<true, true> : (const void*)dwconv7_ln_kernel<false, true>;
-    GDRNPP_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wbytes));
-    int per_cu = 1;
-    GDRNPP_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, wbytes));
-    if (per_cu < 1) per_cu = 1;
     long blocks = (long)n_cu * per_cu;
     if (blocks > n_groups) blocks = n_groups;
     if (fuse) {

@@ -180,7 +180,7 @@ extern "C" int gdrnpp_yolox_postprocess(const float* det_preds, int B, int A, in
   int npad = 64;
   while (npad < A) npad <<= 1;
   const int lds1 = npad * 8;
-  GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)yolox_decode_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+  if (int rc = gdrnpp::ensure_dynamic_lds((const void*)yolox_decode_sort_kernel, lds1)) return rc;
   hipLaunchKernelGGL(yolox_decode_sort_kernel, dim3(B), dim3(1024), lds1, st, det_preds, A, C, conf_thre, cands, n_cand, max_coord);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, st, cands, n_cand, max_coord, A, nms_thre,
                      class_agnostic, mask, words);
