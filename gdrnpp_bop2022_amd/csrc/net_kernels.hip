@@ -294,6 +294,28 @@ __global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict
 }
 
 // --------------------------------------------------------------------------------------------------
+// y = act(x + bias[c] (+ resid)), NHWC float4 lanes: what is left of [BatchNorm2d, (residual add,) ReLU] once the
+// inference-mode BatchNorm is folded into the preceding convolution's weights (ResNet BasicBlock, timm resnet.py).
+// In place when y == x.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                       const float* __restrict__ resid, float* __restrict__ y, long total4,
+                                                       int Q, int relu) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    float4 v = ld4(x + 4 * i);
+    const float4 b = ld4(bias + 4 * q);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (resid) {
+      const float4 r = ld4(resid + 4 * i);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    st4(y + 4 * i, v);
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
 // Transposed convolution (nn.ConvTranspose2d, square kernel / stride / padding) as a GEMM plus this gather: the GEMM
 // cols[n, iy, ix, (ky, kx, co)] = sum_ci x[n, iy, ix, ci] * w[ci, co, ky, kx] does exactly the useful multiplies (a
 // zero-stuffed convolution would do stride^2 times as many); output pixel (oy, ox) then sums the taps whose input
@@ -724,6 +746,18 @@ int gdrnpp_groupnorm_act_nhwc(const float* x, const float* gamma, const float* b
     hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)bx, N), dim3(256), 0, st, x, (const double*)workspace,
                        gamma, beta, y, HW, C, G, P, eps);
   return gdrnpp::check_launch("gdrnpp_groupnorm_act_nhwc");
+}
+
+int gdrnpp_bias_act_nhwc(const float* x, const float* bias, const float* resid, float* y, long n_pix, int C, int relu,
+                         void* stream) {
+  if (n_pix == 0) return 0;
+  GDRNPP_REQUIRE(x && bias && y, GDRNPP_EINVAL, "gdrnpp_bias_act_nhwc: null pointer");
+  GDRNPP_REQUIRE(n_pix > 0 && C > 0 && C % 4 == 0, GDRNPP_EINVAL, "gdrnpp_bias_act_nhwc: n_pix=%ld C=%d (C %% 4 == 0)", n_pix, C);
+  const long total4 = n_pix * (C / 4);
+  const long blocks = (total4 + 255) / 256;
+  hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)(blocks < 65536 * 8 ? blocks : 65536 * 8)), dim3(256), 0,
+                     (hipStream_t)stream, x, bias, resid, y, total4, C / 4, relu);
+  return gdrnpp::check_launch("gdrnpp_bias_act_nhwc");
 }
 
 int gdrnpp_deconv_col2im_nhwc(const float* cols, const float* bias, float* y, int N, int H, int W, int C, int KS, int stride,

@@ -115,6 +115,16 @@ class BasicBlock(nn.Module):
                                             nn.BatchNorm2d(planes))
 
     def forward(self, x):
+        if hip_layers.enabled_for(x) and not self.training:
+            # inference on the GPU: BatchNorms folded into the convolutions, one elementwise kernel behind each of the two
+            # 3x3 convolutions (bias + ReLU; bias + shortcut + ReLU); the downsample branch's folded bias joins conv2's
+            sc, sc_bias = x, None
+            if self.downsample is not None:
+                w_ds, sc_bias = hip_layers.folded_conv_bn(self.downsample[0], self.downsample[1])
+                d = self.downsample[0]
+                sc = F.conv2d(x, w_ds, None, d.stride, d.padding, d.dilation, d.groups)
+            y = hip_layers.conv_bn_act(self.conv1, self.bn1, x, relu=True)
+            return hip_layers.conv_bn_act(self.conv2, self.bn2, y, relu=True, resid=sc, extra_bias=sc_bias)
         sc = x if self.downsample is None else self.downsample(x)
         x = self.act1(self.bn1(self.conv1(x)))
         x = self.bn2(self.conv2(x))
@@ -143,7 +153,10 @@ class ResNetFeatures(nn.Module):
     def forward(self, x):
         x = x.contiguous(memory_format=torch.channels_last)
         feats = []
-        x = self.act1(self.bn1(self.conv1(x)))
+        if hip_layers.enabled_for(x) and not self.training:
+            x = hip_layers.conv_bn_act(self.conv1, self.bn1, x, relu=True)
+        else:
+            x = self.act1(self.bn1(self.conv1(x)))
         if 0 in self.out_indices:
             feats.append(x)
         x = self.maxpool(x)

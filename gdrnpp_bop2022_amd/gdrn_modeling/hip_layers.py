@@ -192,6 +192,44 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     return conv(x)
 
 
+def folded_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    """(weight, bias) of the convolution that equals ``bn(conv(x))`` in inference mode: w * s and beta - mean * s with
+    s = gamma / sqrt(var + eps) per output channel, formed in float64, cached on the conv module until a parameter or a
+    running statistic changes."""
+    cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
+    tag = weight_tag(conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    hit = cache.get("bn_fold")
+    if hit is None or hit[0] != tag:
+        with torch.no_grad():
+            s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            w = (conv.weight.double() * s.view(-1, 1, 1, 1)).float().contiguous(memory_format=torch.channels_last)
+            b0 = conv.bias.double() if conv.bias is not None else 0.0
+            b = (bn.bias.double() + (b0 - bn.running_mean.double()) * s).float().contiguous()
+        hit = (tag, w, b)
+        cache["bn_fold"] = hit
+    return hit[1], hit[2]
+
+
+def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, resid: torch.Tensor | None = None,
+                extra_bias: torch.Tensor | None = None) -> torch.Tensor:
+    """[Conv2d, BatchNorm2d (inference), (+ resid), (ReLU)] of a ResNet block as the folded convolution + ONE elementwise
+    kernel (``gdrnpp_bias_act_nhwc``) instead of BatchNorm, add and ReLU kernels.  ``extra_bias`` is added to the folded
+    bias (the folded bias of a downsample branch whose convolution output arrives as ``resid``)."""
+    if (enabled_for(x) and not bn.training and bn.affine and bn.track_running_stats and conv.out_channels % 4 == 0
+            and x.dtype == torch.float32):
+        w, b = folded_conv_bn(conv, bn)
+        if extra_bias is not None:
+            b = b + extra_bias
+        y = F.conv2d(_cl(x), w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return hip_lib.bias_act_nhwc_(_cl(y), b, None if resid is None else _cl(resid), relu)
+    y = bn(conv(x))
+    if extra_bias is not None:
+        y = y + extra_bias.view(1, -1, 1, 1)
+    if resid is not None:
+        y = y + resid
+    return torch.relu_(y) if relu else y
+
+
 def conv_transpose2d(deconv: nn.ConvTranspose2d, x: torch.Tensor) -> torch.Tensor:
     """nn.ConvTranspose2d forward; the head's square-kernel / stride-2 form with Cin % 32 == 0 and KS*KS*Cout % 128 == 0
     runs as split GEMM + col2im gather (``hip_lib.conv_transpose2d_f32_split``), everything else in MIOpen."""

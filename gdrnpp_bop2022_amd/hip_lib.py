@@ -95,6 +95,7 @@ SIGNATURES = {
     "gdrnpp_upsample_bilinear2x_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_groupnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gdrnpp_groupnorm_act_nhwc": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "gdrnpp_bias_act_nhwc": (c_int, [_P, _P, _P, _P, ctypes.c_long, c_int, c_int, _P]),
     "gdrnpp_deconv_col2im_nhwc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_conv3x3_gnstats_partials": (c_int, [c_int, c_int]),
     "gdrnpp_conv3x3_f32_split_gnstats": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -731,6 +732,20 @@ def conv3x3_f32_split(x_cl, weight_packed, bias, gelu: bool = False):
     _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split(*args), nbytes),
            "gdrnpp_conv3x3_f32_split")
     return out
+
+
+def bias_act_nhwc_(x_cl, bias, resid=None, relu: bool = True):
+    """In place: x = act(x + bias[c] (+ resid)) on a channels_last float32 tensor [N,C,H,W] (C % 4 == 0)."""
+    n, c, h, w = x_cl.shape
+    if not x_cl.is_contiguous(memory_format=torch.channels_last) or x_cl.dtype != torch.float32 or not x_cl.is_cuda:
+        raise ValueError("bias_act_nhwc_ expects a float32 channels_last device tensor")
+    if resid is not None and (resid.shape != x_cl.shape or not resid.is_contiguous(memory_format=torch.channels_last)
+                              or resid.dtype != torch.float32 or resid.device != x_cl.device):
+        raise ValueError("resid must match x (float32, channels_last, same device)")
+    _check(load().gdrnpp_bias_act_nhwc(x_cl.data_ptr(), _dev(bias, torch.float32, "bias"),
+                                       resid.data_ptr() if resid is not None else None, x_cl.data_ptr(), n * h * w, c,
+                                       1 if relu else 0, _stream()), "gdrnpp_bias_act_nhwc")
+    return x_cl
 
 
 def pack_deconv_weight_bf16x3(weight):

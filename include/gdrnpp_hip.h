@@ -394,6 +394,11 @@ int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const fl
  * (N = KS*KS*Cout columns) -> cols f32[n, H, W, KS*KS, Cout], then this gather: y f32 NHWC [n, OH, OW, Cout],
  * OH = (H-1)*stride - 2*pad + KS + out_pad; every output pixel adds its <= ceil(KS/stride)^2 taps in (ky, kx) order
  * (+ bias, may be NULL).  Cout % 4 == 0. */
+/* y = act(x + bias[c] (+ resid)) over n_pix NHWC pixels of C channels (C % 4 == 0; resid may be NULL; relu 0 / 1; y may be
+ * x): the [BatchNorm2d (inference), residual add, ReLU] tail of a ResNet BasicBlock (timm resnet.py BasicBlock.forward)
+ * once the BatchNorm is folded into the convolution in front of it (hip_layers.conv_bn_act). */
+int gdrnpp_bias_act_nhwc(const float* x, const float* bias, const float* resid, float* y, long n_pix, int C, int relu,
+                         void* stream);
 int gdrnpp_deconv_col2im_nhwc(const float* cols, const float* bias, float* y, int N, int H, int W, int C, int KS,
                               int stride, int pad, int out_pad, void* stream);
 int gdrnpp_conv3x3_gnstats_partials(int H, int W);
