@@ -120,9 +120,8 @@ class BasicBlock(nn.Module):
             # 3x3 convolutions (bias + ReLU; bias + shortcut + ReLU); the downsample branch's folded bias joins conv2's
             sc, sc_bias = x, None
             if self.downsample is not None:
-                w_ds, sc_bias = hip_layers.folded_conv_bn(self.downsample[0], self.downsample[1])
-                d = self.downsample[0]
-                sc = F.conv2d(x, w_ds, None, d.stride, d.padding, d.dilation, d.groups)
+                _, sc_bias = hip_layers.folded_conv_bn(self.downsample[0], self.downsample[1])
+                sc = hip_layers.folded_conv(self.downsample[0], self.downsample[1], x)
             y = hip_layers.conv_bn_act(self.conv1, self.bn1, x, relu=True)
             return hip_layers.conv_bn_act(self.conv2, self.bn2, y, relu=True, resid=sc, extra_bias=sc_bias)
         sc = x if self.downsample is None else self.downsample(x)

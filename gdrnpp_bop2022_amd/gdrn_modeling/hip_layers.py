@@ -168,16 +168,21 @@ def set_conv_split(flag: bool) -> None:
     _CONV_SPLIT = bool(flag)
 
 
-def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
-    """nn.Conv2d forward; dense convolutions with square kernel / stride / padding, Cin % 32 == 0 and Cout % 128 == 0 (the
-    head's 3x3/1, ConvNeXt's 2x2/2 downsamples, Patch-PnP's 3x3/2) run as an implicit GEMM in ``gdrnpp_conv2d_f32_split``
-    (bf16 matrix cores, fp32-accurate), everything else in MIOpen."""
-    if (_CONV_SPLIT and _MLP_GEMM == "split" and isinstance(conv, nn.Conv2d) and enabled_for(x)
+def _conv_split_ok(conv, x) -> bool:
+    """Shapes ``gdrnpp_conv2d_f32_split`` takes: dense, square kernel / stride / zero padding, Cin % 32 == 0, Cout % 128 == 0."""
+    return (_CONV_SPLIT and _MLP_GEMM == "split" and isinstance(conv, nn.Conv2d) and enabled_for(x)
             and conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1]
             and conv.padding[0] == conv.padding[1] and isinstance(conv.padding[0], int) and conv.padding[0] < conv.kernel_size[0]
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros" and conv.in_channels % 32 == 0
             and conv.out_channels % 128 == 0
-            and (x.shape[2] + 2 * conv.padding[0] - conv.kernel_size[0]) // conv.stride[0] * conv.stride[0] < x.shape[2]):
+            and (x.shape[2] + 2 * conv.padding[0] - conv.kernel_size[0]) // conv.stride[0] * conv.stride[0] < x.shape[2])
+
+
+def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d forward; dense convolutions with square kernel / stride / padding, Cin % 32 == 0 and Cout % 128 == 0 (the
+    head's 3x3/1, ConvNeXt's 2x2/2 downsamples, Patch-PnP's 3x3/2) run as an implicit GEMM in ``gdrnpp_conv2d_f32_split``
+    (bf16 matrix cores, fp32-accurate), everything else in MIOpen."""
+    if _conv_split_ok(conv, x):
         cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
         w = conv.weight
         tag = weight_tag(w)
@@ -210,6 +215,27 @@ def folded_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
     return hit[1], hit[2]
 
 
+_BN_SPLIT_MIN_TILES = 256   # 128x128 output tiles from which the split implicit GEMM beats MIOpen's fp32 kernels on the ResNet
+                            # layers (config 1, 32 ROIs: 6.06 ms per step all-MIOpen, 5.91 at 256, 6.30 at 128, 7.2 at 64 and below)
+
+
+def folded_conv(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor) -> torch.Tensor:
+    """conv(x) with the BatchNorm scale folded into the weights and no bias: the split implicit GEMM when the layer fits it
+    and gives the chip enough output tiles, else MIOpen."""
+    w, _ = folded_conv_bn(conv, bn)
+    k, st, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    if _conv_split_ok(conv, x):
+        oh, ow = (x.shape[2] + 2 * pd - k) // st + 1, (x.shape[3] + 2 * pd - k) // st + 1
+        if hip_lib.split_gemm_tiles(x.shape[0] * oh * ow, conv.out_channels) >= _BN_SPLIT_MIN_TILES:
+            cache = conv.__dict__["_gdrnpp_cache"]
+            hit = cache.get("bn_fold_pk")
+            if hit is None or hit[0] is not w:
+                hit = (w, hip_lib.pack_conv_weight_bf16x3(w))
+                cache["bn_fold_pk"] = hit
+            return hip_lib.conv2d_f32_split(_cl(x), hit[1], None, k, k, st, pd)
+    return F.conv2d(_cl(x), w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
 def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, resid: torch.Tensor | None = None,
                 extra_bias: torch.Tensor | None = None) -> torch.Tensor:
     """[Conv2d, BatchNorm2d (inference), (+ resid), (ReLU)] of a ResNet block as the folded convolution + ONE elementwise
@@ -220,7 +246,7 @@ def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool
         w, b = folded_conv_bn(conv, bn)
         if extra_bias is not None:
             b = b + extra_bias
-        y = F.conv2d(_cl(x), w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        y = folded_conv(conv, bn, x)
         return hip_lib.bias_act_nhwc_(_cl(y), b, None if resid is None else _cl(resid), relu)
     y = bn(conv(x))
     if extra_bias is not None:
