@@ -404,14 +404,25 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, roi_ids):
             hip_lib.set_refine_event_sink(None)
             torch.cuda.synchronize()
             roofline, refine_roofline = None, None
-            if gemm_timer.records:
-                fl = sum(r[1] for r in gemm_timer.records)
-                ms_all = sum(r[2].elapsed_time(r[3]) for r in gemm_timer.records)
-                n_l = len(gemm_timer.records)
+            hbm_records = [r for r in gemm_timer.records if r[0].startswith("hbm:")]
+            gemm_records = [r for r in gemm_timer.records if not r[0].startswith("hbm:")]
+            hbm_rooflines = []
+            for kind in sorted({r[0] for r in hbm_records}):   # memory-bound network kernels: algorithmic bytes / event time
+                rs = [r for r in hbm_records if r[0] == kind]
+                t_k = sum(r[2].elapsed_time(r[3]) for r in rs)
+                gbs = sum(r[4] for r in rs) / (t_k * 1e-3) / 1e9
+                hbm_rooflines.append(dict(kernel=kind[4:], bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                                          frac=gbs / HBM_PEAK_GBS, traffic=None, launch_ms=t_k / len(rs),
+                                          launches_per_step=len(rs) / args.steps, ms_per_step=t_k / args.steps,
+                                          bytes_per_launch=sum(r[4] for r in rs) / len(rs)))
+            if gemm_records:
+                fl = sum(r[1] for r in gemm_records)
+                ms_all = sum(r[2].elapsed_time(r[3]) for r in gemm_records)
+                n_l = len(gemm_records)
                 bf16_tflops = 6.0 * fl / (ms_all * 1e-3) / 1e12
                 by_kind = {}
-                for kind in sorted({r[0] for r in gemm_timer.records}):
-                    rs = [r for r in gemm_timer.records if r[0] == kind]
+                for kind in sorted({r[0] for r in gemm_records}):
+                    rs = [r for r in gemm_records if r[0] == kind]
                     t_k = sum(r[2].elapsed_time(r[3]) for r in rs)
                     by_kind[kind] = dict(launches_per_step=len(rs) / args.steps, ms_per_step=t_k / args.steps,
                                          fp32_equiv_tflops=sum(r[1] for r in rs) / (t_k * 1e-3) / 1e12)
@@ -421,7 +432,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, roi_ids):
                     g_traffic = json.load(open(pmc)).get("gemm_split_kernel", {}).get("traffic_bytes_per_launch")
                 roofline = dict(kernel="gemm_split_kernel", bound="mfma", achieved=bf16_tflops, peak=BF16_MFMA_PEAK_TFLOPS,
                                 unit="TFLOP/s", frac=bf16_tflops / BF16_MFMA_PEAK_TFLOPS, traffic=g_traffic,
-                                algorithmic_bytes_per_launch=sum(r[4] for r in gemm_timer.records) / n_l,
+                                algorithmic_bytes_per_launch=sum(r[4] for r in gemm_records) / n_l,
                                 launch_ms=ms_all / n_l, launches_per_step=n_l / args.steps, ms_per_step=ms_all / args.steps,
                                 flops_per_launch=6.0 * fl / n_l, fp32_equiv_tflops=fl / (ms_all * 1e-3) / 1e12,
                                 fp32_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS, by_kind=by_kind,
@@ -442,7 +453,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, roi_ids):
                                        unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic, launch_ms=mean_ms,
                                        bytes_per_launch=bytes_launch, bytes_per_roi=per_roi, rois_per_launch=b)
             out["roofline"] = roofline or refine_roofline
-            out["roofline_other_kernels"] = [refine_roofline] if (refine_roofline and roofline) else []
+            out["roofline_other_kernels"] = ([refine_roofline] if (refine_roofline and roofline) else []) + hbm_rooflines
 
         if do_cpu and refine and not args.no_cpu_baseline:
             torch.cuda.synchronize()

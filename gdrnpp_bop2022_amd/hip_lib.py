@@ -423,11 +423,11 @@ def dwconv7x7_ln(x, w49c, bias, ln_w=None, ln_b=None, eps: float = 1e-6):
     """x (N,C,H,W) channels_last -> depthwise 7x7 (+ LayerNorm over C), same shape/format."""
     n, c, h, w = x.shape
     y = torch.empty_like(x, memory_format=torch.channels_last)
-    _check(load().gdrnpp_dwconv7x7_ln_nhwc(
-        _nhwc(x, "x"), _dev(w49c, torch.float32, "w49c"), _dev(bias, torch.float32, "bias"),
-        _dev(ln_w, torch.float32, "ln_w") if ln_w is not None else None,
-        _dev(ln_b, torch.float32, "ln_b") if ln_b is not None else None, y.data_ptr(), n, h, w, c, float(eps),
-        _stream()), "gdrnpp_dwconv7x7_ln_nhwc")
+    args = (_nhwc(x, "x"), _dev(w49c, torch.float32, "w49c"), _dev(bias, torch.float32, "bias"),
+            _dev(ln_w, torch.float32, "ln_w") if ln_w is not None else None,
+            _dev(ln_b, torch.float32, "ln_b") if ln_b is not None else None, y.data_ptr(), n, h, w, c, float(eps), _stream())
+    _check(_timed("hbm:dwconv7_ln", 0.0, lambda: load().gdrnpp_dwconv7x7_ln_nhwc(*args), 8.0 * x.numel()),
+           "gdrnpp_dwconv7x7_ln_nhwc")
     return y
 
 
@@ -435,15 +435,17 @@ def layernorm_nhwc(x, weight, bias, eps: float = 1e-6):
     """x (N,C,H,W) channels_last -> LayerNorm over C per pixel, same shape/format."""
     n, c, h, w = x.shape
     y = torch.empty_like(x, memory_format=torch.channels_last)
-    _check(load().gdrnpp_layernorm_nhwc(_nhwc(x, "x"), _dev(weight, torch.float32, "weight"), _dev(bias, torch.float32, "bias"),
-                                        y.data_ptr(), n * h * w, c, float(eps), _stream()), "gdrnpp_layernorm_nhwc")
+    args = (_nhwc(x, "x"), _dev(weight, torch.float32, "weight"), _dev(bias, torch.float32, "bias"), y.data_ptr(), n * h * w, c,
+            float(eps), _stream())
+    _check(_timed("hbm:layernorm", 0.0, lambda: load().gdrnpp_layernorm_nhwc(*args), 8.0 * x.numel()), "gdrnpp_layernorm_nhwc")
     return y
 
 
 def upsample_bilinear2x(x):
     n, c, h, w = x.shape
     y = torch.empty((n, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    _check(load().gdrnpp_upsample_bilinear2x_nhwc(_nhwc(x, "x"), y.data_ptr(), n, h, w, c, _stream()),
+    args = (_nhwc(x, "x"), y.data_ptr(), n, h, w, c, _stream())
+    _check(_timed("hbm:upsample2x", 0.0, lambda: load().gdrnpp_upsample_bilinear2x_nhwc(*args), 20.0 * x.numel()),
            "gdrnpp_upsample_bilinear2x_nhwc")
     return y
 
@@ -452,9 +454,10 @@ def groupnorm_act(x, gamma, beta, groups: int, eps: float = 1e-5, gelu: bool = F
     n, c, h, w = x.shape
     y = torch.empty_like(x, memory_format=torch.channels_last)
     ws = torch.empty((load().gdrnpp_groupnorm_workspace_bytes(n, h * w, groups),), dtype=torch.uint8, device=x.device)
-    _check(load().gdrnpp_groupnorm_act_nhwc(
-        _nhwc(x, "x"), _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"), y.data_ptr(),
-        ws.data_ptr(), n, h * w, c, groups, float(eps), 1 if gelu else 0, _stream()), "gdrnpp_groupnorm_act_nhwc")
+    args = (_nhwc(x, "x"), _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"), y.data_ptr(),
+            ws.data_ptr(), n, h * w, c, groups, float(eps), 1 if gelu else 0, _stream())
+    _check(_timed("hbm:groupnorm", 0.0, lambda: load().gdrnpp_groupnorm_act_nhwc(*args), 12.0 * x.numel()),   # read twice, write once
+           "gdrnpp_groupnorm_act_nhwc")
     return y
 
 
@@ -555,9 +558,10 @@ def epnp_batched(img_pts, mdl_pts, K):
 
 
 class LaunchTimer:
-    """Optional per-launch timing of the split-GEMM entry points with HIP events recorded on the stream the kernel is
-    launched on (bench.py's roofline leg).  records: (kind, fp32-equivalent flops, start event, end event,
-    algorithmic bytes = operands read once + result written once)."""
+    """Optional per-launch timing of the split-GEMM entry points (kinds "linear", "conv3x3", ...) and of the memory-bound
+    network kernels (kinds "hbm:<kernel>", flops 0) with HIP events recorded on the stream the kernel is launched on
+    (bench.py's roofline leg).  records: (kind, fp32-equivalent flops, start event, end event, algorithmic bytes =
+    operands read once + result written once)."""
 
     def __init__(self):
         self.records = []
@@ -792,9 +796,10 @@ def conv3x3_groupnorm_act(x_cl, weight_packed, bias, gamma, beta, groups: int, e
     _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split_gnstats(*args), nbytes),
            "gdrnpp_conv3x3_f32_split_gnstats")
     out = torch.empty_like(y)
-    _check(load().gdrnpp_groupnorm_apply_nhwc(
-        y.data_ptr(), part.data_ptr(), P, _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"),
-        out.data_ptr(), n, h * w, cout, groups, float(eps), 1 if gelu else 0, _stream()), "gdrnpp_groupnorm_apply_nhwc")
+    a2 = (y.data_ptr(), part.data_ptr(), P, _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"),
+          out.data_ptr(), n, h * w, cout, groups, float(eps), 1 if gelu else 0, _stream())
+    _check(_timed("hbm:groupnorm_apply", 0.0, lambda: load().gdrnpp_groupnorm_apply_nhwc(*a2), 8.0 * y.numel()),
+           "gdrnpp_groupnorm_apply_nhwc")
     return out
 
 
