@@ -67,6 +67,17 @@ struct HalfSplit {
 
   template <int S>
   __device__ __forceinline__ void step() {
+#ifdef GDRNPP_TIMING_NO_SPLIT  // timing-only build (results invalid): the k-loop without the split arithmetic, m = l = h
+    if constexpr (S < 2) {
+      h[2 * S] = cvt_pk_bf16(x[4 * S], x[4 * S + 1]);
+      h[2 * S + 1] = cvt_pk_bf16(x[4 * S + 2], x[4 * S + 3]);
+    } else if constexpr (S == 10 || S == 11) {
+      m[2 * (S - 10)] = h[2 * (S - 10)]; m[2 * (S - 10) + 1] = h[2 * (S - 10) + 1];
+    } else if constexpr (S == 20 || S == 21) {
+      l[2 * (S - 20)] = h[2 * (S - 20)]; l[2 * (S - 20) + 1] = h[2 * (S - 20) + 1];
+    }
+    return;
+#endif
     if constexpr (S < 2) {
       h[2 * S] = cvt_pk_bf16(x[4 * S], x[4 * S + 1]);
       h[2 * S + 1] = cvt_pk_bf16(x[4 * S + 2], x[4 * S + 3]);
