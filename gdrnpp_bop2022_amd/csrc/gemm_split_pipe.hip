@@ -276,9 +276,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
       if constexpr (S >= 4 && S < 26) nxt[0].template step<S - 4>();
       if constexpr (S >= 26) nxt[1].template step<S - 26>();
       if constexpr (S == 39) {
+#ifndef GDRNPP_TIMING_NO_VMWAIT   // timing-only builds (results invalid): the k-loop without the DMA wait / without the barrier
         wait_vmcnt<NA == 3 ? 4 : 0>();
+#endif
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): every LDS read of the stages about to be refilled has returned
+#ifndef GDRNPP_TIMING_NO_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
       }
       // behind the barrier: first fragments of k-tile kt+1 (its weight split l; fbY's split m is dead since slot 23) and the
       // raw first half of k-tile kt+2 (cur[0] is nxt[0] of the next k-tile; only cur[0].h is still in use)
