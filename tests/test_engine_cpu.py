@@ -243,3 +243,35 @@ def test_detections_from_bop_json_selection_rules():
     d2 = engine.detections_from_bop_json(dets, ["48/1"], obj_ids=[1, 5, 9], cam=None, extents=None, top_k_per_obj=2,
                                          train_obj_ids=[5])
     assert d2["roi_cls"].tolist() == [1, 1] and np.allclose(d2["score"], [0.9, 0.6])
+
+
+def test_folded_conv_bn_equals_batchnorm_of_conv():
+    """hip_layers.folded_conv_bn (inference BatchNorm folded into the convolution in front of it, ResNet path of config 1):
+    conv(x, w', b') == bn(conv(x)) in eval mode, for a biased and an unbiased convolution, and the cache follows in-place
+    changes of the running statistics."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
+
+    torch.manual_seed(0)
+    for bias in (False, True):
+        conv = nn.Conv2d(8, 12, 3, 2, 1, bias=bias).double()
+        bn = nn.BatchNorm2d(12).double().eval()
+        with torch.no_grad():
+            bn.running_mean.normal_(0.0, 0.3)
+            bn.running_var.uniform_(0.4, 1.6)
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0.0, 0.3)
+        x = torch.randn(2, 8, 9, 11, dtype=torch.float64)
+        with torch.no_grad():
+            w, b = hip_layers.folded_conv_bn(conv, bn)
+            assert w.dtype == torch.float32 and b.dtype == torch.float32
+            got = F.conv2d(x, w.double(), b.double(), conv.stride, conv.padding)
+            want = bn(conv(x))
+            assert (got - want).abs().max().item() < 5e-6
+            bn.running_mean.add_(0.5)                      # in-place update bumps the version counter: the fold is rebuilt
+            w2, b2 = hip_layers.folded_conv_bn(conv, bn)
+            got2 = F.conv2d(x, w2.double(), b2.double(), conv.stride, conv.padding)
+            assert (got2 - bn(conv(x))).abs().max().item() < 5e-6
+            assert (b2 - b).abs().max().item() > 0.1
