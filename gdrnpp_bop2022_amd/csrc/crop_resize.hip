@@ -320,6 +320,7 @@ int gdrnpp_crop_resize_roi(const unsigned char* images, const float* depths, int
                            const int* im_idx, const double* centers, const double* scales, float* roi_img,
                            float* roi_depth, float* roi_coord2d, int b, int out_res, int out_res_small,
                            const double* h_mean3, const double* h_std3, void* stream) {
+  if (b == 0) return 0;  // an image / a rank without detections: nothing to crop
   GDRNPP_REQUIRE(centers && scales && b > 0 && H > 0 && W > 0 && n_im > 0, GDRNPP_EINVAL,
                  "gdrnpp_crop_resize_roi: bad arguments b=%d H=%d W=%d n_im=%d", b, H, W, n_im);
   GDRNPP_REQUIRE(b <= 65535, GDRNPP_ELIMIT, "gdrnpp_crop_resize_roi: b=%d > 65535", b);

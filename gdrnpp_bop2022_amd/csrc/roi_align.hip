@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
 extern "C" int gdrnpp_roi_align(const float* x, const float* rois, float* out, int n_rois, int C, int H, int W,
                                 int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned,
                                 void* stream) {
+  if (n_rois == 0) return 0;
   GDRNPP_REQUIRE(x && rois && out, GDRNPP_EINVAL, "gdrnpp_roi_align: null pointer");
   GDRNPP_REQUIRE(n_rois > 0 && C > 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0 && sampling_ratio >= 0,
                  GDRNPP_EINVAL, "gdrnpp_roi_align: bad sizes");
