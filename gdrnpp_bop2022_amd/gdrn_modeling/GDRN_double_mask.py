@@ -255,7 +255,7 @@ class GDRN_DoubleMask(nn.Module):
         return out_dict
 
 
-def build_model_optimizer(cfg, is_test=True):
+def build_model_optimizer(cfg, is_test=True, model_cls=None):
     """GDRN_double_mask.py:539-615 — returns (model, optimizer); the optimizer is None (inference build)."""
     if not is_test:
         raise NotImplementedError("training is out of scope of this build (SURVEY.md §2.1)")
@@ -288,7 +288,7 @@ def build_model_optimizer(cfg, is_test=True):
     pnp_cfg.update(nIn=n_in, rot_dim=rot_dim, num_regions=g.NUM_REGIONS, mask_attention_type=p.MASK_ATTENTION)
     pnp_net = HEADS[pnp_type](**pnp_cfg)
 
-    model = GDRN_DoubleMask(cfg, backbone, neck=None, geo_head_net=geo_head, pnp_net=pnp_net)
+    model = (model_cls or GDRN_DoubleMask)(cfg, backbone, neck=None, geo_head_net=geo_head, pnp_net=pnp_net)
     model.eval()
     if cfg.MODEL.DEVICE != "cpu" and torch.cuda.is_available():
         model.to(torch.device(cfg.MODEL.DEVICE))

@@ -64,7 +64,7 @@ def _merge(base: dict, child: dict) -> dict:
 def gdrn_base() -> dict:
     """configs/_base_/gdrn_base.py:5-174 + the TEST/INPUT keys of common_base.py the path reads."""
     return dict(
-        INPUT=dict(DZI_PAD_SCALE=1.5, WITH_DEPTH=False, BP_DEPTH=False),
+        INPUT=dict(DZI_PAD_SCALE=1.0, WITH_DEPTH=False, BP_DEPTH=False),   # common_base.py:60
         MODEL=dict(
             DEVICE="cuda", WEIGHTS="", PIXEL_MEAN=[0, 0, 0], PIXEL_STD=[255.0, 255.0, 255.0], LOAD_DETS_TEST=False,
             POSE_NET=dict(
@@ -139,7 +139,9 @@ def get_cfg(name: str = "ycbv_convnext_a6", opts=None) -> Config:
         cfg = _merge(cfg, dict(VAL=dict(DATASET_NAME=_VAL_DATASET_NAME.get(ds, ds), SPLIT="test", SPLIT_TYPE=""), EXP_ID=name))
     elif name == "lmo_resnet34_ape":
         # BASELINE config 1: base GDRN (ResNet-34, single object, class-agnostic head)
-        cfg = _merge(base, dict(MODEL=dict(POSE_NET=dict(NUM_CLASSES=1))))
+        # = configs/_base_/gdrn_base.py with one class; the ROI padding of every shipped single-object LM-O config
+        # (configs/gdrn/lmoPbrSO/convnext_AugCosyAAEGray_DMask_amodalClipBox_lmo/ape.py:6), the base file's is 1.0
+        cfg = _merge(base, dict(INPUT=dict(DZI_PAD_SCALE=1.5), MODEL=dict(POSE_NET=dict(NUM_CLASSES=1))))
     else:
         raise KeyError(name)
     cfg = Config(cfg)

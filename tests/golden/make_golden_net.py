@@ -11,9 +11,13 @@ absent third-party packages):
   lib/torch_utils/layers/conv_module.py, layer_utils.py                    ConvModule, get_norm, get_nn_act_func
   core/gdrn_modeling/models/pose_from_pred_centroid_z.py, core/utils/utils.py, core/utils/rot_reps.py
   configs/gdrn/{ycbv,tless}/convnext_a6_..._classAware_*.py + configs/_base_/{gdrn_base,common_base}.py   the config values
+  core/gdrn_modeling/models/GDRN.py               build_model_optimizer, GDRN.forward (BASELINE configs[0]: the BASE config
+                                                  configs/_base_/gdrn_base.py itself — ResNet-34, single mask,
+                                                  class-agnostic TopDownMaskXyzRegionHead, Patch-PnP on xyz only, ego_rot6d)
+  core/gdrn_modeling/models/heads/top_down_mask_xyz_region_head.py         TopDownMaskXyzRegionHead
 
-with ONE substitution: ``BACKBONES["timm/convnext_base"]`` (timm.create_model — timm 0.6.7 is not installed) builds this
-repo's re-declared ConvNeXt-B in its plain-PyTorch form, so the fixture pins everything downstream of the backbone module
+with ONE substitution: ``BACKBONES["timm/convnext_base"]`` / ``BACKBONES["timm/resnet34"]`` (timm.create_model — timm 0.6.7
+is not installed) build this repo's re-declared ConvNeXt-B / ResNet-34 in their plain-PyTorch form, so the fixture pins everything downstream of the backbone module
 boundary against the reference, and the backbone against PyTorch's operators on the same parameters.
 
 Parameters are not stored (head + Patch-PnP + backbone are ~100 M values): every state_dict entry is
@@ -45,7 +49,7 @@ CONFIGS = {
     "ycbv": "configs/gdrn/ycbv/convnext_a6_AugCosyAAEGray_BG05_mlL1_DMask_amodalClipBox_classAware_ycbv.py",
     "tless": "configs/gdrn/tless/convnext_a6_AugCosyAAEGray_BG05_mlL1_DMask_amodalClipBox_classAware_tless.py",
 }
-from tests.netgolden import B, SEED, net_detections, net_image, norm_alias  # noqa: E402
+from tests.netgolden import SEED, net_detections, net_image, norm_alias  # noqa: E402
 
 
 def jsonable(o):
@@ -134,5 +138,68 @@ def main():
         print("wrote", f"net_golden_{ds}.npz")
 
 
+def record_resnet34():
+    """BASELINE configs[0]: models/GDRN.py built from configs/_base_/gdrn_base.py (NUM_CLASSES=1 for the single LM-O object;
+    the base file's 13 gives the same graph — nothing in it is class-aware), 32 ROIs = the batch of configs[0].
+    Full maps for the first 4 ROIs, every second pixel for the rest, R / t / Patch-PnP outputs for all."""
+    from core.gdrn_modeling.models import GDRN as REFG
+    from core.gdrn_modeling.models import net_factory
+
+    net_factory.BACKBONES["timm/resnet34"] = lambda model_name=None, **kw: create_backbone(type="timm/" + model_name, **kw)
+    raw = _refimport.load_ref_config("configs/_base_/gdrn_base.py")
+    cfg = Config(raw)
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.MODEL.POSE_NET.NUM_CLASSES = 1
+    cfg.MODEL.POSE_NET.BACKBONE.INIT_CFG.pretrained = False
+    cfg.TEST.USE_PNP = True               # configs[0] feeds the maps to (uncertainty-)PnP: forward returns them
+    cfg.SOLVER.BASE_LR = cfg.SOLVER.OPTIMIZER_CFG["lr"]
+    model, opt = REFG.build_model_optimizer(cfg, is_test=True)
+    assert opt is None and type(model).__module__ == "core.gdrn_modeling.models.GDRN"
+    assert type(model.geo_head_net).__name__ == "TopDownMaskXyzRegionHead"
+    model.eval()
+    sd = model.state_dict()
+    model.load_state_dict(S.seeded_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], SEED, alias=norm_alias),
+                          strict=True)
+    b = 32
+    x, det = net_image(b), net_detections(1, b)
+    T = torch.from_numpy
+    grab = {}
+    model.pnp_net.register_forward_hook(lambda m, i, o: grab.update(pred_rot_=o[0].clone(), pred_t_=o[1].clone()))
+    model.backbone.register_forward_hook(lambda m, i, o: grab.update(conv_feat=o[0].clone()))
+    out = model(T(x), roi_classes=T(det["roi_cls"]), roi_cams=T(det["roi_cam"]), roi_whs=T(det["roi_wh"]),
+                roi_centers=T(det["roi_center"]), resize_ratios=T(det["resize_ratio"]),
+                roi_coord_2d=T(S.coord2d_roi(det["roi_center"], det["scale"])), roi_extents=T(det["roi_extent"]),
+                do_loss=False)
+    assert "full_mask" not in out
+    region = out["region"].numpy()
+    raw["MODEL"]["POSE_NET"]["NUM_CLASSES"] = 1
+    raw["TEST"]["USE_PNP"] = True
+    rec = dict(
+        cfg_json=json.dumps(jsonable({k: raw[k] for k in ("MODEL", "TEST", "INPUT")})),
+        head_keys=json.dumps([[k, list(v.shape)] for k, v in sd.items() if not k.startswith("backbone.")]),
+        backbone_keys=json.dumps([[k, list(v.shape)] for k, v in sd.items() if k.startswith("backbone.")]),
+        roi_cls=det["roi_cls"], roi_cam=det["roi_cam"], roi_wh=det["roi_wh"], roi_center=det["roi_center"],
+        resize_ratio=det["resize_ratio"], scale=det["scale"], roi_extent=det["roi_extent"],
+        conv_feat_sub=grab["conv_feat"].numpy()[:, ::8], pred_rot_=grab["pred_rot_"].numpy(), pred_t_=grab["pred_t_"].numpy(),
+        rot=out["rot"].numpy(), trans=out["trans"].numpy(),
+        region_sub=np.ascontiguousarray(region[:, :, 1::8, 2::8]), region_argmax=region.argmax(1).astype(np.uint8),
+        region_absmax=np.float32(np.abs(region).max()))
+    for k in ("mask", "coor_x", "coor_y", "coor_z"):
+        m = out[k].numpy()
+        rec[k] = np.ascontiguousarray(m[:4])
+        rec[k + "_sub"] = np.ascontiguousarray(m[4:, :, ::2, 1::2])
+    for k in ("mask", "coor_x", "rot", "trans", "pred_rot_", "pred_t_"):
+        print("lmo_resnet34", k, rec[k].shape, float(np.abs(rec[k]).mean()), float(np.abs(rec[k]).max()))
+    np.savez_compressed(os.path.join(HERE, "net_golden_lmo_resnet34.npz"), **rec)
+    print("wrote net_golden_lmo_resnet34.npz")
+
+
 if __name__ == "__main__":
-    main()
+    if "--resnet34-only" in sys.argv:
+        torch.set_num_threads(os.cpu_count())
+        torch.set_grad_enabled(False)
+        hip_layers.set_enabled(False)
+        record_resnet34()
+    else:
+        main()
+        record_resnet34()

@@ -30,7 +30,7 @@ def net_detections(num_classes, b=B, seed=SEED):
     rng = np.random.default_rng(seed + num_classes)
     ext = rng.uniform(0.05, 0.25, (num_classes, 3)).astype(np.float32)
     det = S.make_detections(b, num_classes, ext, rng)
-    det["roi_cls"] = np.array([0, num_classes - 1, 7 % num_classes, 13 % num_classes][:b], np.int64)
+    det["roi_cls"] = np.resize(np.array([0, num_classes - 1, 7 % num_classes, 13 % num_classes], np.int64), b)
     det["roi_extent"] = ext[det["roi_cls"]]
     return det
 
@@ -46,7 +46,10 @@ def load_fixture(ds):
 def seeded_reference_state_dict(model, fx):
     """The state_dict the reference model held when the fixture was recorded: geo head + Patch-PnP entries by the
     REFERENCE's key/shape manifest (incl. its duplicate ``norm.*`` keys), backbone entries by this model's own keys."""
-    named = [(k, tuple(v.shape)) for k, v in model.state_dict().items() if k.startswith("backbone.")]
+    if "backbone_keys" in fx:       # ResNet fixtures also carry the reference-side backbone manifest (BatchNorm buffers)
+        named = [(k, tuple(s)) for k, s in json.loads(str(fx["backbone_keys"]))]
+    else:
+        named = [(k, tuple(v.shape)) for k, v in model.state_dict().items() if k.startswith("backbone.")]
     named += list(fx["head_keys"])
     return S.seeded_state_dict(named, SEED, alias=norm_alias)
 

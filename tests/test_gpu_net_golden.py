@@ -105,3 +105,50 @@ def test_fused_head_tail_matches_module_path(hip, ds):
         assert ((a - b).abs().max() / b.abs().max()).item() < 2e-5, k
     assert (fused["rot"] - plain["rot"]).abs().max().item() < 2e-5
     assert (fused["trans"] - plain["trans"]).abs().max().item() < 2e-5 * max(1.0, plain["trans"].abs().max().item())
+
+
+# ---- BASELINE configs[0]: models/GDRN.py + TopDownMaskXyzRegionHead + ResNet-34, reference outputs recorded at 32 ROIs ------
+@pytest.fixture(scope="module")
+def resnet_model(hip):
+    from gdrnpp_bop2022_amd.gdrn_modeling import GDRN as G
+    fx = NG.load_fixture("lmo_resnet34")
+    cfg = get_cfg("lmo_resnet34_ape", opts=["TEST.USE_PNP=True"])
+    model, _ = G.build_model_optimizer(cfg)
+    assert next(model.parameters()).is_cuda
+    x = torch.from_numpy(NG.net_image(32)).cuda()
+    kw = NG.forward_kwargs(fx, "cuda")
+    with torch.no_grad():
+        model(x[:2], **{k: v[:2] for k, v in kw.items()})     # warm the BatchNorm-fold / packed-weight caches on the random init
+    model.load_state_dict(NG.seeded_reference_state_dict(model, fx), strict=True)   # ... which the load must invalidate
+    return fx, model, x, kw
+
+
+def test_resnet34_hip_path_matches_reference_forward_32_rois(resnet_model):
+    """The folded-BatchNorm / bias_act / split implicit-GEMM path of the ResNet-34 configuration (layer 2 on the split
+    convolution at 32 ROIs) against GDRN.forward of the reference: maps 1e-4 of scale, R / t 1e-4."""
+    from tests.test_net_golden import check_resnet34_outputs
+    fx, model, x, kw = resnet_model
+    with torch.no_grad():
+        out = model(x, **kw)
+        rot6, t3, _ = model.forward_maps(x, kw["roi_classes"], kw["roi_coord_2d"], None, kw["roi_extents"])
+    torch.cuda.synchronize()
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    check_resnet34_outputs(fx, o, rot6.cpu().numpy(), t3.cpu().numpy(), 1e-4, 1e-4)
+    assert np.abs(o["rot"] - fx["rot"]).max() <= 1e-4
+    assert np.abs(o["trans"] - fx["trans"]).max() <= 1e-4 * max(1.0, np.abs(fx["trans"]).max())
+
+
+def test_resnet34_hip_path_matches_reference_forward_4_rois(resnet_model):
+    """Same at 4 ROIs (eval-mode BatchNorm: a ROI's outputs do not depend on the batch) — below the tile-count thresholds,
+    so the small-problem kernels serve the layers the 32-ROI case sends to the 256-row tiles."""
+    fx, model, x, kw = resnet_model
+    with torch.no_grad():
+        out = model(x[:4], **{k: v[:4] for k, v in kw.items()})
+    torch.cuda.synchronize()
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    for k in ("mask", "coor_x", "coor_y", "coor_z"):
+        scale = max(np.abs(fx[k]).max(), np.abs(fx[k + "_sub"]).max())
+        assert _err(o[k], fx[k], scale) <= 1e-4, k
+    assert _err(o["region"][:, :, 1::8, 2::8], fx["region_sub"][:4], float(fx["region_absmax"])) <= 1e-4
+    assert np.abs(o["rot"] - fx["rot"][:4]).max() <= 1e-4
+    assert np.abs(o["trans"] - fx["trans"][:4]).max() <= 1e-4 * max(1.0, np.abs(fx["trans"]).max())

@@ -183,3 +183,96 @@ def test_class_sliced_output_layer_with_two_channel_ce_masks(name):
             assert (a[2][k] - b[2][k]).abs().max().item() <= 1e-5 * b[2][k].abs().max().item(), k
     finally:
         hip_layers.set_enabled(True)
+
+
+# ---- BASELINE configs[0]: models/GDRN.py + TopDownMaskXyzRegionHead + ResNet-34 (configs/_base_/gdrn_base.py) -------------
+def _timm067_resnet34_keys(layers=(3, 4, 6, 3), in_chans=3):
+    """Parameter / buffer names of ``timm.create_model("resnet34", features_only=True, out_indices=(4,))`` as published in
+    timm 0.6.7 (timm/models/resnet.py: ``conv1 7x7/2, bn1, act1, maxpool, layer1..4``; ``BasicBlock(conv1, bn1, act1,
+    conv2, bn2, act2, downsample = Sequential(conv 1x1, norm))``; FeatureListNet keeps the top-level names — none of them
+    contains a dot).  Written from the published source, NOT executed (timm is not installed)."""
+    def bn(prefix, c):
+        return {prefix + ".weight": (c,), prefix + ".bias": (c,), prefix + ".running_mean": (c,),
+                prefix + ".running_var": (c,), prefix + ".num_batches_tracked": ()}
+    k = {"conv1.weight": (64, in_chans, 7, 7), **bn("bn1", 64)}
+    inpl = 64
+    for i, (n, planes) in enumerate(zip(layers, (64, 128, 256, 512))):
+        for j in range(n):
+            b = f"layer{i + 1}.{j}."
+            stride = 2 if (j == 0 and i > 0) else 1
+            k[b + "conv1.weight"] = (planes, inpl, 3, 3)
+            k.update(bn(b + "bn1", planes))
+            k[b + "conv2.weight"] = (planes, planes, 3, 3)
+            k.update(bn(b + "bn2", planes))
+            if stride != 1 or inpl != planes:
+                k[b + "downsample.0.weight"] = (planes, inpl, 1, 1)
+                k.update(bn(b + "downsample.1", planes))
+            inpl = planes
+    return k
+
+
+@pytest.fixture(scope="module")
+def resnet_case():
+    from gdrnpp_bop2022_amd.gdrn_modeling import GDRN as G
+    fx = NG.load_fixture("lmo_resnet34")
+    cfg = get_cfg("lmo_resnet34_ape", opts=["TEST.USE_PNP=True", "MODEL.DEVICE=cpu"])
+    model, _ = G.build_model_optimizer(cfg)
+    assert type(model) is G.GDRN and type(model.geo_head_net).__name__ == "TopDownMaskXyzRegionHead"
+    res = model.load_state_dict(NG.seeded_reference_state_dict(model, fx), strict=True)
+    return fx, model, res
+
+
+def test_resnet34_config_values_equal_gdrn_base(resnet_case):
+    fx, model, _ = resnet_case
+    ref = _flat(fx["cfg"])
+    ours = _flat({k: dict(get_cfg("lmo_resnet34_ape", opts=["TEST.USE_PNP=True"]))[k] for k in ("MODEL", "TEST", "INPUT")})
+    assert not [k for k in ours if k not in ref]
+    assert ref["INPUT.DZI_PAD_SCALE"] == 1.0 and ours.pop("INPUT.DZI_PAD_SCALE") == 1.5   # lmoPbrSO/.../ape.py:6 over the base
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import gdrn_base
+    assert gdrn_base()["INPUT"]["DZI_PAD_SCALE"] == 1.0
+    diff = {k: (ours[k], ref[k]) for k in ours if ours[k] != ref[k]}
+    assert not diff, diff
+
+
+def test_resnet34_reference_state_dict_loads_strict(resnet_case):
+    fx, model, res = resnet_case
+    assert not res.missing_keys and not res.unexpected_keys
+    ours = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.startswith("backbone.")}
+    assert ours == {k: s for k, s in fx["head_keys"] if ".norm." not in k}
+    bb = {k[len("backbone."):]: tuple(v.shape) for k, v in model.state_dict().items() if k.startswith("backbone.")}
+    assert bb == _timm067_resnet34_keys()
+
+
+def check_resnet34_outputs(fx, maps, rot6, t3, tol_maps, tol_pnp):
+    """Shared with tests/test_gpu_net_golden.py: full maps of the first 4 ROIs, every second pixel of the other 28."""
+    assert "full_mask" not in maps
+    for k in ("mask", "coor_x", "coor_y", "coor_z"):
+        m = np.asarray(maps[k])
+        assert m.shape == (32, 1, 64, 64)
+        scale = max(np.abs(fx[k]).max(), np.abs(fx[k + "_sub"]).max())
+        _close(m[:4], fx[k], tol_maps, scale)
+        _close(m[4:, :, ::2, 1::2], fx[k + "_sub"], tol_maps, scale)
+    region = np.asarray(maps["region"])
+    assert region.shape == (32, 65, 64, 64)
+    _close(region[:, :, 1::8, 2::8], fx["region_sub"], tol_maps, scale=float(fx["region_absmax"]))
+    assert (region.argmax(1) == fx["region_argmax"]).mean() > 0.999
+    _close(rot6, fx["pred_rot_"], tol_pnp)
+    _close(t3, fx["pred_t_"], tol_pnp)
+
+
+def test_resnet34_pytorch_graph_reproduces_reference_outputs(resnet_case):
+    """GDRN.forward of the reference (GDRN.py:66-205) at the 32 ROIs of BASELINE configs[0]: Patch-PnP sees xyz only
+    (WITH_2D_COORD / REGION_ATTENTION off), LeakyReLU(0.1) fc activations (act="relu", conv_pnp_net.py:44-48), ego_rot6d."""
+    fx, model, _ = resnet_case
+    hip_layers.set_enabled(False)
+    torch.set_grad_enabled(False)
+    try:
+        x = torch.from_numpy(NG.net_image(32))
+        kw = NG.forward_kwargs(fx, "cpu")
+        feat = model.backbone(x)[0]
+        _close(feat.numpy()[:, ::8], fx["conv_feat_sub"], 1e-5)
+        rot6, t3, maps = model.forward_maps(x, kw["roi_classes"], kw["roi_coord_2d"], None, kw["roi_extents"])
+    finally:
+        hip_layers.set_enabled(True)
+        torch.set_grad_enabled(True)
+    check_resnet34_outputs(fx, {k: v.numpy() for k, v in maps.items()}, rot6.numpy(), t3.numpy(), 2e-5, 5e-5)
