@@ -1,6 +1,7 @@
 // libgdrnpp_hip.so — library-level entry points (version, last error).
 #include "gemm_split.hpp"
 #include <cstring>
+#include <atomic>
 #include <mutex>
 
 namespace gdrnpp {
@@ -43,7 +44,8 @@ int ensure_dynamic_lds(const void* kernel, int bytes) {
   else if (n < 128) table[n++] = Entry{kernel, dev, bytes};
   return 0;
 }
-static int g_opt_glds = 1, g_opt_mi4 = -1, g_opt_pipe = 3, g_opt_pipe_conv = 0, g_opt_panel = 4, g_opt_big_tiles = 256;
+// tuning switches: written by gdrnpp_set_option, read by launches on any host thread
+static std::atomic<int> g_opt_glds{1}, g_opt_mi4{-1}, g_opt_pipe{3}, g_opt_pipe_conv{0}, g_opt_panel{4}, g_opt_big_tiles{256};
 int option_split_gemm_glds() { return g_opt_glds; }
 int option_split_gemm_pipe() { return g_opt_pipe; }
 int option_split_gemm_pipe_conv() { return g_opt_pipe_conv; }

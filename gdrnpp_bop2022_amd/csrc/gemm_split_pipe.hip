@@ -119,6 +119,8 @@ struct Grouped {
   int bias_stride;         // floats between consecutive bias slices
   int n_store;
   int panel;               // > 1: tiles are walked in panels of that many row blocks, column tile outer (launch_split_pipe)
+  int n_groups;            // slices in the stack: a selector outside [0, n_groups) poisons its tiles with NaN instead of reading
+                           // out of bounds (a detector label >= NUM_CLASSES must not come out as finite garbage maps)
 };
 
 // CONV: 0 = linear (A row-major [M,K]), 1 = 3x3 / stride 1 / pad 1 convolution over an NHWC image (implicit im2col)
@@ -183,6 +185,15 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
   if constexpr (CONV) cpt = cg.C / BK;
   const unsigned boff = (unsigned)((wave * 3) * 64 + lane) * 16u;
   const int grp_i = grp.sel ? grp.sel[m0 / grp.rows_per_group] : 0;   // weight / bias slice of this tile's rows
+  if (grp.sel && (unsigned)grp_i >= (unsigned)grp.n_groups) {          // workgroup-uniform: nothing was issued yet
+    const float qnan = __builtin_nanf("");
+    const int c4n = BN / 4;
+    for (int idx = tid; idx < 256 * c4n; idx += 256) {
+      const int row = m0 + idx / c4n, col = n0 + (idx % c4n) * 4;
+      if (row < M && col < grp.n_store) *reinterpret_cast<float4*>(C + (size_t)row * N + col) = make_float4(qnan, qnan, qnan, qnan);
+    }
+    return;
+  }
   const char* const wbase = reinterpret_cast<const char*>(Wp + (size_t)grp_i * grp.w_stride + (size_t)tile_n * nk * W_TILE_SLOTS);
   const float* const bias_t = bias ? bias + (size_t)grp_i * grp.bias_stride : nullptr;
   const unsigned ldsA = lds0 + (unsigned)(wave * 4) * 1024u;
@@ -413,7 +424,7 @@ int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const 
   // 348/357/575 MB (profiles/r02l_gemm_traffic_by_shape.md); launch time unchanged (the operands come from the memory-side
   // cache either way).
   const int panel = (!conv && N / BN >= 8 && (long)N * K * 6 > (2l << 20)) ? gdrnpp::option_split_gemm_panel() : 0;
-  const Grouped grp{nullptr, 1, 0, 0, N, panel};
+  const Grouped grp{nullptr, 1, 0, 0, N, panel, 1};
   if (conv) {
     if (!(cg.KW == 3 && cg.stride == 1 && cg.pad == 1 && K == 9 * cg.C && cg.C % BK == 0)) return -1;
     return launch_epi<1>(epilogue, a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, grp, st, what);
@@ -426,19 +437,20 @@ int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const 
 }  // namespace gdrnpp
 
 extern "C" int gdrnpp_linear_f32_split_grouped(const float* A, const void* W_packed_stack, const float* bias_stack,
-                                               const int* group_sel, int rows_per_group, float* C, int M, int N, int K,
-                                               int n_store, void* stream) {
+                                               const int* group_sel, int n_groups, int rows_per_group, float* C, int M, int N,
+                                               int K, int n_store, void* stream) {
   using namespace gdrnpp::splitgemm;
   GDRNPP_REQUIRE(A && W_packed_stack && group_sel && C, GDRNPP_EINVAL, "gdrnpp_linear_f32_split_grouped: null pointer");
   GDRNPP_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % 32 == 0, GDRNPP_ELIMIT,
                  "gdrnpp_linear_f32_split_grouped: N=%d K=%d must be multiples of %d/32", N, K, BN);
+  GDRNPP_REQUIRE(n_groups > 0, GDRNPP_EINVAL, "gdrnpp_linear_f32_split_grouped: n_groups=%d", n_groups);
   GDRNPP_REQUIRE(rows_per_group > 0 && rows_per_group % 256 == 0 && M % rows_per_group == 0, GDRNPP_EINVAL,
                  "gdrnpp_linear_f32_split_grouped: rows_per_group=%d must be a multiple of 256 that divides M=%d", rows_per_group, M);
   GDRNPP_REQUIRE(n_store > 0 && n_store <= N && n_store % 4 == 0, GDRNPP_EINVAL, "gdrnpp_linear_f32_split_grouped: n_store=%d", n_store);
   GDRNPP_REQUIRE((unsigned long long)M * (unsigned long long)K * 4ull < (1ull << 32), GDRNPP_ELIMIT,
                  "gdrnpp_linear_f32_split_grouped: M*K*4 must stay below 4 GiB");
   GDRNPP_REQUIRE((long)(M / 256) * (N / BN) < (1l << 30), GDRNPP_ELIMIT, "gdrnpp_linear_f32_split_grouped: grid too large");
-  const Grouped grp{group_sel, rows_per_group, (long)(N / BN) * (K / BK) * W_TILE_SLOTS, N, n_store, 0};
+  const Grouped grp{group_sel, rows_per_group, (long)(N / BN) * (K / BK) * W_TILE_SLOTS, N, n_store, 0, n_groups};
   return launch_epi<0>(EPI_BIAS, gdrnpp::option_split_gemm_pipe() == 2 ? 2 : 3, A, (const uint4*)W_packed_stack, bias_stack, nullptr,
                        nullptr, C, M, N, K, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0}, grp, (hipStream_t)stream, "gdrnpp_linear_f32_split_grouped");
 }

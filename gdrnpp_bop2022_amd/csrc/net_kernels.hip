@@ -296,10 +296,10 @@ __global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict
 // --------------------------------------------------------------------------------------------------
 // y = act(x + bias[c] (+ resid)), NHWC float4 lanes: what is left of [BatchNorm2d, (residual add,) ReLU] once the
 // inference-mode BatchNorm is folded into the preceding convolution's weights (ResNet BasicBlock, timm resnet.py).
-// In place when y == x.
+// In place when y == x (the only way the ResNet path calls it): x and y therefore carry no __restrict__.
 // --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias,
-                                                       const float* __restrict__ resid, float* __restrict__ y, long total4,
+__global__ __launch_bounds__(256) void bias_act_kernel(const float* x, const float* __restrict__ bias,
+                                                       const float* resid, float* y, long total4,
                                                        int Q, int relu) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % Q);

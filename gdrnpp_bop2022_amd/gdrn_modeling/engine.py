@@ -188,9 +188,52 @@ class GdrnHipPost:
             batch["roi_cls"].to(torch.int32).contiguous(), roi_ids)
 
 
+def class_sorted_order(roi_cls):
+    """within a rank ROIs run sorted by class (consecutive 256-row tiles of the class-sliced output layer
+    then share a weight slice, consecutive refine workgroups a mesh), the original index travels in the record.  Returns the
+    STABLE permutation ``order`` with ``roi_cls[order]`` non-decreasing — ROIs of one class keep their detection order, like
+    the reference's per-object ordering of load_detections_into_dataset (dataset_utils.py:202-227)."""
+    import numpy as np
+
+    if isinstance(roi_cls, torch.Tensor):
+        return torch.sort(roi_cls.reshape(-1), stable=True).indices
+    return np.argsort(np.asarray(roi_cls).reshape(-1), kind="stable")
+
+
+_PER_ROI_DETECTION_KEYS = ("bbox", "im_idx", "roi_cls", "score", "time")
+
+
+def sort_detections_by_class(detections: dict, roi_id_base: int = 0):
+    """-> (detections with every per-ROI array permuted into class order, roi_id i32[n] = ``roi_id_base`` + the position the
+    ROI had before).  Sorting the DETECTIONS costs nothing on the device: the crop kernel simply reads its ROI parameters in
+    the new order, no ROI tensor is ever permuted."""
+    import numpy as np
+
+    order = class_sorted_order(np.asarray(detections["roi_cls"]))
+    out = dict(detections)
+    n = len(order)
+    for k in _PER_ROI_DETECTION_KEYS:
+        if k in detections:
+            out[k] = np.asarray(detections[k])[order]
+    cam = np.asarray(detections["cam"])
+    if cam.ndim == 3 and cam.shape[0] == n:
+        out["cam"] = cam[order]
+    return out, (roi_id_base + order).astype(np.int32)
+
+
+def records_in_roi_order(rec: torch.Tensor) -> torch.Tensor:
+    """Valid records of a (gathered) block ordered by their ``roi_id`` column — undoes the per-rank class sort and drops the
+    padding rows of ``gather_records``."""
+    rec = rec[rec[:, 15] > 0.5]
+    return rec[torch.sort(rec[:, 14], stable=True).indices]
+
+
 @torch.no_grad()
 def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor | None = None) -> torch.Tensor:
-    """One pass of the hot path over one batch of ROIs (the unit ``bench.py`` times)."""
+    """One pass of the hot path over one batch of ROIs (the unit ``bench.py`` times).  ``roi_ids`` (or ``batch["roi_id"]``,
+    set by ``batch_data_test_gpu(sort_by_class=True)``) = the global index each record carries."""
+    if roi_ids is None:
+        roi_ids = batch.get("roi_id")
     if batch["roi_img"].shape[0] == 0:            # empty shard (shard_range may give trailing ranks nothing): the caller
         return torch.zeros((0, 16), dtype=torch.float32, device=batch["roi_img"].device)   # still reaches gather_records
     out_dict = model(
@@ -447,14 +490,20 @@ def detections_from_bop_json(detections: dict, scene_im_ids, obj_ids, cam, exten
                 time=np.asarray(times, np.float32))
 
 
-def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, device=None) -> dict:
+def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, device=None, sort_by_class: bool = False,
+                        roi_id_base: int = 0) -> dict:
     """``read_data_test`` + ``batch_data_test`` (data_loader.py:647-818, engine_utils.py:213-241) with the crops made
     on the GPU.  images u8[n_im,H,W,3] (BGR, device), depths f32[n_im,H,W] or None, detections:
     {"bbox": [n,4] xyxy, "im_idx": [n], "roi_cls": [n], "score": [n], "cam": [n,3,3] or [3,3], "extents": [C,3]}.
-    Returns the batch dict ``GDRN_Net.forward`` / ``GdrnHipPost`` consume (all tensors on the device)."""
+    Returns the batch dict ``GDRN_Net.forward`` / ``GdrnHipPost`` consume (all tensors on the device).
+    ``sort_by_class``: ROIs are laid out in class order and ``batch["roi_id"]`` = ``roi_id_base`` + the
+    detection's original position, which ``inference_step`` writes into the records (``records_in_roi_order`` restores it)."""
     import numpy as np
 
     dev = device or images.device
+    roi_id = None
+    if sort_by_class:
+        detections, roi_id = sort_detections_by_class(detections, roi_id_base)
     net_cfg = cfg.MODEL.POSE_NET
     n_im, H, W, _ = images.shape
     r = rois_from_detections(detections["bbox"], H, W, cfg.INPUT.DZI_PAD_SCALE, net_cfg.OUTPUT_RES)
@@ -480,6 +529,8 @@ def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, dev
         im_H=torch.full((n,), float(H), device=dev), im_W=torch.full((n,), float(W), device=dev))
     if roi_depth is not None:
         batch["roi_depth"] = roi_depth
+    if roi_id is not None:
+        batch["roi_id"] = T(roi_id)
     if net_cfg.PNP_NET.COORD_2D_TYPE == "rel":
         # data_loader.py:799-804: (bbox_center - roi_coord_2d * (im_W, im_H)) / scale, float64 like NumPy, stored float32
         wh = torch.tensor([float(W), float(H)], dtype=torch.float64, device=dev).view(1, 2, 1, 1)

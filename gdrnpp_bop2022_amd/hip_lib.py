@@ -74,7 +74,7 @@ SIGNATURES = {
     "gdrnpp_debug_refine_profile": (c_int, [_P]),
     "gdrnpp_pack_weight_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "gdrnpp_linear_f32_split_grouped": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_linear_f32_split_grouped": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_stem_conv4x4_ln": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "gdrnpp_head_tail_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gdrnpp_linear_f32_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -625,7 +625,8 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
 def linear_f32_split_grouped(x2d, weight_packed_stack, bias_stack, group_sel, rows_per_group: int, n_store: int | None = None):
     """out[m] = x2d[m] @ W[sel[m // rows_per_group]]^T + bias[sel[...]]: the class-sliced output layer of the geometry head.
     ``weight_packed_stack`` = pack_weight_bf16x3 of the slices stacked along N ([groups * N, K]), ``bias_stack`` f32[groups, N],
-    ``group_sel`` i32[M / rows_per_group].  Returns f32[M, N]; columns >= n_store are left unwritten."""
+    ``group_sel`` i32[M / rows_per_group].  Returns f32[M, N]; columns >= n_store are left unwritten.  Rows whose selector is
+    outside [0, groups) come back as NaN (nothing is read out of bounds)."""
     m, k = x2d.shape
     n = bias_stack.shape[1]
     if weight_packed_stack.dtype != torch.bfloat16 or weight_packed_stack.dim() != 6 or weight_packed_stack.shape[1] * 16 != k \
@@ -633,7 +634,7 @@ def linear_f32_split_grouped(x2d, weight_packed_stack, bias_stack, group_sel, ro
         raise ValueError("weight_packed_stack must come from pack_weight_bf16x3 of the stacked [groups*N, K] weight")
     out = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
     args = (_dev(x2d, torch.float32, "x"), weight_packed_stack.data_ptr(), _dev(bias_stack, torch.float32, "bias_stack"),
-            _dev(group_sel, torch.int32, "group_sel"), int(rows_per_group), out.data_ptr(), m, n, k,
+            _dev(group_sel, torch.int32, "group_sel"), int(bias_stack.shape[0]), int(rows_per_group), out.data_ptr(), m, n, k,
             int(n_store if n_store is not None else n), _stream())
     nbytes = 4.0 * m * k + 6.0 * n * k * group_sel.numel() + 4.0 * m * (n_store or n)
     _check(_timed("linear_grouped", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split_grouped(*args), nbytes),

@@ -361,9 +361,12 @@ int gdrnpp_stem_conv4x4_ln(const float* x_nchw, const float* weight, const float
 /* Grouped form for the class-sliced 1x1 output layer of the geometry head (GDRN_double_mask.py:107-126 folded into the
  * weights): W_packed_stack holds one gdrnpp_pack_weight_bf16x3 image per group (all [N,K]), bias_stack f32[groups][N];
  * rows [g*rows_per_group, (g+1)*rows_per_group) of A use slice group_sel[g] (device i32[M / rows_per_group]); rows_per_group a
- * multiple of 256 dividing M.  C is f32[M][N]; columns >= n_store (multiple of 4) are not written.  Bias epilogue only. */
+ * multiple of 256 dividing M.  C is f32[M][N]; columns >= n_store (multiple of 4) are not written.  Bias epilogue only.
+ * n_groups = slices in the stack: rows whose selector lies outside [0, n_groups) are written as NaN (the reference's
+ * t.view(B,C,k,h,w)[arange(B), roi_classes] raises an index error for such a label, GDRN_double_mask.py:107-126; a stream-ordered
+ * launch cannot raise, so the result is poisoned instead of read out of bounds). */
 int gdrnpp_linear_f32_split_grouped(const float* A, const void* W_packed_stack, const float* bias_stack, const int* group_sel,
-                                    int rows_per_group, float* C, int M, int N, int K, int n_store, void* stream);
+                                    int n_groups, int rows_per_group, float* C, int M, int N, int K, int n_store, void* stream);
 /* Tail of the geometry head on that NHWC result (GDRN_double_mask.py:128-160, conv_pnp_net.py:120-134): out_nhwc
  * f32[b*hw][pitch] with channels [vis | full (double_mask) | x | y | z | region bg, 1..64] ->
  *   pnp_in f32[b*hw][96] = [(xyz - 0.5) * extent | coord2d (f32[b,2,hw]) | softmax(region[1..64]) | 27 zeros]  (Patch-PnP input, NHWC,

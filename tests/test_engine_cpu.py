@@ -275,3 +275,58 @@ def test_folded_conv_bn_equals_batchnorm_of_conv():
             got2 = F.conv2d(x, w2.double(), b2.double(), conv.stride, conv.padding)
             assert (got2 - bn(conv(x))).abs().max().item() < 5e-6
             assert (b2 - b).abs().max().item() > 0.1
+
+
+# ---- ROIs sorted by class within a rank, the original index carried in the record -------------------------
+def test_sort_detections_by_class_is_stable_and_carries_the_original_index():
+    rng = np.random.default_rng(5)
+    n = 37
+    det = dict(bbox=rng.uniform(0, 400, (n, 4)).astype(np.float32), im_idx=rng.integers(0, 4, n), roi_cls=rng.integers(0, 6, n),
+               score=rng.uniform(0, 1, n).astype(np.float32), cam=np.eye(3, dtype=np.float32), extents=np.ones((6, 3), np.float32),
+               time=rng.uniform(0, 1, n).astype(np.float32))
+    out, roi_id = engine.sort_detections_by_class(det, roi_id_base=100)
+    assert (np.diff(out["roi_cls"]) >= 0).all() and out["cam"].shape == (3, 3)
+    orig = roi_id - 100
+    assert sorted(orig.tolist()) == list(range(n))
+    for k in ("bbox", "im_idx", "roi_cls", "score", "time"):
+        assert np.array_equal(out[k], det[k][orig])
+    for c in range(6):                                    # stable: detection order kept inside a class
+        assert (np.diff(orig[out["roi_cls"] == c]) > 0).all()
+    cams = np.repeat(np.eye(3, dtype=np.float32)[None], n, 0) * np.arange(1, n + 1, dtype=np.float32)[:, None, None]
+    out2, _ = engine.sort_detections_by_class(dict(det, cam=cams))
+    assert np.array_equal(out2["cam"], cams[orig])
+    assert torch.equal(engine.class_sorted_order(torch.from_numpy(det["roi_cls"])), torch.from_numpy(orig.astype(np.int64)))
+
+
+def _sorted_shard_worker(rank, world, port, n_total, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cls_all = np.random.default_rng(11).integers(0, 5, n_total)          # the iteration's detections, same on every rank
+    b, e = engine.shard_range(n_total, rank, world)
+    n_max = engine.shard_range(n_total, 0, world)[1]
+    det = dict(roi_cls=cls_all[b:e], score=np.arange(b, e, dtype=np.float32), cam=np.eye(3, dtype=np.float32))
+    det, roi_id = engine.sort_detections_by_class(det, roi_id_base=b)   # this rank's shard in class order
+    rec = torch.zeros((e - b, 16))
+    rec[:, 12] = torch.from_numpy(det["score"])                           # stands for the pose of that ROI
+    rec[:, 13] = torch.from_numpy(det["roi_cls"]).float()
+    rec[:, 14] = torch.from_numpy(roi_id).float()
+    rec[:, 15] = 1.0
+    ret[rank] = (engine.gather_records(rec, n_max).numpy(), det["roi_cls"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [12, 9])
+def test_class_sorted_shards_gather_and_restore_roi_order_gloo_world2(n_total):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sorted_shard_worker, args=(world, _free_port(), n_total, ret), nprocs=world, join=True)
+    (a, cls0), (b, cls1) = ret[0], ret[1]
+    assert np.array_equal(a, b)
+    assert (np.diff(cls0) >= 0).all() and (np.diff(cls1) >= 0).all()       # each rank ran its ROIs in class order
+    rec = engine.records_in_roi_order(torch.from_numpy(a)).numpy()
+    assert rec.shape[0] == n_total                                           # padding rows dropped
+    assert np.array_equal(rec[:, 14], np.arange(n_total))                   # original order restored
+    assert np.array_equal(rec[:, 12], np.arange(n_total))                   # ... and every record is its own ROI's
+    assert np.array_equal(rec[:, 13], np.random.default_rng(11).integers(0, 5, n_total))

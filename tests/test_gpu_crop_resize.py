@@ -89,6 +89,13 @@ def test_batch_data_test_gpu_end_to_end(hip):
         assert np.array_equal(batch["roi_img"][i].cpu().numpy(), o_img)
         assert np.array_equal(batch["roi_depth"][i].cpu().numpy(), o_dep)
         assert np.array_equal(batch["roi_coord_2d"][i].cpu().numpy(), o_c2d)
+    # class-sorted layout — the same ROIs, permuted, with the original index in batch["roi_id"]
+    bs = engine.batch_data_test_gpu(cfg, torch.from_numpy(images).to(DEV), torch.from_numpy(depths).to(DEV), det,
+                                    sort_by_class=True, roi_id_base=40)
+    rid = (bs["roi_id"].cpu().numpy() - 40).tolist()
+    assert sorted(rid) == list(range(n)) and (np.diff(bs["roi_cls"].cpu().numpy()) >= 0).all()
+    for k in ("roi_img", "roi_depth", "roi_coord_2d", "roi_cls", "roi_center", "scale", "roi_extent", "score", "roi_wh"):
+        assert torch.equal(bs[k], batch[k][rid]), k
     # COORD_2D_TYPE = "rel" (data_loader.py:799-804): (bbox_center - roi_coord_2d * (W, H)) / scale in float64, stored float32
     cfg_rel = get_cfg("ycbv_convnext_a6", ["MODEL.POSE_NET.PNP_NET.COORD_2D_TYPE=rel"])
     b_rel = engine.batch_data_test_gpu(cfg_rel, torch.from_numpy(images).to(DEV), None, det)
