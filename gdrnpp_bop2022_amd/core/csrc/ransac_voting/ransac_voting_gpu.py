@@ -1,8 +1,10 @@
 """core/csrc/ransac_voting/ransac_voting_gpu.py:7-309 with the same signatures; the RANSAC rounds use the fused
 vote+count kernel so the ``[round_hyp_num, vn, tn]`` u8 tensor (4.7 MB per round at 128x9x4096) is never
 written; only the final single-hypothesis vote materialises flags (they feed the 2x2 least squares).
-``idxs_fn(bi, round_hyp_num, vn, tn)`` injects the index draw for parity tests (the reference draws with
-``Tensor.random_``); like the reference, the layers draw ONE index set per image and reuse it in every round."""
+``idxs_fn`` injects the index draw for parity tests (the reference draws with ``Tensor.random_``).  ONE signature in this
+module, always called with keywords: ``idxs_fn(bi=, round_idx=, round_hyp_num=, vn=, tn=) -> i32[round_hyp_num, vn, 2]``.
+Like the reference, ``ransac_voting_layer[_v3]`` draw ONE index set per image and reuse it in every round (they pass
+``round_idx=0``); ``estimate_voting_distribution_with_mean`` draws once per round."""
 import numpy as np
 import torch
 
@@ -34,7 +36,7 @@ def _draw(idxs_fn, bi, round_hyp_num, vn, tn, device):
     (ransac_voting_gpu.py:48,164): the confidence test can only be met by the first round's hypotheses, later rounds
     re-vote the same set.  Reference behaviour, kept."""
     if idxs_fn is not None:
-        return idxs_fn(bi, round_hyp_num, vn, tn)
+        return idxs_fn(bi=bi, round_idx=0, round_hyp_num=round_hyp_num, vn=vn, tn=tn)
     return torch.zeros([round_hyp_num, vn, 2], dtype=torch.int32, device=device).random_(0, tn)
 
 
@@ -129,7 +131,7 @@ def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256
         cur_hyp_pts, cur_inlier_ratio = [], []
         for round_idx in range(int(np.ceil(min_hyp_num / round_hyp_num))):
             if idxs_fn is not None:
-                idxs = idxs_fn(bi, round_hyp_num, vn, tn, round_idx)
+                idxs = idxs_fn(bi=bi, round_idx=round_idx, round_hyp_num=round_hyp_num, vn=vn, tn=tn)
             else:
                 idxs = torch.zeros([round_hyp_num, vn, 2], dtype=torch.int32, device=mask.device).random_(0, tn)
             hyp_pts = ransac_voting.generate_hypothesis(direct, coords, idxs)

@@ -8,7 +8,8 @@
 // polished by five Gauss-Newton steps on the six control-point distances, Horn/Arun absolute orientation, smallest mean
 // reprojection error wins; RANSAC = 5-point minimal sets from cv::RNG(2^64-1) (or injected 32-bit words), float32
 // squared reprojection error against reprojErr^2, strictly-more-inliers update, adaptive iteration count, final EPnP
-// on the inliers of the best hypothesis.
+// on the inliers of the best hypothesis.  One documented deviation: exactly 4 correspondences (OpenCV: P3P) report "no
+// model", see final_kernel.
 //
 // Work decomposition (nothing here is bandwidth-relevant: ~100 hypotheses x <= 4096 points per ROI):
 //   subsets_kernel     one thread per ROI      the RNG stream is sequential by definition: draws every minimal set
@@ -568,7 +569,11 @@ __global__ __launch_bounds__(64) void final_kernel(const float* __restrict__ img
   int good = 0;
   bool ok = false;
   const double* Pbest = nullptr;
-  if (n >= 4 && n <= kModelPts) {  // solvePnPRansac: model_points == npoints -> plain solve, every point an inlier
+  // solvePnPRansac: model_points == npoints -> plain solve, every point an inlier.  DEVIATION for exactly 4 correspondences:
+  // OpenCV then solves with SOLVEPNP_P3P (model_points = 4), which is not restated here — a 4-pixel mask is a failed
+  // detection, and an under-determined EPnP on 4 points would return a finite but arbitrary pose.  n == 4 reports "no
+  // model" (status 0) like n < 4, so the caller applies the reference's own fallbacks (-100 sentinel / network pose).
+  if (n == kModelPts) {
     for (int i = lane; i < n; i += 64) m[i] = 1;
     good = n;
     ok = true;

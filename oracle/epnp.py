@@ -239,9 +239,9 @@ def solve_pnp_ransac_epnp(pw, uv, K, reproj_err=3.0, iters=100, confidence=0.99,
     pw32, uv32 = np.asarray(pw, np.float32), np.asarray(uv, np.float32)      # solvePnPRansac converts to CV_32F
     K = np.asarray(K, np.float64)
     n = len(pw32)
-    if n < 4:
+    if n <= 4:      # n == 4: OpenCV solves with P3P (model_points = 4), not restated — product and oracle report "no model"
         return False, np.eye(3), np.zeros(3), np.zeros(n, bool)
-    model_points = 5 if n >= 5 else 4
+    model_points = 5
     if n == model_points:
         sol = epnp(pw32, uv32, K)
         if sol is None:

@@ -57,8 +57,11 @@ def test_ransac_inlier_set_is_the_uncontaminated_points():
     ok, Re, te, mask = E.solve_pnp_ransac_epnp(pw, uv, K)
     assert ok and np.array_equal(mask, ~bad)
     assert np.abs(Re - R).max() < 2e-3 and np.abs(te - t).max() < 2e-3
-    # fewer than 4 points: no model; exactly 5: plain EPnP
+    # fewer than 4 points: no model; exactly 4 (OpenCV: P3P, not restated): no model either — the documented deviation,
+    # pinned here and on the device (test_gpu_epnp counts include 4); exactly 5: plain EPnP
     assert not E.solve_pnp_ransac_epnp(pw[:3], uv[:3], K)[0]
+    ok4, R4, t4, m4 = E.solve_pnp_ransac_epnp(pw[:4], uv[:4], K)
+    assert not ok4 and np.array_equal(R4, np.eye(3)) and not t4.any() and not m4.any()
     R5, t5, pw5, uv5, _ = _case(rng, 5)
     ok, Re, te, mask = E.solve_pnp_ransac_epnp(pw5, uv5, K)
     assert ok and mask.all() and np.abs(te - t5).max() < 1e-4

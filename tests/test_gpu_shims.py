@@ -67,9 +67,9 @@ def test_ransac_voting_layer_replays_reference_draw(golden_dir):
     mask, vertex, win_ref, draws = g["rv_mask"], g["rv_vertex"], g["rv_win"], g["rv_idxs"]
     calls = []
 
-    def idxs_fn(bi, hn_, vn_, tn_):
+    def idxs_fn(bi, round_idx, round_hyp_num, vn, tn):
         calls.append(bi)
-        assert draws[bi].shape == (hn_, vn_, 2) and draws[bi].max() < tn_
+        assert round_idx == 0 and draws[bi].shape == (round_hyp_num, vn, 2) and draws[bi].max() < tn
         return torch.from_numpy(draws[bi]).to(DEV)
 
     for layer in (ransac_voting_layer, ransac_voting_layer_v3):
@@ -100,7 +100,7 @@ def test_ransac_voting_layer_matches_oracle():
     tn0 = int(mask[0].sum())
     draw = rng.integers(0, tn0, (hn, vn, 2)).astype(np.int32)
 
-    def idxs_fn(bi, hn_, vn_, tn_):
+    def idxs_fn(bi, round_idx, round_hyp_num, vn, tn):
         return torch.from_numpy(draw).to(DEV)
 
     out = ransac_voting_layer_v3(torch.from_numpy(mask).to(DEV), torch.from_numpy(vertex).to(DEV), hn, idxs_fn=idxs_fn)
@@ -109,8 +109,16 @@ def test_ransac_voting_layer_matches_oracle():
     np.testing.assert_allclose(out[0], ref, atol=2e-3)      # fp32 torch LSQ vs fp64 NumPy
     assert np.abs(out[0] - kp[0]).max() < 1.0                # the keypoints are recovered
     assert np.array_equal(out[1], np.zeros((vn, 2), np.float32))
+    rounds = []
+
+    def idxs_fn_rounds(bi, round_idx, round_hyp_num, vn, tn):    # same keyword signature, one draw per round here
+        rounds.append((bi, round_idx))
+        return torch.from_numpy(np.random.default_rng(round_idx).integers(0, tn, (round_hyp_num, vn, 2)).astype(np.int32)).to(DEV)
+
     mean, cov = estimate_voting_distribution_with_mean(torch.from_numpy(mask).to(DEV), torch.from_numpy(vertex).to(DEV),
-                                                       torch.from_numpy(out).to(DEV), round_hyp_num=hn, min_hyp_num=512)
+                                                       torch.from_numpy(out).to(DEV), round_hyp_num=hn, min_hyp_num=512,
+                                                       idxs_fn=idxs_fn_rounds)
+    assert rounds == [(0, r) for r in range(4)]
     cov = cov.cpu().numpy()
     assert cov.shape == (b, vn, 2, 2) and np.isfinite(cov).all()
     assert (np.linalg.eigvalsh(cov[0]) > -1e-4).all()
