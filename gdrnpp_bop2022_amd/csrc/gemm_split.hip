@@ -567,11 +567,39 @@ inline int splitk_chunk(int M, int N, int K) {
   return c;
 }
 
+// Plan of gdrnpp_linear_f32_splitk.  From 192 rows on the pipelined kernel (256x128 tiles, gemm_split_pipe.hip) does the
+// work: at the reference's own batch sizes (one image = a few to ~30 ROIs per forward, data_loader.py:901) the deep ConvNeXt
+// stages have 16-128 such tiles for 256 CUs.  The number of K chunks minimises a two-term model measured on the stage-2 /
+// stage-3 MLP shapes: a workgroup alone on its CU takes ~0.73 us per k-tile (48 MFMAs per wave at 32 cycles), rounds of 256
+// workgroups run back to back, and a split costs the partials' trip through memory (written once, read once, the result
+// written once) plus one kernel boundary.  splits == 1 means: no workspace, one launch with the fused epilogue.
+struct SplitKPlan { bool pipe; int nkc; int splits; };
+inline SplitKPlan splitk_plan(int M, int N, int K) {
+  const int nk = K / BK;
+  if (M < 192 || !gdrnpp::option_split_gemm_pipe() || (unsigned long long)M * (unsigned long long)K * 4ull >= (1ull << 32)) {
+    const int c = splitk_chunk(M, N, K);
+    return SplitKPlan{false, c, nk / c};
+  }
+  const double tiles = (double)((M + 255) / 256) * (N / BN);
+  const double t_k = 0.73, t_boundary = 3.0, bytes_per_us = 3.0e6;
+  int best = 1;
+  double best_t = 1e30;
+  for (int s = 1; s <= 64; s *= 2) {
+    if (nk % s || (nk / s) < 4 || (nk / s) % 2) break;
+    const double rounds = tiles * s <= 256.0 ? 1.0 : tiles * s / 256.0;
+    double t = rounds * (nk / s) * t_k + 3.0;
+    if (s > 1) t += t_boundary + (double)(s + 2) * M * (double)N * 4.0 / bytes_per_us;
+    if (t < best_t) { best_t = t; best = s; }
+  }
+  return SplitKPlan{true, nk / best, best};
+}
+
 }  // namespace
 
 extern "C" size_t gdrnpp_linear_f32_splitk_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 32 || N % BN) return 0;
-  return (size_t)((K / BK) / splitk_chunk(M, N, K)) * M * N * sizeof(float);
+  const SplitKPlan p = splitk_plan(M, N, K);
+  return (p.splits > 1 || !p.pipe) ? (size_t)p.splits * M * N * sizeof(float) : 16;   // the 128-row kernel always goes through partials
 }
 
 extern "C" int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, const float* bias, const float* gamma,
@@ -585,14 +613,27 @@ extern "C" int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, co
                  "gdrnpp_linear_f32_splitk: scale+residual epilogue needs gamma and resid");
   GDRNPP_REQUIRE(workspace_bytes >= gdrnpp_linear_f32_splitk_workspace_bytes(M, N, K), GDRNPP_EINVAL,
                  "gdrnpp_linear_f32_splitk: workspace too small");
-  const int nkc = splitk_chunk(M, N, K);
-  const int splits = (K / BK) / nkc;
+  const SplitKPlan plan = splitk_plan(M, N, K);
+  const int nkc = plan.nkc, splits = plan.splits;
   const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
   GDRNPP_REQUIRE(tiles < (1l << 31) && splits < 65536, GDRNPP_ELIMIT, "gdrnpp_linear_f32_splitk: grid too large");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((gemm_split_kernel<EPI_BIAS, 0, 2>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st, A,
-                     (const uint4*)W_packed, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                     (float*)workspace, M, N, K, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, nkc});
+  const int a_stages = gdrnpp::option_split_gemm_pipe() == 2 ? 2 : 3;
+  if (plan.pipe && splits == 1) {   // enough tiles for the chip (or K too short to cut): one launch, fused epilogue
+    const int rc = launch_split_pipe(A, (const uint4*)W_packed, bias, gamma, resid, C, M, N, K, epilogue, false,
+                                     ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0}, a_stages, st, "gdrnpp_linear_f32_splitk");
+    if (rc >= 0) return rc;
+  }
+  int rc = -1;
+  if (plan.pipe && splits > 1)
+    rc = launch_split_pipe_splitk(A, (const uint4*)W_packed, (float*)workspace, M, N, K, nkc, a_stages, st, "gdrnpp_linear_f32_splitk");
+  if (rc > 0) return rc;
+  if (rc < 0) {
+    GDRNPP_REQUIRE(workspace_bytes >= (size_t)splits * M * N * sizeof(float), GDRNPP_EINVAL, "gdrnpp_linear_f32_splitk: workspace too small");
+    hipLaunchKernelGGL((gemm_split_kernel<EPI_BIAS, 0, 2>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st, A,
+                       (const uint4*)W_packed, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (float*)workspace, M, N, K, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, nkc});
+  }
   const long mn4 = (long)M * N / 4;
   const dim3 grid((unsigned)((mn4 + 255) / 256));
   const float* ws = (const float*)workspace;

@@ -45,6 +45,11 @@ using gdrnpp::gelu_erf;  // common.hpp
 int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
                       int M, int N, int K, int epilogue, bool conv, ConvGeom cg, int a_stages, hipStream_t st, const char* what);
 
+// The same kernel as a split-K launch (linear form): grid (256x128 tiles, K chunks of nk_split k-tiles), raw partial sums to
+// partials[chunk][M][N]; -1 outside its domain.
+int launch_split_pipe_splitk(const float* A, const uint4* Wp, float* partials, int M, int N, int K, int nk_split, int a_stages,
+                             hipStream_t st, const char* what);
+
 }  // namespace splitgemm
 
 int option_split_gemm_pipe();       // 0: off, 2 / 3 (default): pipelined kernel with that many A stages for 256-row tiles (linear form)

@@ -149,7 +149,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
     tile_n = tile - tile_m * ntn;
   }
   const int m0 = tile_m * 256, n0 = tile_n * BN;
-  const int nk = K / BK;
+  // split-K (linear form, cg.nk_split > 0): workgroup (x, y) multiplies k-tiles [y * nk_split, (y + 1) * nk_split) and writes
+  // the partial result C + y*M*N; gdrnpp_linear_f32_splitk sums the partials in fixed order and applies bias / epilogue
+  const int kt0 = (!CONV && cg.nk_split > 0) ? (int)blockIdx.y * cg.nk_split : 0;
+  const int nk = (!CONV && cg.nk_split > 0) ? cg.nk_split : K / BK;
+  if (!CONV && cg.nk_split > 0) C += (size_t)blockIdx.y * (size_t)M * (size_t)N;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
 
   // ---- DMA lanes: piece c (0..3) of this wave fills A slots (wave*4 + c)*64 + lane = rows wave*64 + c*16 + lane/4, chunk
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
     }
     return;
   }
-  const char* const wbase = reinterpret_cast<const char*>(Wp + (size_t)grp_i * grp.w_stride + (size_t)tile_n * nk * W_TILE_SLOTS);
+  const char* const wbase = reinterpret_cast<const char*>(Wp + (size_t)grp_i * grp.w_stride + (size_t)tile_n * (K / BK) * W_TILE_SLOTS);
   const float* const bias_t = bias ? bias + (size_t)grp_i * grp.bias_stride : nullptr;
   const unsigned ldsA = lds0 + (unsigned)(wave * 4) * 1024u;
   const unsigned ldsB = lds0 + (unsigned)(NA * A_STAGE_B) + (unsigned)(wave * 3) * 1024u;
@@ -210,12 +214,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
       const bool ok = (okmask[c] >> tap) & 1u;
       dma_v(ok ? (const void*)(ap[c] + off) : (const void*)g_pipe_zero_page, ldsA + sb + c * 1024u);
     } else {
-      dma_s(aoff[c], reinterpret_cast<const char*>(A) + (size_t)kt * (BK * 4), ldsA + sb + c * 1024u);
+      dma_s(aoff[c], reinterpret_cast<const char*>(A) + (size_t)(kt0 + kt) * (BK * 4), ldsA + sb + c * 1024u);
     }
   };
   auto dma_b = [&](int kt, unsigned sb, auto cc) {
     constexpr int c = decltype(cc)::value;
-    int wkt = kt;
+    int wkt = kt0 + kt;
     if constexpr (CONV) {
       const int cps = (cpt & 1) ? 1 : 2, sup = kt / (9 * cps), rem = kt - sup * (9 * cps), tap = rem / cps;
       wkt = tap * cpt + sup * cps + (rem - tap * cps);
@@ -387,7 +391,8 @@ int launch_one(const float* A, const uint4* Wp, const float* bias, const float* 
     raised[dev] = true;
   }
   const long tiles = (long)((M + 255) / 256) * (N / BN);
-  hipLaunchKernelGGL((gemm_split_pipe_kernel<EPI, CONV, NA>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, A, Wp, bias,
+  const unsigned splits = (!CONV && cg.nk_split > 0) ? (unsigned)((K / BK) / cg.nk_split) : 1u;
+  hipLaunchKernelGGL((gemm_split_pipe_kernel<EPI, CONV, NA>), dim3((unsigned)tiles, splits), dim3(256), lds_bytes, st, A, Wp, bias,
                      gamma, resid, C, M, N, K, cg, grp);
   return gdrnpp::check_launch(what);
 }
@@ -431,6 +436,16 @@ int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const 
   }
   if ((unsigned long long)M * (unsigned long long)K * 4ull >= (1ull << 32)) return -1;  // 32-bit lane offsets
   return launch_epi<0>(epilogue, a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, grp, st, what);
+}
+
+// Split-K launch of the pipelined kernel: partials[y][M][N] for the (K/16) / nk_split chunks of nk_split (even) k-tiles.
+int launch_split_pipe_splitk(const float* A, const uint4* Wp, float* partials, int M, int N, int K, int nk_split, int a_stages,
+                             hipStream_t st, const char* what) {
+  if (K % 32 || N % BN || M <= 0 || nk_split < 2 || nk_split % 2 || (K / BK) % nk_split) return -1;
+  if ((unsigned long long)M * (unsigned long long)K * 4ull >= (1ull << 32)) return -1;  // 32-bit lane offsets
+  const Grouped grp{nullptr, 1, 0, 0, N, 0, 1};
+  return launch_epi<0>(EPI_BIAS, a_stages, A, Wp, nullptr, nullptr, nullptr, partials, M, N, K,
+                       ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, nk_split}, grp, st, what);
 }
 
 }  // namespace splitgemm

@@ -32,13 +32,8 @@ using gdrnpp::gelu_erf;  // common.hpp
 // NP pixel tiles, so every global access is a contiguous 16 B x (C/4) run.  Input rows stream through
 // registers (10 float4 per row), weights are read tap-major [49][C] (L1/L2 resident, 49*C*4 B).
 // --------------------------------------------------------------------------------------------------
-#ifndef DW_TH
-#define DW_TH 2
-#endif
-#ifndef DW_TW
-#define DW_TW 8
-#endif
-constexpr int TH = DW_TH, TW = DW_TW;
+// Tile per thread (TH x TW output pixels): 2 x 8 at the headline batch; 2 x 4 and 1 x 4 when a launch has too few tiles to
+// give every SIMD two waves (the reference's own batches: one image = a few to ~30 ROIs) — see gdrnpp_dwconv7x7_ln_nhwc.
 
 // LDS_W: the [49][C] weights live in LDS (loaded once per workgroup) and the workgroup is persistent, walking tile
 // groups with a grid stride.  Without it every thread re-reads its 49 weight quads per output row from L1/L2 — at
@@ -79,7 +74,7 @@ __device__ __forceinline__ f4 fma4s(f4 a, f4 b, f4 c) {
 #else
 #define DW_FMA(a, b, c) fma4s(a, b, c)
 #endif
-template <bool FUSE_LN, bool LDS_W>
+template <bool FUSE_LN, bool LDS_W, int TH, int TW>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DW_WPE))) void dwconv7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w49c,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ ln_w,
@@ -145,15 +140,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DW_WPE))) v
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(x) + ((size_t)n_u * H + iy) * W * C, 0, row_bytes, 0x00020000);
       f4 row[TW + 6];
+#ifdef DW_TIMING_NO_LOAD   // timing-only builds (results invalid): the kernel without its input loads / without its weight reads
+#pragma unroll
+      for (int c = 0; c < TW + 6; ++c) row[c] = b4 * (float)(c + r);
+      (void)rs;
+#else
 #pragma unroll
       for (int c = 0; c < TW + 6; ++c) row[c] = __builtin_bit_cast(f4, (u4)__builtin_amdgcn_raw_buffer_load_b128(rs, coff[c], 0, 0));
+#endif
 #pragma unroll
       for (int i = 0; i < TH; ++i) {
         const int ky = r - i;
         if (ky < 0 || ky > 6) continue;
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx) {
+#ifdef DW_TIMING_NO_WLDS
+          const f4 wv = b4 * (float)(ky * 7 + kx);
+#else
           const f4 wv = LDS_W ? wldsv[(ky * 7 + kx) * Q + q] : ld4v(w49c + (size_t)(ky * 7 + kx) * C + 4 * q);
+#endif
 #pragma unroll
           for (int j = 0; j < TW; ++j) acc[i][j] = DW_FMA(row[j + kx], wv, acc[i][j]);
         }
@@ -618,6 +623,71 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
   }
 }
 
+template <int TH, int TW>
+int launch_dwconv(const float* x, const float* w49c, const float* bias, const float* ln_w, const float* ln_b, float* y, int N,
+                  int H, int W, int C, float eps, hipStream_t st) {
+  const int Q = C / 4;
+  const long n_tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  // buffer-load rows need the image (n) and tile row of a wave to be uniform: one tile per wave or more (Q >= 64), or the
+  // 64 / Q tiles of a wave side by side in one tile row; the row must fit a 32-bit buffer range
+  const int tiles_x = (W + TW - 1) / TW;
+  const int buf_rows = ((Q >= 64) || (tiles_x % (64 / Q) == 0)) && (long)W * C * 4 < (1l << 31) ? 1 : 0;
+  const size_t wbytes = (size_t)49 * C * sizeof(float);
+  const bool fuse = ln_w && ln_b;
+  if (wbytes <= 112 * 1024) {
+    // weights in LDS, persistent workgroups: 512 threads when the weight set allows only one workgroup per CU
+    const int threads = wbytes > 52 * 1024 ? 512 : 256;
+    const long n_groups = (n_tiles + threads / Q - 1) / (threads / Q);
+    // CU count, LDS attribute and occupancy are per (device, kernel, launch shape): looked up once, not per launch
+    struct Cfg { int dev; bool fuse; int threads; size_t wbytes; int n_cu, per_cu; };
+    static std::mutex mu;   // one cache per (TH, TW) instantiation
+    static Cfg cache[16];
+    static int n_cached = 0;
+    int dev = 0, n_cu = 0, per_cu = 1;
+    GDRNPP_HIP_TRY(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      const Cfg* hit = nullptr;
+      for (int i = 0; i < n_cached; ++i)
+        if (cache[i].dev == dev && cache[i].fuse == fuse && cache[i].threads == threads && cache[i].wbytes == wbytes) hit = &cache[i];
+      if (!hit) {
+        Cfg c{dev, fuse, threads, wbytes, 0, 1};
+        GDRNPP_HIP_TRY(hipDeviceGetAttribute(&c.n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        const void* fn = fuse ? (const void*)dwconv7_ln_kernel<true, true, TH, TW> : (const void*)dwconv7_ln_kernel<false, true, TH, TW>;
+        if (int rc = gdrnpp::ensure_dynamic_lds(fn, 112 * 1024)) return rc;
+        GDRNPP_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.per_cu, fn, threads, wbytes));
+        if (c.per_cu < 1) c.per_cu = 1;
+        cache[n_cached < 16 ? n_cached++ : 15] = c;
+        hit = &cache[n_cached - 1 < 15 ? n_cached - 1 : 15];
+      }
+      n_cu = hit->n_cu;
+      per_cu = hit->per_cu;
+    }
+    long blocks = (long)n_cu * per_cu;
+    if (blocks > n_groups) blocks = n_groups;
+    if (fuse) {
+      hipLaunchKernelGGL((dwconv7_ln_kernel<true, true, TH, TW>), dim3((unsigned)blocks), dim3(threads), wbytes, st, x, w49c, bias,
+                         ln_w, ln_b, y, N, H, W, C, eps, buf_rows);
+    } else {
+      hipLaunchKernelGGL((dwconv7_ln_kernel<false, true, TH, TW>), dim3((unsigned)blocks), dim3(threads), wbytes, st, x, w49c, bias,
+                         nullptr, nullptr, y, N, H, W, C, eps, buf_rows);
+    }
+  } else {
+    const int tiles_per_block = 256 / Q;
+    const long blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "gdrnpp_dwconv7x7_ln_nhwc: grid too large");
+    if (fuse) {
+      hipLaunchKernelGGL((dwconv7_ln_kernel<true, false, TH, TW>), dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias, ln_w,
+                         ln_b, y, N, H, W, C, eps, buf_rows);
+    } else {
+      hipLaunchKernelGGL((dwconv7_ln_kernel<false, false, TH, TW>), dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias,
+                         nullptr, nullptr, y, N, H, W, C, eps, buf_rows);
+    }
+  }
+  return gdrnpp::check_launch("gdrnpp_dwconv7x7_ln_nhwc");
+}
+
+
 }  // namespace
 
 
@@ -631,65 +701,15 @@ int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bia
   GDRNPP_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, GDRNPP_ELIMIT,
                  "gdrnpp_dwconv7x7_ln_nhwc: C=%d must give a power-of-two quad count <= 256", C);
   const int Q = C / 4;
-  const long n_tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-  hipStream_t st = (hipStream_t)stream;
-  // buffer-load rows need the image (n) and tile row of a wave to be uniform: one tile per wave or more (Q >= 64), or the
-  // 64 / Q tiles of a wave side by side in one tile row; the row must fit a 32-bit buffer range
-  const int tiles_x = (W + TW - 1) / TW;
-  const int buf_rows = ((Q >= 64) || (tiles_x % (64 / Q) == 0)) && (long)W * C * 4 < (1l << 31) ? 1 : 0;
-  const size_t wbytes = (size_t)49 * C * sizeof(float);
-  const bool fuse = ln_w && ln_b;
-  if (wbytes <= 112 * 1024) {
-    // weights in LDS, persistent workgroups: 512 threads when the weight set allows only one workgroup per CU
-    const int threads = wbytes > 52 * 1024 ? 512 : 256;
-    const long n_groups = (n_tiles + threads / Q - 1) / (threads / Q);
-    // CU count, LDS attribute and occupancy are per (device, kernel, launch shape): looked up once, not per launch
-    struct Cfg { int dev; bool fuse; int threads; size_t wbytes; int n_cu, per_cu; };
-    static std::mutex mu;
-    static Cfg cache[16];
-    static int n_cached = 0;
-    int dev = 0, n_cu = 0, per_cu = 1;
-    GDRNPP_HIP_TRY(hipGetDevice(&dev));
-    {
-      std::lock_guard<std::mutex> lock(mu);
-      const Cfg* hit = nullptr;
-      for (int i = 0; i < n_cached; ++i)
-        if (cache[i].dev == dev && cache[i].fuse == fuse && cache[i].threads == threads && cache[i].wbytes == wbytes) hit = &cache[i];
-      if (!hit) {
-        Cfg c{dev, fuse, threads, wbytes, 0, 1};
-        GDRNPP_HIP_TRY(hipDeviceGetAttribute(&c.n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        const void* fn = fuse ? (const void*)dwconv7_ln_kernel<true, true> : (const void*)dwconv7_ln_kernel<false, true>;
-        if (int rc = gdrnpp::ensure_dynamic_lds(fn, 112 * 1024)) return rc;
-        GDRNPP_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.per_cu, fn, threads, wbytes));
-        if (c.per_cu < 1) c.per_cu = 1;
-        cache[n_cached < 16 ? n_cached++ : 15] = c;
-        hit = &cache[n_cached - 1 < 15 ? n_cached - 1 : 15];
-      }
-      n_cu = hit->n_cu;
-      per_cu = hit->per_cu;
-    }
-    long blocks = (long)n_cu * per_cu;
-    if (blocks > n_groups) blocks = n_groups;
-    if (fuse) {
-      hipLaunchKernelGGL((dwconv7_ln_kernel<true, true>), dim3((unsigned)blocks), dim3(threads), wbytes, st, x, w49c, bias,
-                         ln_w, ln_b, y, N, H, W, C, eps, buf_rows);
-    } else {
-      hipLaunchKernelGGL((dwconv7_ln_kernel<false, true>), dim3((unsigned)blocks), dim3(threads), wbytes, st, x, w49c, bias,
-                         nullptr, nullptr, y, N, H, W, C, eps, buf_rows);
-    }
-  } else {
-    const int tiles_per_block = 256 / Q;
-    const long blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;
-    GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "gdrnpp_dwconv7x7_ln_nhwc: grid too large");
-    if (fuse) {
-      hipLaunchKernelGGL((dwconv7_ln_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias, ln_w,
-                         ln_b, y, N, H, W, C, eps, buf_rows);
-    } else {
-      hipLaunchKernelGGL((dwconv7_ln_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias,
-                         nullptr, nullptr, y, N, H, W, C, eps, buf_rows);
-    }
-  }
-  return gdrnpp::check_launch("gdrnpp_dwconv7x7_ln_nhwc");
+  // tile per thread: the largest of 2x8 / 2x4 / 1x4 that still gives the chip ~1.5 waves per SIMD (1024 SIMDs); the small
+  // tiles re-read more halo and weights per output, which only pays when the launch is latency-bound (few ROIs)
+  auto waves_of = [&](int th, int tw) { return (double)N * ((H + th - 1) / th) * ((W + tw - 1) / tw) * Q / 64.0; };
+  const int force = gdrnpp::option_dwconv_tile();
+  int cfg = waves_of(2, 8) >= 1536.0 ? 0 : (waves_of(2, 4) >= 1536.0 ? 1 : 2);
+  if (force >= 0 && force <= 2) cfg = force;
+  if (cfg == 0) return launch_dwconv<2, 8>(x, w49c, bias, ln_w, ln_b, y, N, H, W, C, eps, (hipStream_t)stream);
+  if (cfg == 1) return launch_dwconv<2, 4>(x, w49c, bias, ln_w, ln_b, y, N, H, W, C, eps, (hipStream_t)stream);
+  return launch_dwconv<1, 4>(x, w49c, bias, ln_w, ln_b, y, N, H, W, C, eps, (hipStream_t)stream);
 }
 
 int gdrnpp_layernorm_nhwc(const float* x, const float* weight, const float* bias, float* y, long n_pix, int C,

@@ -103,8 +103,10 @@ def dwconv_ln(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor, cache: dict) -
 #   "torch"           hipBLASLt / MIOpen fp32 + separate elementwise kernels everywhere (A/B measurements).
 _MLP_GEMM = "split"
 _SPLITK_BELOW_TILES = 512
-_LIBRARY_BELOW_TILES = 128  # blocks whose fc2 has fewer output tiles than this go to hipBLASLt (measured: batch 8
-                            # 1071 -> 1210 ROIs/s, batch 16 unchanged, 300 already hurts batch 16)
+_LIBRARY_BELOW_TILES = 0    # A/B switch: blocks whose fc2 has fewer 128x128 output tiles than this go to hipBLASLt + elementwise
+                            # kernels.  Round 2 shipped 128 (the register-staged split-K kernel lost to the library's small-tile
+                            # kernels at 8 ROIs); since round 3 gdrnpp_linear_f32_splitk runs such shapes on the pipelined kernel
+                            # with a modelled number of K chunks and no block leaves this library
 
 
 def set_mlp_gemm(mode: str) -> None:

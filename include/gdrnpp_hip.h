@@ -50,6 +50,8 @@ const char* gdrnpp_last_error(void);
  *   "split_gemm_panel"      0, 2..64  wide layers (packed weight > 2 MB, N >= 1024) walk their tiles in panels of that many
  *                                   256-row blocks, column tile outer, for L2 reuse of both operands (default 4; 0: row-major)
  *   "split_gemm_mi4"   -1 / 0 / 1   tile height by tile count (default) / force 128 rows / force 256 rows
+ *   "dwconv_tile"      -1 / 0 / 1 / 2   output pixels per thread of the depthwise 7x7 kernel: by launch size (default: 2x8 at
+ *                                   the headline batch, 2x4 / 1x4 when a launch has too few tiles for the chip) / force 2x8 / 2x4 / 1x4
  * unknown name -> GDRNPP_EINVAL. */
 int gdrnpp_set_option(const char* name, int value);
 

@@ -16,7 +16,9 @@ def _cl(x):
 @pytest.mark.parametrize("n,c,h,w", [(3, 128, 64, 64), (2, 256, 32, 32), (2, 512, 16, 16), (2, 1024, 8, 8),
                                       (1, 128, 5, 7)])
 @pytest.mark.parametrize("fuse_ln", [True, False])
-def test_dwconv7x7_ln(hip, n, c, h, w, fuse_ln):
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+def test_dwconv7x7_ln(hip, n, c, h, w, fuse_ln, tile):
+    """tile: -1 = the launch-size rule, 0 / 1 / 2 = the 2x8 / 2x4 / 1x4 pixel tile forced (option dwconv_tile)."""
     torch.manual_seed(c + h)
     conv = nn.Conv2d(c, c, 7, padding=3, groups=c).to(DEV)
     ln = nn.LayerNorm(c, eps=1e-6).to(DEV)
@@ -25,7 +27,11 @@ def test_dwconv7x7_ln(hip, n, c, h, w, fuse_ln):
         ln.bias.normal_(0.0, 0.2)
         x = _cl(torch.randn(n, c, h, w, device=DEV))
         w49c = conv.weight.reshape(c, 49).t().contiguous()
-        y = hip.dwconv7x7_ln(x, w49c, conv.bias, ln.weight if fuse_ln else None, ln.bias if fuse_ln else None, 1e-6)
+        hip.set_option("dwconv_tile", tile)
+        try:
+            y = hip.dwconv7x7_ln(x, w49c, conv.bias, ln.weight if fuse_ln else None, ln.bias if fuse_ln else None, 1e-6)
+        finally:
+            hip.set_option("dwconv_tile", -1)
         ref = conv(x)
         if fuse_ln:
             ref = F.layer_norm(ref.permute(0, 2, 3, 1), (c,), ln.weight, ln.bias, 1e-6).permute(0, 3, 1, 2)
@@ -87,12 +93,10 @@ def test_model_forward_hip_layers_vs_torch_ops(hip, mlp_gemm):
     with torch.no_grad():
         hip_layers.set_enabled(True)
         hip_layers.set_mlp_gemm(mlp_gemm)
-        hip_layers.set_library_below_tiles(0)      # keep every block on the HIP GEMM at this small ROI count
         try:
             o1 = model(x, **args)
         finally:
             hip_layers.set_mlp_gemm("split")
-            hip_layers.set_library_below_tiles(128)
         hip_layers.set_enabled(False)
         o2 = model(x, **args)
         hip_layers.set_enabled(True)
@@ -301,26 +305,27 @@ def test_model_forward_odd_roi_count(hip):
     args = dict(roi_classes=torch.randint(0, 21, (b,), device=DEV), roi_cams=K, roi_whs=torch.full((b, 2), 120.0, device=DEV),
                 roi_centers=torch.full((b, 2), 250.0, device=DEV), resize_ratios=torch.full((b,), 64 / 180.0, device=DEV),
                 roi_coord_2d=torch.rand(b, 2, 64, 64, device=DEV), roi_extents=torch.full((b, 3), 0.1, device=DEV))
-    timer, timer_default = hip.LaunchTimer(), hip.LaunchTimer()
+    timer, timer_lib = hip.LaunchTimer(), hip.LaunchTimer()
     with torch.no_grad():
-        hip.set_launch_timer(timer)
-        hip_layers.set_library_below_tiles(0)      # every block on the HIP GEMM
+        hip.set_launch_timer(timer)                # default dispatch: every block on this library's GEMM, whatever the ROI count
         try:
             o1 = model(x, **args)
         finally:
-            hip_layers.set_library_below_tiles(128)
-        hip.set_launch_timer(timer_default)        # default dispatch: deep stages (few tiles at 5 ROIs) go to hipBLASLt
+            hip.set_launch_timer(None)
+        hip.set_launch_timer(timer_lib)            # A/B switch of round 2: deep stages (few tiles at 5 ROIs) on hipBLASLt
+        hip_layers.set_library_below_tiles(128)
         try:
             o3 = model(x, **args)
         finally:
             hip.set_launch_timer(None)
+            hip_layers.set_library_below_tiles(0)
         hip_layers.set_enabled(False)
         o2 = model(x, **args)
         hip_layers.set_enabled(True)
     # 36 blocks x (fc1, fc2) + the two Patch-PnP fc layers, plain or split-K depending on the tile count
     assert sum(1 for r in timer.records if r[0] in ("linear", "linear_splitk")) == 74
     assert sum(1 for r in timer.records if r[0] == "conv3x3") >= 4
-    assert sum(1 for r in timer_default.records if r[0] in ("linear", "linear_splitk")) == 3 * 2 + 2   # stage 0 + Patch-PnP fc
+    assert sum(1 for r in timer_lib.records if r[0] in ("linear", "linear_splitk")) == 3 * 2 + 2   # stage 0 + Patch-PnP fc
     torch.testing.assert_close(o3["trans"], o1["trans"], rtol=0, atol=1e-4)
     for key in ("mask", "coor_x", "coor_y", "coor_z", "region"):
         assert (o1[key] - o2[key]).abs().max().item() <= 1e-4 * max(o2[key].abs().max().item(), 1.0), key
@@ -328,7 +333,8 @@ def test_model_forward_odd_roi_count(hip):
     torch.testing.assert_close(o1["trans"], o2["trans"], rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize("m,k,n", [(128, 8192, 1024), (5, 8192, 1024), (300, 1024, 256), (64, 96, 128), (2048, 2048, 512), (2048, 512, 2048)])
+@pytest.mark.parametrize("m,k,n", [(128, 8192, 1024), (5, 8192, 1024), (300, 1024, 256), (64, 96, 128), (2048, 2048, 512), (2048, 512, 2048),
+                                   (512, 1024, 4096), (512, 4096, 1024), (4096, 2048, 512), (8192, 2048, 512), (200, 2048, 512), (256, 512, 2048)])
 def test_linear_f32_splitk(hip, m, k, n):
     """Split-K form (Patch-PnP fc layers, deep ConvNeXt stages at small ROI counts): vs fp64 as accurate as the fp32 GEMM,
     all three epilogues; deterministic across runs."""
