@@ -1,5 +1,5 @@
 """core/utils/zoom_utils.py:80-96 and core/utils/data_utils.py:65-112 with detectron2's ROIAlign replaced by the
-HIP kernel (``gdrnpp_roi_align``).  ``interpolation="nearest"`` (torchvision RoIPool) is not carried."""
+HIP kernel (``gdrnpp_roi_align``) and torchvision's RoIPool (``interpolation="nearest"``) by ``gdrnpp_roi_pool``."""
 import numpy as np
 import torch
 
@@ -8,9 +8,11 @@ from ... import hip_lib
 
 def batch_crop_resize(x, rois, out_H, out_W, aligned=True, interpolation="bilinear"):
     """x: BCHW (device), rois: Bx5 with rois[:, 0] the index into x."""
-    if interpolation != "bilinear":
-        raise NotImplementedError("only the bilinear (ROIAlign) flavour is provided")
-    return hip_lib.roi_align(x.contiguous(), rois.contiguous().float(), (out_H, out_W), 1.0, 0, aligned)
+    if interpolation == "bilinear":
+        return hip_lib.roi_align(x.contiguous(), rois.contiguous().float(), (out_H, out_W), 1.0, 0, aligned)
+    if interpolation == "nearest":
+        return hip_lib.roi_pool(x.contiguous(), rois.contiguous().float(), (out_H, out_W), 1.0)
+    raise ValueError(f"Wrong interpolation type: {interpolation}")
 
 
 _TO_CHW = {"HW": lambda a: a[None], "HWC": lambda a: np.moveaxis(a, 2, 0), "CHW": lambda a: a}

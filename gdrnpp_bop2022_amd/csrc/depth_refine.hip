@@ -67,7 +67,10 @@ __device__ __forceinline__ void face_setup(const MeshView& m, int f, const doubl
 __device__ long long g_refine_prof[16];
 #define PROF_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (k) < 16) g_refine_prof[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
 
-constexpr int kTS = 512;
+#ifndef GDRNPP_REFINE_THREADS
+#define GDRNPP_REFINE_THREADS 512
+#endif
+constexpr int kTS = GDRNPP_REFINE_THREADS;
 constexpr int kWavesS = kTS / 64;
 constexpr int kPPTS = kMaxPix / kTS;
 constexpr int kStageBytes = 40;        // staged per vertex: homogeneous pixel-space h[3] (fp64) + {u = h0/h2, v = h1/h2, z} as one fp32 float4

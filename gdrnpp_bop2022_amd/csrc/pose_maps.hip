@@ -232,7 +232,8 @@ __global__ __launch_bounds__(kRegThreads) void decode_corr_reg_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// rot_mode: 0 = 6-d representation, 1 = quaternion (w,x,y,z), 2 = rotation matrix (row-major)
+// rot_mode: 0 = 6-d representation, 1 = quaternion (w,x,y,z), 2 = rotation matrix (row-major), 3 = log-quaternion (3 values:
+//           quaternion_lf.qexp then quat2mat_torch), 4 = Lie vector / angle-axis (3 values: lie_algebra.lie_vec_to_rot)
 // t_mode:   0 = centroid_z with relative z (SITE), 1 = centroid_z with absolute z, 2 = centroid_z_abs (absolute 2-d centre
 //           and z: pose_from_pred_centroid_z_abs.py:44-76), 3 = trans (the head's output IS the translation: pose_from_pred.py:25-27)
 __global__ void pose_from_pred_kernel(const float* __restrict__ rot_in, const float* __restrict__ t_,
@@ -254,9 +255,19 @@ __global__ void pose_from_pred_kernel(const float* __restrict__ rot_in, const fl
     z0 /= nz; z1 /= nz; z2 /= nz;
     float y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0;
     Ra[0] = x0; Ra[1] = y0; Ra[2] = z0; Ra[3] = x1; Ra[4] = y1; Ra[5] = z1; Ra[6] = x2; Ra[7] = y2; Ra[8] = z2;
-  } else if (rot_mode == 1) {
+  } else if (rot_mode == 1 || rot_mode == 3) {
+    float q[4];
+    if (rot_mode == 1) {
+      for (int k = 0; k < 4; ++k) q[k] = rot_in[4 * (size_t)i + k];
+    } else {
+      // quaternion_lf.qexp on a 3-vector (core/utils/quaternion_lf.py:294-318): s = 0, theta = |v|, exp(q) = (cos theta,
+      // sin theta / max(theta, 1e-8) * v); get_rot_mat feeds it to quat2mat_torch (model_utils.py:350-352)
+      const float* v = rot_in + 3 * (size_t)i;
+      const float theta = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+      const float k = 1.0f / fmaxf(theta, 1e-8f) * sinf(theta);
+      q[0] = cosf(theta); q[1] = k * v[0]; q[2] = k * v[1]; q[3] = k * v[2];
+    }
     // quat2mat_torch (core/utils/pose_utils.py:349-400, eps = 0): normalise, then the (w,x,y,z) -> matrix polynomial
-    const float* q = rot_in + 4 * (size_t)i;
     const float nq = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
     const float qw = q[0] / nq, qx = q[1] / nq, qy = q[2] / nq, qz = q[3] / nq;
     const float X = qx * 2.f, Y = qy * 2.f, Z = qz * 2.f;
@@ -264,6 +275,22 @@ __global__ void pose_from_pred_kernel(const float* __restrict__ rot_in, const fl
     Ra[0] = 1.f - (yY + zZ); Ra[1] = xY - wZ; Ra[2] = xZ + wY;
     Ra[3] = xY + wZ; Ra[4] = 1.f - (xX + zZ); Ra[5] = yZ - wX;
     Ra[6] = xZ - wY; Ra[7] = yZ + wX; Ra[8] = 1.f - (xX + yY);
+  } else if (rot_mode == 4) {
+    // lie_algebra.lie_vec_to_rot (core/utils/lie_algebra.py:7-77, kornia's angle_axis_to_rotation_matrix): Rodrigues with the
+    // axis divided by (theta + 1e-6); theta^2 <= 1e-6 takes the first-order form I + [r]x
+    const float* v = rot_in + 3 * (size_t)i;
+    const float rx = v[0], ry = v[1], rz = v[2];
+    const float theta2 = (rx * rx + ry * ry) + rz * rz;
+    if (theta2 > 1e-6f) {
+      const float theta = sqrtf(theta2);
+      const float wx = rx / (theta + 1e-6f), wy = ry / (theta + 1e-6f), wz = rz / (theta + 1e-6f);
+      const float c = cosf(theta), sn = sinf(theta), C = 1.0f - c;
+      Ra[0] = c + wx * wx * C;       Ra[1] = wx * wy * C - wz * sn; Ra[2] = wy * sn + wx * wz * C;
+      Ra[3] = wz * sn + wx * wy * C; Ra[4] = c + wy * wy * C;       Ra[5] = -wx * sn + wy * wz * C;
+      Ra[6] = -wy * sn + wx * wz * C; Ra[7] = wx * sn + wy * wz * C; Ra[8] = c + wz * wz * C;
+    } else {
+      Ra[0] = 1.f; Ra[1] = -rz; Ra[2] = ry; Ra[3] = rz; Ra[4] = 1.f; Ra[5] = -rx; Ra[6] = -ry; Ra[7] = rx; Ra[8] = 1.f;
+    }
   } else {
     for (int k = 0; k < 9; ++k) Ra[k] = rot_in[9 * (size_t)i + k];
   }
@@ -382,7 +409,7 @@ int gdrnpp_pose_from_pred(const float* rot_in, int rot_mode, const float* t_, in
                           int b, int is_allo, void* stream) {
   if (b == 0) return 0;
   GDRNPP_REQUIRE(rot_in && t_ && cams && rot && trans, GDRNPP_EINVAL, "gdrnpp_pose_from_pred: null pointer");
-  GDRNPP_REQUIRE(b > 0 && rot_mode >= 0 && rot_mode <= 2 && t_mode >= 0 && t_mode <= 3, GDRNPP_EINVAL,
+  GDRNPP_REQUIRE(b > 0 && rot_mode >= 0 && rot_mode <= 4 && t_mode >= 0 && t_mode <= 3, GDRNPP_EINVAL,
                  "gdrnpp_pose_from_pred: b=%d rot_mode=%d t_mode=%d", b, rot_mode, t_mode);
   GDRNPP_REQUIRE(t_mode >= 2 || (centers && whs && (t_mode == 1 || resize_ratios)), GDRNPP_EINVAL,
                  "gdrnpp_pose_from_pred: centroid_z needs centers, whs (and resize_ratios for relative z)");

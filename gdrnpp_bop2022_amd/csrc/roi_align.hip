@@ -11,6 +11,7 @@
 // pw fastest (coalesced stores), grid (plane tiles, channel, ROI); taps are gathers inside one [H,W] channel plane
 // (L2-resident for image-sized inputs).  Write-bound: 4 B per output element.
 #include "common.hpp"
+#include <cfloat>
 
 namespace {
 
@@ -102,7 +103,51 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
     if (ph0 + k < PH) __builtin_nontemporal_store(acc[k] / count, out + (((size_t)n * C + c) * PH + ph0 + k) * PW + pw);
 }
 
+// torchvision.ops.RoIPool forward (the "nearest" flavour of batch_crop_resize, core/utils/zoom_utils.py:92-93): ROI corners
+// rounded half away from zero to pixels, width / height = max(end - start + 1, 1), bin [floor(p * bin), ceil((p + 1) * bin))
+// shifted by the ROI start and clipped to the image; output = max over the bin, 0 for an empty bin.  One thread per output
+// element, the bin's row segments are contiguous reads; a max is order-independent, so results equal the CPU form bit for bit.
+__global__ __launch_bounds__(256) void roi_pool_kernel(const float* __restrict__ x, const float* __restrict__ rois,
+                                                       float* __restrict__ out, int C, int H, int W, int PH, int PW,
+                                                       float spatial_scale, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int pw = (int)(i % PW), ph = (int)((i / PW) % PH), c = (int)((i / ((long)PW * PH)) % C);
+    const int n = (int)(i / ((long)PW * PH * C));
+    const float* r = rois + 5 * (size_t)n;
+    const int bi = (int)r[0];
+    const int sw = (int)roundf(r[1] * spatial_scale), sh = (int)roundf(r[2] * spatial_scale);
+    const int ew = (int)roundf(r[3] * spatial_scale), eh = (int)roundf(r[4] * spatial_scale);
+    const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    int h0 = (int)floorf((float)ph * bh), w0 = (int)floorf((float)pw * bw);
+    int h1 = (int)ceilf((float)(ph + 1) * bh), w1 = (int)ceilf((float)(pw + 1) * bw);
+    h0 = min(max(h0 + sh, 0), H); h1 = min(max(h1 + sh, 0), H);
+    w0 = min(max(w0 + sw, 0), W); w1 = min(max(w1 + sw, 0), W);
+    const bool empty = h1 <= h0 || w1 <= w0;
+    float m = empty ? 0.f : -FLT_MAX;
+    const float* img = x + ((size_t)bi * C + c) * H * W;
+    for (int hh = h0; hh < h1; ++hh)
+      for (int ww = w0; ww < w1; ++ww) {
+        const float v = img[(size_t)hh * W + ww];
+        if (v > m) m = v;
+      }
+    out[i] = m;
+  }
+}
+
 }  // namespace
+
+extern "C" int gdrnpp_roi_pool(const float* x, const float* rois, float* out, int n_rois, int C, int H, int W, int pooled_h,
+                               int pooled_w, float spatial_scale, void* stream) {
+  if (n_rois == 0) return 0;
+  GDRNPP_REQUIRE(x && rois && out, GDRNPP_EINVAL, "gdrnpp_roi_pool: null pointer");
+  GDRNPP_REQUIRE(n_rois > 0 && C > 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0, GDRNPP_EINVAL, "gdrnpp_roi_pool: bad sizes");
+  const long total = (long)n_rois * C * pooled_h * pooled_w;
+  const long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(roi_pool_kernel, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(256), 0, (hipStream_t)stream,
+                     x, rois, out, C, H, W, pooled_h, pooled_w, spatial_scale, total);
+  return gdrnpp::check_launch("gdrnpp_roi_pool");
+}
 
 extern "C" int gdrnpp_roi_align(const float* x, const float* rois, float* out, int n_rois, int C, int H, int W,
                                 int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned,

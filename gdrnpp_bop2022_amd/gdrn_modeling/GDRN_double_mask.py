@@ -231,8 +231,12 @@ class GDRN_DoubleMask(nn.Module):
             rot_mode = "rot6d"
         elif rot_type in ("allo_quat", "ego_quat"):
             rot_mode = "quat"
+        elif rot_type in ("allo_log_quat", "ego_log_quat"):
+            rot_mode = "log_quat"
+        elif rot_type in ("allo_lie_vec", "ego_lie_vec"):
+            rot_mode = "lie_vec"
         else:
-            raise NotImplementedError(f"ROT_TYPE={rot_type} (log-quaternion / Lie-vector heads are not used by the GDRNPP configs)")
+            raise ValueError(f"Wrong pred_rot type: {rot_type}")      # model_utils.py:358
         trans_type = pnp_net_cfg.TRANS_TYPE
         if trans_type == "centroid_z":
             if pnp_net_cfg.Z_TYPE not in ("REL", "ABS"):
@@ -282,7 +286,9 @@ def build_model_optimizer(cfg, is_test=True, model_cls=None):
     n_in += 2 if p.WITH_2D_COORD else 0
     n_in += g.NUM_REGIONS if p.REGION_ATTENTION else 0
     n_in += 1 if p.MASK_ATTENTION == "concat" else 0
-    rot_dim = {"allo_rot6d": 6, "ego_rot6d": 6, "allo_quat": 4, "ego_quat": 4}[p.ROT_TYPE]
+    # model_utils.py:219-230: quaternion 4, log-quaternion / Lie vector 3, else 6
+    rot_dim = {"allo_rot6d": 6, "ego_rot6d": 6, "allo_quat": 4, "ego_quat": 4, "allo_log_quat": 3, "ego_log_quat": 3,
+               "allo_lie_vec": 3, "ego_lie_vec": 3}[p.ROT_TYPE]
     pnp_cfg = copy.deepcopy(dict(p.INIT_CFG))
     pnp_type = pnp_cfg.pop("type")
     pnp_cfg.update(nIn=n_in, rot_dim=rot_dim, num_regions=g.NUM_REGIONS, mask_attention_type=p.MASK_ATTENTION)

@@ -182,8 +182,11 @@ def gdrn_inference_on_dataset(cfg, model, data_loader, evaluator, amp_test=False
     """gdrn_evaluator.py:668-809: the inference loop with the reference's timing protocol — host ``perf_counter``, device
     synchronise before the clock stops, the first ``min(5, total - 1)`` iterations discarded — returning
     ``evaluator.evaluate()`` (or ``{}``).  ``stats`` of the run are left on ``gdrn_inference_on_dataset.last_stats``."""
-    if amp_test:
-        raise NotImplementedError("TEST.AMP_TEST: the parity configuration is fp32 (common_base.py:219)")
+    # TEST.AMP_TEST (gdrn_evaluator.py:736-747: ``with autocast(enabled=amp_test)`` around the forward).  The HIP network
+    # layers of this library are fp32 computations (the parity configuration, common_base.py:219); under AMP the forward runs
+    # as the plain PyTorch module graph inside ``torch.autocast`` — the reference's own mixed-precision path — and the outputs
+    # are cast back to fp32 for the HIP post-processing.
+    from . import hip_layers
     total = len(data_loader)
     evaluator.reset()
     num_warmup = min(5, total - 1)
@@ -207,11 +210,20 @@ def gdrn_inference_on_dataset(cfg, model, data_loader, evaluator, amp_test=False
                 names = [evaluator.obj_names[_l] for _l in batch["roi_cls"].cpu().numpy().tolist()]
                 if all(_o not in evaluator.train_objs for _o in names):
                     continue
-            out_dict = model(
-                batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"], roi_whs=batch["roi_wh"],
-                roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"],
-                roi_coord_2d=batch.get("roi_coord_2d", None), roi_coord_2d_rel=batch.get("roi_coord_2d_rel", None),
-                roi_extents=batch.get("roi_extent", None))
+            hip_on = hip_layers.is_enabled()
+            if amp_test:
+                hip_layers.set_enabled(False)
+            try:
+                with torch.autocast("cuda", dtype=torch.float16, enabled=bool(amp_test) and dev.type == "cuda"):
+                    out_dict = model(
+                        batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"], roi_whs=batch["roi_wh"],
+                        roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"],
+                        roi_coord_2d=batch.get("roi_coord_2d", None), roi_coord_2d_rel=batch.get("roi_coord_2d_rel", None),
+                        roi_extents=batch.get("roi_extent", None))
+            finally:
+                hip_layers.set_enabled(hip_on)
+            if amp_test:
+                out_dict = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in out_dict.items()}
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             cur_compute_time = time.perf_counter() - start_compute_time

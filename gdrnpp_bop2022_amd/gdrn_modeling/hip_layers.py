@@ -17,6 +17,10 @@ def set_enabled(flag: bool) -> None:
     _ENABLED = bool(flag)
 
 
+def is_enabled() -> bool:
+    return _ENABLED
+
+
 def enabled_for(x: torch.Tensor) -> bool:
     return _ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
 

@@ -82,6 +82,7 @@ SIGNATURES = {
     "gdrnpp_conv2d_f32_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_conv3x3_f32_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_roi_align": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
+    "gdrnpp_roi_pool": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "gdrnpp_debug_stream_read": (c_int, [_P, c_size_t, c_int, _P, c_int, _P]),
     "gdrnpp_crop_resize_roi": (
         c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
@@ -278,12 +279,12 @@ def pose_from_pred_centroid_z(rot6d, t_, cams, centers, whs, resize_ratios, z_ty
 
 def pose_from_pred(rot_in, t_, cams, centers=None, whs=None, resize_ratios=None, rot_mode: str = "rot6d",
                    t_mode: str = "centroid_z_rel", is_allo: bool = True):
-    """``gdrnpp_pose_from_pred``: every ROT_TYPE (rot6d / quat / matrix) x TRANS_TYPE (centroid_z REL or ABS,
-    centroid_z_abs, trans) combination of GDRN_double_mask.py:162-200 -> (R_ego f32[b,3,3], t f32[b,3])."""
+    """``gdrnpp_pose_from_pred``: every ROT_TYPE (rot6d / quat / log_quat / lie_vec / matrix) x TRANS_TYPE (centroid_z REL or
+    ABS, centroid_z_abs, trans) combination of GDRN_double_mask.py:162-200 -> (R_ego f32[b,3,3], t f32[b,3])."""
     b = rot_in.shape[0]
     rot = torch.empty((b, 3, 3), dtype=torch.float32, device=rot_in.device)
     trans = torch.empty((b, 3), dtype=torch.float32, device=rot_in.device)
-    rm = {"rot6d": 0, "quat": 1, "mat": 2}[rot_mode]
+    rm = {"rot6d": 0, "quat": 1, "mat": 2, "log_quat": 3, "lie_vec": 4}[rot_mode]
     tm = {"centroid_z_rel": 0, "centroid_z_abs_z": 1, "centroid_z_abs": 2, "trans": 3}[t_mode]
     opt = lambda x, n: _dev(x, torch.float32, n) if x is not None else None  # noqa: E731
     _check(load().gdrnpp_pose_from_pred(_dev(rot_in, torch.float32, "rot_in"), rm, _dev(t_, torch.float32, "t_"), tm,
@@ -496,6 +497,18 @@ def roi_align(x, rois, output_size, spatial_scale: float = 1.0, sampling_ratio: 
     _check(load().gdrnpp_roi_align(_dev(x, torch.float32, "x"), _dev(rois, torch.float32, "rois"), out.data_ptr(), n, c,
                                    h, w, oh, ow, float(spatial_scale), int(sampling_ratio), 1 if aligned else 0,
                                    _stream()), "gdrnpp_roi_align")
+    return out
+
+
+def roi_pool(x, rois, output_size, spatial_scale: float = 1.0):
+    """torchvision.ops.RoIPool(output_size, spatial_scale)(x, rois): x f32[B,C,H,W] (NCHW contiguous), rois f32[N,5] ->
+    f32[N,C,oh,ow] (max over integer pixel bins)."""
+    oh, ow = (output_size, output_size) if isinstance(output_size, int) else output_size
+    bsz, c, h, w = x.shape
+    n = rois.shape[0]
+    out = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
+    _check(load().gdrnpp_roi_pool(_dev(x, torch.float32, "x"), _dev(rois, torch.float32, "rois"), out.data_ptr(), n, c, h, w,
+                                  oh, ow, float(spatial_scale), _stream()), "gdrnpp_roi_pool")
     return out
 
 

@@ -205,7 +205,9 @@ int gdrnpp_pose_from_pred_centroid_z(const float* rot6d, const float* t_,
                                      int is_allo, void* stream);
 /* the other ROT_TYPE / TRANS_TYPE variants of GDRN_double_mask.py:162-200 through the same kernel:
  * rot_mode 0 = 6-d representation f32[b,6], 1 = quaternion (w,x,y,z) f32[b,4] (quat2mat_torch, pose_utils.py:349-400),
- *          2 = rotation matrix f32[b,9];
+ *          2 = rotation matrix f32[b,9], 3 = log-quaternion f32[b,3] (quaternion_lf.qexp, core/utils/quaternion_lf.py:294-318,
+ *          then quat2mat_torch), 4 = Lie vector / angle-axis f32[b,3] (lie_algebra.lie_vec_to_rot, core/utils/lie_algebra.py:7-77)
+ *          — get_rot_mat, model_utils.py:347-359;
  * t_mode   0 = centroid_z with relative z, 1 = centroid_z with absolute z, 2 = centroid_z_abs (absolute 2-d centre and z,
  *          pose_from_pred_centroid_z_abs.py:44-76; centers / whs / resize_ratios unused), 3 = trans (t_ is the translation,
  *          pose_from_pred.py:25-27). */
@@ -330,6 +332,11 @@ int gdrnpp_crop_resize_roi(const unsigned char* images, const float* depths, int
 int gdrnpp_roi_align(const float* x, const float* rois, float* out, int n_rois, int C,
                      int H, int W, int pooled_h, int pooled_w, float spatial_scale,
                      int sampling_ratio, int aligned, void* stream);
+
+/* the "nearest" flavour of batch_crop_resize (core/utils/zoom_utils.py:92-93): torchvision RoIPool(output_size, spatial_scale)
+ * forward — max over integer pixel bins, 0 for an empty bin.  Same tensor conventions as gdrnpp_roi_align. */
+int gdrnpp_roi_pool(const float* x, const float* rois, float* out, int n_rois, int C, int H, int W, int pooled_h, int pooled_w,
+                    float spatial_scale, void* stream);
 
 /* ---- fp32 linear layer with fused epilogue (ConvNeXt Mlp of GDRN_Net, a3) --------------------------------------
  * C[M,N] = A[M,K] * W[N,K]^T + bias[N]; epilogue 0 = none, 1 = exact-erf GELU (timm Mlp.fc1 + act),

@@ -463,6 +463,18 @@ def roi_align(x, rois, output_size, spatial_scale=1.0, sampling_ratio=0, aligned
     return out
 
 
+def roi_pool(x, rois, output_size, spatial_scale=1.0):
+    """torchvision RoIPool forward (oracle/roi_align_oracle.c): x f32[B,C,H,W], rois f32[N,5] -> f32[N,C,oh,ow]."""
+    oh, ow = (output_size, output_size) if isinstance(output_size, int) else output_size
+    x = np.ascontiguousarray(x, np.float32)
+    rois = np.ascontiguousarray(rois, np.float32)
+    b, c, h, w = x.shape
+    out = np.zeros((rois.shape[0], c, oh, ow), np.float32)
+    _lib().oracle_roi_pool(_p(x, _f32p), _p(rois, _f32p), _p(out, _f32p), rois.shape[0], c, h, w, oh, ow,
+                           ctypes.c_float(spatial_scale))
+    return out
+
+
 def yolox_postprocess(det_preds, num_classes, conf_thre=0.7, nms_thre=0.45, class_agnostic=False):
     """det/yolox/utils/boxes.py:34-74 restated (oracle/nms_oracle.c): det_preds f32[B,A,5+C] -> list of f32[n_i,7]
     (x1, y1, x2, y2, obj_conf, class_conf, class) per image in NMS keep order (None when nothing survives)."""

@@ -54,3 +54,36 @@ void oracle_roi_align(const float* x, const float* rois, float* out, int n_rois,
     }
   }
 }
+
+/* torchvision.ops.RoIPool forward (core/utils/zoom_utils.py:92-93, interpolation = "nearest") restated from its published
+ * CPU kernel (torchvision/csrc/ops/cpu/roi_pool_kernel.cpp): corners rounded with round() (half away from zero), width /
+ * height = max(end - start + 1, 1), bin = [floor(p * bin_size), ceil((p + 1) * bin_size)) + start, clipped to the image;
+ * max over the bin, 0 when empty.  PARITY UNPINNED (torchvision not importable here). */
+void oracle_roi_pool(const float* x, const float* rois, float* out, int n_rois, int C, int H, int W, int PH, int PW,
+                     float spatial_scale) {
+  for (int n = 0; n < n_rois; ++n) {
+    const float* r = rois + 5 * n;
+    int bi = (int)r[0];
+    int sw = (int)roundf(r[1] * spatial_scale), sh = (int)roundf(r[2] * spatial_scale);
+    int ew = (int)roundf(r[3] * spatial_scale), eh = (int)roundf(r[4] * spatial_scale);
+    int rw = ew - sw + 1 > 1 ? ew - sw + 1 : 1, rh = eh - sh + 1 > 1 ? eh - sh + 1 : 1;
+    float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    for (int ph = 0; ph < PH; ++ph)
+      for (int pw = 0; pw < PW; ++pw) {
+        int h0 = (int)floorf((float)ph * bh), w0 = (int)floorf((float)pw * bw);
+        int h1 = (int)ceilf((float)(ph + 1) * bh), w1 = (int)ceilf((float)(pw + 1) * bw);
+        h0 += sh; h1 += sh; w0 += sw; w1 += sw;
+        h0 = h0 < 0 ? 0 : (h0 > H ? H : h0); h1 = h1 < 0 ? 0 : (h1 > H ? H : h1);
+        w0 = w0 < 0 ? 0 : (w0 > W ? W : w0); w1 = w1 < 0 ? 0 : (w1 > W ? W : w1);
+        int empty = h1 <= h0 || w1 <= w0;
+        for (int c = 0; c < C; ++c) {
+          const float* img = x + ((long)bi * C + c) * H * W;
+          float m = empty ? 0.f : -3.402823466e+38f;
+          for (int hh = h0; hh < h1; ++hh)
+            for (int ww = w0; ww < w1; ++ww)
+              if (img[hh * W + ww] > m) m = img[hh * W + ww];
+          out[(((long)n * C + c) * PH + ph) * PW + pw] = m;
+        }
+      }
+  }
+}

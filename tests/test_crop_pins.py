@@ -176,3 +176,41 @@ def test_nms_oracle_closed_form_cases():
     np.testing.assert_allclose(out[:, 0], [0, 8], atol=1e-5)
     # score threshold: obj * class_conf >= conf_thre
     assert P.yolox_postprocess(_preds([[0, 0, 10, 10]], [0.5], [0], 1), 1, 0.7, 0.45)[0] is None
+
+
+def test_roi_pool_oracle_against_an_independent_formulation_and_closed_forms():
+    """RoIPool (batch_crop_resize(interpolation="nearest"), core/utils/zoom_utils.py:92-93): torchvision is absent, so the
+    restatement (oracle/roi_align_oracle.c, parity unpinned) is held against an independent NumPy formulation of the published
+    definition and against closed forms: a pixel-aligned box with one pixel per bin returns the pixels themselves; a box outside
+    the image returns zeros; with the box equal to the image and an evenly dividing output it equals max pooling."""
+    import math
+
+    import torch
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((2, 3, 17, 23)).astype(np.float32)
+    rois = np.array([[0, 2, 3, 9, 10], [1, -4.4, -2.6, 6.5, 7.49], [0, 30, 30, 40, 40], [1, 0.49, 0.51, 21.7, 15.2],
+                     [0, 5, 5, 5, 5], [1, 10.5, 2.5, 3.5, 1.5]], np.float32)
+    out = P.roi_pool(x, rois, (4, 5))
+
+    def rnd(v):                                    # std::round: half away from zero
+        return int(math.floor(abs(float(v)) + 0.5) * (1 if v >= 0 else -1))
+
+    for n, r in enumerate(rois):
+        sw, sh, ew, eh = rnd(r[1]), rnd(r[2]), rnd(r[3]), rnd(r[4])
+        rw, rh = max(ew - sw + 1, 1), max(eh - sh + 1, 1)
+        bh, bw = np.float32(rh) / np.float32(4), np.float32(rw) / np.float32(5)
+        for ph in range(4):
+            for pw in range(5):
+                h0 = min(max(int(np.floor(np.float32(ph) * bh)) + sh, 0), 17)
+                h1 = min(max(int(np.ceil(np.float32(ph + 1) * bh)) + sh, 0), 17)
+                w0 = min(max(int(np.floor(np.float32(pw) * bw)) + sw, 0), 23)
+                w1 = min(max(int(np.ceil(np.float32(pw + 1) * bw)) + sw, 0), 23)
+                want = x[int(r[0]), :, h0:h1, w0:w1].reshape(3, -1).max(1) if (h1 > h0 and w1 > w0) else np.zeros(3, np.float32)
+                assert np.array_equal(out[n, :, ph, pw], want), (n, ph, pw)
+    assert not out[2].any()                                                        # box outside the image
+    px = P.roi_pool(x, np.array([[0, 4, 6, 8, 9]], np.float32), (4, 5))            # 5 x 4 pixels, one per bin
+    assert np.array_equal(px[0], x[0, :, 6:10, 4:9])
+    whole = P.roi_pool(x[:, :, :16, :20], np.array([[1, 0, 0, 19, 15]], np.float32), (4, 5))
+    assert np.array_equal(whole[0], F.max_pool2d(torch.from_numpy(x[1:2, :, :16, :20]), 4)[0].numpy())

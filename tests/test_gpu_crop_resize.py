@@ -63,6 +63,28 @@ def test_roi_align_matches_oracle_and_torch_reference(hip):
     np.testing.assert_array_equal(r, out[0].transpose(1, 2, 0))
 
 
+def test_roi_pool_matches_oracle_bit_for_bit(hip):
+    """batch_crop_resize(..., interpolation="nearest") = torchvision RoIPool (core/utils/zoom_utils.py:92-93): the HIP kernel
+    against the CPU restatement, boxes inside, across and outside the image, half-integer corners (round half away from zero)."""
+    from gdrnpp_bop2022_amd.core.utils.zoom_utils import batch_crop_resize
+
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((3, 4, 60, 80)).astype(np.float32)
+    n = 40
+    x1 = rng.uniform(-20, 70, n); y1 = rng.uniform(-20, 50, n)
+    rois = np.stack([rng.integers(0, 3, n), x1, y1, x1 + rng.uniform(0, 60, n), y1 + rng.uniform(0, 50, n)], 1).astype(np.float32)
+    rois[:6, 1:] = np.round(rois[:6, 1:]) + 0.5                     # .5 corners
+    rois[6] = [1, 100, 100, 120, 130]                                # outside: zeros
+    for size in (16, (7, 5)):
+        oh, ow = (size, size) if isinstance(size, int) else size
+        out = batch_crop_resize(torch.from_numpy(x).to(DEV), torch.from_numpy(rois).to(DEV), oh, ow, interpolation="nearest")
+        ref = P.roi_pool(x, rois, (oh, ow))
+        assert out.shape == ref.shape and np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert not out[6].any()
+    with pytest.raises(ValueError):
+        batch_crop_resize(torch.from_numpy(x).to(DEV), torch.from_numpy(rois).to(DEV), 8, 8, interpolation="bicubic")
+
+
 def test_batch_data_test_gpu_end_to_end(hip):
     """detections -> GPU crops -> batch dict -> GDRN_Net forward + refine: shapes and values consistent with the
     per-ROI oracle crop."""

@@ -90,3 +90,12 @@ def test_inference_loop_protocol(hip, tmp_path):
     assert len(ev._predictions) == sum(len(b[0]["roi_cls"]) for b in loader)
     assert all(np.isfinite(p["t"]).all() and p["time"] > 0.01 for p in ev._predictions)
     assert len(open(tmp_path / "ycbv-convnext-a6-iter0_ycbv-test.csv").read().strip().split("\n")) == 1 + len(ev._predictions)
+    # TEST.AMP_TEST (gdrn_evaluator.py:736-747): the forward under torch.autocast(fp16) as the plain module graph, fp32
+    # post-processing — same records to mixed-precision accuracy, and the fp32 HIP path is back on afterwards
+    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
+    fp32 = [(p["R"], p["t"]) for p in ev._predictions]
+    assert gdrn_inference_on_dataset(cfg, model, loader, ev, amp_test=True) == {}
+    assert hip_layers.is_enabled() and len(ev._predictions) == len(fp32)
+    for p, (R, t) in zip(ev._predictions, fp32):
+        assert np.abs(np.array(p["R"]) - np.array(R)).max() < 5e-2
+        assert np.isfinite(p["t"]).all()

@@ -583,3 +583,34 @@ def test_pose_from_pred_variants(hip):
     K = cams.view(b, 3, 3)
     want = torch.stack([c[:, 2] * (c[:, 0] - K[:, 0, 2]) / K[:, 0, 0], c[:, 2] * (c[:, 1] - K[:, 1, 2]) / K[:, 1, 1], c[:, 2]], 1)
     assert torch.equal(ta, want)
+
+
+def test_rot_types_match_reference_get_rot_mat(hip, golden_dir):
+    """Every ROT_TYPE family of get_rot_mat (model_utils.py:347-359) — quaternion, log-quaternion (quaternion_lf.qexp),
+    Lie vector (lie_algebra.lie_vec_to_rot, incl. its first-order small-angle branch) and rot6d — against the reference's own
+    functions run from source (tests/golden/make_golden_rot.py -> rot_golden.npz); 2e-6 (fp32 sin / cos of the device)."""
+    g = np.load(f"{golden_dir}/rot_golden.npz")
+    b = g["quat_in"].shape[0]
+    cams = T(np.repeat(S.YCBV_K.reshape(1, 9), b, 0))
+    t_ = torch.zeros(b, 3, device=DEV)
+    t_[:, 2] = 1.0
+    for mode in ("quat", "log_quat", "lie_vec", "rot6d"):
+        R, _ = hip.pose_from_pred(T(g[mode + "_in"]), t_, cams, rot_mode=mode, t_mode="trans", is_allo=False)
+        err = np.abs(R.cpu().numpy() - g[mode + "_R"]).max()
+        assert err < 2e-6, (mode, err)
+    # and through GDRN_Net.forward: the config surface accepts the types (rot_dim 3) and returns orthonormal rotations
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+    from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+    for rt in ("allo_log_quat", "ego_lie_vec"):
+        cfg = get_cfg("lmo_resnet34_ape", [f"MODEL.POSE_NET.PNP_NET.ROT_TYPE={rt}"])
+        torch.manual_seed(0)
+        model, _ = build_model_optimizer(cfg)
+        assert model.pnp_net.fc_r.out_features == 3
+        x = torch.rand(3, 3, 256, 256, device=DEV)
+        with torch.no_grad():
+            out = model(x, roi_classes=torch.zeros(3, dtype=torch.long, device=DEV), roi_cams=cams[:3].view(3, 3, 3),
+                        roi_whs=torch.full((3, 2), 100.0, device=DEV), roi_centers=torch.full((3, 2), 240.0, device=DEV),
+                        resize_ratios=torch.full((3,), 0.4, device=DEV), roi_coord_2d=torch.rand(3, 2, 64, 64, device=DEV),
+                        roi_extents=torch.full((3, 3), 0.1, device=DEV))
+        Rm = out["rot"].double()
+        assert (Rm @ Rm.transpose(1, 2) - torch.eye(3, device=DEV, dtype=torch.float64)).abs().max().item() < 1e-5
