@@ -21,6 +21,20 @@ using f4 = __attribute__((ext_vector_type(4))) float;
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ f4 ld4v(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streaming store: the big activation tensors (hundreds of MB at the headline batch) are written once and read back by the next
+// layer after everything else in between.  Round 3 measured it: dwconv+LN alone 2.63 -> 2.46 ms per forward, the whole step
+// unchanged (36.30 vs 36.25 ms, three same-box pairs, gpurun_out/r03k) — the consumers pay it back; off by default
+#ifndef NK_NT_STORE
+#define NK_NT_STORE 0
+#endif
+__device__ __forceinline__ void st4s(float* p, float4 v) {
+#if NK_NT_STORE
+  const f4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
@@ -65,6 +79,9 @@ __device__ __forceinline__ float group_sum_dpp(float s, int width, int lane) {
 #endif
 #ifndef DW_PK
 #define DW_PK 1
+#endif
+#ifndef DW_NT_STORE
+#define DW_NT_STORE 0
 #endif
 __device__ __forceinline__ f4 fma4s(f4 a, f4 b, f4 c) {
   return f4{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
@@ -260,7 +277,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DW_WPE))) v
 #pragma unroll
       for (int j = 0; j < TW; ++j) {
         const int oy = ty0 + i, ox = tx0 + j;
+#if DW_NT_STORE
+        if (oy < H && ox < W) __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f4*>(yn + ((size_t)oy * W + ox) * C));
+#else
         if (oy < H && ox < W) *reinterpret_cast<f4*>(yn + ((size_t)oy * W + ox) * C) = acc[i][j];
+#endif
       }
   }
   }  // tile-group loop
@@ -294,7 +315,7 @@ __global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict
     o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
     o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
     o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
-    st4(y + (((size_t)n * OH + oy) * OW + ox) * C + 4 * q, o);
+    st4s(y + (((size_t)n * OH + oy) * OW + ox) * C + 4 * q, o);
   }
 }
 
@@ -432,7 +453,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     v.z = (v.z - m) * r * ga.z + be.z;
     v.w = (v.w - m) * r * ga.w + be.w;
     if (GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-    st4(y + off, v);
+    st4s(y + off, v);
   }
 }
 
