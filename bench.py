@@ -88,7 +88,6 @@ def parse(argv=None):
                    help="run the reference's full 1470-channel output layer + gather instead of the class-sliced one")
     p.add_argument("--no-hip-layers", action="store_true", help="A/B: run the memory-bound network layers with PyTorch ops")
     p.add_argument("--no-conv-gn-fusion", action="store_true", help="A/B: GroupNorm statistics in their own pass instead of the conv epilogue")
-    p.add_argument("--no-fused-mlp", action="store_true", help="A/B: stage-0 ConvNeXt MLPs as two split-GEMM launches instead of the fused one")
     p.add_argument("--mlp-gemm", choices=["split", "torch"], default="split",
                    help="GEMM engine of the ConvNeXt MLPs / head convolutions: split = exact 3-way bf16 operand split on the "
                         "bf16 matrix cores (fp32-accurate); torch = hipBLASLt / MIOpen fp32 + separate elementwise kernels")
@@ -277,7 +276,6 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
     hip_layers.set_enabled(not args.no_hip_layers)
     hip_layers.set_conv_gn_fused(not args.no_conv_gn_fusion)
     hip_layers.set_mlp_gemm(args.mlp_gemm)
-    hip_layers.set_fused_mlp_c128(not args.no_fused_mlp)
     opts = ["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"] if refine else []
 
     def T(a):

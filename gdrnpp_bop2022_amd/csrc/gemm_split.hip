@@ -25,7 +25,6 @@
 //      ds_read_b128 lane group read 32 consecutive slots (conflict-free), a fragment is one ds_read_b128;
 //   per k-tile: 12 fragment reads (ds_read_b128) feed 24 MFMAs.
 #include "gemm_split.hpp"
-#include <type_traits>
 
 namespace {
 
@@ -535,253 +534,6 @@ int launch_split(const float* A, const uint4* Wp, const float* bias, const float
 }
 
 
-// --------------------------------------------------------------------------------------------------------------------
-// Fused ConvNeXt MLP for the shallow stage (C = 128, hidden 512):  y = resid + gamma * (fc2(gelu(fc1(x))))  in ONE launch.
-//
-// Why: all eight MLP GEMMs of a ConvNeXt-B block have the same 34.4 G multiply-adds, yet at 128 ROIs stage-0 fc1 takes 616 us
-// and fc2 422 us against 300-330 us for the deep stages (tools/mlp_shapes.py, profiles/r03*): K = 128 gives an output tile only
-// 8 k-tiles of matrix work before 128 KB of epilogue stores, and the 1.07 GB hidden tensor is written and read back.  Here a
-// workgroup owns 128 rows: x (64 KB) stays in LDS, the hidden tile is produced 128 columns at a time (GEMM 1, K = 128),
-// passed through bias + GELU and parked in LDS in the same raw-fp32 "A image" the fragment loader of the split GEMM reads
-// (64 KB), and consumed at once by GEMM 2 (K chunk of 128 -> the 128 output columns, accumulators stay in registers across the
-// four chunks).  The hidden tensor never exists; per row 512 B in + 512 B residual + 512 B out instead of 5 KB.
-//
-// Numerics: the same six partial products in the same order per accumulator, the same k order, the same epilogue expressions
-// as gemm_split_pipe_kernel -> the result is BITWISE equal to the two-launch path (tests/test_gpu_net_kernels.py).
-//
-// 8 waves = 4 row groups of 32 rows x 2 column halves of 64 (two waves per SIMD: with one, every LDS read / split / barrier of a
-// k-tile sat in front of its 24 MFMAs and the kernel ran at 128 TFLOP/s fp32-equivalent, no faster than the two launches);
-// weights stream through two 12 KB LDS stages by LDS-DMA, one tile (128 x 16 of W1 or W2) per k-tile, one barrier per k-tile.
-// LDS: 64 (x) + 64 (hidden) + 24 (weights) = 152 KB -> one workgroup per CU.
-// --------------------------------------------------------------------------------------------------------------------
-constexpr int FM_ROWS = 128, FM_C = 128, FM_HID = 512;
-constexpr int FM_X_SLOTS = (FM_C / BK) * FM_ROWS * 4;    // 8 k-tiles x 128 rows x 4 chunks of 16 B
-constexpr int FM_H_SLOTS = (128 / BK) * FM_ROWS * 4;     // one 128-column chunk of the hidden tile
-#ifndef FM_NH
-#define FM_NH 2   // column halves per row group: 2 = eight waves of 32 x 64 (two per SIMD), 1 = four waves of 32 x 128
-#endif
-constexpr int FM_NJ = 4 / FM_NH, FM_THREADS = 256 * FM_NH;
-constexpr int FM_LDS_BYTES = (FM_X_SLOTS + FM_H_SLOTS + 2 * GB_SLOTS) * 16;
-
-__global__ __launch_bounds__(FM_THREADS, 1) void mlp_fused_c128_kernel(const float* __restrict__ X, const uint4* __restrict__ W1p,
-                                                                const float* __restrict__ b1, const uint4* __restrict__ W2p,
-                                                                const float* __restrict__ b2, const float* __restrict__ gamma,
-                                                                const float* __restrict__ resid, float* __restrict__ Y, int M) {
-  extern __shared__ uint4 fm_smem[];
-  uint4* const sX = fm_smem;
-  uint4* const sH = fm_smem + FM_X_SLOTS;
-  uint4* const sB = fm_smem + FM_X_SLOTS + FM_H_SLOTS;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 8 waves: two per SIMD, so one wave's LDS / VALU phases hide
-  const int rg = wave & 3, nh = wave >> 2;                      // (FM_NH = 1: four waves, nh = 0, 32 rows x 128 columns each)                      // behind the other's MFMAs; wave = 32 rows (rg) x 64 columns (nh)
-  const int m0 = blockIdx.x * FM_ROWS;
-  constexpr int NK1 = FM_C / BK, NK2C = 128 / BK, NCH = FM_HID / 128;   // 8 k-tiles per GEMM-1 chunk, 8 per GEMM-2 chunk, 4 chunks
-  constexpr int NT = NCH * (NK1 + NK2C);                                // weight tiles per workgroup: 64
-
-  // ---- x tile -> LDS (A image per k-tile, swizzle on the source side): wave w stages rows 16 w .. 16 w + 15
-  const int prow = lane >> 2, pq = lane & 3;
-  {
-    const unsigned ldsX = lds_addr(sX);
-#pragma unroll
-    for (int c = 0; c < FM_NJ / 2; ++c) {       // 16-row pieces per wave: one (8 waves) or two (4 waves)
-      const int piece = wave * (FM_NJ / 2) + c, lrow = piece * 16 + prow;
-      const int q = pq ^ ((lrow >> 2) & 3);
-      const float* src = X + (size_t)min(m0 + lrow, M - 1) * FM_C + q * 4;
-#pragma unroll
-      for (int kt = 0; kt < NK1; ++kt) glds16(src + kt * BK, ldsX + (unsigned)(kt * (FM_ROWS * 4) + piece * 64) * 16u);
-    }
-  }
-  // ---- weight tile t of the workgroup's sequence: chunk j = t / 16; first 8 = W1 tile (n-tile j, k-tile t % 16), last 8 = W2
-  // tile (n-tile 0, k-tile 8 j + t % 16 - 8); 12 pieces of 1 KB: waves 0-3 two each, waves 4-7 one each
-  const int np = FM_NH == 1 ? 3 : (wave < 4 ? 2 : 1), p0 = FM_NH == 1 ? 3 * wave : (wave < 4 ? 2 * wave : 4 + wave);
-  const unsigned ldsB = lds_addr(sB) + (unsigned)p0 * 1024u;
-  auto issue_b = [&](int t, int stage) {
-    const int j = t >> 4, u = t & 15;
-    const uint4* w = (u < NK1 ? W1p + ((size_t)j * NK1 + u) * W_TILE_SLOTS : W2p + ((size_t)j * NK2C + (u - NK1)) * W_TILE_SLOTS) +
-                     p0 * 64 + lane;
-    const unsigned db = ldsB + (unsigned)stage * (GB_SLOTS * 16u);
-    glds16(w, db);
-    if (np >= 2) glds16(w + 64, db + 1024u);
-    if (np == 3) glds16(w + 128, db + 2048u);
-  };
-
-  const int frow = lane & 31, fk = lane >> 5;
-  const int lrow_f = rg * 32 + frow, gsw = (lrow_f >> 2) & 3;
-  const int aslot0 = 4 * lrow_f + ((2 * fk) ^ gsw), aslot1 = 4 * lrow_f + ((2 * fk + 1) ^ gsw);
-
-  f32x16 acc1[FM_NJ], acc2[FM_NJ];
-#pragma unroll
-  for (int j = 0; j < FM_NJ; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
-
-  // Register-level pipeline over the 64 weight tiles: while the matrix pipe works on tile t (fragments in registers), the wave
-  // reads the fragments of tile t+1 from LDS and splits its A half, and the LDS-DMA of tile t+2 is in flight into the stage
-  // tile t has left (its fragments were read during iteration t-1).  One barrier per k-tile, at the top, publishes tile t+1.
-  struct Frags { bf16x8 fa[3]; bf16x8 fb[3][FM_NJ]; };
-  auto load_b = [&](Frags& f, int stage) {
-    const uint4* bp = sB + stage * GB_SLOTS + fk * BN + nh * 64 + frow;
-#pragma unroll
-    for (int sp = 0; sp < 3; ++sp)
-#pragma unroll
-      for (int j = 0; j < FM_NJ; ++j) f.fb[sp][j] = __builtin_bit_cast(bf16x8, bp[sp * KB * BN + j * 32]);
-  };
-  auto load_a = [&](Frags& f, const uint4* a) {
-    const float4 r0 = __builtin_bit_cast(float4, a[aslot0]), r1 = __builtin_bit_cast(float4, a[aslot1]);
-    const Split3 p0s = split_pair(r0.x, r0.y), p1s = split_pair(r0.z, r0.w), p2s = split_pair(r1.x, r1.y), p3s = split_pair(r1.z, r1.w);
-    f.fa[0] = __builtin_bit_cast(bf16x8, make_uint4(p0s.h, p1s.h, p2s.h, p3s.h));
-    f.fa[1] = __builtin_bit_cast(bf16x8, make_uint4(p0s.m, p1s.m, p2s.m, p3s.m));
-    f.fa[2] = __builtin_bit_cast(bf16x8, make_uint4(p0s.l, p1s.l, p2s.l, p3s.l));
-  };
-  auto mma = [&](const Frags& f, f32x16 (&acc)[FM_NJ]) {
-#ifdef FM_TIMING_NO_MFMA
-    acc[0][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, f.fa[0]).x ^ __builtin_bit_cast(uint4, f.fb[0][0]).x ^ __builtin_bit_cast(uint4, f.fb[1][1]).y ^ __builtin_bit_cast(uint4, f.fb[2][0]).z ^ __builtin_bit_cast(uint4, f.fa[2]).w);
-    return;
-#endif
-    GDRNPP_SPLIT_PRODUCT_ORDER
-#pragma unroll
-    for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-      for (int j = 0; j < FM_NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.fa[TA[t6]], f.fb[TB[t6]][j], acc[j], 0, 0, 0);
-  };
-  // A image of tile t: GEMM-1 tiles read x, GEMM-2 tiles the hidden chunk
-  auto a_image = [&](int t) -> const uint4* {
-    const int u = t & 15;
-    return u < NK1 ? sX + u * (FM_ROWS * 4) : sH + (u - NK1) * (FM_ROWS * 4);
-  };
-
-  float* const sHf = reinterpret_cast<float*>(sH);
-  Frags f0, f1;
-  issue_b(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  issue_b(1, 1);
-  load_b(f0, 0);
-  load_a(f0, a_image(0));
-
-  // one iteration: tile t in `cur`, tile t+1 -> `nxt`.  G1: tile t belongs to GEMM 1 (else GEMM 2); LAST: last k-tile of its
-  // GEMM in this chunk.  Straight-line bodies (no branch between the MFMAs and the next tile's fragment work) so that the
-  // scheduler can interleave them: one MFMA, then a slice of the LDS reads / split arithmetic of tile t+1.
-  auto step = [&](int t, Frags& cur, Frags& nxt, auto g1_, auto last_) {
-    constexpr bool G1 = decltype(g1_)::value, LAST = decltype(last_)::value;
-#ifndef FM_TIMING_NO_VMWAIT   // timing-only builds (results invalid): the loop without the DMA wait / barrier / DMA / split / GELU / MFMAs
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t+1 have landed
-#endif
-    __builtin_amdgcn_s_waitcnt(0xc07f);                    // its fragment reads of tile t (stage about to be refilled) have returned
-#ifndef FM_TIMING_NO_BARRIER
-    __syncthreads();                                       // tile t+1 visible; every wave has the fragments of tile t in registers
-#endif
-#ifndef FM_TIMING_NO_DMA
-    issue_b(min(t + 2, NT - 1), t & 1);
-#endif
-    load_b(nxt, (t + 1) & 1);
-    if constexpr (G1 && LAST) {
-      mma(cur, acc1);
-      // ---- bias + GELU, hidden chunk -> LDS as the A image of GEMM 2 (this wave: 32 rows x its 64 columns)
-      const int ch = t >> 4;
-#pragma unroll
-      for (int j = 0; j < FM_NJ; ++j) {
-        const int col = nh * 64 + j * 32 + (lane & 31);
-        const float bv = b1[ch * 128 + col];
-        const int kt2 = col >> 4, q = (col & 15) >> 2, e = col & 3;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int lrow = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#ifdef FM_TIMING_NO_GELU
-          sHf[(kt2 * (FM_ROWS * 4) + 4 * lrow + (q ^ ((lrow >> 2) & 3))) * 4 + e] = acc1[j][r] + bv;
-#else
-          sHf[(kt2 * (FM_ROWS * 4) + 4 * lrow + (q ^ ((lrow >> 2) & 3))) * 4 + e] = gelu_erf(acc1[j][r] + bv);
-#endif
-        }
-      }
-      __syncthreads();                                     // a row's other 64 hidden columns come from the partner wave
-      load_a(nxt, sH);
-    } else {
-      const uint4* an = G1 ? sX + ((t & 15) + 1) * (FM_ROWS * 4) : (LAST ? sX : sH + ((t & 15) - NK1 + 1) * (FM_ROWS * 4));
-      const float4 r0 = __builtin_bit_cast(float4, an[aslot0]), r1 = __builtin_bit_cast(float4, an[aslot1]);
-      if constexpr (G1) mma(cur, acc1); else mma(cur, acc2);
-#ifdef FM_TIMING_NO_SPLIT
-      nxt.fa[0] = nxt.fa[1] = nxt.fa[2] = __builtin_bit_cast(bf16x8, make_uint4(__float_as_uint(r0.x), __float_as_uint(r0.z), __float_as_uint(r1.x), __float_as_uint(r1.z)));
-#else
-      const Split3 p0s = split_pair(r0.x, r0.y), p1s = split_pair(r0.z, r0.w), p2s = split_pair(r1.x, r1.y), p3s = split_pair(r1.z, r1.w);
-      nxt.fa[0] = __builtin_bit_cast(bf16x8, make_uint4(p0s.h, p1s.h, p2s.h, p3s.h));
-      nxt.fa[1] = __builtin_bit_cast(bf16x8, make_uint4(p0s.m, p1s.m, p2s.m, p3s.m));
-      nxt.fa[2] = __builtin_bit_cast(bf16x8, make_uint4(p0s.l, p1s.l, p2s.l, p3s.l));
-#endif
-      // 6 FM_NJ MFMAs, 3 FM_NJ + 2 fragment reads, ~50 VALU operations of the split: one MFMA, then one read while there are
-      // some and a share of the VALU work
-#pragma unroll
-      for (int i = 0; i < 6 * FM_NJ; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < 3 * FM_NJ + 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, FM_NJ == 2 ? 4 : 2, 0);
-      }
-    }
-  };
-  using TrueT = std::integral_constant<bool, true>;
-  using FalseT = std::integral_constant<bool, false>;
-#pragma unroll 1
-  for (int ch = 0; ch < NCH; ++ch) {
-    const int t0 = ch * 16;
-#pragma unroll
-    for (int j = 0; j < FM_NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
-    // 16 tiles per chunk: even t in f0, odd t in f1
-    step(t0 + 0, f0, f1, TrueT{}, FalseT{});
-    step(t0 + 1, f1, f0, TrueT{}, FalseT{});
-    step(t0 + 2, f0, f1, TrueT{}, FalseT{});
-    step(t0 + 3, f1, f0, TrueT{}, FalseT{});
-    step(t0 + 4, f0, f1, TrueT{}, FalseT{});
-    step(t0 + 5, f1, f0, TrueT{}, FalseT{});
-    step(t0 + 6, f0, f1, TrueT{}, FalseT{});
-    step(t0 + 7, f1, f0, TrueT{}, TrueT{});
-    step(t0 + 8, f0, f1, FalseT{}, FalseT{});
-    step(t0 + 9, f1, f0, FalseT{}, FalseT{});
-    step(t0 + 10, f0, f1, FalseT{}, FalseT{});
-    step(t0 + 11, f1, f0, FalseT{}, FalseT{});
-    step(t0 + 12, f0, f1, FalseT{}, FalseT{});
-    step(t0 + 13, f1, f0, FalseT{}, FalseT{});
-    step(t0 + 14, f0, f1, FalseT{}, FalseT{});
-    step(t0 + 15, f1, f0, FalseT{}, TrueT{});
-  }
-  __syncthreads();   // every wave is done with the hidden tile before it becomes the epilogue staging
-
-  // ---- epilogue: y = resid + gamma * (acc2 + b2), per wave one 16 x 64 slice at a time through LDS (the hidden tile is dead)
-  static_assert(FM_H_SLOTS * sizeof(uint4) >= 8 * 16 * 65 * sizeof(float), "epilogue staging fits the hidden tile");
-  float* T = reinterpret_cast<float*>(sH) + wave * 16 * 65;
-  const int c4 = (lane & 15) * 4;
-#pragma unroll
-  for (int jh = 0; jh < FM_NJ / 2; ++jh) {
-  const int nb = (nh + jh) * 64 + c4;
-  const float4 bv = *reinterpret_cast<const float4*>(b2 + nb);
-  const float4 gv = *reinterpret_cast<const float4*>(gamma + nb);
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-        T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 65 + j * 32 + (lane & 31)] = acc2[jh * 2 + j][h * 8 + r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = rr * 4 + (lane >> 4);
-      const float* tt = T + row * 65 + c4;
-      float4 v = make_float4(tt[0] + bv.x, tt[1] + bv.y, tt[2] + bv.z, tt[3] + bv.w);
-      const int grow = m0 + rg * 32 + h * 16 + row;
-      if (grow >= M) continue;
-      const size_t off = (size_t)grow * FM_C + nb;
-      const float4 rs = *reinterpret_cast<const float4*>(resid + off);
-      v.x = rs.x + gv.x * v.x; v.y = rs.y + gv.y * v.y; v.z = rs.z + gv.z * v.z; v.w = rs.w + gv.w * v.w;
-      const f32x4v t4 = {v.x, v.y, v.z, v.w};
-      __builtin_nontemporal_store(t4, reinterpret_cast<f32x4v*>(Y + off));
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-  }
-  }
-}
-
 }  // namespace
 
 namespace {
@@ -890,18 +642,6 @@ extern "C" int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, co
   else if (epilogue == EPI_GELU) hipLaunchKernelGGL(splitk_reduce_kernel<EPI_GELU>, grid, dim3(256), 0, st, ws, bias, gamma, resid, C, mn4, N, splits);
   else hipLaunchKernelGGL(splitk_reduce_kernel<EPI_SCALE_RES>, grid, dim3(256), 0, st, ws, bias, gamma, resid, C, mn4, N, splits);
   return gdrnpp::check_launch("gdrnpp_linear_f32_splitk");
-}
-
-extern "C" int gdrnpp_convnext_mlp_f32_split(const float* x, const void* W1_packed, const float* b1, const void* W2_packed,
-                                             const float* b2, const float* gamma, const float* resid, float* y, int M, int C,
-                                             void* stream) {
-  GDRNPP_REQUIRE(x && W1_packed && b1 && W2_packed && b2 && gamma && resid && y, GDRNPP_EINVAL, "gdrnpp_convnext_mlp_f32_split: null pointer");
-  GDRNPP_REQUIRE(M > 0, GDRNPP_EINVAL, "gdrnpp_convnext_mlp_f32_split: M=%d", M);
-  GDRNPP_REQUIRE(C == FM_C, GDRNPP_ELIMIT, "gdrnpp_convnext_mlp_f32_split: C=%d (the fused form exists for C = %d, hidden %d)", C, FM_C, FM_HID);
-  if (int rc = gdrnpp::ensure_dynamic_lds((const void*)mlp_fused_c128_kernel, FM_LDS_BYTES)) return rc;
-  hipLaunchKernelGGL(mlp_fused_c128_kernel, dim3((unsigned)((M + FM_ROWS - 1) / FM_ROWS)), dim3(FM_THREADS), FM_LDS_BYTES, (hipStream_t)stream,
-                     x, (const uint4*)W1_packed, b1, (const uint4*)W2_packed, b2, gamma, resid, y, M);
-  return gdrnpp::check_launch("gdrnpp_convnext_mlp_f32_split");
 }
 
 extern "C" int gdrnpp_linear_f32_split(const float* A, const void* W_packed, const float* bias, const float* gamma,

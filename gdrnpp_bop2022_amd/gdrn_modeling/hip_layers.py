@@ -113,15 +113,6 @@ _LIBRARY_BELOW_TILES = 0    # A/B switch: blocks whose fc2 has fewer 128x128 out
                             # with a modelled number of K chunks and no block leaves this library
 
 
-_FUSED_MLP_C128 = True
-
-
-def set_fused_mlp_c128(flag: bool) -> None:
-    """A/B switch: ConvNeXt blocks with 128 channels in the one-launch fused MLP (default) or as two split-GEMM launches."""
-    global _FUSED_MLP_C128
-    _FUSED_MLP_C128 = bool(flag)
-
-
 def set_mlp_gemm(mode: str) -> None:
     global _MLP_GEMM
     if mode not in ("split", "torch"):
@@ -164,11 +155,6 @@ def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: 
     m = x_nhwc.numel() // c
     ok = (_MLP_GEMM != "torch" and enabled_for(x_nhwc) and x_nhwc.is_contiguous() and shortcut_nhwc.is_contiguous()
           and c % 128 == 0)
-    if ok and _MLP_GEMM == "split" and _FUSED_MLP_C128 and c == 128:
-        # stage 0 of ConvNeXt-B: both GEMMs in one launch, the hidden tile never leaves the CU (bitwise equal to the two launches)
-        y = hip_lib.convnext_mlp_f32_split(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk"), mlp.fc1.bias,
-                                           _packed(mlp.fc2, cache, "fc2_pk"), mlp.fc2.bias, gamma, shortcut_nhwc.view(m, c))
-        return y.view(x_nhwc.shape)
     if ok and _MLP_GEMM == "split" and hip_lib.split_gemm_tiles(m, c) >= _LIBRARY_BELOW_TILES:
         # fewer than two output tiles per CU (small ROI counts at the deep stages): split K as well, or most of the chip idles
         f1 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, 4 * c) < _SPLITK_BELOW_TILES else hip_lib.linear_f32_split

@@ -75,7 +75,6 @@ SIGNATURES = {
     "gdrnpp_pack_weight_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split_grouped": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
-    "gdrnpp_convnext_mlp_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "gdrnpp_stem_conv4x4_ln": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "gdrnpp_head_tail_nhwc": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gdrnpp_linear_f32_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -653,24 +652,6 @@ def linear_f32_split_grouped(x2d, weight_packed_stack, bias_stack, group_sel, ro
     nbytes = 4.0 * m * k + 6.0 * n * k * group_sel.numel() + 4.0 * m * (n_store or n)
     _check(_timed("linear_grouped", 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split_grouped(*args), nbytes),
            "gdrnpp_linear_f32_split_grouped")
-    return out
-
-
-def convnext_mlp_f32_split(x2d, fc1_packed, fc1_bias, fc2_packed, fc2_bias, gamma, resid2d):
-    """ConvNeXt block tail in ONE launch (C = 128): resid + gamma * fc2(gelu(fc1(x))) with the hidden tile kept in LDS — bitwise
-    equal to linear_f32_split(gelu) followed by linear_f32_split(scale_res).  x2d / resid2d f32[M,128]; weights from
-    pack_weight_bf16x3 of fc1.weight [512,128] and fc2.weight [128,512]."""
-    m, c = x2d.shape
-    if (fc1_packed.dtype != torch.bfloat16 or fc1_packed.dim() != 6 or fc1_packed.shape[0] * 128 != 4 * c or fc1_packed.shape[1] * 16 != c
-            or fc2_packed.shape[0] * 128 != c or fc2_packed.shape[1] * 16 != 4 * c):
-        raise ValueError("fc1_packed / fc2_packed must come from pack_weight_bf16x3 of the [4C,C] and [C,4C] weights")
-    out = torch.empty((m, c), dtype=torch.float32, device=x2d.device)
-    args = (_dev(x2d, torch.float32, "x"), fc1_packed.data_ptr(), _dev(fc1_bias, torch.float32, "fc1_bias"), fc2_packed.data_ptr(),
-            _dev(fc2_bias, torch.float32, "fc2_bias"), _dev(gamma, torch.float32, "gamma"), _dev(resid2d, torch.float32, "resid"),
-            out.data_ptr(), m, c, _stream())
-    nbytes = 4.0 * m * c * 3 + 6.0 * 2 * 4 * c * c
-    _check(_timed("mlp_fused", 2.0 * m * 8 * c * c, lambda: load().gdrnpp_convnext_mlp_f32_split(*args), nbytes),
-           "gdrnpp_convnext_mlp_f32_split")
     return out
 
 

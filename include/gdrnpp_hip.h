@@ -376,12 +376,6 @@ int gdrnpp_stem_conv4x4_ln(const float* x_nchw, const float* weight, const float
  * launch cannot raise, so the result is poisoned instead of read out of bounds). */
 int gdrnpp_linear_f32_split_grouped(const float* A, const void* W_packed_stack, const float* bias_stack, const int* group_sel,
                                     int n_groups, int rows_per_group, float* C, int M, int N, int K, int n_store, void* stream);
-/* ConvNeXt block tail (timm ConvNeXtBlock: x = shortcut + gamma * mlp(norm(conv_dw(x)))) in ONE launch for C = 128 (stage 0 of
- * ConvNeXt-B, hidden 512): y[M][128] = resid + gamma * (gelu(x W1^T + b1) W2^T + b2), W1_packed / W2_packed =
- * gdrnpp_pack_weight_bf16x3 of fc1.weight [512][128] / fc2.weight [128][512].  The hidden tensor stays in LDS; the result is
- * bitwise equal to gdrnpp_linear_f32_split (GELU) followed by gdrnpp_linear_f32_split (scale + residual).  Other C: GDRNPP_ELIMIT. */
-int gdrnpp_convnext_mlp_f32_split(const float* x, const void* W1_packed, const float* b1, const void* W2_packed, const float* b2,
-                                  const float* gamma, const float* resid, float* y, int M, int C, void* stream);
 /* Tail of the geometry head on that NHWC result (GDRN_double_mask.py:128-160, conv_pnp_net.py:120-134): out_nhwc
  * f32[b*hw][pitch] with channels [vis | full (double_mask) | x | y | z | region bg, 1..64] ->
  *   pnp_in f32[b*hw][96] = [(xyz - 0.5) * extent | coord2d (f32[b,2,hw]) | softmax(region[1..64]) | 27 zeros]  (Patch-PnP input, NHWC,

@@ -323,7 +323,7 @@ def test_model_forward_odd_roi_count(hip):
         o2 = model(x, **args)
         hip_layers.set_enabled(True)
     # 36 blocks x (fc1, fc2) + the two Patch-PnP fc layers, plain or split-K depending on the tile count
-    assert sum(1 for r in timer.records if r[0] in ("linear", "linear_splitk")) + 2 * sum(1 for r in timer.records if r[0] == "mlp_fused") == 74
+    assert sum(1 for r in timer.records if r[0] in ("linear", "linear_splitk")) == 74
     assert sum(1 for r in timer.records if r[0] == "conv3x3") >= 4
     assert sum(1 for r in timer_lib.records if r[0] in ("linear", "linear_splitk")) == 3 * 2 + 2   # stage 0 + Patch-PnP fc
     torch.testing.assert_close(o3["trans"], o1["trans"], rtol=0, atol=1e-4)
@@ -503,28 +503,3 @@ def test_model_forward_more_roi_counts(hip, b):
     torch.testing.assert_close(o1["rot"], o2["rot"], rtol=0, atol=1e-4)
     torch.testing.assert_close(o1["trans"], o2["trans"], rtol=0, atol=1e-4)
 
-
-@pytest.mark.parametrize("m", [128 * 64, 128 * 64 * 3 + 77, 50])
-def test_convnext_mlp_fused_is_bitwise_equal_to_two_launches(hip, m):
-    """gdrnpp_convnext_mlp_f32_split (C = 128): fc1 + GELU + fc2 + layer scale + residual in one launch with the hidden tile in
-    LDS — the same products in the same order as the two split-GEMM launches, so every output bit agrees; and fp32-accurate
-    against an fp64 evaluation of the block tail."""
-    torch.manual_seed(m)
-    c = 128
-    x = torch.randn(m, c, device=DEV)
-    w1 = torch.randn(4 * c, c, device=DEV) * c ** -0.5
-    b1 = torch.randn(4 * c, device=DEV) * 0.3
-    w2 = torch.randn(c, 4 * c, device=DEV) * (4 * c) ** -0.5
-    b2 = torch.randn(c, device=DEV) * 0.3
-    g = torch.rand(c, device=DEV) * 0.4 + 0.2
-    res = torch.randn(m, c, device=DEV)
-    p1, p2 = hip.pack_weight_bf16x3(w1), hip.pack_weight_bf16x3(w2)
-    y = hip.convnext_mlp_f32_split(x, p1, b1, p2, b2, g, res)
-    h = hip.linear_f32_split(x, p1, b1, "gelu")
-    y2 = hip.linear_f32_split(h, p2, b2, "scale_res", g, res)
-    assert torch.isfinite(y).all() and torch.equal(y, y2)
-    want = res.double() + g.double() * (F.gelu(x.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
-    got32 = torch.addcmul(res, F.linear(F.gelu(F.linear(x, w1, b1)), w2, b2), g)
-    scale = want.abs().max().item()
-    e, e32 = (y.double() - want).abs().max().item() / scale, (got32.double() - want).abs().max().item() / scale
-    assert e <= 1.25 * e32 + 1.2e-7, (e, e32)

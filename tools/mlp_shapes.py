@@ -37,21 +37,3 @@ for st, (hw, c, nblk) in enumerate([(64, 128, 3), (32, 256, 3), (16, 512, 27), (
               f"{by / t / 1e6:.0f} GB/s algorithmic")
         tot += nblk * t
 print(f"36 blocks: {tot:.2f} ms")
-# the fused one-launch form of the stage-0 block (C = 128)
-m, c = B * 64 * 64, 128
-x = torch.randn(m, c, device=dev); res = torch.randn(m, c, device=dev)
-w1 = torch.randn(4 * c, c, device=dev) * c ** -0.5; w2 = torch.randn(c, 4 * c, device=dev) * (4 * c) ** -0.5
-b1 = torch.randn(4 * c, device=dev); b2 = torch.randn(c, device=dev); g = torch.rand(c, device=dev)
-p1, p2 = hip.pack_weight_bf16x3(w1), hip.pack_weight_bf16x3(w2)
-fn = lambda: hip.convnext_mlp_f32_split(x, p1, b1, p2, b2, g, res)  # noqa: E731
-for _ in range(3):
-    fn()
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(10):
-    fn()
-e1.record()
-torch.cuda.synchronize()
-t = e0.elapsed_time(e1) / 10
-print(f"stage 0 fused fc1+GELU+fc2+residual: M={m}: {t * 1e3:.0f} us  {2.0 * m * 8 * c * c / t / 1e9:.0f} TFLOP/s fp32-equivalent")
