@@ -125,9 +125,10 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
     if (CONV) {
       // the loads are unconditional (address clamped to the centre pixel, value zeroed afterwards): a predicated load
       // would make the outstanding-load count unknown to the compiler and collapse the software pipeline
-      const int sup = kt / (ntaps * cps), rem = kt - sup * (ntaps * cps), tap = rem / cps;
+      const int ka = kt0 + kt;   // absolute k-tile (split-K chunks of a convolution start mid-sequence)
+      const int sup = ka / (ntaps * cps), rem = ka - sup * (ntaps * cps), tap = rem / cps;
       const int chunk = sup * cps + (rem - tap * cps), c0 = chunk * BK;
-      wkt = tap * cpt + chunk;
+      wkt = tap * cpt + chunk - kt0;   // Wg already points at weight tile kt0
       const int KW = CONV == 1 ? 3 : cg.KW, pad = CONV == 1 ? 1 : cg.pad;
       const int ky = tap / KW, dy = ky - pad, dx = tap - ky * KW - pad;
       const int off = (dy * cg.W + dx) * cg.C;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256, MI == 2 ? SPLIT_OCC : 2) void gemm_split_kerne
 #pragma unroll
       for (int p = 0; p < MI; ++p) r.a[p] = *reinterpret_cast<const float4*>(ap[p] + (kt0 + kt) * BK);
     }
-    const uint4* w = Wg + (size_t)wkt * W_TILE_SLOTS;
+    const uint4* w = Wg + (long)wkt * W_TILE_SLOTS;
     r.b0 = w[0]; r.b1 = w[256]; r.b2 = w[512];
     return r;
   };
@@ -620,6 +621,9 @@ extern "C" int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, co
   GDRNPP_REQUIRE(tiles < (1l << 31) && splits < 65536, GDRNPP_ELIMIT, "gdrnpp_linear_f32_splitk: grid too large");
   hipStream_t st = (hipStream_t)stream;
   const int a_stages = gdrnpp::option_split_gemm_pipe() == 2 ? 2 : 3;
+  if (plan.pipe && splits == 1 && gdrnpp::option_splitk_small_tiles())   // A/B: tile height by tile count (128 rows below 256 tiles)
+    return launch_split<false>(A, (const uint4*)W_packed, bias, gamma, resid, C, M, N, K, epilogue, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0}, st,
+                               "gdrnpp_linear_f32_splitk");
   if (plan.pipe && splits == 1) {   // enough tiles for the chip (or K too short to cut): one launch, fused epilogue
     const int rc = launch_split_pipe(A, (const uint4*)W_packed, bias, gamma, resid, C, M, N, K, epilogue, false,
                                      ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0}, a_stages, st, "gdrnpp_linear_f32_splitk");
@@ -673,6 +677,69 @@ extern "C" int gdrnpp_conv2d_f32_split(const float* x_nhwc, const void* W_packed
   GDRNPP_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_GELU, GDRNPP_EINVAL, "gdrnpp_conv2d_f32_split: epilogue=%d", epilogue);
   return launch_split<true>(x_nhwc, (const uint4*)W_packed, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, KH * KW * Cin, epilogue,
                             ConvGeom{H, W, Cin, OH, OW, KW, stride, pad, 0}, (hipStream_t)stream, "gdrnpp_conv2d_f32_split");
+}
+
+// Split-K form of the convolution for launches with too few output tiles for the chip (the head's 16x16 / 32x32 convolutions and
+// Patch-PnP's at the reference's own batch sizes: K = 9 * Cin is 54-144 k-tiles long while 8 ROIs give 32-128 tiles of 128x128):
+// grid (tiles, K chunks), partial sums to the workspace, fixed-order reduction with bias / GELU.  The number of chunks divides
+// the k-tile count into even pieces of at least 6 k-tiles and aims at >= 256 workgroups.
+namespace {
+inline int conv_splitk_chunks(long M, int N, int K) {
+  const long tiles = ((M + BM - 1) / BM) * (N / BN);
+  const int nk = K / BK;
+  int best = 1;
+  for (int sp = 2; sp <= 16; ++sp) {
+    if (nk % sp || (nk / sp) % 2 || nk / sp < 6) continue;
+    best = sp;
+    if (tiles * sp >= 256) break;
+  }
+  return tiles >= 192 ? 1 : best;
+}
+}  // namespace
+
+extern "C" size_t gdrnpp_conv2d_f32_splitk_workspace_bytes(int n_img, int OH, int OW, int Cin, int Cout, int KH, int KW) {
+  if (n_img <= 0 || OH <= 0 || OW <= 0 || Cin <= 0 || Cout <= 0 || Cout % BN || Cin % 32) return 0;
+  const long M = (long)n_img * OH * OW;
+  const int sp = conv_splitk_chunks(M, Cout, KH * KW * Cin);
+  return sp > 1 ? (size_t)sp * M * Cout * sizeof(float) : 0;   // 0: this shape runs as one launch, call gdrnpp_conv2d_f32_split
+}
+
+extern "C" int gdrnpp_conv2d_f32_splitk(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc, int n_img,
+                                        int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int epilogue,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  GDRNPP_REQUIRE(x_nhwc && W_packed && y_nhwc, GDRNPP_EINVAL, "gdrnpp_conv2d_f32_splitk: null pointer");
+  GDRNPP_REQUIRE(n_img > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && H < 32768 && W < 32768 && KH > 0 && KW > 0 &&
+                     stride > 0 && pad >= 0 && pad < KH && pad < KW,
+                 GDRNPP_EINVAL, "gdrnpp_conv2d_f32_splitk: bad shape");
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  GDRNPP_REQUIRE(OH > 0 && OW > 0 && (OH - 1) * stride < H && (OW - 1) * stride < W, GDRNPP_EINVAL,
+                 "gdrnpp_conv2d_f32_splitk: empty output or anchor pixel outside the image");
+  const long M = (long)n_img * OH * OW;
+  GDRNPP_REQUIRE(M < (1l << 31) && Cout % BN == 0 && Cin % 32 == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_conv2d_f32_splitk: Cout=%d Cin=%d must be multiples of %d/32", Cout, Cin, BN);
+  GDRNPP_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_GELU, GDRNPP_EINVAL, "gdrnpp_conv2d_f32_splitk: epilogue=%d", epilogue);
+  const int K = KH * KW * Cin, splits = conv_splitk_chunks(M, Cout, K);
+  if (splits == 1)
+    return gdrnpp_conv2d_f32_split(x_nhwc, W_packed, bias, y_nhwc, n_img, H, W, Cin, Cout, KH, KW, stride, pad, epilogue, stream);
+  GDRNPP_REQUIRE(workspace && workspace_bytes >= (size_t)splits * M * Cout * sizeof(float), GDRNPP_EINVAL,
+                 "gdrnpp_conv2d_f32_splitk: workspace too small");
+  const long tiles = ((M + BM - 1) / BM) * (Cout / BN);
+  const ConvGeom cg{H, W, Cin, OH, OW, KW, stride, pad, (K / BK) / splits};
+  hipStream_t st = (hipStream_t)stream;
+  const bool fast3x3 = KH == 3 && KW == 3 && stride == 1 && pad == 1;
+  if (fast3x3)
+    hipLaunchKernelGGL((gemm_split_kernel<EPI_BIAS, 1, 2>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st, x_nhwc,
+                       (const uint4*)W_packed, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (float*)workspace, (int)M, Cout, K, cg);
+  else
+    hipLaunchKernelGGL((gemm_split_kernel<EPI_BIAS, 2, 2>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st, x_nhwc,
+                       (const uint4*)W_packed, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (float*)workspace, (int)M, Cout, K, cg);
+  const long mn4 = M * Cout / 4;
+  const dim3 grid((unsigned)((mn4 + 255) / 256));
+  if (epilogue == EPI_BIAS) hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS>, grid, dim3(256), 0, st, (const float*)workspace, bias, (const float*)nullptr, (const float*)nullptr, y_nhwc, mn4, Cout, splits);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<EPI_GELU>, grid, dim3(256), 0, st, (const float*)workspace, bias, (const float*)nullptr, (const float*)nullptr, y_nhwc, mn4, Cout, splits);
+  return gdrnpp::check_launch("gdrnpp_conv2d_f32_splitk");
 }
 
 extern "C" int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,

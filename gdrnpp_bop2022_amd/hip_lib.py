@@ -82,6 +82,9 @@ SIGNATURES = {
     "gdrnpp_conv2d_f32_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_conv3x3_f32_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_roi_align": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
+    "gdrnpp_conv2d_f32_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "gdrnpp_conv2d_f32_splitk": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                         c_size_t, _P]),
     "gdrnpp_roi_pool": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "gdrnpp_debug_stream_read": (c_int, [_P, c_size_t, c_int, _P, c_int, _P]),
     "gdrnpp_crop_resize_roi": (
@@ -715,7 +718,16 @@ def pack_conv_weight_bf16x3(weight):
 pack_conv3x3_weight_bf16x3 = pack_conv_weight_bf16x3
 
 
-def conv2d_f32_split(x_cl, weight_packed, bias, kh: int, kw: int, stride: int, pad: int, gelu: bool = False):
+_CONV_SPLITK = True
+
+
+def set_conv_splitk(flag: bool) -> None:
+    """A/B switch: convolutions with too few output tiles for the chip run split-K (default) or as one launch."""
+    global _CONV_SPLITK
+    _CONV_SPLITK = bool(flag)
+
+
+def conv2d_f32_split(x_cl, weight_packed, bias, kh: int, kw: int, stride: int, pad: int, gelu: bool = False, _kind: str = "conv"):
     """KHxKW / stride / zero-pad convolution of a channels_last tensor [N,Cin,H,W] on the bf16 matrix cores (fp32-accurate
     split GEMM, implicit im2col) -> channels_last [N,Cout,OH,OW]."""
     n, cin, h, w = x_cl.shape
@@ -727,29 +739,23 @@ def conv2d_f32_split(x_cl, weight_packed, bias, kh: int, kw: int, stride: int, p
     oh, ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
     out = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
     args = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
-            out.data_ptr(), n, h, w, cin, cout, kh, kw, stride, pad, 1 if gelu else 0, _stream())
+            out.data_ptr(), n, h, w, cin, cout, kh, kw, stride, pad, 1 if gelu else 0)
     nbytes = 4.0 * n * (h * w * cin + oh * ow * cout) + 6.0 * cout * kh * kw * cin
-    _check(_timed("conv", 2.0 * n * oh * ow * cout * kh * kw * cin, lambda: load().gdrnpp_conv2d_f32_split(*args), nbytes),
-           "gdrnpp_conv2d_f32_split")
+    flops = 2.0 * n * oh * ow * cout * kh * kw * cin
+    ws_bytes = load().gdrnpp_conv2d_f32_splitk_workspace_bytes(n, oh, ow, cin, cout, kh, kw) if _CONV_SPLITK else 0
+    if ws_bytes:    # few output tiles (small ROI batches): K in chunks, partial sums through a workspace
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x_cl.device)
+        _check(_timed("conv_splitk", flops, lambda: load().gdrnpp_conv2d_f32_splitk(*args, ws.data_ptr(), ws_bytes, _stream()), nbytes),
+               "gdrnpp_conv2d_f32_splitk")
+    else:
+        _check(_timed(_kind, flops, lambda: load().gdrnpp_conv2d_f32_split(*args, _stream()), nbytes), "gdrnpp_conv2d_f32_split")
     return out
 
 
 def conv3x3_f32_split(x_cl, weight_packed, bias, gelu: bool = False):
     """3x3 / stride 1 / pad 1 convolution of a channels_last tensor [N,Cin,H,W] on the bf16 matrix cores (fp32-accurate
-    split GEMM, implicit im2col) -> channels_last [N,Cout,H,W]."""
-    n, cin, h, w = x_cl.shape
-    if not x_cl.is_contiguous(memory_format=torch.channels_last) or x_cl.dtype != torch.float32 or not x_cl.is_cuda:
-        raise ValueError("conv3x3_f32_split expects a float32 channels_last device tensor")
-    if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or weight_packed.shape[1] * 16 != 9 * cin:
-        raise ValueError("weight_packed must come from pack_conv3x3_weight_bf16x3 with matching Cin")
-    cout = weight_packed.shape[0] * 128
-    out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
-    args = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
-            out.data_ptr(), n, h, w, cin, cout, 1 if gelu else 0, _stream())
-    nbytes = 4.0 * n * h * w * (cin + cout) + 6.0 * cout * 9 * cin
-    _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split(*args), nbytes),
-           "gdrnpp_conv3x3_f32_split")
-    return out
+    split GEMM, implicit im2col) -> channels_last [N,Cout,H,W] (gdrnpp_conv3x3_f32_split = the general entry with 3, 3, 1, 1)."""
+    return conv2d_f32_split(x_cl, weight_packed, bias, 3, 3, 1, 1, gelu, _kind="conv3x3")
 
 
 def bias_act_nhwc_(x_cl, bias, resid=None, relu: bool = True):

@@ -393,6 +393,13 @@ int gdrnpp_head_tail_nhwc(const float* out_nhwc, int pitch, const float* coord2d
 int gdrnpp_conv2d_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                             int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                             int epilogue, void* stream);
+/* Split-K form for launches with too few output tiles for the chip (few ROIs x small maps, K = KH*KW*Cin long): K cut into
+ * chunks, partial sums in `workspace` (gdrnpp_conv2d_f32_splitk_workspace_bytes; 0 = the shape runs as one launch and needs
+ * none), fixed-order reduction with bias / GELU.  Same arguments and result as gdrnpp_conv2d_f32_split. */
+size_t gdrnpp_conv2d_f32_splitk_workspace_bytes(int n_img, int OH, int OW, int Cin, int Cout, int KH, int KW);
+int gdrnpp_conv2d_f32_splitk(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc, int n_img, int H, int W,
+                             int Cin, int Cout, int KH, int KW, int stride, int pad, int epilogue, void* workspace,
+                             size_t workspace_bytes, void* stream);
 int gdrnpp_conv3x3_f32_split(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                              int n_img, int H, int W, int Cin, int Cout, int epilogue, void* stream);
 /* The ConvModule pair conv3x3 -> GroupNorm of the geometry head (lib/torch_utils/layers/conv_module.py:222-236,

@@ -324,7 +324,7 @@ def test_model_forward_odd_roi_count(hip):
         hip_layers.set_enabled(True)
     # 36 blocks x (fc1, fc2) + the two Patch-PnP fc layers, plain or split-K depending on the tile count
     assert sum(1 for r in timer.records if r[0] in ("linear", "linear_splitk")) == 74
-    assert sum(1 for r in timer.records if r[0] == "conv3x3") >= 4
+    assert sum(1 for r in timer.records if r[0] in ("conv3x3", "conv_splitk")) >= 4
     assert sum(1 for r in timer_lib.records if r[0] in ("linear", "linear_splitk")) == 3 * 2 + 2   # stage 0 + Patch-PnP fc
     torch.testing.assert_close(o3["trans"], o1["trans"], rtol=0, atol=1e-4)
     for key in ("mask", "coor_x", "coor_y", "coor_z", "region"):
@@ -503,3 +503,34 @@ def test_model_forward_more_roi_counts(hip, b):
     torch.testing.assert_close(o1["rot"], o2["rot"], rtol=0, atol=1e-4)
     torch.testing.assert_close(o1["trans"], o2["trans"], rtol=0, atol=1e-4)
 
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,stride,pad,gelu", [(8, 256, 256, 16, 16, 3, 1, 1, False), (8, 256, 256, 32, 32, 3, 1, 1, True),
+                                                              (3, 96, 128, 64, 64, 3, 2, 1, False), (5, 128, 128, 17, 19, 3, 1, 1, False),
+                                                              (2, 256, 256, 8, 8, 2, 2, 0, True)])
+def test_conv_splitk_small_batches(hip, n, cin, cout, h, w, k, stride, pad, gelu):
+    """Few output tiles (the head's small maps / Patch-PnP at the reference's own batch sizes): the split-K form of the implicit
+    GEMM vs an fp64 convolution at the usual bar, deterministic, and really taken (a workspace is requested) for these shapes."""
+    torch.manual_seed(n + h + k)
+    x = _cl(torch.randn(n, cin, h, w, device=DEV))
+    wt = torch.randn(cout, cin, k, k, device=DEV) * (k * k * cin) ** -0.5
+    b = torch.randn(cout, device=DEV)
+    pk = hip.pack_conv_weight_bf16x3(wt)
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    assert hip.load().gdrnpp_conv2d_f32_splitk_workspace_bytes(n, oh, ow, cin, cout, k, k) > 0
+    out = hip.conv2d_f32_split(x, pk, b, k, k, stride, pad, gelu)
+    ref64 = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=pad)
+    ref32 = F.conv2d(x, wt, b, stride=stride, padding=pad)
+    if gelu:
+        ref64, ref32 = F.gelu(ref64), F.gelu(ref32)
+    scale = ref64.abs().max().item()
+    e_split = (out.double() - ref64).abs().max().item() / scale
+    e_f32 = (ref32.double() - ref64).abs().max().item() / scale
+    assert e_split <= max(1.5 * e_f32 + 1.5e-7, 4e-8 * (k * k * cin) ** 0.5), (e_split, e_f32)
+    assert torch.equal(out, hip.conv2d_f32_split(x, pk, b, k, k, stride, pad, gelu))
+    hip.set_conv_splitk(False)
+    try:
+        one = hip.conv2d_f32_split(x, pk, b, k, k, stride, pad, gelu)
+    finally:
+        hip.set_conv_splitk(True)
+    assert ((out - one).abs().max() / scale).item() < 2e-6
