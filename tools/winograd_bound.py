@@ -1,12 +1,14 @@
 """Bound of a Winograd F(2x2,3x3) form of the head's 3x3 convolutions on the split-GEMM engine.
 
-F(2x2,3x3) replaces the direct implicit GEMM [P x 9*Cin] x [9*Cin x Cout] (P = 128*64*64 pixels) by 16 independent GEMMs
-[P/4 x Cin] x [Cin x Cout] — one per position of the 4x4 transformed tile — 4/9 of the multiplies.  Whatever a fused kernel
-does around them (4-pixel input transform at fragment-read time, 16 weight matrices through LDS, output transform across
-the 16 accumulator sets), it cannot be faster than those 16 short-K GEMMs run by the same pipelined kernel with PERFECT
-weight reuse (256-row tiles of one position share a weight tile) and NO result traffic.  That lower bound is measured here
-with the grouped launch: 16 groups (positions) of P/4 rows, K = Cin = 256, N = Cout = 256, n_store = 4 (no stores), against
-the direct convolution the path runs today."""
+F(2x2,3x3) replaces the direct implicit GEMM [P x 9*Cin] x [9*Cin x Cout] (P pixels) by 16 independent GEMMs
+[P/4 x Cin] x [Cin x Cout] — one per position of the 4x4 transformed tile — 4/9 of the multiplies.  Two bounds per map size:
+
+  (a) whatever a kernel does around them, it cannot beat those 16 short-K GEMMs run by the pipelined kernel with PERFECT weight
+      reuse (256-row tiles of one position share a weight tile) and NO result traffic: the grouped launch with n_store = 4;
+  (b) the form that fits this engine: the 16 accumulator sets of a tile cannot share a workgroup (16 weight matrices through one
+      CU's LDS: 196 KB per k-tile against 12 KB today), so the products M[16][P/4][Cout] are written (4x the output bytes) and an
+      output-transform pass reads them back: (a) with stores + that pass at the box's measured copy rate.
+The input transform is assumed free (done at fragment-read time) in both."""
 import os
 import sys
 
@@ -17,8 +19,7 @@ from gdrnpp_bop2022_amd import hip_lib as hip  # noqa: E402
 
 dev = "cuda"
 torch.manual_seed(0)
-n, c, h = 128, 256, 64
-tiles = n * h * h // 4
+n, c = int(os.environ.get("B", "128")), 256
 
 
 def timeit(fn, reps=10):
@@ -34,25 +35,30 @@ def timeit(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
-x = torch.randn(n, c, h, h, device=dev).contiguous(memory_format=torch.channels_last)
-wt = torch.randn(c, c, 3, 3, device=dev) * 0.03
-pk = hip.pack_conv_weight_bf16x3(wt)
-t_direct = timeit(lambda: hip.conv3x3_f32_split(x, pk, None))
-g = torch.rand(c, device=dev) + 0.5
-be = torch.randn(c, device=dev) * 0.1
-t_fused = timeit(lambda: hip.conv3x3_groupnorm_act(x, pk, None, g, be, 32, 1e-5, gelu=True))
-
-v = torch.randn(16 * tiles, c, device=dev)                      # stands for the transformed input V[16][tiles][Cin]
-u = torch.randn(16 * c, c, device=dev) * (c ** -0.5)            # 16 transformed weight matrices U[16][Cout][Cin]
-upk = hip.pack_weight_bf16x3(u)
-ub = torch.zeros(16, c, device=dev)
-sel = torch.arange(16, device=dev, dtype=torch.int32)
-t_nostore = timeit(lambda: hip.linear_f32_split_grouped(v, upk, ub, sel, tiles, n_store=4))
-t_store = timeit(lambda: hip.linear_f32_split_grouped(v, upk, ub, sel, tiles, n_store=c))
-fl_direct = 2.0 * n * h * h * 9 * c * c
-fl_wino = 2.0 * 16 * tiles * c * c
-print(f"direct conv3x3 128x64x64x256->256: {t_direct:.3f} ms ({fl_direct / t_direct / 1e9:.0f} TFLOP/s fp32-equivalent); "
-      f"+ fused GroupNorm/GELU apply pass: {t_fused:.3f} ms")
-print(f"16 x [{tiles} x 256] x [256 x 256] GEMMs, perfect weight reuse, no stores: {t_nostore:.3f} ms "
-      f"({fl_wino / t_nostore / 1e9:.0f} TFLOP/s); with the 4x-size M tensor written: {t_store:.3f} ms")
-print(f"upper bound of the gain per convolution: {t_direct - t_nostore:.3f} ms; x 6 convolutions per step: {6 * (t_direct - t_nostore):.2f} ms")
+a = torch.empty(64 * 1024 * 1024, device=dev)
+b = torch.empty_like(a)
+copy_bps = 2 * a.numel() * 4 / (timeit(lambda: b.copy_(a)) * 1e-3)
+del a, b
+print(f"copy rate of this box: {copy_bps / 1e12:.2f} TB/s read + written")
+gain_a = gain_b = 0.0
+for h in (64, 32, 16):                                # the head has two 3x3 convolutions at each of these map sizes
+    tiles = n * h * h // 4
+    x = torch.randn(n, c, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(c, c, 3, 3, device=dev) * 0.03
+    pk = hip.pack_conv_weight_bf16x3(wt)
+    hip.set_conv_splitk(False)
+    t_direct = timeit(lambda: hip.conv3x3_f32_split(x, pk, None))
+    v = torch.randn(16 * tiles, c, device=dev)            # stands for the transformed input V[16][tiles][Cin]
+    u = torch.randn(16 * c, c, device=dev) * (c ** -0.5)  # 16 transformed weight matrices U[16][Cout][Cin]
+    upk = hip.pack_weight_bf16x3(u)
+    ub = torch.zeros(16, c, device=dev)
+    sel = torch.arange(16, device=dev, dtype=torch.int32)
+    t_a = timeit(lambda: hip.linear_f32_split_grouped(v, upk, ub, sel, tiles, n_store=4))
+    t_store = timeit(lambda: hip.linear_f32_split_grouped(v, upk, ub, sel, tiles, n_store=c))
+    t_pass = (16 * tiles * c * 4 + n * h * h * c * 4) / copy_bps * 1e3          # read M, write y
+    t_b = t_store + t_pass
+    print(f"{h}x{h}: direct {t_direct:.3f} ms ({2.0 * n * h * h * 9 * c * c / t_direct / 1e9:.0f} TFLOP/s fp32-eq) | (a) 16 GEMMs, no stores "
+          f"{t_a:.3f} ms | (b) M written {t_store:.3f} + output-transform pass {t_pass:.3f} = {t_b:.3f} ms")
+    gain_a += 2 * (t_direct - t_a)
+    gain_b += 2 * max(t_direct - t_b, 0.0)
+print(f"per step (two convolutions per size): bound (a) {gain_a:.2f} ms, bound (b) {gain_b:.2f} ms")
