@@ -444,6 +444,13 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                     t_k = sum(r[2].elapsed_time(r[3]) for r in rs)
                     by_kind[kind] = dict(launches_per_step=len(rs) / args.steps, ms_per_step=t_k / args.steps,
                                          fp32_equiv_tflops=sum(r[1] for r in rs) / (t_k * 1e-3) / 1e12)
+                # the same events by launch shape (kind + algorithmic bytes identify a layer shape): in-situ time per launch
+                by_shape = []
+                for key in sorted({(r[0], int(r[4]), int(r[1])) for r in gemm_records}):
+                    rs = [r for r in gemm_records if (r[0], int(r[4]), int(r[1])) == key]
+                    t_k = sum(r[2].elapsed_time(r[3]) for r in rs)
+                    by_shape.append(dict(kind=key[0], algorithmic_mb=round(key[1] / 1e6, 1), gflop_fp32=round(key[2] / 1e9, 1),
+                                         launches_per_step=len(rs) / args.steps, us_per_launch=round(t_k / len(rs) * 1e3, 1)))
                 g_traffic = None  # HBM-side bytes per launch from the committed PMC passes (same workload only)
                 pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
                 if os.path.exists(pmc) and b == 128 and wname == "refine" and args.mlp_gemm == "split":
@@ -454,7 +461,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                                 algorithmic_bytes_per_launch=sum(r[4] for r in gemm_records) / n_l,
                                 launch_ms=ms_all / n_l, launches_per_step=n_l / args.steps, ms_per_step=ms_all / args.steps,
                                 flops_per_launch=6.0 * fl / n_l, fp32_equiv_tflops=fl / (ms_all * 1e-3) / 1e12,
-                                fp32_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS, by_kind=by_kind,
+                                fp32_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS, by_kind=by_kind, by_shape=by_shape,
                                 measured_in="separate event pass of the same steps after the timed region",
                                 note="bf16 MFMA flops executed = 6 x fp32-equivalent flops (exact 3-way operand split, six "
                                      "partial products, fp32 accumulate)")

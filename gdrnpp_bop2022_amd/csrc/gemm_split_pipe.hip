@@ -370,7 +370,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
           const float4 rs = *reinterpret_cast<const float4*>(resid + off);
           v.x = rs.x + gv.x * v.x; v.y = rs.y + gv.y * v.y; v.z = rs.z + gv.z * v.z; v.w = rs.w + gv.w * v.w;
         }
+#ifdef GDRNPP_TIMING_NO_STORE   // timing-only build (results invalid): the epilogue without its global stores
+        if (v.x == 1.2345e38f) C[off] = v.y;
+#else
         { const f32x4v t4 = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t4, reinterpret_cast<f32x4v*>(C + off)); }
+#endif
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
     }
