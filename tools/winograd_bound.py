@@ -8,7 +8,10 @@ F(2x2,3x3) replaces the direct implicit GEMM [P x 9*Cin] x [9*Cin x Cout] (P pix
   (b) the form that fits this engine: the 16 accumulator sets of a tile cannot share a workgroup (16 weight matrices through one
       CU's LDS: 196 KB per k-tile against 12 KB today), so the products M[16][P/4][Cout] are written (4x the output bytes) and an
       output-transform pass reads them back: (a) with stores + that pass at the box's measured copy rate.
-The input transform is assumed free (done at fragment-read time) in both."""
+      The input transform is assumed free (done at fragment-read time) in (a) and (b) — which this engine cannot do either: the
+      LDS-DMA moves one source pixel per A row, the transform needs four (64 KB per k-tile stage of 256 rows instead of 16);
+  (c) the form that can be built from the existing kernels: an input-transform pass that writes V[16][P/4][Cin] (4x the input
+      bytes), the grouped GEMM reading V and writing M, the output-transform pass: (b) + one more streaming pass."""
 import os
 import sys
 
@@ -57,8 +60,11 @@ for h in (64, 32, 16):                                # the head has two 3x3 con
     t_store = timeit(lambda: hip.linear_f32_split_grouped(v, upk, ub, sel, tiles, n_store=c))
     t_pass = (16 * tiles * c * 4 + n * h * h * c * 4) / copy_bps * 1e3          # read M, write y
     t_b = t_store + t_pass
+    t_in = (n * h * h * c * 4 + 16 * tiles * c * 4) / copy_bps * 1e3           # read x, write V
+    t_c = t_b + t_in
+    gain_c = globals().get("gain_c", 0.0) + 2 * max(t_direct - t_c, 0.0)
     print(f"{h}x{h}: direct {t_direct:.3f} ms ({2.0 * n * h * h * 9 * c * c / t_direct / 1e9:.0f} TFLOP/s fp32-eq) | (a) 16 GEMMs, no stores "
-          f"{t_a:.3f} ms | (b) M written {t_store:.3f} + output-transform pass {t_pass:.3f} = {t_b:.3f} ms")
+          f"{t_a:.3f} ms | (b) M written {t_store:.3f} + output-transform pass {t_pass:.3f} = {t_b:.3f} ms | (c) + input-transform pass {t_in:.3f} = {t_c:.3f} ms")
     gain_a += 2 * (t_direct - t_a)
     gain_b += 2 * max(t_direct - t_b, 0.0)
-print(f"per step (two convolutions per size): bound (a) {gain_a:.2f} ms, bound (b) {gain_b:.2f} ms")
+print(f"per step (two convolutions per size): bound (a) {gain_a:.2f} ms, bound (b) {gain_b:.2f} ms, bound (c) {gain_c:.2f} ms")
