@@ -108,7 +108,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DW_WPE))) v
   const long n_tiles = (long)N * tiles_y * tiles_x;
   const long n_groups = (n_tiles + tiles_per_block - 1) / tiles_per_block;
   if (LDS_W) {
-    for (int i = threadIdx.x; i < 49 * Q; i += blockDim.x) wlds[i] = ld4(w49c + 4 * (size_t)i);
+    // all loads of the weight image in flight before the first LDS write (a load -> ds_write loop paid the memory latency per
+    // trip: ~12 us per workgroup, the whole launch at the reference's batch sizes)
+    constexpr int WMAX = 13;                  // 49 * C / 4 slots over >= 256 threads: <= 12.25 per thread for C <= 512
+    const int n_slots = 49 * Q;
+    if (n_slots <= WMAX * (int)blockDim.x) {
+      float4 wtmp[WMAX];
+#pragma unroll
+      for (int k = 0; k < WMAX; ++k) {
+        const int i = threadIdx.x + k * blockDim.x;
+        if (i < n_slots) wtmp[k] = ld4(w49c + 4 * (size_t)i);
+      }
+#pragma unroll
+      for (int k = 0; k < WMAX; ++k) {
+        const int i = threadIdx.x + k * blockDim.x;
+        if (i < n_slots) wlds[i] = wtmp[k];
+      }
+    } else {
+      for (int i = threadIdx.x; i < n_slots; i += blockDim.x) wlds[i] = ld4(w49c + 4 * (size_t)i);
+    }
     __syncthreads();
   }
   const f4 b4 = ld4v(bias + 4 * q);
