@@ -548,8 +548,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
   if (i >= mn4) return;
   const int n = (int)((i * 4) % N);
   float4 acc = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < splits; ++s) {
-    const float4 v = reinterpret_cast<const float4*>(part)[(size_t)s * mn4 + i];
+  const float4* pp = reinterpret_cast<const float4*>(part) + i;
+  int s = 0;
+  for (; s + 4 <= splits; s += 4) {   // four partials in flight, added in split order (the sum stays in fixed order)
+    const float4 v0 = pp[(size_t)s * mn4], v1 = pp[(size_t)(s + 1) * mn4], v2 = pp[(size_t)(s + 2) * mn4], v3 = pp[(size_t)(s + 3) * mn4];
+    acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+    acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+    acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+    acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+  }
+  for (; s < splits; ++s) {
+    const float4 v = pp[(size_t)s * mn4];
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
   if (EPI == EPI_GELU) { acc.x = gelu_erf(acc.x); acc.y = gelu_erf(acc.y); acc.z = gelu_erf(acc.z); acc.w = gelu_erf(acc.w); }

@@ -345,17 +345,27 @@ __global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict
 __global__ __launch_bounds__(256) void bias_act_kernel(const float* x, const float* __restrict__ bias,
                                                        const float* resid, float* y, long total4,
                                                        int Q, int relu) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % Q);
-    float4 v = ld4(x + 4 * i);
-    const float4 b = ld4(bias + 4 * q);
-    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    if (resid) {
-      const float4 r = ld4(resid + 4 * i);
-      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  // four elements per trip, loads first (one 16-byte load in flight per thread caps a streaming pass at ~4 TB/s)
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += 4 * stride) {
+    float4 v[4], r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * stride < total4) {
+        v[u] = ld4(x + 4 * (i + u * stride));
+        if (resid) r[u] = ld4(resid + 4 * (i + u * stride));
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long k = i + u * stride;
+      if (k >= total4) break;
+      const float4 b = ld4(bias + 4 * (int)(k % Q));
+      float4 w = v[u];
+      w.x += b.x; w.y += b.y; w.z += b.z; w.w += b.w;
+      if (resid) { w.x += r[u].x; w.y += r[u].y; w.z += r[u].z; w.w += r[u].w; }
+      if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+      st4(y + 4 * k, w);
     }
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    st4(y + 4 * i, v);
   }
 }
 
