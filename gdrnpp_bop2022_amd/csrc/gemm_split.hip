@@ -519,6 +519,10 @@ int launch_split_epi(const float* A, const uint4* Wp, const float* bias, const f
     else hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV ? 2 : 0, 4>), dim3((unsigned)tiles256), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
     return gdrnpp::check_launch(what);
   }
+  if (!CONV && !big && gdrnpp::option_split_gemm_pipe() && M >= 96) {   // few tiles: the 128-row form of the pipelined kernel
+    const int rc = launch_split_pipe128(A, Wp, bias, gamma, resid, C, M, N, K, EPI, 0, st, what);
+    if (rc >= 0) return rc;
+  }
   const long blocks = (long)((M + BM - 1) / BM) * (N / BN);
   GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "%s: grid too large", what);
   if (CONV && fast3x3) hipLaunchKernelGGL((gemm_split_kernel<EPI, CONV ? 1 : 0, 2>), dim3((unsigned)blocks), dim3(256), 0, st, A, Wp, bias, gamma, resid, C, M, N, K, cg);
@@ -578,21 +582,25 @@ inline int splitk_chunk(int M, int N, int K) {
   return c;
 }
 
-// Plan of gdrnpp_linear_f32_splitk.  From 192 rows on the pipelined kernel (256x128 tiles, gemm_split_pipe.hip) does the
-// work: at the reference's own batch sizes (one image = a few to ~30 ROIs per forward, data_loader.py:901) the deep ConvNeXt
+// Plan of gdrnpp_linear_f32_splitk.  From 96 rows on the pipelined kernel (gemm_split_pipe.hip: 256x128 tiles, or its 128-row
+// form below 256 such tiles) does the work: at the reference's own batch sizes (one image = a few to ~30 ROIs per forward, data_loader.py:901) the deep ConvNeXt
 // stages have 16-128 such tiles for 256 CUs.  The number of K chunks minimises a two-term model measured on the stage-2 /
 // stage-3 MLP shapes: a workgroup alone on its CU takes ~0.73 us per k-tile (48 MFMAs per wave at 32 cycles), rounds of 256
 // workgroups run back to back, and a split costs the partials' trip through memory (written once, read once, the result
 // written once) plus one kernel boundary.  splits == 1 means: no workspace, one launch with the fused epilogue.
-struct SplitKPlan { bool pipe; int nkc; int splits; };
+struct SplitKPlan { bool pipe; int rows; int nkc; int splits; };   // rows: 256 / 128 = tile height of the pipelined kernel
 inline SplitKPlan splitk_plan(int M, int N, int K) {
   const int nk = K / BK;
-  if (M < 192 || !gdrnpp::option_split_gemm_pipe() || (unsigned long long)M * (unsigned long long)K * 4ull >= (1ull << 32)) {
+  if (M < 96 || !gdrnpp::option_split_gemm_pipe() || (unsigned long long)M * (unsigned long long)K * 4ull >= (1ull << 32)) {
     const int c = splitk_chunk(M, N, K);
-    return SplitKPlan{false, c, nk / c};
+    return SplitKPlan{false, 128, c, nk / c};
   }
-  const double tiles = (double)((M + 255) / 256) * (N / BN);
-  const double t_k = 0.73, t_boundary = 3.0, bytes_per_us = 3.0e6;
+  // fewer than 256 tiles of 256 x 128: 128-row tiles (twice the workgroups; a k-tile of 24 MFMAs per wave takes 0.65 us there, not
+  // half of 0.73: five LDS-DMA pieces per wave and k-tile for half the MFMAs)
+  const double tiles256 = (double)((M + 255) / 256) * (N / BN);
+  const bool small = tiles256 < 256.0 && gdrnpp::option_splitk_small_tiles();
+  const double tiles = small ? (double)((M + 127) / 128) * (N / BN) : tiles256;
+  const double t_k = small ? 0.65 : 0.73, t_boundary = 3.0, bytes_per_us = 3.0e6;   // measured us per k-tile, one workgroup per CU
   int best = 1;
   double best_t = 1e30;
   for (int s = 1; s <= 64; s *= 2) {
@@ -602,7 +610,7 @@ inline SplitKPlan splitk_plan(int M, int N, int K) {
     if (s > 1) t += t_boundary + (double)(s + 2) * M * (double)N * 4.0 / bytes_per_us;
     if (t < best_t) { best_t = t; best = s; }
   }
-  return SplitKPlan{true, nk / best, best};
+  return SplitKPlan{true, small ? 128 : 256, nk / best, best};
 }
 
 }  // namespace
@@ -630,16 +638,19 @@ extern "C" int gdrnpp_linear_f32_splitk(const float* A, const void* W_packed, co
   GDRNPP_REQUIRE(tiles < (1l << 31) && splits < 65536, GDRNPP_ELIMIT, "gdrnpp_linear_f32_splitk: grid too large");
   hipStream_t st = (hipStream_t)stream;
   const int a_stages = gdrnpp::option_split_gemm_pipe() == 2 ? 2 : 3;
-  if (plan.pipe && splits == 1 && gdrnpp::option_splitk_small_tiles())   // A/B: tile height by tile count (128 rows below 256 tiles)
-    return launch_split<false>(A, (const uint4*)W_packed, bias, gamma, resid, C, M, N, K, epilogue, ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0}, st,
-                               "gdrnpp_linear_f32_splitk");
-  if (plan.pipe && splits == 1) {   // enough tiles for the chip (or K too short to cut): one launch, fused epilogue
+  if (plan.pipe && splits == 1 && plan.rows == 128) {   // few tiles, K too short to cut: one launch of the 128-row form, fused epilogue
+    const int rc = launch_split_pipe128(A, (const uint4*)W_packed, bias, gamma, resid, C, M, N, K, epilogue, 0, st, "gdrnpp_linear_f32_splitk");
+    if (rc >= 0) return rc;
+  }
+  if (plan.pipe && splits == 1) {   // enough tiles for the chip: one launch, fused epilogue
     const int rc = launch_split_pipe(A, (const uint4*)W_packed, bias, gamma, resid, C, M, N, K, epilogue, false,
                                      ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0}, a_stages, st, "gdrnpp_linear_f32_splitk");
     if (rc >= 0) return rc;
   }
   int rc = -1;
-  if (plan.pipe && splits > 1)
+  if (plan.pipe && splits > 1 && plan.rows == 128)
+    rc = launch_split_pipe128(A, (const uint4*)W_packed, nullptr, nullptr, nullptr, (float*)workspace, M, N, K, EPI_BIAS, nkc, st, "gdrnpp_linear_f32_splitk");
+  else if (plan.pipe && splits > 1)
     rc = launch_split_pipe_splitk(A, (const uint4*)W_packed, (float*)workspace, M, N, K, nkc, a_stages, st, "gdrnpp_linear_f32_splitk");
   if (rc > 0) return rc;
   if (rc < 0) {

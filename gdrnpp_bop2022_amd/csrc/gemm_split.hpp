@@ -50,6 +50,10 @@ int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const 
 int launch_split_pipe_splitk(const float* A, const uint4* Wp, float* partials, int M, int N, int K, int nk_split, int a_stages,
                              hipStream_t st, const char* what);
 
+// 128-row form of the pipelined kernel (linear): fused epilogue (nk_split == 0) or split-K partials to C = partials[chunk][M][N]
+int launch_split_pipe128(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
+                         int M, int N, int K, int epilogue, int nk_split, hipStream_t st, const char* what);
+
 }  // namespace splitgemm
 
 int option_split_gemm_pipe();       // 0: off, 2 / 3 (default): pipelined kernel with that many A stages for 256-row tiles (linear form)

@@ -381,6 +381,217 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
   }
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// 128-row form of the pipelined kernel (linear only) for launches with fewer than 256 tiles of 256 x 128 — the deep ConvNeXt
+// stages at the reference's own batch sizes (one image = a few to ~30 ROIs per forward, data_loader.py:901): twice the
+// workgroups for the same problem, and the same k-loop per workgroup as above at half the size.  Block tile 128 x 128 x 16, 4
+// waves stacked along M (32 rows x 128 columns = 1 x 4 MFMA tiles, 24 MFMAs per k-tile), four 8 KB A stages private to the
+// wave (its 32 rows: two LDS-DMA pieces) and three 12 KB weight stages — the A DMA runs four k-tiles ahead, the weight DMA two:
+// with the 3 + 2 stages of the 256-row kernel a k-tile took 0.83 us at one workgroup per CU, the memory latency of the operand
+// issued one 24-MFMA k-tile earlier; one barrier per k-tile behind slot 19 of 24; the register
+// pipeline is the one of gemm_split_pipe_kernel with one half instead of two (split of k-tile t+1 in slots 1..22 of k-tile t,
+// weight fragments one split set ahead, raw A of k-tile t+2 read behind the barrier).  68 KB of LDS.  Split-K through
+// cg.nk_split like the 256-row kernel.  Same products in the same order per accumulator: bitwise equal to the other kernels.
+// --------------------------------------------------------------------------------------------------------------------
+constexpr int A128_STAGE_B = 128 * BK * 4;   // 8 KB
+constexpr int P128_NA = 4, P128_NB = 3;      // A and weight stages of the 128-row kernel
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_split_pipe128_kernel(const float* __restrict__ A, const uint4* __restrict__ Wp,
+                                                                    const float* __restrict__ bias,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ resid, float* __restrict__ C,
+                                                                    int M, int N, int K, int nk_split) {
+  constexpr int NA = P128_NA, NB = P128_NB;
+  extern __shared__ uint4 smem[];  // [NA][512] A slots | [NB][768] weight slots
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = N / BN;
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
+  const int m0 = tile_m * 128, n0 = tile_n * BN;
+  const int kt0 = nk_split > 0 ? (int)blockIdx.y * nk_split : 0;
+  const int nk = nk_split > 0 ? nk_split : K / BK;
+  if (nk_split > 0) C += (size_t)blockIdx.y * (size_t)M * (size_t)N;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+
+  const int prow = lane >> 2, pq = lane & 3;
+  unsigned aoff[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int lrow = wave * 32 + c * 16 + prow;
+    const int q = pq ^ ((lrow >> 2) & 3);
+    const int arow = min(m0 + lrow, M - 1);
+    aoff[c] = (unsigned)arow * (unsigned)(K * 4) + (unsigned)(q * 16);
+  }
+  const unsigned boff = (unsigned)((wave * 3) * 64 + lane) * 16u;
+  const char* const wbase = reinterpret_cast<const char*>(Wp + (size_t)tile_n * (K / BK) * W_TILE_SLOTS);
+  const unsigned ldsA = lds0 + (unsigned)(wave * 2) * 1024u;
+  const unsigned ldsB = lds0 + (unsigned)(NA * A128_STAGE_B) + (unsigned)(wave * 3) * 1024u;
+  auto dma_a = [&](int kt, unsigned sb, auto cc) {
+    constexpr int c = decltype(cc)::value;
+    dma_s(aoff[c], reinterpret_cast<const char*>(A) + (size_t)(kt0 + kt) * (BK * 4), ldsA + sb + c * 1024u);
+  };
+  auto dma_b = [&](int kt, unsigned sb, auto cc) {
+    constexpr int c = decltype(cc)::value;
+    dma_s(boff, wbase + ((size_t)(kt0 + kt) * B_STAGE_B + c * 1024), ldsB + sb + c * 1024u);
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int frow = lane & 31, fk = lane >> 5;
+  const int lrow0 = wave * 32 + frow, g0 = (lrow0 >> 2) & 3;
+  const int aslot0 = 4 * lrow0 + ((2 * fk) ^ g0), aslot1 = 4 * lrow0 + ((2 * fk + 1) ^ g0);
+  const uint4* const sA = smem;
+  const uint4* const sBf = smem + NA * (A128_STAGE_B / 16) + fk * BN + frow;
+  auto load_raw = [&](HalfSplit& hs, int stage) { hs.load(sA + stage * (A128_STAGE_B / 16), aslot0, aslot1); };
+
+  // One k-tile.  cur: split A fragments of k-tile kt; nxt.x: raw A of k-tile kt+1 on entry, its split on exit.  fbX: weight
+  // split l of kt on entry, then its split h; fbY: its split m, then the split l of kt+1.  BS: weight stage of kt.
+  // sa2 / sa_wr: A stage of kt+2, and the one receiving kt+NA (= the stage kt has left).
+  auto ktile = [&](int kt, HalfSplit& cur, HalfSplit& nxt, bf16x8 (&fbX)[4], bf16x8 (&fbY)[4], int bs, int sa2, int sa_wr) {
+    const int bs1 = bs + 1 == NB ? 0 : bs + 1, bs2 = bs1 + 1 == NB ? 0 : bs1 + 1;   // weight stages of kt+1, and of kt+2 (written now)
+    const uint4* const b = sBf + bs * (B_STAGE_B / 16);
+    const uint4* const bn = sBf + bs1 * (B_STAGE_B / 16);
+    const int kt_b = min(kt + 2, nk - 1), kt_a = min(kt + NA, nk - 1);
+    const unsigned sb_wr = (unsigned)(bs2 * B_STAGE_B), sa_wr_b = (unsigned)(sa_wr * A128_STAGE_B);
+    static_for<0, 24>([&](auto s_) {
+      constexpr int S = decltype(s_)::value;
+      constexpr int G = S / 4, J = S & 3;
+      GDRNPP_SPLIT_PRODUCT_ORDER
+      constexpr int SA_ = TA[G], SB_ = TB[G];
+      const bf16x8 fa = cur.template frag<SA_>();
+      const bf16x8 fb = (SB_ == 1) ? fbY[J] : fbX[J];
+      acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[J], 0, 0, 0);
+      // weight DMA of k-tile kt+2, then A DMA of k-tile kt+NA: both operands run two or more k-tiles ahead — at one workgroup
+      // per CU (what this kernel is for) nothing else hides the memory latency, and a k-tile is only 24 MFMAs long
+      if constexpr (S == 0) dma_b(kt_b, sb_wr, std::integral_constant<int, 0>{});
+      if constexpr (S == 1) dma_b(kt_b, sb_wr, std::integral_constant<int, 1>{});
+      if constexpr (S == 2) dma_b(kt_b, sb_wr, std::integral_constant<int, 2>{});
+      if constexpr (S == 3) dma_a(kt_a, sa_wr_b, std::integral_constant<int, 0>{});
+      if constexpr (S == 5) dma_a(kt_a, sa_wr_b, std::integral_constant<int, 1>{});
+      // weight split m for groups 1-2 (slots 4..11); weight split h for groups 3-5 (slots 12..23; reuses the l registers,
+      // free after group 0)
+      if constexpr (S == 0 || S == 1) {
+        constexpr int j0 = 2 * S;
+        fbY[j0] = __builtin_bit_cast(bf16x8, b[1 * KB * BN + j0 * 32]);
+        fbY[j0 + 1] = __builtin_bit_cast(bf16x8, b[1 * KB * BN + (j0 + 1) * 32]);
+      }
+      if constexpr (S == 4 || S == 6) {
+        constexpr int j0 = S - 4;
+        fbX[j0] = __builtin_bit_cast(bf16x8, b[j0 * 32]);
+        fbX[j0 + 1] = __builtin_bit_cast(bf16x8, b[(j0 + 1) * 32]);
+      }
+      // split of the next k-tile in slots 1..22
+      if constexpr (S >= 1 && S < 23) nxt.template step<S - 1>();
+      if constexpr (S == 19) {
+        wait_vmcnt<7>();                      // all but the newest A(kt-1+NA), W(kt+2), A(kt+NA) pieces: weights of kt+1, A of kt+2 are in
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): every LDS read of the stages about to be refilled has returned
+        __builtin_amdgcn_s_barrier();
+      }
+      // behind the barrier (the last four MFMAs use only cur's h fragments): weight split l of k-tile kt+1 (fbY's split m is
+      // dead since slot 11) and the raw A of k-tile kt+2 (cur is nxt of the next k-tile)
+      if constexpr (S == 20 || S == 21) {
+        constexpr int j0 = 2 * (S - 20);
+        fbY[j0] = __builtin_bit_cast(bf16x8, bn[2 * KB * BN + j0 * 32]);
+        fbY[j0 + 1] = __builtin_bit_cast(bf16x8, bn[2 * KB * BN + (j0 + 1) * 32]);
+      }
+      if constexpr (S == 22) load_raw(cur, sa2);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // ---- prologue: A of k-tiles 0..2, weights of k-tile 0; split k-tile 0; first fragments of the loop
+  static_for<0, 2>([&](auto c) { dma_a(0, 0u, c); });
+  static_for<0, 3>([&](auto c) { dma_b(0, 0u, c); });
+  static_for<0, 2>([&](auto c) { dma_a(min(1, nk - 1), (unsigned)A128_STAGE_B, c); });
+  static_for<0, 3>([&](auto c) { dma_b(min(1, nk - 1), (unsigned)B_STAGE_B, c); });
+  static_for<0, 2>([&](auto c) { dma_a(min(2, nk - 1), 2u * A128_STAGE_B, c); });
+  static_for<0, 2>([&](auto c) { dma_a(min(3, nk - 1), 3u * A128_STAGE_B, c); });
+  wait_vmcnt<7>();               // A(0), W(0), A(1) are in
+  __builtin_amdgcn_s_barrier();
+  HalfSplit f0, f1;
+  bf16x8 fbA[4], fbB[4];
+  load_raw(f0, 0);
+  static_for<0, 22>([&](auto s) { f0.template step<decltype(s)::value>(); });
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fbA[j] = __builtin_bit_cast(bf16x8, sBf[2 * KB * BN + j * 32]);
+  load_raw(f1, 1);
+
+  static_assert(NA == 4 && NB == 3, "the wait counts and the prologue above are written for four A and three weight stages");
+  int sa = 0, bs = 0;  // kt % NA, kt % NB
+  for (int kt = 0; kt < nk; kt += 2) {
+    const int sa1 = (sa + 1) & 3, sa2 = (sa + 2) & 3, sa3 = (sa + 3) & 3;
+    const int bsn = bs + 1 == NB ? 0 : bs + 1;
+    ktile(kt, f0, f1, fbA, fbB, bs, sa2, sa);
+    ktile(kt + 1, f1, f0, fbB, fbA, bsn, sa3, sa1);
+    sa = sa2;
+    bs = bsn + 1 == NB ? 0 : bsn + 1;
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_s_barrier();  // every wave's stages are dead: the epilogue reuses them
+
+  // ---- epilogue: per wave one 16x64 slice at a time through LDS, written back row-wise as float4
+  float* T = reinterpret_cast<float*>(smem) + wave * 16 * 65;
+  const int c4 = (lane & 15) * 4;
+#pragma unroll
+  for (int jh = 0; jh < 2; ++jh) {
+    const int nb = n0 + jh * 64 + c4;
+    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (EPI == EPI_SCALE_RES) gv = *reinterpret_cast<const float4*>(gamma + nb);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 65 + j * 32 + (lane & 31)] = acc[jh * 2 + j][h * 8 + r];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = rr * 4 + (lane >> 4);
+        const float* t = T + row * 65 + c4;
+        float4 v = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
+        const int grow = m0 + wave * 32 + h * 16 + row;
+        if (grow >= M) continue;
+        const size_t off = (size_t)grow * N + nb;
+        if (EPI == EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        if (EPI == EPI_SCALE_RES) {
+          const float4 rs = *reinterpret_cast<const float4*>(resid + off);
+          v.x = rs.x + gv.x * v.x; v.y = rs.y + gv.y * v.y; v.z = rs.z + gv.z * v.z; v.w = rs.w + gv.w * v.w;
+        }
+        { const f32x4v t4 = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t4, reinterpret_cast<f32x4v*>(C + off)); }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+  }
+}
+
+template <int EPI>
+int launch_pipe128(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M,
+                   int N, int K, int nk_split, hipStream_t st, const char* what) {
+  constexpr int lds_bytes = P128_NA * A128_STAGE_B + P128_NB * B_STAGE_B;   // 68 KB
+  static bool raised[64] = {};
+  int dev = 0;
+  GDRNPP_HIP_TRY(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && !raised[dev]) {
+    GDRNPP_HIP_TRY(hipFuncSetAttribute((const void*)gemm_split_pipe128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    raised[dev] = true;
+  }
+  const long tiles = (long)((M + 127) / 128) * (N / BN);
+  const unsigned splits = nk_split > 0 ? (unsigned)((K / BK) / nk_split) : 1u;
+  hipLaunchKernelGGL((gemm_split_pipe128_kernel<EPI>), dim3((unsigned)tiles, splits), dim3(256), lds_bytes, st, A, Wp, bias, gamma,
+                     resid, C, M, N, K, nk_split);
+  return gdrnpp::check_launch(what);
+}
+
 // hipFuncSetAttribute is a per-device setting: done once per (kernel, device), not per launch
 template <int EPI, int CONV, int NA>
 int launch_one(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M,
@@ -440,6 +651,18 @@ int launch_split_pipe(const float* A, const uint4* Wp, const float* bias, const 
   }
   if ((unsigned long long)M * (unsigned long long)K * 4ull >= (1ull << 32)) return -1;  // 32-bit lane offsets
   return launch_epi<0>(epilogue, a_stages, A, Wp, bias, gamma, resid, C, M, N, K, cg, grp, st, what);
+}
+
+// 128-row form: plain launch with the fused epilogue (nk_split == 0) or split-K partials (nk_split > 0, bias-less raw sums)
+int launch_split_pipe128(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C,
+                         int M, int N, int K, int epilogue, int nk_split, hipStream_t st, const char* what) {
+  if (K % 32 || N % BN || M <= 0 || (nk_split > 0 && (nk_split < 2 || nk_split % 2 || (K / BK) % nk_split))) return -1;
+  if ((unsigned long long)M * (unsigned long long)K * 4ull >= (1ull << 32)) return -1;  // 32-bit lane offsets
+  if ((long)((M + 127) / 128) * (N / BN) >= (1l << 30)) return -1;
+  if (nk_split > 0) return launch_pipe128<EPI_BIAS>(A, Wp, nullptr, nullptr, nullptr, C, M, N, K, nk_split, st, what);
+  if (epilogue == EPI_BIAS) return launch_pipe128<EPI_BIAS>(A, Wp, bias, gamma, resid, C, M, N, K, 0, st, what);
+  if (epilogue == EPI_GELU) return launch_pipe128<EPI_GELU>(A, Wp, bias, gamma, resid, C, M, N, K, 0, st, what);
+  return launch_pipe128<EPI_SCALE_RES>(A, Wp, bias, gamma, resid, C, M, N, K, 0, st, what);
 }
 
 // Split-K launch of the pipelined kernel: partials[y][M][N] for the (K/16) / nk_split chunks of nk_split (even) k-tiles.

@@ -534,3 +534,25 @@ def test_conv_splitk_small_batches(hip, n, cin, cout, h, w, k, stride, pad, gelu
     finally:
         hip.set_conv_splitk(True)
     assert ((out - one).abs().max() / scale).item() < 2e-6
+
+
+@pytest.mark.parametrize("m,k,n", [(1000, 512, 512), (2048, 512, 2048), (128, 2048, 512), (96, 64, 128), (4100, 128, 256)])
+def test_pipelined_128_row_kernel_is_bitwise_equal_to_the_256_row_kernel(hip, m, k, n):
+    """Launches with fewer than 256 tiles of 256x128 run the 128-row form of the pipelined kernel: same six products in the
+    same order per accumulator, so every epilogue agrees bit for bit with the 256-row kernel (forced by split_gemm_mi4 = 1)."""
+    torch.manual_seed(m + k)
+    x = torch.randn(m, k, device=DEV)
+    w = torch.randn(n, k, device=DEV) * k ** -0.5
+    b = torch.randn(n, device=DEV)
+    g = torch.randn(n, device=DEV)
+    r = torch.randn(m, n, device=DEV)
+    pk = hip.pack_weight_bf16x3(w)
+    for epi in ("none", "gelu", "scale_res"):
+        extra = (g, r) if epi == "scale_res" else ()
+        small = hip.linear_f32_split(x, pk, b, epi, *extra)
+        hip.set_option("split_gemm_mi4", 1)
+        try:
+            big = hip.linear_f32_split(x, pk, b, epi, *extra)
+        finally:
+            hip.set_option("split_gemm_mi4", -1)
+        assert torch.isfinite(small).all() and torch.equal(small, big), epi
