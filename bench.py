@@ -65,6 +65,9 @@ WORKLOADS = {  # name -> (index into BASELINE.json configs, cfg names, ROIs per 
     "tless": (3, ["tless_convnext_a6"], 128, True, "T-LESS 30 objects convnext_a6 + fast depth refine, ROI-sharded"),
     "bop7": (4, [f"{d}_convnext_a6" for d in ("lmo", "ycbv", "tless", "icbin", "hb", "itodd", "tudl")], 128, True,
              "BOP-7 mixed stream (lmo/ycbv/tless/icbin/hb/itodd/tudl convnext_a6 models cycled per step) + fast depth refine"),
+    # not a BASELINE.json config (index None): the class-agnostic head of the reference's single-object config families
+    "ycbv_so": (None, ["ycbv_convnext_so"], 128, True,
+                "YCB-V single-object convnext (configs/gdrn/ycbvSO/*, class-agnostic head) + fast depth refine"),
 }
 
 

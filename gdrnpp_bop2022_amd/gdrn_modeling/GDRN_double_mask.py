@@ -74,10 +74,14 @@ class GDRN_DoubleMask(nn.Module):
         self.xyz_out_dim, self.mask_out_dim, self.region_out_dim = get_xyz_mask_region_out_dim(cfg, self.double_mask)
         g = cfg.MODEL.POSE_NET.GEO_HEAD
         self.class_aware = bool(g.XYZ_CLASS_AWARE and g.MASK_CLASS_AWARE and g.REGION_CLASS_AWARE)
+        # Output-layer slices: one per class for the class-aware heads (the 7 BOP convnext_a6 configs); ONE slice — the whole
+        # layer — for the class-agnostic heads (the reference's 162 single-object configs, configs/gdrn/*SO/*, and the base
+        # config): the same grouped GEMM / head-tail kernels serve both, with every ROI selecting slice 0.
+        agnostic = not (g.XYZ_CLASS_AWARE or g.MASK_CLASS_AWARE or g.REGION_CLASS_AWARE)
+        self.slice_classes = cfg.MODEL.POSE_NET.NUM_CLASSES if self.class_aware else (1 if agnostic else None)
         self.exact_reference_order = False
-        if self.class_aware and self.xyz_out_dim == 3:
-            self.register_buffer("_cls_rows", geo_head_net.class_channel_index(cfg.MODEL.POSE_NET.NUM_CLASSES),
-                                 persistent=False)
+        if self.slice_classes is not None and self.xyz_out_dim == 3:
+            self.register_buffer("_cls_rows", geo_head_net.class_channel_index(self.slice_classes), persistent=False)
         self._sliced_w = None  # cache of (weight[C,70,256], bias[C,70]) for eval
         self._sliced_pk = None  # cache of the packed, 128-row padded slices for the grouped split GEMM
         self.fused_head_tail = True   # all-NHWC head tail on the HIP path (False: baddbmm + torch ops, for A/B)
@@ -108,7 +112,7 @@ class GDRN_DoubleMask(nn.Module):
         net_cfg = self.cfg.MODEL.POSE_NET
         pn = net_cfg.PNP_NET
         return (hip_layers.enabled_for(x) and hip_layers.mlp_gemm() == "split" and self.fused_head_tail
-                and self.class_aware and self.xyz_out_dim == 3 and not self.exact_reference_order and not self.training
+                and self.slice_classes is not None and self.xyz_out_dim == 3 and not self.exact_reference_order and not self.training
                 and self.region_out_dim == 65 and self.mask_out_dim == (2 if self.double_mask else 1)
                 and pn.WITH_2D_COORD and pn.REGION_ATTENTION and pn.MASK_ATTENTION == "none"
                 and roi_classes is not None and coord2d is not None and roi_extents is not None
@@ -163,15 +167,25 @@ class GDRN_DoubleMask(nn.Module):
             conv_feat = self.neck(conv_feat)
 
         full_mask = None
-        if self.class_aware and self.xyz_out_dim == 3 and not self.exact_reference_order:
-            assert roi_classes is not None
+        sliced = False
+        if self.slice_classes is not None and self.xyz_out_dim == 3 and not self.exact_reference_order:
+            if self.class_aware:
+                assert roi_classes is not None
+                sel = roi_classes
+            else:       # class-agnostic head: every ROI uses the one slice (= the whole output layer)
+                sel = torch.zeros((bs,), dtype=torch.long, device=x.device)
             feat = self.geo_head_net.trunk(conv_feat)
             coord2d = roi_coord_2d_rel if pnp_net_cfg.WITH_2D_COORD and pnp_net_cfg.COORD_2D_TYPE == "rel" else roi_coord_2d
-            if self._fused_tail_ok(x, feat, roi_classes, coord2d, roi_extents):
-                return self._fused_tail(feat, roi_classes, coord2d, roi_extents)
-            vis_mask, full_mask, coor_x, coor_y, coor_z, region = self._sliced_out_layer(feat, roi_classes)
+            if self._fused_tail_ok(x, feat, sel, coord2d, roi_extents):
+                return self._fused_tail(feat, sel, coord2d, roi_extents)
+            if self.class_aware:
+                vis_mask, full_mask, coor_x, coor_y, coor_z, region = self._sliced_out_layer(feat, sel)
+                sliced = True
+            else:
+                outs = self.geo_head_net.split(self.geo_head_net.out_layer(feat))
         else:
             outs = self.geo_head_net(conv_feat)
+        if not sliced:
             if self.double_mask:
                 vis_mask, full_mask, coor_x, coor_y, coor_z, region = outs
             else:

@@ -137,6 +137,15 @@ def get_cfg(name: str = "ycbv_convnext_a6", opts=None) -> Config:
         ds = name.split("_")[0]
         cfg = _merge(base, _gdrnpp_convnext(num_cls[ds]))
         cfg = _merge(cfg, dict(VAL=dict(DATASET_NAME=_VAL_DATASET_NAME.get(ds, ds), SPLIT="test", SPLIT_TYPE=""), EXP_ID=name))
+    elif name.endswith("_convnext_so"):
+        # the ten single-object families (configs/gdrn/{ycbv,tless,tudl}SO, {ycbv,lmo,tless,tudl,icbin,itodd,hb}PbrSO:
+        # one config per object, e.g. ycbvSO/convnext_AugCosyAAEGray_DMask_amodalClipBox_ycbv/002_master_chef_can.py): the
+        # convnext_a6 MODEL block with a class-AGNOSTIC head; NUM_CLASSES keeps gdrn_base.py's 13 and is not used
+        ds = name.split("_")[0]
+        cfg = _merge(base, _gdrnpp_convnext(13))
+        cfg = _merge(cfg, dict(MODEL=dict(POSE_NET=dict(GEO_HEAD=dict(XYZ_CLASS_AWARE=False, MASK_CLASS_AWARE=False,
+                                                                     REGION_CLASS_AWARE=False))),
+                               VAL=dict(DATASET_NAME=_VAL_DATASET_NAME.get(ds, ds), SPLIT="test", SPLIT_TYPE=""), EXP_ID=name))
     elif name == "lmo_resnet34_ape":
         # BASELINE config 1: base GDRN (ResNet-34, single object, class-agnostic head)
         # = configs/_base_/gdrn_base.py with one class; the ROI padding of every shipped single-object LM-O config

@@ -49,6 +49,11 @@ CONFIGS = {
     "ycbv": "configs/gdrn/ycbv/convnext_a6_AugCosyAAEGray_BG05_mlL1_DMask_amodalClipBox_classAware_ycbv.py",
     "tless": "configs/gdrn/tless/convnext_a6_AugCosyAAEGray_BG05_mlL1_DMask_amodalClipBox_classAware_tless.py",
 }
+# One of the 162 single-object configs (ycbvSO / lmoPbrSO / tlessPbrSO / ...): the same ConvNeXt-B network with a
+# class-AGNOSTIC double-mask head (XYZ/MASK/REGION_CLASS_AWARE = False; NUM_CLASSES is set but unused).
+SO_CONFIGS = {
+    "ycbvso": "configs/gdrn/ycbvSO/convnext_AugCosyAAEGray_DMask_amodalClipBox_ycbv/002_master_chef_can.py",
+}
 from tests.netgolden import SEED, net_detections, net_image, norm_alias  # noqa: E402
 
 
@@ -83,8 +88,10 @@ def write_config_fixture():
     print("wrote cfg_golden.json")
 
 
-def main():
-    write_config_fixture()
+def main(configs=None):
+    if configs is None:
+        write_config_fixture()
+        configs = dict(CONFIGS, **SO_CONFIGS)
     torch.set_num_threads(os.cpu_count())
     torch.set_grad_enabled(False)
     hip_layers.set_enabled(False)
@@ -97,7 +104,7 @@ def main():
     for bname in ("convnext_base",):
         net_factory.BACKBONES[f"timm/{bname}"] = backbone_factory
 
-    for ds, path in CONFIGS.items():
+    for ds, path in configs.items():
         raw = _refimport.load_ref_config(path)
         cfg = Config(raw)
         cfg.MODEL.DEVICE = "cpu"
@@ -200,6 +207,8 @@ if __name__ == "__main__":
         torch.set_grad_enabled(False)
         hip_layers.set_enabled(False)
         record_resnet34()
+    elif "--so-only" in sys.argv:
+        main(SO_CONFIGS)
     else:
         main()
         record_resnet34()

@@ -35,6 +35,11 @@ def net_detections(num_classes, b=B, seed=SEED):
     return det
 
 
+def cfg_name(ds):
+    """Fixture name -> named config: "ycbvso" is a single-object config (class-agnostic head, configs/gdrn/ycbvSO/...)."""
+    return f"{ds[:-2]}_convnext_so" if ds.endswith("so") else f"{ds}_convnext_a6"
+
+
 def load_fixture(ds):
     z = np.load(os.path.join(GOLDEN, f"net_golden_{ds}.npz"))
     fx = {k: z[k] for k in z.files}

@@ -12,11 +12,11 @@ from tests import netgolden as NG
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["ycbv", "tless"])
+@pytest.fixture(scope="module", params=["ycbv", "tless", "ycbvso"])
 def case(request, hip):
     ds = request.param
     fx = NG.load_fixture(ds)
-    cfg = get_cfg(f"{ds}_convnext_a6", opts=["TEST.USE_DEPTH_REFINE=True"])
+    cfg = get_cfg(NG.cfg_name(ds), opts=["TEST.USE_DEPTH_REFINE=True"])
     model, _ = build_model_optimizer(cfg)
     assert next(model.parameters()).is_cuda
     x = torch.from_numpy(NG.net_image()).cuda()
@@ -82,20 +82,28 @@ def test_config_surface_variants_run_through_forward_and_post(hip):
             assert rec.shape == (NG.B, 16) and torch.isfinite(rec).all()
 
 
-@pytest.mark.parametrize("ds", ["ycbv", "tless"])
+@pytest.mark.parametrize("ds", ["ycbv", "tless", "ycbvso"])
 def test_fused_head_tail_matches_module_path(hip, ds):
     """The all-NHWC head tail (grouped class-sliced GEMM, head_tail kernel, Patch-PnP's first convolution with Cin padded to 96)
     against the module path (baddbmm + torch softmax / cat + MIOpen / CK convolution) on the same weights: maps and Patch-PnP
-    outputs agree to fp32 rounding; the fused path is really the one taken by default."""
+    outputs agree to fp32 rounding; the fused path is really the one taken by default — also for the class-agnostic head of the
+    single-object configs ("ycbvso": one slice, every ROI selects it)."""
     fx = NG.load_fixture(ds)
-    cfg = get_cfg(f"{ds}_convnext_a6", opts=["TEST.USE_DEPTH_REFINE=True"])
+    cfg = get_cfg(NG.cfg_name(ds), opts=["TEST.USE_DEPTH_REFINE=True"])
     model, _ = build_model_optimizer(cfg)
     model.load_state_dict(NG.seeded_reference_state_dict(model, fx), strict=True)
     x = torch.from_numpy(NG.net_image()).cuda()
     kw = NG.forward_kwargs(fx, "cuda")
+    from gdrnpp_bop2022_amd import hip_lib
     with torch.no_grad():
         assert model.fused_head_tail
-        fused = model(x, **kw)
+        timer = hip_lib.LaunchTimer()
+        hip_lib.set_launch_timer(timer)
+        try:
+            fused = model(x, **kw)
+        finally:
+            hip_lib.set_launch_timer(None)
+        assert sum(1 for r in timer.records if r[0] == "linear_grouped") == 1
         model.fused_head_tail = False
         plain = model(x, **kw)
     assert not fused["region"].is_contiguous() and plain["region"].shape == fused["region"].shape   # NHWC view vs NCHW tensor

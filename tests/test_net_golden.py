@@ -14,7 +14,7 @@ from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
 from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
 from tests import netgolden as NG
 
-DATASETS = ["ycbv", "tless"]
+DATASETS = ["ycbv", "tless", "ycbvso"]
 
 
 def _flat(d, prefix=""):
@@ -45,11 +45,20 @@ def test_config_values_equal_the_reference_files(ds):
 def case(request):
     ds = request.param
     fx = NG.load_fixture(ds)
-    cfg = get_cfg(f"{ds}_convnext_a6", opts=["TEST.USE_DEPTH_REFINE=True", "MODEL.DEVICE=cpu"])
+    cfg = get_cfg(NG.cfg_name(ds), opts=["TEST.USE_DEPTH_REFINE=True", "MODEL.DEVICE=cpu"])
     model, _ = build_model_optimizer(cfg)
     sd = NG.seeded_reference_state_dict(model, fx)
     res = model.load_state_dict(sd, strict=True)          # the reference's key set, duplicates and all
     return ds, fx, model, res
+
+
+def test_single_object_config_values_equal_the_reference_file():
+    fx = NG.load_fixture("ycbvso")
+    ref = _flat(fx["cfg"])
+    ours = _flat({k: dict(get_cfg("ycbv_convnext_so"))[k] for k in ("MODEL", "TEST", "INPUT")})
+    assert not [k for k in ours if k not in ref]
+    diff = {k: (ours[k], ref[k]) for k in ours if ours[k] != ref[k]}
+    assert not diff, diff
 
 
 def test_reference_state_dict_loads_strict(case):
