@@ -266,6 +266,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_pipe_kernel(const float* __
       constexpr int SA_ = TA[G], SB_ = TB[G];
       const bf16x8 fa = cur[I].template frag<SA_>();
       const bf16x8 fb = (SB_ == 1) ? fbY[J] : fbX[J];
+#ifdef GDRNPP_TIMING_HALF_PRODUCTS   // timing-only build (results invalid): three of the six products
+      if constexpr (G >= 3)
+#endif
       acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[I][J], 0, 0, 0);
       // weight DMA of k-tile kt+1, then A DMA of k-tile kt+NA (the A pieces are the newest four loads at the wait)
       if constexpr (S == 0) dma_b(kt_b, sb_wr, std::integral_constant<int, 0>{});

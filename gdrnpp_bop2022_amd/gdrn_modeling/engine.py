@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 
 from .. import hip_lib
+from . import hip_layers
 
 
 def shard_range(n: int, rank: int, world: int):
@@ -238,12 +239,24 @@ def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor 
         roi_ids = batch.get("roi_id")
     if batch["roi_img"].shape[0] == 0:            # empty shard (shard_range may give trailing ranks nothing): the caller
         return torch.zeros((0, 16), dtype=torch.float32, device=batch["roi_img"].device)   # still reaches gather_records
-    out_dict = model(
-        batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"], roi_whs=batch["roi_wh"],
-        roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"],
-        roi_coord_2d=batch.get("roi_coord_2d"), roi_coord_2d_rel=batch.get("roi_coord_2d_rel"),
-        roi_extents=batch.get("roi_extent"))
-    return post.process(batch, out_dict, roi_ids)
+    def run():
+        out_dict = model(
+            batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"], roi_whs=batch["roi_wh"],
+            roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"],
+            roi_coord_2d=batch.get("roi_coord_2d"), roi_coord_2d_rel=batch.get("roi_coord_2d_rel"),
+            roi_extents=batch.get("roi_extent"))
+        return post.process(batch, out_dict, roi_ids)
+
+    rec = run()
+    # three-product GEMM mode (hip_layers.set_gemm_products(3)): an activation beyond the fp16 range made an output non-finite
+    # -> the step is repeated with the six-product kernels (one 4-byte read-back + stream sync per step in that mode)
+    if hip_layers.gemm_products() == 3 and batch["roi_img"].is_cuda and hip_lib.split2_nonfinite(reset=True):
+        hip_layers.set_gemm_products(6)
+        try:
+            rec = run()
+        finally:
+            hip_layers.set_gemm_products(3)
+    return rec
 
 
 def gather_records(rec: torch.Tensor, n_local_max: int, group=None) -> torch.Tensor:

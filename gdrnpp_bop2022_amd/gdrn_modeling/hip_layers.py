@@ -113,6 +113,41 @@ _LIBRARY_BELOW_TILES = 0    # A/B switch: blocks whose fc2 has fewer 128x128 out
                             # with a modelled number of K chunks and no block leaves this library
 
 
+# Partial products per fp32 product in the split GEMMs: 6 (default; bf16x3, exact to 2^-26) or 3 (fp16x2, 22 significant operand
+# bits: 1.5e-7 .. 2.5e-7 of the output scale against fp64 — below an ordinary fp32 GEMM's 1e-6 — for half the matrix work;
+# csrc/gemm_split2_pipe.hip).  3 applies where the three-product kernels exist and pay (ConvNeXt MLPs, 3x3/1/1 convolutions and
+# the transposed-convolution GEMM from 256 tiles of 256 x 128 on); every other layer stays on the six-product kernels.  An
+# activation beyond the fp16 range turns the outputs non-finite and raises hip_lib.split2_nonfinite(): engine.inference_step
+# then repeats the step with 6.
+_GEMM_PRODUCTS = 6
+
+
+def set_gemm_products(n: int) -> None:
+    global _GEMM_PRODUCTS
+    if n not in (3, 6):
+        raise ValueError(f"gemm products must be 6 (bf16x3) or 3 (fp16x2), got {n!r}")
+    _GEMM_PRODUCTS = int(n)
+
+
+def gemm_products() -> int:
+    return _GEMM_PRODUCTS
+
+
+def _use_x3(m: int, n: int) -> bool:
+    return _GEMM_PRODUCTS == 3 and hip_lib.split2_tiles_ok(m, n)
+
+
+def _packed_weight(cache: dict, key: str, weight: torch.Tensor, x3: bool, pack6, pack3) -> torch.Tensor:
+    """Packed split image of ``weight`` in the six- (key) or three-product (key + "_x3") format, rebuilt when the weight changes."""
+    key = key + "_x3" if x3 else key
+    tag = weight_tag(weight)
+    hit = cache.get(key)
+    if hit is None or hit[0] != tag:
+        hit = (tag, (pack3 if x3 else pack6)(weight.detach()))
+        cache[key] = hit
+    return hit[1]
+
+
 def set_mlp_gemm(mode: str) -> None:
     global _MLP_GEMM
     if mode not in ("split", "torch"):
@@ -137,14 +172,8 @@ def set_fused_mlp(flag: bool) -> None:
     set_mlp_gemm("split" if flag else "torch")
 
 
-def _packed(linear: nn.Linear, cache: dict, key: str) -> torch.Tensor:
-    w = linear.weight
-    tag = weight_tag(w)
-    hit = cache.get(key)
-    if hit is None or hit[0] != tag:
-        hit = (tag, hip_lib.pack_weight_bf16x3(w.detach()))
-        cache[key] = hit
-    return hit[1]
+def _packed(linear: nn.Linear, cache: dict, key: str, x3: bool = False) -> torch.Tensor:
+    return _packed_weight(cache, key, linear.weight, x3, hip_lib.pack_weight_bf16x3, hip_lib.pack_weight_f16x2)
 
 
 def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: torch.Tensor, cache: dict) -> torch.Tensor:
@@ -157,10 +186,11 @@ def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: 
           and c % 128 == 0)
     if ok and _MLP_GEMM == "split" and hip_lib.split_gemm_tiles(m, c) >= _LIBRARY_BELOW_TILES:
         # fewer than two output tiles per CU (small ROI counts at the deep stages): split K as well, or most of the chip idles
-        f1 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, 4 * c) < _SPLITK_BELOW_TILES else hip_lib.linear_f32_split
-        f2 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, c) < _SPLITK_BELOW_TILES else hip_lib.linear_f32_split
-        h = f1(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk"), mlp.fc1.bias, "gelu")
-        y = f2(h, _packed(mlp.fc2, cache, "fc2_pk"), mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
+        x3_1, x3_2 = _use_x3(m, 4 * c), _use_x3(m, c)
+        f1 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, 4 * c) < _SPLITK_BELOW_TILES and not x3_1 else hip_lib.linear_f32_split
+        f2 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, c) < _SPLITK_BELOW_TILES and not x3_2 else hip_lib.linear_f32_split
+        h = f1(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk", x3_1), mlp.fc1.bias, "gelu")
+        y = f2(h, _packed(mlp.fc2, cache, "fc2_pk", x3_2), mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
         return y.view(x_nhwc.shape)
     return torch.addcmul(shortcut_nhwc, mlp(x_nhwc), gamma)
 
@@ -190,15 +220,12 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     (bf16 matrix cores, fp32-accurate), everything else in MIOpen."""
     if _conv_split_ok(conv, x):
         cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
-        w = conv.weight
-        tag = weight_tag(w)
-        hit = cache.get("w_pk")
-        if hit is None or hit[0] != tag:
-            hit = (tag, hip_lib.pack_conv_weight_bf16x3(w.detach()))
-            cache["w_pk"] = hit
-        if conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1):
-            return hip_lib.conv3x3_f32_split(_cl(x), hit[1], conv.bias)
-        return hip_lib.conv2d_f32_split(_cl(x), hit[1], conv.bias, conv.kernel_size[0], conv.kernel_size[1], conv.stride[0],
+        is3x3 = conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+        x3 = is3x3 and _use_x3(x.shape[0] * x.shape[2] * x.shape[3], conv.out_channels)
+        w_pk = _packed_weight(cache, "w_pk", conv.weight, x3, hip_lib.pack_conv_weight_bf16x3, hip_lib.pack_conv_weight_f16x2)
+        if is3x3:
+            return hip_lib.conv3x3_f32_split(_cl(x), w_pk, conv.bias)
+        return hip_lib.conv2d_f32_split(_cl(x), w_pk, conv.bias, conv.kernel_size[0], conv.kernel_size[1], conv.stride[0],
                                        conv.padding[0])
     return conv(x)
 
@@ -272,12 +299,9 @@ def conv_transpose2d(deconv: nn.ConvTranspose2d, x: torch.Tensor) -> torch.Tenso
             and deconv.dilation == (1, 1) and deconv.groups == 1 and deconv.in_channels % 32 == 0
             and deconv.out_channels % 4 == 0 and (ks * ks * deconv.out_channels) % 128 == 0):
         cache = deconv.__dict__.setdefault("_gdrnpp_cache", {})
-        tag = weight_tag(deconv.weight)
-        hit = cache.get("w_pk")
-        if hit is None or hit[0] != tag:
-            hit = (tag, hip_lib.pack_deconv_weight_bf16x3(deconv.weight))
-            cache["w_pk"] = hit
-        return hip_lib.conv_transpose2d_f32_split(_cl(x), hit[1], deconv.bias, ks, deconv.stride[0], deconv.padding[0],
+        x3 = _use_x3(x.shape[0] * x.shape[2] * x.shape[3], ks * ks * deconv.out_channels)
+        w_pk = _packed_weight(cache, "w_pk", deconv.weight, x3, hip_lib.pack_deconv_weight_bf16x3, hip_lib.pack_deconv_weight_f16x2)
+        return hip_lib.conv_transpose2d_f32_split(_cl(x), w_pk, deconv.bias, ks, deconv.stride[0], deconv.padding[0],
                                                   deconv.output_padding[0])
     return deconv(x)
 
@@ -302,12 +326,9 @@ def conv3x3_groupnorm_act(conv: nn.Conv2d, gn: nn.GroupNorm, act: nn.Module | No
             and (act is None or (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none"))):
         return None
     cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
-    tag = weight_tag(conv.weight)
-    hit = cache.get("w_pk")
-    if hit is None or hit[0] != tag:
-        hit = (tag, hip_lib.pack_conv_weight_bf16x3(conv.weight.detach()))
-        cache["w_pk"] = hit
-    return hip_lib.conv3x3_groupnorm_act(_cl(x), hit[1], conv.bias, gn.weight, gn.bias, gn.num_groups, gn.eps,
+    x3 = _use_x3(x.shape[0] * x.shape[2] * x.shape[3], conv.out_channels)
+    w_pk = _packed_weight(cache, "w_pk", conv.weight, x3, hip_lib.pack_conv_weight_bf16x3, hip_lib.pack_conv_weight_f16x2)
+    return hip_lib.conv3x3_groupnorm_act(_cl(x), w_pk, conv.bias, gn.weight, gn.bias, gn.num_groups, gn.eps,
                                          gelu=act is not None)
 
 

@@ -104,6 +104,11 @@ SIGNATURES = {
     "gdrnpp_conv3x3_gnstats_partials": (c_int, [c_int, c_int]),
     "gdrnpp_conv3x3_f32_split_gnstats": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_groupnorm_apply_nhwc": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "gdrnpp_pack_weight_f16x2_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "gdrnpp_pack_weight_f16x2": (c_int, [_P, _P, c_int, c_int, _P]),
+    "gdrnpp_linear_f32_split2": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_conv3x3_f32_split2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_split2_nonfinite": (c_int, [_P, c_int, _P]),
 }
 
 
@@ -613,19 +618,67 @@ def pack_weight_bf16x3(weight):
     return packed
 
 
+def pack_weight_f16x2(weight):
+    """nn.Linear weight f32[N,K] -> fp16[N/128, K/16, 2, 2, 128, 8]: two-way fp16 split (w * 2^e ~ h + l, 22 significant bits) of
+    every 128x16 tile for the three-product kernels (csrc/gemm_split2_pipe.hip).  The returned tensor is a VIEW of a buffer that
+    also carries the 16-byte trailer with the power-of-two scale behind the tiles: pass it on as it is (a copy loses the trailer)."""
+    n, k = weight.shape
+    nbytes = load().gdrnpp_pack_weight_f16x2_bytes(n, k)
+    buf = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
+    _check(load().gdrnpp_pack_weight_f16x2(_dev(weight, torch.float32, "weight"), buf.data_ptr(), n, k, _stream()),
+           "gdrnpp_pack_weight_f16x2")
+    packed = buf[:n * k * 4].view(torch.float16).view(n // 128, k // 16, 2, 2, 128, 8)
+    packed._gdrnpp_base = buf
+    return packed
+
+
+def unpack_weight_f16x2(packed):
+    """For tests: (fp16[2, N, K] planes h / l of the SCALED weight, 2^-e) of a pack_weight_f16x2 result."""
+    tn, tk = packed.shape[:2]
+    planes = packed.permute(2, 0, 4, 1, 3, 5).reshape(2, tn * 128, tk * 16)
+    trailer = packed._gdrnpp_base[packed.numel() * 2:].view(torch.float32)
+    return planes, float(trailer[1])
+
+
+def pack_conv_weight_f16x2(weight):
+    """nn.Conv2d weight [Cout, Cin, KH, KW] -> pack_weight_f16x2 of the (tap, channel)-ordered [Cout, KH*KW*Cin] matrix."""
+    cout, cin, kh, kw = weight.shape
+    return pack_weight_f16x2(weight.detach().permute(0, 2, 3, 1).reshape(cout, kh * kw * cin).contiguous())
+
+
+SPLIT2_MIN_TILES = 256   # tests lower it to run the three-product kernels on the 4-ROI reference fixtures
+
+
+def split2_tiles_ok(m: int, n: int) -> bool:
+    """The three-product kernels exist as 256-row tiles only: used from 256 tiles of 256 x 128 on (every CU gets a workgroup)."""
+    return n % 128 == 0 and ((m + 255) // 256) * (n // 128) >= SPLIT2_MIN_TILES
+
+
+def split2_nonfinite(reset: bool = True) -> bool:
+    """True when a three-product kernel stored an inf / NaN since the last reset (an activation beyond the fp16 range, or a
+    non-finite input): the caller repeats the work with the six-product kernels.  Synchronises the current stream."""
+    flag = ctypes.c_int(0)
+    _check(load().gdrnpp_split2_nonfinite(ctypes.byref(flag), 1 if reset else 0, _stream()), "gdrnpp_split2_nonfinite")
+    return bool(flag.value)
+
+
 def unpack_weight_bf16x3(packed):
     """Inverse view of pack_weight_bf16x3 for tests: bf16[3, N, K] planes."""
     tn, tk = packed.shape[:2]
     return packed.permute(2, 0, 4, 1, 3, 5).reshape(3, tn * 128, tk * 16)
 
 
+X3 = "_x3"   # LaunchTimer kind suffix of the three-product (fp16x2) kernels: 3 instead of 6 MFMA flops per fp32-equivalent flop
+
+
 def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None, _kind: str = "linear"):
     """out = epilogue(x2d @ W^T + bias) with the weight given as pack_weight_bf16x3(weight); runs on the bf16 matrix cores
     with six partial products per fp32 product (fp32-accurate, see csrc/gemm_split.hip)."""
     m, k = x2d.shape
-    if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or not weight_packed.is_contiguous() \
-            or weight_packed.shape[1] * 16 != k:
-        raise ValueError("weight_packed must be the contiguous bf16 tensor from pack_weight_bf16x3 with matching K")
+    fp16x2 = weight_packed.dtype == torch.float16     # pack_weight_f16x2: the three-product kernel
+    if weight_packed.dtype not in (torch.bfloat16, torch.float16) or weight_packed.dim() != 6 or not weight_packed.is_contiguous() \
+            or weight_packed.shape[1] * 16 != k or weight_packed.shape[2] != (2 if fp16x2 else 3):
+        raise ValueError("weight_packed must be the contiguous tensor from pack_weight_bf16x3 / pack_weight_f16x2 with matching K")
     n = weight_packed.shape[0] * 128
     out = torch.empty((m, n), dtype=torch.float32, device=x2d.device)
     args = (_dev(x2d, torch.float32, "x"), weight_packed.data_ptr(),
@@ -633,8 +686,11 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
             _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
             _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
             {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream())
-    nbytes = 4.0 * m * k + 6.0 * n * k + 4.0 * m * n * (2 if epilogue == "scale_res" else 1)
-    _check(_timed(_kind, 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split(*args), nbytes), "gdrnpp_linear_f32_split")
+    nbytes = 4.0 * m * k + (4.0 if fp16x2 else 6.0) * n * k + 4.0 * m * n * (2 if epilogue == "scale_res" else 1)
+    if fp16x2:
+        _check(_timed(_kind + X3, 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split2(*args), nbytes), "gdrnpp_linear_f32_split2")
+    else:
+        _check(_timed(_kind, 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split(*args), nbytes), "gdrnpp_linear_f32_split")
     return out
 
 
@@ -733,11 +789,21 @@ def conv2d_f32_split(x_cl, weight_packed, bias, kh: int, kw: int, stride: int, p
     n, cin, h, w = x_cl.shape
     if not x_cl.is_contiguous(memory_format=torch.channels_last) or x_cl.dtype != torch.float32 or not x_cl.is_cuda:
         raise ValueError("conv2d_f32_split expects a float32 channels_last device tensor")
-    if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or weight_packed.shape[1] * 16 != kh * kw * cin:
-        raise ValueError("weight_packed must come from pack_conv_weight_bf16x3 with matching Cin and kernel size")
+    fp16x2 = weight_packed.dtype == torch.float16
+    if weight_packed.dtype not in (torch.bfloat16, torch.float16) or weight_packed.dim() != 6 \
+            or weight_packed.shape[1] * 16 != kh * kw * cin or weight_packed.shape[2] != (2 if fp16x2 else 3):
+        raise ValueError("weight_packed must come from pack_conv_weight_bf16x3 / pack_conv_weight_f16x2 with matching Cin and kernel size")
     cout = weight_packed.shape[0] * 128
     oh, ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
     out = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
+    if fp16x2:
+        if (kh, kw, stride, pad) != (3, 3, 1, 1):
+            raise ValueError("the three-product convolution exists for 3x3 / stride 1 / pad 1 only")
+        a2 = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
+              out.data_ptr(), None, n, h, w, cin, cout, 0, 1 if gelu else 0, _stream())
+        _check(_timed(_kind + X3, 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split2(*a2),
+                      4.0 * n * h * w * (cin + cout) + 4.0 * cout * 9 * cin), "gdrnpp_conv3x3_f32_split2")
+        return out
     args = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
             out.data_ptr(), n, h, w, cin, cout, kh, kw, stride, pad, 1 if gelu else 0)
     nbytes = 4.0 * n * (h * w * cin + oh * ow * cout) + 6.0 * cout * kh * kw * cin
@@ -778,6 +844,12 @@ def pack_deconv_weight_bf16x3(weight):
     return pack_weight_bf16x3(weight.detach().permute(2, 3, 1, 0).reshape(kh * kw * cout, cin).contiguous())
 
 
+def pack_deconv_weight_f16x2(weight):
+    """pack_deconv_weight_bf16x3 in the three-product format."""
+    cin, cout, kh, kw = weight.shape
+    return pack_weight_f16x2(weight.detach().permute(2, 3, 1, 0).reshape(kh * kw * cout, cin).contiguous())
+
+
 def conv_transpose2d_f32_split(x_cl, weight_packed, bias, ks: int, stride: int, pad: int, out_pad: int):
     """nn.ConvTranspose2d of a channels_last tensor [N,Cin,H,W] as split GEMM + col2im gather -> channels_last
     [N,Cout,OH,OW] (``weight_packed`` from pack_deconv_weight_bf16x3)."""
@@ -802,8 +874,10 @@ def conv3x3_groupnorm_act(x_cl, weight_packed, bias, gamma, beta, groups: int, e
     n, cin, h, w = x_cl.shape
     if not x_cl.is_contiguous(memory_format=torch.channels_last) or x_cl.dtype != torch.float32 or not x_cl.is_cuda:
         raise ValueError("conv3x3_groupnorm_act expects a float32 channels_last device tensor")
-    if weight_packed.dtype != torch.bfloat16 or weight_packed.dim() != 6 or weight_packed.shape[1] * 16 != 9 * cin:
-        raise ValueError("weight_packed must come from pack_conv3x3_weight_bf16x3 with matching Cin")
+    fp16x2 = weight_packed.dtype == torch.float16
+    if weight_packed.dtype not in (torch.bfloat16, torch.float16) or weight_packed.dim() != 6 \
+            or weight_packed.shape[1] * 16 != 9 * cin or weight_packed.shape[2] != (2 if fp16x2 else 3):
+        raise ValueError("weight_packed must come from pack_conv_weight_bf16x3 / pack_conv_weight_f16x2 with matching Cin")
     cout = weight_packed.shape[0] * 128
     P = load().gdrnpp_conv3x3_gnstats_partials(h, w)
     if P <= 0 or cout != 8 * groups or (n * h * w // 256) * (cout // 128) < 256:   # below: the 128x128-tile kernels are faster
@@ -812,9 +886,14 @@ def conv3x3_groupnorm_act(x_cl, weight_packed, bias, gamma, beta, groups: int, e
     part = torch.empty((n, P, groups, 2), dtype=torch.float64, device=x_cl.device)
     args = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
             y.data_ptr(), part.data_ptr(), n, h, w, cin, cout, groups, _stream())
-    nbytes = 4.0 * n * h * w * (cin + cout) + 6.0 * cout * 9 * cin
-    _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split_gnstats(*args), nbytes),
-           "gdrnpp_conv3x3_f32_split_gnstats")
+    nbytes = 4.0 * n * h * w * (cin + cout) + (4.0 if fp16x2 else 6.0) * cout * 9 * cin
+    if fp16x2:
+        a3 = args[:4] + (part.data_ptr(), n, h, w, cin, cout, groups, 0, _stream())
+        _check(_timed("conv3x3" + X3, 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split2(*a3), nbytes),
+               "gdrnpp_conv3x3_f32_split2")
+    else:
+        _check(_timed("conv3x3", 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split_gnstats(*args), nbytes),
+               "gdrnpp_conv3x3_f32_split_gnstats")
     out = torch.empty_like(y)
     a2 = (y.data_ptr(), part.data_ptr(), P, _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"),
           out.data_ptr(), n, h * w, cout, groups, float(eps), 1 if gelu else 0, _stream())

@@ -9,6 +9,7 @@ import torch  # noqa: E402
 from gdrnpp_bop2022_amd import hip_lib as hip  # noqa: E402
 
 B = int(os.environ.get("B", "128"))
+X3 = os.environ.get("X3", "0") == "1"   # three-product (fp16x2) kernels
 dev = "cuda"
 torch.manual_seed(0)
 tot = 0.0
@@ -20,7 +21,7 @@ for st, (hw, c, nblk) in enumerate([(64, 128, 3), (32, 256, 3), (16, 512, 27), (
         b = torch.randn(n, device=dev)
         g = torch.randn(n, device=dev) if epi == "scale_res" else None
         r = torch.randn(m, n, device=dev) if epi == "scale_res" else None
-        pk = hip.pack_weight_bf16x3(w)
+        pk = hip.pack_weight_f16x2(w) if X3 else hip.pack_weight_bf16x3(w)
         fn = lambda: hip.linear_f32_split(x, pk, b, epi, g, r)  # noqa: E731
         for _ in range(3):
             fn()
