@@ -94,10 +94,12 @@ def parse(argv=None):
     p.add_argument("--mlp-gemm", choices=["split", "torch"], default="split",
                    help="GEMM engine of the ConvNeXt MLPs / head convolutions: split = exact 3-way bf16 operand split on the "
                         "bf16 matrix cores (fp32-accurate); torch = hipBLASLt / MIOpen fp32 + separate elementwise kernels")
-    p.add_argument("--gemm-products", type=int, choices=[6, 3], default=6,
-                   help="partial products per fp32 product in the split GEMMs: 6 = bf16x3 (exact to 2^-26, the headline), 3 = fp16x2 "
-                        "(22 operand bits, opt-in fast mode; overflow detected per step and repeated with 6)")
-    p.add_argument("--no-fast-mode-line", action="store_true", help="skip the extra --gemm-products 3 measurement after the timed region")
+    p.add_argument("--gemm-products", type=int, choices=[6, 3], default=3,
+                   help="partial products per fp32 product in the split GEMMs (hip_layers.set_gemm_products): 3 = the library default "
+                        "(fp16x2 operand split where the batch is large enough, overflow detected per step and repeated with 6), "
+                        "6 = bf16x3 everywhere (exact to 2^-26)")
+    p.add_argument("--no-other-mode-line", action="store_true",
+                   help="skip the extra measurement of the other --gemm-products setting after the timed region")
     p.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                    help="library tuning switch (gdrnpp_set_option), e.g. --opt split_gemm_glds=0 for A/B measurements")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --stub-step: CPU test of the launch path")
@@ -236,10 +238,11 @@ def worker(args):
     extras = {}
     if state is not None:
         extras = state["measure_after"](rank == 0 and world == 1)
-    if state is not None and world == 1 and args.gemm_products == 6 and not args.no_fast_mode_line and args.mlp_gemm == "split" \
-            and not args.graph and not args.no_hip_layers:
-        # the same K steps once more with the opt-in three-product GEMM mode (reported beside the headline, never as `value`)
-        extras["fast_mode"] = state["fast_mode_line"](args.steps, n_global, sync)
+    if state is not None and world == 1 and not args.no_other_mode_line and args.mlp_gemm == "split" and not args.graph \
+            and not args.no_hip_layers:
+        # the same K steps once more with the other split-GEMM setting (reported beside the headline, never as `value`)
+        other = 6 if args.gemm_products == 3 else 3
+        extras["six_product_mode" if other == 6 else "three_product_mode"] = state["other_mode_line"](other, args.steps, n_global, sync)
     if rank == 0:
         metric = ("ROIs/sec (GDRNPP fwd + PnP + depth refine), 256x256 crops" if refine else
                   "ROIs/sec (GDRNPP fwd + uncertainty-PnP), 256x256 crops" if wname == "lmo_upnp" else
@@ -247,7 +250,7 @@ def worker(args):
         line = {
             "metric": metric, "value": n_global * args.steps / dt, "unit": "ROIs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32",
+            "vs_baseline": None, "dtype": "f32",   # fp32 in, fp32 accumulate, fp32 out; operand splits: config.gemm_products
             "data": "synthetic (seeded ROIs sorted by class within the rank, two alternating batches per model, ellipsoid meshes "
                     "2562V/5120F, " + ("PyTorch default-init weights" if args.random_init else
                                         "seeded O(1) parameters = synthetic.seeded_state_dict, the parity tests' set") +
@@ -388,8 +391,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         if args.graph and not args.with_crop and upnp is None:
             if k not in m["graphs"]:
                 m["graphs"][k] = GraphedInference(m["model"], m["post"], m["batches"][k], m["batches"][k]["roi_id"])
-            m["graphs"][k].graph.replay()   # inputs already live in the graph's static buffers (resident in HBM)
-            return m["graphs"][k].records
+            return m["graphs"][k].replay()   # inputs already live in the graph's static buffers (resident in HBM)
         rec = inference_step(m["model"], m["post"], prepared(m, k))     # records carry batch["roi_id"]
         if upnp is not None:
             u = upnp[k]
@@ -397,9 +399,9 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             rec[:, 9:12] = rt[:, 3:6].float()   # the PVNet-style pose replaces the direct translation in the records
         return rec
 
-    def fast_mode_line(steps, n_rois, sync):
+    def other_mode_line(products, steps, n_rois, sync):
         try:
-            hip_layers.set_gemm_products(3)
+            hip_layers.set_gemm_products(products)
             hip_lib.split2_nonfinite(reset=True)
             for i in range(2 * len(models) * 2):
                 step(i)
@@ -409,15 +411,16 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                 step(i)
             sync()
             dt = time.perf_counter() - t0
-            return {"gemm_products": 3, "value": n_rois * steps / dt, "unit": "ROIs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-                    "nonfinite_flag_after": bool(hip_lib.split2_nonfinite(reset=True)),
-                    "note": "hip_layers.set_gemm_products(3): ConvNeXt MLPs / 3x3 convolutions / deconv GEMM on the fp16x2 three-product "
-                            "kernels (22 operand bits; tests/test_gpu_split2.py: <= 6e-7 of scale vs fp64, network outputs within 1e-4 "
-                            "of the reference fixtures); the per-step overflow check (4-byte read-back + sync) is inside the timing"}
-        except Exception as e:  # the headline line must not depend on the optional mode
-            return {"gemm_products": 3, "error": repr(e)}
+            return {"gemm_products": products, "value": n_rois * steps / dt, "unit": "ROIs/s", "ms_per_step": dt / steps * 1e3,
+                    "steps": steps, "nonfinite_flag_after": bool(hip_lib.split2_nonfinite(reset=True)),
+                    "note": ("hip_layers.set_gemm_products(6): every split GEMM on the six-product bf16x3 kernels (exact to 2^-26)"
+                             if products == 6 else
+                             "hip_layers.set_gemm_products(3): ConvNeXt MLPs / 3x3 convolutions / deconv GEMM on the fp16x2 three-product "
+                             "kernels; the per-step overflow check (4-byte read-back + sync) is inside the timing")}
+        except Exception as e:  # the headline line must not depend on the extra measurement
+            return {"gemm_products": products, "error": repr(e)}
         finally:
-            hip_layers.set_gemm_products(6)
+            hip_layers.set_gemm_products(args.gemm_products)
 
     def measure_after(do_cpu):
         out = {}
@@ -491,7 +494,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                 pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
                 if os.path.exists(pmc) and b == 128 and wname == "refine" and args.mlp_gemm == "split" and args.gemm_products == 6:
                     g_traffic = json.load(open(pmc)).get("gemm_split_kernel", {}).get("traffic_bytes_per_launch")
-                roofline = dict(kernel="gemm_split_kernel", bound="mfma", achieved=bf16_tflops, peak=BF16_MFMA_PEAK_TFLOPS,
+                roofline = dict(kernel="gemm_split2_pipe_kernel + gemm_split_*_kernel (all split-GEMM launches)" if any(r[0].endswith(hip_lib.X3) for r in gemm_records) else "gemm_split_kernel", bound="mfma", achieved=bf16_tflops, peak=BF16_MFMA_PEAK_TFLOPS,
                                 unit="TFLOP/s", frac=bf16_tflops / BF16_MFMA_PEAK_TFLOPS, traffic=g_traffic,
                                 traffic_source=None if g_traffic is None else PMC_SOURCE,
                                 algorithmic_bytes_per_launch=sum(r[4] for r in gemm_records) / n_l,
@@ -547,7 +550,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                 out["cpu_baseline"] = dict(value=None, error=r.stderr[-400:])
         return out
 
-    return dict(step=step, measure_after=measure_after, fast_mode_line=fast_mode_line)
+    return dict(step=step, measure_after=measure_after, other_mode_line=other_mode_line)
 
 
 if __name__ == "__main__":

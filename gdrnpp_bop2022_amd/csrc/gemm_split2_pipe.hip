@@ -38,8 +38,7 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int NA = 3;                          // A stages: the A DMA runs two k-tiles ahead
 constexpr int A_STAGE_B = 256 * BK * 4;        // fp32 A image of one k-tile: 16 KB
 constexpr int W2_TILE_SLOTS = 2 * KB * BN;     // uint4 slots of one packed 128x16 fp16x2 weight tile
-constexpr int B_STAGE_B = W2_TILE_SLOTS * 16;  // 8 KB
-constexpr int LDS_BYTES = NA * A_STAGE_B + 2 * B_STAGE_B;
+constexpr int W2_TILE_B = W2_TILE_SLOTS * 16;  // 8 KB
 
 __device__ int g_split2_nonfinite;  // sticky: a stored value was inf / NaN (activation beyond the fp16 range, or non-finite input)
 __device__ __attribute__((aligned(64))) float g_split2_zero_page[16];
@@ -167,16 +166,25 @@ struct GnStats2 { double* part; int G; int tiles_per_img; };   // as GnStats of 
 
 // CONV: 0 = linear (A row-major [M,K]), 1 = 3x3 / stride 1 / pad 1 convolution over an NHWC image
 // GNS: GroupNorm (sum, sum of squares) partials of the stored result per wave (64 rows x 8-channel groups), CONV only
-template <int EPI, int CONV, bool GNS>
-__global__ __launch_bounds__(256, 2) void gemm_split2_pipe_kernel(const float* __restrict__ A, const uint4* __restrict__ Wp,
+// NJ: 32-column MFMA tiles per wave.  4: block tile 256 x 128, 24 slots per k-tile, 64 KB LDS, two workgroups per CU.
+//     8: block tile 256 x 256 (two packed weight tiles side by side), 48 slots per k-tile, 256 accumulator registers — one wave
+//     per SIMD, 80 KB LDS, one workgroup per CU: per MFMA half the A traffic (LDS-DMA, raw fragment reads, split arithmetic) of NJ = 4.
+template <int EPI, int CONV, bool GNS, int NJ>
+__global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(const float* __restrict__ A, const uint4* __restrict__ Wp,
                                                                   const float* __restrict__ bias,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ resid, float* __restrict__ C,
                                                                   int M, int N, int K, ConvGeom cg, int panel, GnStats2 gn) {
-  extern __shared__ uint4 smem[];  // the only LDS object: [NA][1024] A slots | [2][512] weight slots
+  constexpr int BNB = NJ * 32;                     // block columns
+  constexpr int NWT = NJ / 4;                      // packed 128-column weight tiles per block
+  constexpr int B_STAGE_B = NWT * W2_TILE_B;       // 8 / 16 KB
+  constexpr int NS = 6 * NJ;                       // MFMA slots per k-tile
+  constexpr int NBP = 2 * NWT;                     // weight DMA pieces per wave and k-tile
+  constexpr int SB = NS - NJ / 2 - 3;              // slot of the barrier: behind it NJ/2 slots of fragment reads + one raw A read
+  extern __shared__ uint4 smem[];  // the only LDS object: [NA][1024] A slots | [2][NWT * 512] weight slots
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntn = N / BN;
+  const int ntn = N / BNB;
   // XCD-aware tile order, as in gemm_split.hip
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
@@ -190,10 +198,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split2_pipe_kernel(const float* _
     tile_m = tile / ntn;
     tile_n = tile - tile_m * ntn;
   }
-  const int m0 = tile_m * 256, n0 = tile_n * BN;
+  const int m0 = tile_m * 256, n0 = tile_n * BNB;
   const int nk = K / BK;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
-  const float wsc = reinterpret_cast<const float*>(Wp + (size_t)ntn * nk * W2_TILE_SLOTS)[1];   // 2^-e of the weight scale (trailer)
+  const float wsc = reinterpret_cast<const float*>(Wp + (size_t)(N / BN) * nk * W2_TILE_SLOTS)[1];   // 2^-e of the weight scale (trailer)
 
   // ---- DMA lanes: piece c (0..3) of this wave fills A slots (wave*4 + c)*64 + lane = rows wave*64 + c*16 + lane/4, chunk
   // q = (lane & 3) ^ ((row >> 2) & 3) of the row's 64-byte k segment (the swizzle is on the source address)
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split2_pipe_kernel(const float* _
   }
   if constexpr (CONV) cpt = cg.C / BK;
   const unsigned boff = (unsigned)((wave * 2) * 64 + lane) * 16u;
-  const char* const wbase = reinterpret_cast<const char*>(Wp + (size_t)tile_n * nk * W2_TILE_SLOTS);
+  const char* const wbase = reinterpret_cast<const char*>(Wp + (size_t)tile_n * NWT * nk * W2_TILE_SLOTS);
   const unsigned ldsA = lds0 + (unsigned)(wave * 4) * 1024u;
   const unsigned ldsB = lds0 + (unsigned)(NA * A_STAGE_B) + (unsigned)(wave * 2) * 1024u;
 
@@ -252,14 +260,15 @@ __global__ __launch_bounds__(256, 2) void gemm_split2_pipe_kernel(const float* _
       const int cps = (cpt & 1) ? 1 : 2, sup = kt / (9 * cps), rem = kt - sup * (9 * cps), tap = rem / cps;
       wkt = tap * cpt + sup * cps + (rem - tap * cps);
     }
-    dma_s(boff, wbase + ((size_t)wkt * B_STAGE_B + c * 1024), ldsB + sb + c * 1024u);
+    constexpr int t = c >> 1, sub = c & 1;   // piece c = half `sub` of this wave's 2 KB share of the packed 128-column tile t
+    dma_s(boff, wbase + (((size_t)t * nk + wkt) * W2_TILE_B + sub * 1024), ldsB + sb + (unsigned)(t * W2_TILE_B + sub * 1024));
   };
 
-  f32x16 acc[2][4];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -274,52 +283,52 @@ __global__ __launch_bounds__(256, 2) void gemm_split2_pipe_kernel(const float* _
     hs.load(sA + stage * (A_STAGE_B / 16) + half * 128, aslot0, aslot1);
   };
 
-  // One k-tile, 24 slots (slot S: product group G = S / 8 in the order h*l, l*h, h*h; row half I, column tile J).
+  // fragment slot of column tile J, split plane P, relative to sBf (+ stage)
+  auto bslot = [](int P, int J) { return (J >> 2) * W2_TILE_SLOTS + P * KB * BN + (J & 3) * 32; };
+
+  // One k-tile, NS = 6 NJ slots (slot S: product group G = S / (2 NJ) in the order h*l, l*h, h*h; row half I, column tile J).
   // cur: split A fragments of k-tile kt; nxt: receives the split of k-tile kt+1 (its raw first half is already in nxt[0].x).
-  // fbL holds the weight split l of kt on entry (dead after slot 7, refilled with the split l of kt+1 behind the barrier);
-  // fbH is read in slots 1 and 3 and used from slot 8.  BS: weight stage of kt (compile-time parity).
+  // fbL holds the weight split l of kt on entry (dead after slot 2 NJ - 1, refilled with the split l of kt+1 behind the
+  // barrier); fbH is read in slots 1, 3, .. NJ - 1 and used from slot 2 NJ.  BS: weight stage of kt (compile-time parity).
   // sa1 / sa2 / sa_wr: A stages of kt+1, of kt+2, and the one receiving kt+NA (= the stage kt has left).
-  auto ktile = [&](int kt, HalfSplit2 (&cur)[2], HalfSplit2 (&nxt)[2], f16x8 (&fbL)[4], f16x8 (&fbH)[4], auto bs_, int sa1, int sa2,
+  auto ktile = [&](int kt, HalfSplit2 (&cur)[2], HalfSplit2 (&nxt)[2], f16x8 (&fbL)[NJ], f16x8 (&fbH)[NJ], auto bs_, int sa1, int sa2,
                    int sa_wr) {
     constexpr int BS = decltype(bs_)::value;
     const uint4* const b = sBf + BS * (B_STAGE_B / 16);
     const uint4* const bn = sBf + (BS ^ 1) * (B_STAGE_B / 16);
     const int kt_b = min(kt + 1, nk - 1), kt_a = min(kt + NA, nk - 1);
     const unsigned sb_wr = (unsigned)((BS ^ 1) * B_STAGE_B), sa_wr_b = (unsigned)(sa_wr * A_STAGE_B);
-    static_for<0, 24>([&](auto s_) {
+    static_for<0, NS>([&](auto s_) {
       constexpr int S = decltype(s_)::value;
-      constexpr int G = S / 8, I = (S % 8) >> 2, J = S & 3;
+      constexpr int G = S / (2 * NJ), I = (S % (2 * NJ)) / NJ, J = S % NJ;
       const f16x8 fa = (G == 1) ? cur[I].template frag<1>() : cur[I].template frag<0>();
       const f16x8 fb = (G == 0) ? fbL[J] : fbH[J];
       acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[I][J], 0, 0, 0);
       // weight DMA of k-tile kt+1, then A DMA of k-tile kt+NA (the A pieces are the newest four loads at the wait)
 #ifndef GDRNPP2_TIMING_NO_DMA
-      if constexpr (S == 0) dma_b(kt_b, sb_wr, std::integral_constant<int, 0>{});
-      if constexpr (S == 2) dma_b(kt_b, sb_wr, std::integral_constant<int, 1>{});
-      if constexpr (S == 4) dma_a(kt_a, sa_wr_b, std::integral_constant<int, 0>{});
-      if constexpr (S == 6) dma_a(kt_a, sa_wr_b, std::integral_constant<int, 1>{});
-      if constexpr (S == 8) dma_a(kt_a, sa_wr_b, std::integral_constant<int, 2>{});
-      if constexpr (S == 10) dma_a(kt_a, sa_wr_b, std::integral_constant<int, 3>{});
+      if constexpr (S % 2 == 0 && S < 2 * NBP) dma_b(kt_b, sb_wr, std::integral_constant<int, S / 2>{});
+      if constexpr (S % 2 == 0 && S >= 2 * NBP && S < 2 * NBP + 8) dma_a(kt_a, sa_wr_b, std::integral_constant<int, (S - 2 * NBP) / 2>{});
 #endif
 #ifndef GDRNPP2_TIMING_NO_BREAD   // timing-only builds (results invalid)
-      if constexpr (S == 1 || S == 3) {   // weight split h of kt
+      if constexpr (S % 2 == 1 && S < NJ) {   // weight split h of kt
         constexpr int j0 = S - 1;
-        fbH[j0] = __builtin_bit_cast(f16x8, b[j0 * 32]);
-        fbH[j0 + 1] = __builtin_bit_cast(f16x8, b[(j0 + 1) * 32]);
+        fbH[j0] = __builtin_bit_cast(f16x8, b[bslot(0, j0)]);
+        fbH[j0 + 1] = __builtin_bit_cast(f16x8, b[bslot(0, j0 + 1)]);
       }
 #endif
-      if constexpr (S == 9) load_half(nxt[1], sa1, 1);
-      // split of the next k-tile: first half in slots 3..10, second half in slots 13..20
+      constexpr int S1 = NJ == 4 ? 13 : 20;   // first split slot of the second half (its raw read four slots earlier)
+      if constexpr (S == S1 - 4) load_half(nxt[1], sa1, 1);
+      // split of the next k-tile: first half in slots 3..10, second half in slots S1..S1+7
 #ifndef GDRNPP2_TIMING_NO_SPLIT
       if constexpr (S >= 3 && S < 11) nxt[0].template step<S - 3>();
-      if constexpr (S >= 13 && S < 21) nxt[1].template step<S - 13>();
+      if constexpr (S >= S1 && S < S1 + 8) nxt[1].template step<S - S1>();
 #else
       if constexpr (S == 3) { nxt[0].h[0] = __float_as_uint(nxt[0].x[0]); nxt[0].h[1] = __float_as_uint(nxt[0].x[1]); nxt[0].h[2] = __float_as_uint(nxt[0].x[2]); nxt[0].h[3] = __float_as_uint(nxt[0].x[3]);
                               nxt[0].l[0] = __float_as_uint(nxt[0].x[4]); nxt[0].l[1] = __float_as_uint(nxt[0].x[5]); nxt[0].l[2] = __float_as_uint(nxt[0].x[6]); nxt[0].l[3] = __float_as_uint(nxt[0].x[7]); }
-      if constexpr (S == 13) { nxt[1].h[0] = __float_as_uint(nxt[1].x[0]); nxt[1].h[1] = __float_as_uint(nxt[1].x[1]); nxt[1].h[2] = __float_as_uint(nxt[1].x[2]); nxt[1].h[3] = __float_as_uint(nxt[1].x[3]);
+      if constexpr (S == S1) { nxt[1].h[0] = __float_as_uint(nxt[1].x[0]); nxt[1].h[1] = __float_as_uint(nxt[1].x[1]); nxt[1].h[2] = __float_as_uint(nxt[1].x[2]); nxt[1].h[3] = __float_as_uint(nxt[1].x[3]);
                                nxt[1].l[0] = __float_as_uint(nxt[1].x[4]); nxt[1].l[1] = __float_as_uint(nxt[1].x[5]); nxt[1].l[2] = __float_as_uint(nxt[1].x[6]); nxt[1].l[3] = __float_as_uint(nxt[1].x[7]); }
 #endif
-      if constexpr (S == 19) {
+      if constexpr (S == SB) {
 #ifndef GDRNPP2_TIMING_NO_SYNC
         wait_vmcnt<4>();
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): every LDS read of the stages about to be refilled has returned
@@ -329,31 +338,31 @@ __global__ __launch_bounds__(256, 2) void gemm_split2_pipe_kernel(const float* _
       // behind the barrier: weight split l of k-tile kt+1 (fbL is dead since slot 7) and the raw first half of k-tile kt+2
       // (cur[0] is nxt[0] of the next k-tile; only cur[0].h / .l are still in use)
 #ifndef GDRNPP2_TIMING_NO_BREAD
-      if constexpr (S == 20 || S == 21) {
-        constexpr int j0 = 2 * (S - 20);
-        fbL[j0] = __builtin_bit_cast(f16x8, bn[1 * KB * BN + j0 * 32]);
-        fbL[j0 + 1] = __builtin_bit_cast(f16x8, bn[1 * KB * BN + (j0 + 1) * 32]);
+      if constexpr (S > SB && S <= SB + NJ / 2) {
+        constexpr int j0 = 2 * (S - SB - 1);
+        fbL[j0] = __builtin_bit_cast(f16x8, bn[bslot(1, j0)]);
+        fbL[j0 + 1] = __builtin_bit_cast(f16x8, bn[bslot(1, j0 + 1)]);
       }
 #endif
-      if constexpr (S == 22) load_half(cur[0], sa2, 0);
+      if constexpr (S == SB + NJ / 2 + 1) load_half(cur[0], sa2, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
 
   // ---- prologue: k-tiles 0 .. 2 of A and k-tile 0 of the weights; split k-tile 0; first fragments of the loop
   static_for<0, 4>([&](auto c) { dma_a(0, 0u, c); });
-  static_for<0, 2>([&](auto c) { dma_b(0, 0u, c); });
+  static_for<0, NBP>([&](auto c) { dma_b(0, 0u, c); });
   static_for<0, 4>([&](auto c) { dma_a(min(1, nk - 1), (unsigned)A_STAGE_B, c); });
   static_for<0, 4>([&](auto c) { dma_a(min(2, nk - 1), 2u * A_STAGE_B, c); });
   wait_vmcnt<4>();
   __builtin_amdgcn_s_barrier();
   HalfSplit2 f0[2], f1[2];
-  f16x8 fbL[4], fbH[4];
+  f16x8 fbL[NJ], fbH[NJ];
   load_half(f0[0], 0, 0);
   load_half(f0[1], 0, 1);
   static_for<0, 8>([&](auto s) { f0[0].template step<decltype(s)::value>(); f0[1].template step<decltype(s)::value>(); });
 #pragma unroll
-  for (int j = 0; j < 4; ++j) fbL[j] = __builtin_bit_cast(f16x8, sBf[1 * KB * BN + j * 32]);
+  for (int j = 0; j < NJ; ++j) fbL[j] = __builtin_bit_cast(f16x8, sBf[bslot(1, j)]);
   load_half(f1[0], 1, 0);
 
   // ---- main loop, two k-tiles per trip (nk is even: K % 32 == 0)
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split2_pipe_kernel(const float* _
   const int c4 = (lane & 15) * 4;
   bool bad = false;
 #pragma unroll
-  for (int jh = 0; jh < 2; ++jh) {
+  for (int jh = 0; jh < NJ / 2; ++jh) {
     const int nb = n0 + jh * 64 + c4;
     const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -429,16 +438,29 @@ __global__ __launch_bounds__(256, 2) void gemm_split2_pipe_kernel(const float* _
   if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(&g_split2_nonfinite, 1);
 }
 
+template <int EPI, int CONV, bool GNS, int NJ>
+int launch_nj(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
+              int K, ConvGeom cg, int panel, GnStats2 gn, hipStream_t st, const char* what) {
+  constexpr int lds_bytes = NA * A_STAGE_B + 2 * (NJ / 4) * W2_TILE_B;
+  const int rc = gdrnpp::ensure_dynamic_lds((const void*)gemm_split2_pipe_kernel<EPI, CONV, GNS, NJ>, lds_bytes);
+  if (rc) return rc;
+  const long tiles = (long)((M + 255) / 256) * (N / (NJ * 32));
+  GDRNPP_REQUIRE(tiles < (1l << 30), GDRNPP_ELIMIT, "%s: grid too large", what);
+  hipLaunchKernelGGL((gemm_split2_pipe_kernel<EPI, CONV, GNS, NJ>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, A, Wp, bias, gamma,
+                     resid, C, M, N, K, cg, panel, gn);
+  return gdrnpp::check_launch(what);
+}
+
+// 256 x 256 block tiles (NJ = 8) are kept for A/B only (option split2_wide = 1, N % 256 == 0): bitwise equal, and measured slower
+// or equal on every ConvNeXt-B MLP shape of 128 ROIs (36 blocks 18.5 vs 17.0 ms; stage-2 fc2 207 vs 207 us, stage-3 fc2 246 vs
+// 189 us, stage-0 fc1 623 vs 533 us: one wave per SIMD has nobody to hide its LDS / DMA latencies behind)
 template <int EPI, int CONV, bool GNS>
 int launch_one(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
                int K, ConvGeom cg, int panel, GnStats2 gn, hipStream_t st, const char* what) {
-  const int rc = gdrnpp::ensure_dynamic_lds((const void*)gemm_split2_pipe_kernel<EPI, CONV, GNS>, LDS_BYTES);
-  if (rc) return rc;
-  const long tiles = (long)((M + 255) / 256) * (N / BN);
-  GDRNPP_REQUIRE(tiles < (1l << 30), GDRNPP_ELIMIT, "%s: grid too large", what);
-  hipLaunchKernelGGL((gemm_split2_pipe_kernel<EPI, CONV, GNS>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, st, A, Wp, bias, gamma,
-                     resid, C, M, N, K, cg, panel, gn);
-  return gdrnpp::check_launch(what);
+  const int opt = gdrnpp::option_split2_wide();
+  const bool wide = N % 256 == 0 && opt == 1;
+  if (wide) return launch_nj<EPI, CONV, GNS, 8>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, st, what);
+  return launch_nj<EPI, CONV, GNS, 4>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, st, what);
 }
 
 }  // namespace

@@ -231,6 +231,14 @@ def records_in_roi_order(rec: torch.Tensor) -> torch.Tensor:
     return rec[torch.sort(rec[:, 14], stable=True).indices]
 
 
+def _six_product_rerun(run):
+    hip_layers.set_gemm_products(6)
+    try:
+        return run()
+    finally:
+        hip_layers.set_gemm_products(3)
+
+
 @torch.no_grad()
 def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor | None = None) -> torch.Tensor:
     """One pass of the hot path over one batch of ROIs (the unit ``bench.py`` times).  ``roi_ids`` (or ``batch["roi_id"]``,
@@ -247,15 +255,14 @@ def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor 
             roi_extents=batch.get("roi_extent"))
         return post.process(batch, out_dict, roi_ids)
 
+    n_x3 = hip_lib.x3_launch_count()
     rec = run()
-    # three-product GEMM mode (hip_layers.set_gemm_products(3)): an activation beyond the fp16 range made an output non-finite
-    # -> the step is repeated with the six-product kernels (one 4-byte read-back + stream sync per step in that mode)
-    if hip_layers.gemm_products() == 3 and batch["roi_img"].is_cuda and hip_lib.split2_nonfinite(reset=True):
-        hip_layers.set_gemm_products(6)
-        try:
-            rec = run()
-        finally:
-            hip_layers.set_gemm_products(3)
+    # three-product GEMM kernels were launched (hip_layers.gemm_products() == 3 and the batch is large enough for them): an
+    # activation beyond the fp16 range makes their outputs non-finite and raises a device flag -> the step is repeated with the
+    # six-product kernels.  One 4-byte read-back + stream sync per step; under hipGraph capture the check is the caller's
+    # (GraphedInference.replay).
+    if hip_lib.x3_launch_count() != n_x3 and not torch.cuda.is_current_stream_capturing() and hip_lib.split2_nonfinite(reset=True):
+        rec = _six_product_rerun(run)
     return rec
 
 
@@ -419,16 +426,26 @@ class GraphedInference:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        n_x3 = hip_lib.x3_launch_count()
         with torch.cuda.graph(self.graph):
             self.records = inference_step(model, post, self.static, self.roi_ids)
+        self.uses_x3 = hip_lib.x3_launch_count() != n_x3     # the captured step holds three-product kernels
+
+    @torch.no_grad()
+    def replay(self) -> torch.Tensor:
+        """Replay on the static buffers; with three-product kernels in the graph their non-finite flag is checked (one sync) and
+        the step repeated eagerly with six products when it is up."""
+        self.graph.replay()
+        if self.uses_x3 and hip_lib.split2_nonfinite(reset=True):
+            return _six_product_rerun(lambda: inference_step(self.model, self.post, self.static, self.roi_ids))
+        return self.records
 
     @torch.no_grad()
     def __call__(self, batch: dict) -> torch.Tensor:
         for k, v in batch.items():
             if isinstance(v, torch.Tensor) and k in self.static:
                 self.static[k].copy_(v, non_blocking=True)
-        self.graph.replay()
-        return self.records
+        return self.replay()
 
 
 # --------------------------------------------------------------------------------------------------

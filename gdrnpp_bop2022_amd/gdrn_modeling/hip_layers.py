@@ -113,13 +113,17 @@ _LIBRARY_BELOW_TILES = 0    # A/B switch: blocks whose fc2 has fewer 128x128 out
                             # with a modelled number of K chunks and no block leaves this library
 
 
-# Partial products per fp32 product in the split GEMMs: 6 (default; bf16x3, exact to 2^-26) or 3 (fp16x2, 22 significant operand
-# bits: 1.5e-7 .. 2.5e-7 of the output scale against fp64 — below an ordinary fp32 GEMM's 1e-6 — for half the matrix work;
-# csrc/gemm_split2_pipe.hip).  3 applies where the three-product kernels exist and pay (ConvNeXt MLPs, 3x3/1/1 convolutions and
-# the transposed-convolution GEMM from 256 tiles of 256 x 128 on); every other layer stays on the six-product kernels.  An
-# activation beyond the fp16 range turns the outputs non-finite and raises hip_lib.split2_nonfinite(): engine.inference_step
-# then repeats the step with 6.
-_GEMM_PRODUCTS = 6
+# Partial products per fp32 product in the split GEMMs.
+#   3 (default): fp16x2 operand split, 22 significant operand bits, csrc/gemm_split2_pipe.hip — where the three-product kernels
+#      exist and pay: ConvNeXt MLPs, 3x3/1/1 convolutions and the transposed-convolution GEMM from 256 tiles of 256 x 128 on
+#      (batches of ~64 ROIs and more); every other layer and every smaller launch runs the six-product kernels.  Against fp64 the
+#      result is as close as the six-product form and closer than hipBLASLt's fp32 GEMM on the same operands (the fp32
+#      accumulation chain dominates all three; tools/split2_error_probe.py, profiles/r03y_split2_accuracy.txt), and the
+#      network outputs sit at the same 6e-6 from the reference's recorded forward as with six products or the vendor fp32
+#      kernels — for half the matrix-pipe work.  An activation beyond the fp16 range (65504) turns the outputs non-finite and
+#      raises hip_lib.split2_nonfinite(): engine.inference_step then repeats the step with 6.
+#   6: bf16x3 operand split, exact to 2^-26, everywhere.
+_GEMM_PRODUCTS = 3
 
 
 def set_gemm_products(n: int) -> None:

@@ -668,6 +668,18 @@ def unpack_weight_bf16x3(packed):
     return packed.permute(2, 0, 4, 1, 3, 5).reshape(3, tn * 128, tk * 16)
 
 
+_X3_LAUNCHES = 0   # launches of the three-product kernels by this process (engine.inference_step: is there a flag to check?)
+
+
+def x3_launch_count() -> int:
+    return _X3_LAUNCHES
+
+
+def _count_x3():
+    global _X3_LAUNCHES
+    _X3_LAUNCHES += 1
+
+
 X3 = "_x3"   # LaunchTimer kind suffix of the three-product (fp16x2) kernels: 3 instead of 6 MFMA flops per fp32-equivalent flop
 
 
@@ -688,6 +700,7 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
             {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream())
     nbytes = 4.0 * m * k + (4.0 if fp16x2 else 6.0) * n * k + 4.0 * m * n * (2 if epilogue == "scale_res" else 1)
     if fp16x2:
+        _count_x3()
         _check(_timed(_kind + X3, 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split2(*args), nbytes), "gdrnpp_linear_f32_split2")
     else:
         _check(_timed(_kind, 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split(*args), nbytes), "gdrnpp_linear_f32_split")
@@ -799,6 +812,7 @@ def conv2d_f32_split(x_cl, weight_packed, bias, kh: int, kw: int, stride: int, p
     if fp16x2:
         if (kh, kw, stride, pad) != (3, 3, 1, 1):
             raise ValueError("the three-product convolution exists for 3x3 / stride 1 / pad 1 only")
+        _count_x3()
         a2 = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
               out.data_ptr(), None, n, h, w, cin, cout, 0, 1 if gelu else 0, _stream())
         _check(_timed(_kind + X3, 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split2(*a2),
@@ -888,6 +902,7 @@ def conv3x3_groupnorm_act(x_cl, weight_packed, bias, gamma, beta, groups: int, e
             y.data_ptr(), part.data_ptr(), n, h, w, cin, cout, groups, _stream())
     nbytes = 4.0 * n * h * w * (cin + cout) + (4.0 if fp16x2 else 6.0) * cout * 9 * cin
     if fp16x2:
+        _count_x3()
         a3 = args[:4] + (part.data_ptr(), n, h, w, cin, cout, groups, 0, _stream())
         _check(_timed("conv3x3" + X3, 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split2(*a3), nbytes),
                "gdrnpp_conv3x3_f32_split2")

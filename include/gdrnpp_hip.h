@@ -52,6 +52,8 @@ const char* gdrnpp_last_error(void);
  *   "split_gemm_mi4"   -1 / 0 / 1   tile height by tile count (default) / force 128 rows / force 256 rows
  *   "dwconv_tile"      -1 / 0 / 1 / 2   output pixels per thread of the depthwise 7x7 kernel: by launch size (default: 2x8 at
  *                                   the headline batch, 2x4 / 1x4 when a launch has too few tiles for the chip) / force 2x8 / 2x4 / 1x4
+ *   "split2_wide"      0 / 1       three-product kernels (gdrnpp_*_split2): 256x256 block tiles whenever N % 256 == 0 (A/B switch,
+ *                                   default 0: bitwise identical and measured slower than 256x128)
  * unknown name -> GDRNPP_EINVAL. */
 int gdrnpp_set_option(const char* name, int value);
 

@@ -323,9 +323,9 @@ def test_model_forward_odd_roi_count(hip):
         o2 = model(x, **args)
         hip_layers.set_enabled(True)
     # 36 blocks x (fc1, fc2) + the two Patch-PnP fc layers, plain or split-K depending on the tile count
-    assert sum(1 for r in timer.records if r[0] in ("linear", "linear_splitk")) == 74
+    assert sum(1 for r in timer.records if r[0] in ("linear", "linear_splitk", "linear_x3")) == 74
     assert sum(1 for r in timer.records if r[0] in ("conv3x3", "conv_splitk")) >= 4
-    assert sum(1 for r in timer_lib.records if r[0] in ("linear", "linear_splitk")) == 3 * 2 + 2   # stage 0 + Patch-PnP fc
+    assert sum(1 for r in timer_lib.records if r[0] in ("linear", "linear_splitk", "linear_x3")) == 3 * 2 + 2   # stage 0 + Patch-PnP fc
     torch.testing.assert_close(o3["trans"], o1["trans"], rtol=0, atol=1e-4)
     for key in ("mask", "coor_x", "coor_y", "coor_z", "region"):
         assert (o1[key] - o2[key]).abs().max().item() <= 1e-4 * max(o2[key].abs().max().item(), 1.0), key

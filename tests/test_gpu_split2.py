@@ -86,6 +86,33 @@ def test_linear_three_products_panel_walk_is_bitwise_row_major(hip):
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("m,k,n,epi", [(3000, 256, 512, "gelu"), (1024, 2048, 256, "scale_res"), (70000, 128, 1024, "none")])
+def test_wide_block_tiles_are_bitwise_equal(hip, m, k, n, epi):
+    """256 x 256 block tiles (one wave per SIMD, two packed weight tiles side by side) against 256 x 128: same products, same order."""
+    torch.manual_seed(m)
+    x, w, b = torch.randn(m, k, device=DEV), torch.randn(n, k, device=DEV) * k ** -0.5, torch.randn(n, device=DEV)
+    gamma = torch.randn(n, device=DEV) if epi == "scale_res" else None
+    res = torch.randn(m, n, device=DEV) if epi == "scale_res" else None
+    pk = hip.pack_weight_f16x2(w)
+    outs = []
+    for wide in (0, 1):
+        hip.set_option("split2_wide", wide)
+        outs.append(hip.linear_f32_split(x, pk, b, epi, gamma, res))
+    hip.set_option("split2_wide", -1)
+    assert torch.equal(outs[0], outs[1])
+    # the 3x3 convolution with GroupNorm statistics, both forms
+    xc = torch.randn(8, 64, 32, 32, device=DEV).contiguous(memory_format=torch.channels_last)
+    wc = torch.randn(256, 64, 3, 3, device=DEV) * (9 * 64) ** -0.5
+    pkc = hip.pack_conv_weight_f16x2(wc)
+    gw, gb = torch.randn(256, device=DEV), torch.randn(256, device=DEV)
+    ys = []
+    for wide in (0, 1):
+        hip.set_option("split2_wide", wide)
+        ys.append(hip.conv3x3_f32_split(xc, pkc, b[:256].contiguous(), True))
+    hip.set_option("split2_wide", -1)
+    assert torch.equal(ys[0], ys[1])
+
+
 def test_small_scale_activations_degrade_as_documented(hip):
     """A tensor at scale 1e-3: l falls into the fp16 subnormal range, absolute operand error 2^-25 -> ~1e-5 relative — the stated
     limit of the mode (LayerNorm / GroupNorm / GELU outputs sit at scale 1); still inside the 1e-4 tolerance of the path."""
@@ -232,3 +259,27 @@ def test_headline_batch_three_vs_six_products_and_retry(hip, three_products):
         got = engine.inference_step(model, post, batch)  # ... and the step repeats itself with six products
     assert hip_layers.gemm_products() == 3 and not hip.split2_nonfinite()
     assert torch.isfinite(got).all() and torch.equal(got, want)
+
+
+def test_inference_step_needs_no_outer_no_grad(hip):
+    """engine.inference_step switches autograd off itself: called bare it must still run this library's kernels (hip_layers are
+    inference-only and stand aside when grad is enabled — a lost decorator once sent the whole step to the vendor libraries)."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+    from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+
+    fx = NG.load_fixture("ycbv")
+    model, _ = build_model_optimizer(get_cfg("ycbv_convnext_a6"))
+    kw = NG.forward_kwargs(fx, "cuda")
+    batch = dict(roi_img=torch.from_numpy(NG.net_image()).cuda(), roi_cls=kw["roi_classes"], roi_cam=kw["roi_cams"],
+                 roi_wh=kw["roi_whs"], roi_center=kw["roi_centers"], resize_ratio=kw["resize_ratios"],
+                 roi_coord_2d=kw["roi_coord_2d"], roi_extent=kw["roi_extents"])
+    timer = hip.LaunchTimer()
+    hip.set_launch_timer(timer)
+    try:
+        assert torch.is_grad_enabled()
+        rec = engine.inference_step(model, engine.GdrnHipPost(get_cfg("ycbv_convnext_a6")), batch)
+    finally:
+        hip.set_launch_timer(None)
+    assert rec.shape == (NG.B, 16) and not rec.requires_grad
+    assert sum(r[0] in ("linear", "linear_splitk", "linear_x3") for r in timer.records) == 74

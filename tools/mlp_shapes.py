@@ -11,6 +11,8 @@ from gdrnpp_bop2022_amd import hip_lib as hip  # noqa: E402
 B = int(os.environ.get("B", "128"))
 X3 = os.environ.get("X3", "0") == "1"   # three-product (fp16x2) kernels
 dev = "cuda"
+for o in os.environ.get("OPTS", "").split():   # e.g. OPTS="split2_wide=1"
+    hip.set_option(o.split("=")[0], int(o.split("=")[1]))
 torch.manual_seed(0)
 tot = 0.0
 for st, (hw, c, nblk) in enumerate([(64, 128, 3), (32, 256, 3), (16, 512, 27), (8, 1024, 3)]):
