@@ -492,8 +492,9 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                                          launches_per_step=len(rs) / args.steps, us_per_launch=round(t_k / len(rs) * 1e3, 1)))
                 g_traffic = None  # HBM-side bytes per launch from the committed PMC passes (same workload only)
                 pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                if os.path.exists(pmc) and b == 128 and wname == "refine" and args.mlp_gemm == "split" and args.gemm_products == 6:
-                    g_traffic = json.load(open(pmc)).get("gemm_split_kernel", {}).get("traffic_bytes_per_launch")
+                if os.path.exists(pmc) and b == 128 and wname == "refine" and args.mlp_gemm == "split":
+                    g_traffic = json.load(open(pmc)).get("gemm_split_kernel" if args.gemm_products == 6 else "gemm_split_kernel_x3",
+                                                         {}).get("traffic_bytes_per_launch")
                 roofline = dict(kernel="gemm_split2_pipe_kernel + gemm_split_*_kernel (all split-GEMM launches)" if any(r[0].endswith(hip_lib.X3) for r in gemm_records) else "gemm_split_kernel", bound="mfma", achieved=bf16_tflops, peak=BF16_MFMA_PEAK_TFLOPS,
                                 unit="TFLOP/s", frac=bf16_tflops / BF16_MFMA_PEAK_TFLOPS, traffic=g_traffic,
                                 traffic_source=None if g_traffic is None else PMC_SOURCE,

@@ -646,7 +646,7 @@ def pack_conv_weight_f16x2(weight):
     return pack_weight_f16x2(weight.detach().permute(0, 2, 3, 1).reshape(cout, kh * kw * cin).contiguous())
 
 
-SPLIT2_MIN_TILES = 256   # tests lower it to run the three-product kernels on the 4-ROI reference fixtures
+SPLIT2_MIN_TILES = int(os.environ.get("GDRNPP_SPLIT2_MIN_TILES", "256"))   # tests lower it to run the three-product kernels on the 4-ROI reference fixtures; the env var is for A/B runs
 
 
 def split2_tiles_ok(m: int, n: int) -> bool:
