@@ -1,15 +1,18 @@
-// Three-product form of the split GEMM ("fp16x2"): opt-in fast mode of the ConvNeXt MLPs and the head's 3x3 convolutions
-// (gdrnpp_linear_f32_split2 / gdrnpp_conv3x3_f32_split2) — SURVEY.md §8 row a3.
+// Three-product form of the split GEMM ("fp16x2"): the default of the ConvNeXt MLPs, the head's 3x3 convolutions and the
+// transposed-convolution GEMM where a launch has at least 256 tiles of 256x128 (hip_layers.set_gemm_products; entry points
+// gdrnpp_linear_f32_split2 / gdrnpp_conv3x3_f32_split2) — SURVEY.md §8 row a3.
 //
 // Numerical scheme.  Every fp32 operand is written as x = h + l + e with h = rn_f16(x), l = rn_f16(x - h) (the subtraction is
 // exact) and |e| <= 2^-22 |x| as long as l stays in the normal fp16 range (else |e| <= 2^-25 absolute): 22 significant bits in
 // two fp16 values.  Three of the four partial products go through v_mfma_f32_32x32x16_f16 with fp32 accumulation
 // (h*l, l*h, h*h, small terms first); l*l (2^-22 relative) is dropped.  fp16 products are exact in fp32, so what is lost
-// against the six-product bf16x3 form (gemm_split.hip: exact to 2^-26) is the operand representation: measured against an fp64
-// product the result carries 1.5e-7 .. 2.5e-7 of the output scale at K = 128 .. 2304, an ordinary fp32 GEMM (one rounding per
-// fma, hipBLASLt / MIOpen / the reference's cuBLAS / cuDNN fp32 path) 7e-7 .. 1.2e-6 on the same operands, the six-product form
-// 2e-8 (tests/test_gpu_split2.py pins all three).  Half the matrix-pipe work of the six-product form for an error that is
-// still below the arithmetic the reference itself runs in.
+// against the six-product bf16x3 form (gemm_split.hip: exact to 2^-26) is the operand representation: 1.3e-7 .. 2.2e-7 of the
+// output scale (the same three products evaluated in fp64).  On operands with outlier channels (ConvNeXt activations) that sits
+// below the error every fp32-accumulating GEMM makes in its accumulation chain: measured against fp64 at K = 128 .. 4096 the
+// three-product result carries 3.9e-7 .. 3.0e-6, the six-product form 4.8e-7 .. 3.0e-6, hipBLASLt's fp32 GEMM 6.2e-7 .. 3.9e-6
+// (tools/split2_error_probe.py, profiles/r03y_split2_accuracy.txt; tests/test_gpu_split2.py pins the three against each other), and
+// the network outputs sit at the same 4e-6 .. 8e-6 from the reference's recorded forward with any of the three engines.
+// Half the matrix-pipe work of the six-product form for the accuracy of the arithmetic the reference itself runs in.
 //
 // Range.  fp16 has 5 exponent bits, so the operands are brought into range by exact power-of-two scaling:
 //   * weights: gdrnpp_pack_weight_f16x2 scales the tensor by 2^e with max|w| * 2^e in [2^13, 2^14) before splitting and stores

@@ -429,16 +429,19 @@ int gdrnpp_conv3x3_f32_split_gnstats(const float* x_nhwc, const void* W_packed, 
 int gdrnpp_groupnorm_apply_nhwc(const float* x, const double* partials, int P, const float* gamma, const float* beta,
                                 float* y, int N, int HW, int C, int G, float eps, int act_gelu, void* stream);
 
-/* ---- three-product form of the split GEMM ("fp16x2"), an opt-in fast mode of the same layers (a3) ---------------------------
+/* ---- three-product form of the split GEMM ("fp16x2"): what hip_layers uses by default for large launches (a3) ----------------
  * Every fp32 operand is written as h + l with h = rn_f16(x), l = rn_f16(x - h): 22 significant bits; the products h*l, l*h, h*h
- * go through v_mfma_f32_32x32x16_f16 with fp32 accumulation — half the matrix work of the six-product form above.  Error against
- * an fp64 product: 1.5e-7 .. 2.5e-7 of the output scale (an ordinary fp32 GEMM with one rounding per fma: 7e-7 .. 1.2e-6; the
- * six-product form: 2e-8).  Weights are scaled into the fp16 range by an exact power of two when they are packed
+ * go through v_mfma_f32_32x32x16_f16 with fp32 accumulation — half the matrix work of the six-product form above.  The operand
+ * representation costs 1.3e-7 .. 2.2e-7 of the output scale, below the fp32 accumulation error all three engines share on
+ * realistic operands: against an fp64 product at K = 128 .. 4096 three products 3.9e-7 .. 3.0e-6, six products 4.8e-7 .. 3.0e-6,
+ * hipBLASLt fp32 6.2e-7 .. 3.9e-6 (profiles/r03y_split2_accuracy.txt).  Weights are scaled into the fp16 range by an exact power
+ * of two when they are packed
  * (gdrnpp_pack_weight_f16x2: W f32[N][K] -> fp16 [N/128][K/16][2][2][128][8] + a 16-byte trailer holding the scale,
  * gdrnpp_pack_weight_f16x2_bytes(N, K) bytes; conv weights reordered to [Cout][ky][kx][Cin] first, as for bf16x3), activations
  * are split as they are: one beyond the fp16 range (65504) makes the output non-finite, which the epilogues detect on every
  * value they store -> gdrnpp_split2_nonfinite(&flag, reset, stream) (sticky device flag, synchronises the stream); the caller
- * then repeats the work in the six-product form.
+ * then repeats the work in the six-product form (engine.inference_step does).  Activation tensors whose scale is below 2^-3 lose
+ * low bits to the fp16 subnormal spacing (absolute operand error 2^-25).
  * gdrnpp_linear_f32_split2: as gdrnpp_linear_f32_split (N % 128 == 0, K % 32 == 0, any M, M*K*4 < 4 GiB).
  * gdrnpp_conv3x3_f32_split2: 3x3 / stride 1 / pad 1 convolution over NHWC (Cin % 32 == 0, Cout % 128 == 0), epilogue 0 / 1
  * (bias / bias + GELU); gn_partials != NULL additionally writes the GroupNorm partials of gdrnpp_conv3x3_f32_split_gnstats
