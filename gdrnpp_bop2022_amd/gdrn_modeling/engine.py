@@ -231,12 +231,26 @@ def records_in_roi_order(rec: torch.Tensor) -> torch.Tensor:
     return rec[torch.sort(rec[:, 14], stable=True).indices]
 
 
+_X3_OVERFLOW_STEPS = 0          # steps of this process whose three-product kernels overflowed the fp16 range
+X3_OVERFLOW_STEPS_TO_GIVE_UP = 3
+
+
 def _six_product_rerun(run):
+    """Repeat a step with the six-product kernels after the three-product ones raised their non-finite flag.  A model whose
+    activations leave the fp16 range on every batch would pay for both attempts each time: after X3_OVERFLOW_STEPS_TO_GIVE_UP such
+    steps the process stays on six products (with a warning)."""
+    global _X3_OVERFLOW_STEPS
+    _X3_OVERFLOW_STEPS += 1
     hip_layers.set_gemm_products(6)
     try:
         return run()
     finally:
-        hip_layers.set_gemm_products(3)
+        if _X3_OVERFLOW_STEPS < X3_OVERFLOW_STEPS_TO_GIVE_UP:
+            hip_layers.set_gemm_products(3)
+        else:
+            import warnings
+            warnings.warn(f"{_X3_OVERFLOW_STEPS} steps overflowed the fp16 range of the three-product GEMM kernels: staying on the "
+                          "six-product kernels (hip_layers.set_gemm_products(3) switches back)")
 
 
 @torch.no_grad()

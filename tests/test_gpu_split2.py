@@ -259,6 +259,12 @@ def test_headline_batch_three_vs_six_products_and_retry(hip, three_products):
         got = engine.inference_step(model, post, batch)  # ... and the step repeats itself with six products
     assert hip_layers.gemm_products() == 3 and not hip.split2_nonfinite()
     assert torch.isfinite(got).all() and torch.equal(got, want)
+    # a model that overflows on every batch is not paid for twice for ever: after the third such step the process stays on six
+    with torch.no_grad(), pytest.warns(UserWarning, match="staying on the six-product"):
+        for _ in range(engine.X3_OVERFLOW_STEPS_TO_GIVE_UP - engine._X3_OVERFLOW_STEPS):
+            got = engine.inference_step(model, post, batch)
+    assert hip_layers.gemm_products() == 6 and torch.equal(got, want)
+    engine._X3_OVERFLOW_STEPS = 0
 
 
 def test_inference_step_needs_no_outer_no_grad(hip):
