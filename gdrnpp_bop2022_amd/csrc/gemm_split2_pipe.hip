@@ -43,7 +43,7 @@ constexpr int A_STAGE_B = 256 * BK * 4;        // fp32 A image of one k-tile: 16
 constexpr int W2_TILE_SLOTS = 2 * KB * BN;     // uint4 slots of one packed 128x16 fp16x2 weight tile
 constexpr int W2_TILE_B = W2_TILE_SLOTS * 16;  // 8 KB
 
-__device__ int g_split2_nonfinite;  // sticky: a stored value was inf / NaN (activation beyond the fp16 range, or non-finite input)
+__device__ int g_split2_nonfinite;  // sticky: a stored value was inf / NaN (activation beyond the fp16 range, or non-finite input); used when a launch passes no flag of its own
 __device__ __attribute__((aligned(64))) float g_split2_zero_page[16];
 
 __device__ __forceinline__ void dma_s(unsigned voff, const void* sbase, unsigned lds_dst) {
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
                                                                   const float* __restrict__ bias,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ resid, float* __restrict__ C,
-                                                                  int M, int N, int K, ConvGeom cg, int panel, GnStats2 gn) {
+                                                                  int M, int N, int K, ConvGeom cg, int panel, GnStats2 gn, int* nonfinite) {
   constexpr int BNB = NJ * 32;                     // block columns
   constexpr int NWT = NJ / 4;                      // packed 128-column weight tiles per block
   constexpr int B_STAGE_B = NWT * W2_TILE_B;       // 8 / 16 KB
@@ -438,19 +438,19 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
       }
     }
   }
-  if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(&g_split2_nonfinite, 1);
+  if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(nonfinite ? nonfinite : &g_split2_nonfinite, 1);
 }
 
 template <int EPI, int CONV, bool GNS, int NJ>
 int launch_nj(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
-              int K, ConvGeom cg, int panel, GnStats2 gn, hipStream_t st, const char* what) {
+              int K, ConvGeom cg, int panel, GnStats2 gn, int* nonfinite, hipStream_t st, const char* what) {
   constexpr int lds_bytes = NA * A_STAGE_B + 2 * (NJ / 4) * W2_TILE_B;
   const int rc = gdrnpp::ensure_dynamic_lds((const void*)gemm_split2_pipe_kernel<EPI, CONV, GNS, NJ>, lds_bytes);
   if (rc) return rc;
   const long tiles = (long)((M + 255) / 256) * (N / (NJ * 32));
   GDRNPP_REQUIRE(tiles < (1l << 30), GDRNPP_ELIMIT, "%s: grid too large", what);
   hipLaunchKernelGGL((gemm_split2_pipe_kernel<EPI, CONV, GNS, NJ>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, A, Wp, bias, gamma,
-                     resid, C, M, N, K, cg, panel, gn);
+                     resid, C, M, N, K, cg, panel, gn, nonfinite);
   return gdrnpp::check_launch(what);
 }
 
@@ -459,11 +459,11 @@ int launch_nj(const float* A, const uint4* Wp, const float* bias, const float* g
 // 189 us, stage-0 fc1 623 vs 533 us: one wave per SIMD has nobody to hide its LDS / DMA latencies behind)
 template <int EPI, int CONV, bool GNS>
 int launch_one(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
-               int K, ConvGeom cg, int panel, GnStats2 gn, hipStream_t st, const char* what) {
+               int K, ConvGeom cg, int panel, GnStats2 gn, int* nonfinite, hipStream_t st, const char* what) {
   const int opt = gdrnpp::option_split2_wide();
   const bool wide = N % 256 == 0 && opt == 1;
-  if (wide) return launch_nj<EPI, CONV, GNS, 8>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, st, what);
-  return launch_nj<EPI, CONV, GNS, 4>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, st, what);
+  if (wide) return launch_nj<EPI, CONV, GNS, 8>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, nonfinite, st, what);
+  return launch_nj<EPI, CONV, GNS, 4>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, nonfinite, st, what);
 }
 
 }  // namespace
@@ -487,7 +487,8 @@ extern "C" int gdrnpp_pack_weight_f16x2(const float* W, void* packed, int N, int
 }
 
 extern "C" int gdrnpp_linear_f32_split2(const float* A, const void* W_packed, const float* bias, const float* gamma,
-                                        const float* resid, float* C, int M, int N, int K, int epilogue, void* stream) {
+                                        const float* resid, float* C, int M, int N, int K, int epilogue, int* nonfinite_flag,
+                                        void* stream) {
   GDRNPP_REQUIRE(A && W_packed && C, GDRNPP_EINVAL, "gdrnpp_linear_f32_split2: null pointer");
   GDRNPP_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % 32 == 0, GDRNPP_ELIMIT,
                  "gdrnpp_linear_f32_split2: N=%d K=%d must be multiples of %d/32 (M=%d is free)", N, K, BN, M);
@@ -503,14 +504,14 @@ extern "C" int gdrnpp_linear_f32_split2(const float* A, const void* W_packed, co
   hipStream_t st = (hipStream_t)stream;
   const uint4* Wp = (const uint4*)W_packed;
   const char* what = "gdrnpp_linear_f32_split2";
-  if (epilogue == EPI_BIAS) return launch_one<EPI_BIAS, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, st, what);
-  if (epilogue == EPI_GELU) return launch_one<EPI_GELU, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, st, what);
-  return launch_one<EPI_SCALE_RES, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, st, what);
+  if (epilogue == EPI_BIAS) return launch_one<EPI_BIAS, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, nonfinite_flag, st, what);
+  if (epilogue == EPI_GELU) return launch_one<EPI_GELU, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, nonfinite_flag, st, what);
+  return launch_one<EPI_SCALE_RES, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, nonfinite_flag, st, what);
 }
 
 extern "C" int gdrnpp_conv3x3_f32_split2(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                                          double* gn_partials, int n_img, int H, int W, int Cin, int Cout, int groups, int epilogue,
-                                         void* stream) {
+                                         int* nonfinite_flag, void* stream) {
   GDRNPP_REQUIRE(x_nhwc && W_packed && y_nhwc, GDRNPP_EINVAL, "gdrnpp_conv3x3_f32_split2: null pointer");
   GDRNPP_REQUIRE(n_img > 0 && H > 0 && W > 0 && H < 32768 && W < 32768 && Cin > 0 && Cout > 0, GDRNPP_EINVAL,
                  "gdrnpp_conv3x3_f32_split2: bad shape");
@@ -527,15 +528,16 @@ extern "C" int gdrnpp_conv3x3_f32_split2(const float* x_nhwc, const void* W_pack
                    "gdrnpp_conv3x3_f32_split2: GroupNorm statistics need the plain epilogue, H*W %% 256 == 0 and 8 channels per group "
                    "(H*W=%d Cout=%d groups=%d)", H * W, Cout, groups);
     return launch_one<EPI_BIAS, 1, true>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, cg, 0,
-                                         GnStats2{gn_partials, groups, (H * W) / 256}, st, what);
+                                         GnStats2{gn_partials, groups, (H * W) / 256}, nonfinite_flag, st, what);
   }
   const GnStats2 gn{nullptr, 0, 0};
   if (epilogue == EPI_GELU)
-    return launch_one<EPI_GELU, 1, false>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, cg, 0, gn, st, what);
-  return launch_one<EPI_BIAS, 1, false>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, cg, 0, gn, st, what);
+    return launch_one<EPI_GELU, 1, false>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, cg, 0, gn, nonfinite_flag, st, what);
+  return launch_one<EPI_BIAS, 1, false>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, cg, 0, gn, nonfinite_flag, st, what);
 }
 
-// Sticky flag of the fp16x2 kernels: *flag = 1 when a stored value was inf / NaN since the last reset (synchronises the stream).
+// The library's own sticky flag (launches with nonfinite_flag == NULL): *flag = 1 when a stored value was inf / NaN since the
+// last reset (synchronises the stream).  Callers running several streams / host threads pass a flag of their own per launch.
 extern "C" int gdrnpp_split2_nonfinite(int* flag, int reset, void* stream) {
   GDRNPP_REQUIRE(flag, GDRNPP_EINVAL, "gdrnpp_split2_nonfinite: null pointer");
   hipStream_t st = (hipStream_t)stream;

@@ -441,7 +441,8 @@ class GraphedInference:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         n_x3 = hip_lib.x3_launch_count()
-        with torch.cuda.graph(self.graph):
+        self.x3_flag = torch.zeros((1,), dtype=torch.int32, device=self.static["roi_img"].device)   # the graph's own overflow flag
+        with hip_lib.x3_flag_scope(self.x3_flag), torch.cuda.graph(self.graph):
             self.records = inference_step(model, post, self.static, self.roi_ids)
         self.uses_x3 = hip_lib.x3_launch_count() != n_x3     # the captured step holds three-product kernels
 
@@ -450,7 +451,8 @@ class GraphedInference:
         """Replay on the static buffers; with three-product kernels in the graph their non-finite flag is checked (one sync) and
         the step repeated eagerly with six products when it is up."""
         self.graph.replay()
-        if self.uses_x3 and hip_lib.split2_nonfinite(reset=True):
+        if self.uses_x3 and bool(self.x3_flag.item()):
+            self.x3_flag.zero_()
             return _six_product_rerun(lambda: inference_step(self.model, self.post, self.static, self.roi_ids))
         return self.records
 

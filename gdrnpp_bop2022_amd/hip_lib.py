@@ -106,8 +106,8 @@ SIGNATURES = {
     "gdrnpp_groupnorm_apply_nhwc": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "gdrnpp_pack_weight_f16x2_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "gdrnpp_pack_weight_f16x2": (c_int, [_P, _P, c_int, c_int, _P]),
-    "gdrnpp_linear_f32_split2": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "gdrnpp_conv3x3_f32_split2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_linear_f32_split2": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "gdrnpp_conv3x3_f32_split2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "gdrnpp_split2_nonfinite": (c_int, [_P, c_int, _P]),
 }
 
@@ -654,12 +654,51 @@ def split2_tiles_ok(m: int, n: int) -> bool:
     return n % 128 == 0 and ((m + 255) // 256) * (n // 128) >= SPLIT2_MIN_TILES
 
 
+_X3_FLAGS = {}   # (device index, stream handle) -> i32[1] device tensor the three-product launches of that stream OR into
+
+
+def _x3_flag():
+    """The non-finite flag of the current device + stream: launches pass it to the kernels, split2_nonfinite() reads it.  One per
+    stream, so host threads / streams running independent steps do not consume each other's overflow."""
+    if _X3_FLAG_OVERRIDE is not None:
+        return _X3_FLAG_OVERRIDE
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    f = _X3_FLAGS.get(key)
+    if f is None:
+        f = _X3_FLAGS[key] = torch.zeros((1,), dtype=torch.int32, device=f"cuda:{key[0]}")
+    return f
+
+
+_X3_FLAG_OVERRIDE = None
+
+
+class x3_flag_scope:
+    """``with x3_flag_scope(flag):`` — three-product launches inside record into ``flag`` (i32[1] device tensor) instead of the
+    current stream's: a captured hipGraph must write to a flag its owner can read after every replay (engine.GraphedInference)."""
+
+    def __init__(self, flag):
+        self.flag = flag
+
+    def __enter__(self):
+        global _X3_FLAG_OVERRIDE
+        self.prev, _X3_FLAG_OVERRIDE = _X3_FLAG_OVERRIDE, self.flag
+        return self.flag
+
+    def __exit__(self, *exc):
+        global _X3_FLAG_OVERRIDE
+        _X3_FLAG_OVERRIDE = self.prev
+        return False
+
+
 def split2_nonfinite(reset: bool = True) -> bool:
-    """True when a three-product kernel stored an inf / NaN since the last reset (an activation beyond the fp16 range, or a
-    non-finite input): the caller repeats the work with the six-product kernels.  Synchronises the current stream."""
-    flag = ctypes.c_int(0)
-    _check(load().gdrnpp_split2_nonfinite(ctypes.byref(flag), 1 if reset else 0, _stream()), "gdrnpp_split2_nonfinite")
-    return bool(flag.value)
+    """True when a three-product kernel launched on the current stream stored an inf / NaN since the last reset (an activation
+    beyond the fp16 range, or a non-finite input): the caller repeats the work with the six-product kernels.  Synchronises the
+    current stream (4-byte read-back)."""
+    f = _x3_flag()
+    up = bool(f.item())
+    if up and reset:
+        f.zero_()
+    return up
 
 
 def unpack_weight_bf16x3(packed):
@@ -697,7 +736,7 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
             _dev(bias, torch.float32, "bias") if bias is not None else None,
             _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
             _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
-            {"none": 0, "gelu": 1, "scale_res": 2}[epilogue], _stream())
+            {"none": 0, "gelu": 1, "scale_res": 2}[epilogue]) + ((_x3_flag().data_ptr(),) if fp16x2 else ()) + (_stream(),)
     nbytes = 4.0 * m * k + (4.0 if fp16x2 else 6.0) * n * k + 4.0 * m * n * (2 if epilogue == "scale_res" else 1)
     if fp16x2:
         _count_x3()
@@ -814,7 +853,7 @@ def conv2d_f32_split(x_cl, weight_packed, bias, kh: int, kw: int, stride: int, p
             raise ValueError("the three-product convolution exists for 3x3 / stride 1 / pad 1 only")
         _count_x3()
         a2 = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
-              out.data_ptr(), None, n, h, w, cin, cout, 0, 1 if gelu else 0, _stream())
+              out.data_ptr(), None, n, h, w, cin, cout, 0, 1 if gelu else 0, _x3_flag().data_ptr(), _stream())
         _check(_timed(_kind + X3, 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split2(*a2),
                       4.0 * n * h * w * (cin + cout) + 4.0 * cout * 9 * cin), "gdrnpp_conv3x3_f32_split2")
         return out
@@ -903,7 +942,7 @@ def conv3x3_groupnorm_act(x_cl, weight_packed, bias, gamma, beta, groups: int, e
     nbytes = 4.0 * n * h * w * (cin + cout) + (4.0 if fp16x2 else 6.0) * cout * 9 * cin
     if fp16x2:
         _count_x3()
-        a3 = args[:4] + (part.data_ptr(), n, h, w, cin, cout, groups, 0, _stream())
+        a3 = args[:4] + (part.data_ptr(), n, h, w, cin, cout, groups, 0, _x3_flag().data_ptr(), _stream())
         _check(_timed("conv3x3" + X3, 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split2(*a3), nbytes),
                "gdrnpp_conv3x3_f32_split2")
     else:

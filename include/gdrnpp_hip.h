@@ -439,7 +439,7 @@ int gdrnpp_groupnorm_apply_nhwc(const float* x, const double* partials, int P, c
  * (gdrnpp_pack_weight_f16x2: W f32[N][K] -> fp16 [N/128][K/16][2][2][128][8] + a 16-byte trailer holding the scale,
  * gdrnpp_pack_weight_f16x2_bytes(N, K) bytes; conv weights reordered to [Cout][ky][kx][Cin] first, as for bf16x3), activations
  * are split as they are: one beyond the fp16 range (65504) makes the output non-finite, which the epilogues detect on every
- * value they store -> gdrnpp_split2_nonfinite(&flag, reset, stream) (sticky device flag, synchronises the stream); the caller
+ * value they store -> a sticky device flag (nonfinite_flag argument, or the library's own behind gdrnpp_split2_nonfinite); the caller
  * then repeats the work in the six-product form (engine.inference_step does).  Activation tensors whose scale is below 2^-3 lose
  * low bits to the fp16 subnormal spacing (absolute operand error 2^-25).
  * gdrnpp_linear_f32_split2: as gdrnpp_linear_f32_split (N % 128 == 0, K % 32 == 0, any M, M*K*4 < 4 GiB).
@@ -449,9 +449,12 @@ int gdrnpp_groupnorm_apply_nhwc(const float* x, const double* partials, int P, c
 size_t gdrnpp_pack_weight_f16x2_bytes(int N, int K);
 int gdrnpp_pack_weight_f16x2(const float* W, void* packed, int N, int K, void* stream);
 int gdrnpp_linear_f32_split2(const float* A, const void* W_packed, const float* bias, const float* gamma, const float* resid,
-                             float* C, int M, int N, int K, int epilogue, void* stream);
+                             float* C, int M, int N, int K, int epilogue, int* nonfinite_flag, void* stream);
 int gdrnpp_conv3x3_f32_split2(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc, double* gn_partials,
-                              int n_img, int H, int W, int Cin, int Cout, int groups, int epilogue, void* stream);
+                              int n_img, int H, int W, int Cin, int Cout, int groups, int epilogue, int* nonfinite_flag,
+                              void* stream);
+/* nonfinite_flag: device int the launch ORs 1 into when it stores an inf / NaN (the caller owns, zeroes and reads it — one per
+ * stream / host thread keeps concurrent users apart); NULL = the library's own flag, read and reset by gdrnpp_split2_nonfinite. */
 int gdrnpp_split2_nonfinite(int* flag, int reset, void* stream);
 
 /* ---- depth-to-flow (SURVEY §8b boundary "flow") — replaces the flow_cuda torch extension,

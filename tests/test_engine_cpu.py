@@ -330,3 +330,37 @@ def test_class_sorted_shards_gather_and_restore_roi_order_gloo_world2(n_total):
     assert np.array_equal(rec[:, 14], np.arange(n_total))                   # original order restored
     assert np.array_equal(rec[:, 12], np.arange(n_total))                   # ... and every record is its own ROI's
     assert np.array_equal(rec[:, 13], np.random.default_rng(11).integers(0, 5, n_total))
+
+
+def test_gemm_product_switch_and_overflow_give_up(monkeypatch):
+    """Host logic of the three-product mode (no GPU): the switch validates its argument, launches are eligible from 256 tiles of
+    256 x 128 on, and a process whose steps keep overflowing the fp16 range settles on six products after three of them."""
+    import warnings
+
+    import pytest
+
+    from gdrnpp_bop2022_amd import hip_lib
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine, hip_layers
+
+    assert hip_layers.gemm_products() == 3
+    with pytest.raises(ValueError):
+        hip_layers.set_gemm_products(4)
+    assert hip_lib.split2_tiles_ok(128 * 256, 256) and not hip_lib.split2_tiles_ok(127 * 256, 256)
+    assert hip_lib.split2_tiles_ok(64 * 256 + 1, 512) and not hip_lib.split2_tiles_ok(1 << 20, 192)
+    calls = []
+
+    def run():
+        calls.append(hip_layers.gemm_products())
+        return "rec"
+
+    monkeypatch.setattr(engine, "_X3_OVERFLOW_STEPS", 0)
+    try:
+        for i in range(engine.X3_OVERFLOW_STEPS_TO_GIVE_UP - 1):
+            assert engine._six_product_rerun(run) == "rec" and hip_layers.gemm_products() == 3
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert engine._six_product_rerun(run) == "rec"
+        assert hip_layers.gemm_products() == 6 and any("six-product" in str(x.message) for x in w)
+        assert calls == [6] * engine.X3_OVERFLOW_STEPS_TO_GIVE_UP
+    finally:
+        hip_layers.set_gemm_products(3)

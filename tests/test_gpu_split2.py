@@ -169,6 +169,26 @@ def test_overflow_raises_the_sticky_flag(hip):
     x[17, 5] = 6.5e4                                   # the largest binade still works
     out = hip.linear_f32_split(x, pk, None)
     assert torch.isfinite(out).all() and not hip.split2_nonfinite()
+    # flags are per stream: an overflow on a side stream is not consumed by (and does not leak into) the current one
+    x[17, 5] = 7.0e4
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        hip.linear_f32_split(x, pk, None)
+        side.synchronize()
+        assert not torch.cuda.current_stream() == torch.cuda.default_stream()
+    assert not hip.split2_nonfinite()
+    with torch.cuda.stream(side):
+        assert hip.split2_nonfinite() and not hip.split2_nonfinite()
+    # C ABI with nonfinite_flag = NULL: the library's own flag
+    import ctypes
+    out = torch.empty(512, 128, device=DEV)
+    lib = hip.load()
+    args = (x.data_ptr(), pk.data_ptr(), None, None, None, out.data_ptr(), 512, 128, 64, 0, None, None)
+    assert lib.gdrnpp_linear_f32_split2(*args) == 0
+    f = ctypes.c_int(0)
+    assert lib.gdrnpp_split2_nonfinite(ctypes.byref(f), 1, None) == 0 and f.value == 1
+    assert lib.gdrnpp_split2_nonfinite(ctypes.byref(f), 1, None) == 0 and f.value == 0
 
 
 @pytest.fixture()
@@ -264,6 +284,14 @@ def test_headline_batch_three_vs_six_products_and_retry(hip, three_products):
         for _ in range(engine.X3_OVERFLOW_STEPS_TO_GIVE_UP - engine._X3_OVERFLOW_STEPS):
             got = engine.inference_step(model, post, batch)
     assert hip_layers.gemm_products() == 6 and torch.equal(got, want)
+    engine._X3_OVERFLOW_STEPS = 0
+    # the same through a captured hipGraph: the graph owns its flag and checks it after every replay
+    hip_layers.set_gemm_products(3)
+    with torch.no_grad():
+        g = engine.GraphedInference(model, post, batch, warmup=1)
+        assert g.uses_x3 and engine._X3_OVERFLOW_STEPS == 1       # (the eager warm-up step overflowed and repeated itself)
+        got = g.replay()
+    assert torch.equal(got, want) and engine._X3_OVERFLOW_STEPS == 2 and hip_layers.gemm_products() == 3
     engine._X3_OVERFLOW_STEPS = 0
 
 
