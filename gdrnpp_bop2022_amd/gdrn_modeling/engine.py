@@ -253,6 +253,18 @@ def _six_product_rerun(run):
                           "six-product kernels (hip_layers.set_gemm_products(3) switches back)")
 
 
+def run_with_overflow_check(run):
+    """``run()`` (a forward, or a whole step) under the contract of the three-product GEMM kernels: if any of them was launched
+    (hip_layers.gemm_products() == 3 and the batch is large enough) and raised the non-finite flag — an activation beyond the fp16
+    range — the work is repeated with the six-product kernels.  One 4-byte read-back + stream sync; under hipGraph capture the
+    check is the graph owner's (GraphedInference.replay)."""
+    n_x3 = hip_lib.x3_launch_count()
+    out = run()
+    if hip_lib.x3_launch_count() != n_x3 and not torch.cuda.is_current_stream_capturing() and hip_lib.split2_nonfinite(reset=True):
+        out = _six_product_rerun(run)
+    return out
+
+
 @torch.no_grad()
 def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor | None = None) -> torch.Tensor:
     """One pass of the hot path over one batch of ROIs (the unit ``bench.py`` times).  ``roi_ids`` (or ``batch["roi_id"]``,
@@ -269,14 +281,7 @@ def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor 
             roi_extents=batch.get("roi_extent"))
         return post.process(batch, out_dict, roi_ids)
 
-    n_x3 = hip_lib.x3_launch_count()
-    rec = run()
-    # three-product GEMM kernels were launched (hip_layers.gemm_products() == 3 and the batch is large enough for them): an
-    # activation beyond the fp16 range makes their outputs non-finite and raises a device flag -> the step is repeated with the
-    # six-product kernels.  One 4-byte read-back + stream sync per step; under hipGraph capture the check is the caller's
-    # (GraphedInference.replay).
-    if hip_lib.x3_launch_count() != n_x3 and not torch.cuda.is_current_stream_capturing() and hip_lib.split2_nonfinite(reset=True):
-        rec = _six_product_rerun(run)
+    rec = run_with_overflow_check(run)
     return rec
 
 

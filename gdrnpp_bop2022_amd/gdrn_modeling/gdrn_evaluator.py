@@ -26,7 +26,7 @@ import torch
 import torch.distributed as dist
 
 from .. import hip_lib
-from .engine import BOP_CSV_HEADER, GdrnHipPost, save_bop_csv
+from .engine import BOP_CSV_HEADER, GdrnHipPost, run_with_overflow_check, save_bop_csv
 
 logger = logging.getLogger(__name__)
 
@@ -215,11 +215,12 @@ def gdrn_inference_on_dataset(cfg, model, data_loader, evaluator, amp_test=False
                 hip_layers.set_enabled(False)
             try:
                 with torch.autocast("cuda", dtype=torch.float16, enabled=bool(amp_test) and dev.type == "cuda"):
-                    out_dict = model(
+                    # (three-product GEMM kernels: an fp16-range overflow repeats the forward with six products)
+                    out_dict = run_with_overflow_check(lambda: model(
                         batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"], roi_whs=batch["roi_wh"],
                         roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"],
                         roi_coord_2d=batch.get("roi_coord_2d", None), roi_coord_2d_rel=batch.get("roi_coord_2d_rel", None),
-                        roi_extents=batch.get("roi_extent", None))
+                        roi_extents=batch.get("roi_extent", None)))
             finally:
                 hip_layers.set_enabled(hip_on)
             if amp_test:
