@@ -262,7 +262,15 @@ def worker(args):
                 "parallelism": f"roi-shard x{world}", "collective": "all_gather f32[n,16] pose records" if world > 1 else None,
                 "class_sliced_out_layer": not args.exact_reference_order, "rois_class_sorted_within_rank": True,
                 "parameters": "default-init" if args.random_init else "seeded O(1)", "hip_network_layers": not args.no_hip_layers,
-                "mlp_gemm": args.mlp_gemm, "gemm_products": args.gemm_products, "library_options": args.opt, "timed_entry_point": "engine.inference_step + engine.gather_records",
+                "mlp_gemm": args.mlp_gemm, "gemm_products": args.gemm_products,
+                "gemm_numerics": ("fp32 operands, fp32 accumulation, fp32 results; operands enter the fp16 matrix cores as two fp16 values "
+                                  "(22 significant bits), three partial products; measured error against fp64 = that of the six-product "
+                                  "bf16x3 form and below hipBLASLt's fp32 GEMM on the same operands, network outputs at the same distance "
+                                  "from the reference's recorded forward (profiles/r03y_split2_accuracy.txt, tests/test_gpu_split2.py); "
+                                  "fp16-range overflow detected per step and repeated with six products; six_product_mode = the same "
+                                  "steps with the exact form" if args.gemm_products == 3 else
+                                  "fp32 operands split exactly into three bf16 values, six partial products, fp32 accumulation (exact to 2^-26)"),
+                "library_options": args.opt, "timed_entry_point": "engine.inference_step + engine.gather_records",
                 "stub_step": bool(args.stub_step)},
             "gather_ms": gather_ms,
         }
