@@ -137,8 +137,10 @@ def gemm_products() -> int:
     return _GEMM_PRODUCTS
 
 
-def _use_x3(m: int, n: int) -> bool:
-    return _GEMM_PRODUCTS == 3 and hip_lib.split2_tiles_ok(m, n)
+def _use_x3(m: int, n: int, k_linear: int = 0) -> bool:
+    """Three-product kernel for an [m, n] result?  ``k_linear`` = K of a linear-form launch: its A operand is addressed with
+    32-bit lane offsets (m * K * 4 bytes < 4 GiB, ~480 ROIs at stage 0); beyond that the six-product kernels take over."""
+    return _GEMM_PRODUCTS == 3 and hip_lib.split2_tiles_ok(m, n) and m * k_linear * 4 < (1 << 32)
 
 
 def _packed_weight(cache: dict, key: str, weight: torch.Tensor, x3: bool, pack6, pack3) -> torch.Tensor:
@@ -190,7 +192,7 @@ def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: 
           and c % 128 == 0)
     if ok and _MLP_GEMM == "split" and hip_lib.split_gemm_tiles(m, c) >= _LIBRARY_BELOW_TILES:
         # fewer than two output tiles per CU (small ROI counts at the deep stages): split K as well, or most of the chip idles
-        x3_1, x3_2 = _use_x3(m, 4 * c), _use_x3(m, c)
+        x3_1, x3_2 = _use_x3(m, 4 * c, c), _use_x3(m, c, 4 * c)
         f1 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, 4 * c) < _SPLITK_BELOW_TILES and not x3_1 else hip_lib.linear_f32_split
         f2 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, c) < _SPLITK_BELOW_TILES and not x3_2 else hip_lib.linear_f32_split
         h = f1(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk", x3_1), mlp.fc1.bias, "gelu")
@@ -303,7 +305,7 @@ def conv_transpose2d(deconv: nn.ConvTranspose2d, x: torch.Tensor) -> torch.Tenso
             and deconv.dilation == (1, 1) and deconv.groups == 1 and deconv.in_channels % 32 == 0
             and deconv.out_channels % 4 == 0 and (ks * ks * deconv.out_channels) % 128 == 0):
         cache = deconv.__dict__.setdefault("_gdrnpp_cache", {})
-        x3 = _use_x3(x.shape[0] * x.shape[2] * x.shape[3], ks * ks * deconv.out_channels)
+        x3 = _use_x3(x.shape[0] * x.shape[2] * x.shape[3], ks * ks * deconv.out_channels, deconv.in_channels)
         w_pk = _packed_weight(cache, "w_pk", deconv.weight, x3, hip_lib.pack_deconv_weight_bf16x3, hip_lib.pack_deconv_weight_f16x2)
         return hip_lib.conv_transpose2d_f32_split(_cl(x), w_pk, deconv.bias, ks, deconv.stride[0], deconv.padding[0],
                                                   deconv.output_padding[0])

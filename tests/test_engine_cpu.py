@@ -347,6 +347,9 @@ def test_gemm_product_switch_and_overflow_give_up(monkeypatch):
         hip_layers.set_gemm_products(4)
     assert hip_lib.split2_tiles_ok(128 * 256, 256) and not hip_lib.split2_tiles_ok(127 * 256, 256)
     assert hip_lib.split2_tiles_ok(64 * 256 + 1, 512) and not hip_lib.split2_tiles_ok(1 << 20, 192)
+    # linear form: the A operand must stay below 4 GiB (32-bit lane offsets) — 128 ROIs of stage-0 fc2 do, 600 do not
+    assert hip_layers._use_x3(128 * 4096, 128, 512) and not hip_layers._use_x3(600 * 4096, 128, 512)
+    assert hip_layers._use_x3(600 * 4096, 256)            # convolutions address per pixel: no such limit
     calls = []
 
     def run():
