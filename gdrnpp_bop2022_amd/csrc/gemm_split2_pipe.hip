@@ -167,7 +167,8 @@ __global__ void pack_weight2_kernel(const float* __restrict__ W, uint4* __restri
 
 struct GnStats2 { double* part; int G; int tiles_per_img; };   // as GnStats of gemm_split.hip
 
-// CONV: 0 = linear (A row-major [M,K]), 1 = 3x3 / stride 1 / pad 1 convolution over an NHWC image
+// CONV: 0 = linear (A row-major [M,K]), 1 = 3x3 / stride 1 / pad 1 convolution over an NHWC image (geometry folded at compile
+//       time), 2 = any KH x KW / stride / zero padding with at most 32 taps (ConvNeXt's 2x2/2 downsamples, Patch-PnP's 3x3/2)
 // GNS: GroupNorm (sum, sum of squares) partials of the stored result per wave (64 rows x 8-channel groups), CONV only
 // NJ: 32-column MFMA tiles per wave.  4: block tile 256 x 128, 24 slots per k-tile, 64 KB LDS, two workgroups per CU.
 //     8: block tile 256 x 256 (two packed weight tiles side by side), 48 slots per k-tile, 256 accumulator registers — one wave
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
     const int lrow = wave * 64 + c * 16 + prow;
     const int q = pq ^ ((lrow >> 2) & 3);
     const int arow = min(m0 + lrow, M - 1);
-    if constexpr (CONV) {
+    if constexpr (CONV == 1) {
       const int img = arow / (cg.H * cg.W), pp = arow - img * (cg.H * cg.W);
       const int iy = pp / cg.W, ix = pp - iy * cg.W;
       ap[c] = A + ((size_t)arow) * cg.C + q * 4;
@@ -230,6 +231,18 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
       }
       okmask[c] = mk;
       aoff[c] = 0;
+    } else if constexpr (CONV == 2) {   // general KH x KW / stride / pad: row = output pixel, anchor = its input pixel (oy*s, ox*s)
+      const int img = arow / (cg.OH * cg.OW), pp = arow - img * (cg.OH * cg.OW);
+      const int iy = (pp / cg.OW) * cg.stride, ix = (pp % cg.OW) * cg.stride;
+      ap[c] = A + (((size_t)img * cg.H + iy) * cg.W + ix) * cg.C + q * 4;
+      const int ntaps = K / cg.C;     // <= 32 (checked by the entry point)
+      unsigned mk = 0;
+      for (int t = 0; t < ntaps; ++t) {
+        const int ky = t / cg.KW, dy = ky - cg.pad, dx = t - ky * cg.KW - cg.pad;
+        if ((unsigned)(iy + dy) < (unsigned)cg.H && (unsigned)(ix + dx) < (unsigned)cg.W) mk |= 1u << t;
+      }
+      okmask[c] = mk;
+      aoff[c] = 0;
     } else {
       aoff[c] = (unsigned)arow * (unsigned)(K * 4) + (unsigned)(q * 16);
       ap[c] = nullptr;
@@ -237,6 +250,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
     }
   }
   if constexpr (CONV) cpt = cg.C / BK;
+  const int ntaps = CONV == 1 ? 9 : (CONV == 2 ? K / cg.C : 1), ckw = CONV == 1 ? 3 : cg.KW, cpad = CONV == 1 ? 1 : cg.pad;
   const unsigned boff = (unsigned)((wave * 2) * 64 + lane) * 16u;
   const char* const wbase = reinterpret_cast<const char*>(Wp + (size_t)tile_n * NWT * nk * W2_TILE_SLOTS);
   const unsigned ldsA = lds0 + (unsigned)(wave * 4) * 1024u;
@@ -246,9 +260,9 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
   auto dma_a = [&](int kt, unsigned sb, auto cc) {
     constexpr int c = decltype(cc)::value;
     if constexpr (CONV) {
-      const int cps = (cpt & 1) ? 1 : 2, sup = kt / (9 * cps), rem = kt - sup * (9 * cps), tap = rem / cps;  // gemm_split.hpp
+      const int cps = (cpt & 1) ? 1 : 2, sup = kt / (ntaps * cps), rem = kt - sup * (ntaps * cps), tap = rem / cps;  // gemm_split.hpp
       const int c0 = (sup * cps + (rem - tap * cps)) * BK;
-      const int ky = tap / 3, dy = ky - 1, dx = tap - ky * 3 - 1;
+      const int ky = tap / ckw, dy = ky - cpad, dx = tap - ky * ckw - cpad;
       const long off = ((long)dy * cg.W + dx) * cg.C + c0;
       const bool ok = (okmask[c] >> tap) & 1u;
       dma_v(ok ? (const void*)(ap[c] + off) : (const void*)g_split2_zero_page, ldsA + sb + c * 1024u);
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
     constexpr int c = decltype(cc)::value;
     int wkt = kt;
     if constexpr (CONV) {
-      const int cps = (cpt & 1) ? 1 : 2, sup = kt / (9 * cps), rem = kt - sup * (9 * cps), tap = rem / cps;
+      const int cps = (cpt & 1) ? 1 : 2, sup = kt / (ntaps * cps), rem = kt - sup * (ntaps * cps), tap = rem / cps;
       wkt = tap * cpt + sup * cps + (rem - tap * cps);
     }
     constexpr int t = c >> 1, sub = c & 1;   // piece c = half `sub` of this wave's 2 KB share of the packed 128-column tile t
@@ -534,6 +548,32 @@ extern "C" int gdrnpp_conv3x3_f32_split2(const float* x_nhwc, const void* W_pack
   if (epilogue == EPI_GELU)
     return launch_one<EPI_GELU, 1, false>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, cg, 0, gn, nonfinite_flag, st, what);
   return launch_one<EPI_BIAS, 1, false>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, cg, 0, gn, nonfinite_flag, st, what);
+}
+
+extern "C" int gdrnpp_conv2d_f32_split2(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc, int n_img,
+                                        int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int epilogue,
+                                        int* nonfinite_flag, void* stream) {
+  GDRNPP_REQUIRE(x_nhwc && W_packed && y_nhwc, GDRNPP_EINVAL, "gdrnpp_conv2d_f32_split2: null pointer");
+  GDRNPP_REQUIRE(n_img > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && H < 32768 && W < 32768 && KH > 0 && KW > 0 && KH * KW <= 32 &&
+                     stride > 0 && pad >= 0 && pad < KH && pad < KW,
+                 GDRNPP_EINVAL, "gdrnpp_conv2d_f32_split2: bad shape (at most 32 taps)");
+  if (KH == 3 && KW == 3 && stride == 1 && pad == 1)
+    return gdrnpp_conv3x3_f32_split2(x_nhwc, W_packed, bias, y_nhwc, nullptr, n_img, H, W, Cin, Cout, 0, epilogue, nonfinite_flag, stream);
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  GDRNPP_REQUIRE(OH > 0 && OW > 0 && (OH - 1) * stride < H && (OW - 1) * stride < W, GDRNPP_EINVAL,
+                 "gdrnpp_conv2d_f32_split2: empty output or anchor pixel outside the image");
+  const long M = (long)n_img * OH * OW;
+  GDRNPP_REQUIRE(M < (1l << 31) && Cout % BN == 0 && Cin % 32 == 0, GDRNPP_ELIMIT,
+                 "gdrnpp_conv2d_f32_split2: Cout=%d Cin=%d must be multiples of %d/32", Cout, Cin, BN);
+  GDRNPP_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_GELU, GDRNPP_EINVAL, "gdrnpp_conv2d_f32_split2: epilogue=%d", epilogue);
+  const ConvGeom cg{H, W, Cin, OH, OW, KW, stride, pad, 0};
+  const GnStats2 gn{nullptr, 0, 0};
+  hipStream_t st = (hipStream_t)stream;
+  const uint4* Wp = (const uint4*)W_packed;
+  const char* what = "gdrnpp_conv2d_f32_split2";
+  if (epilogue == EPI_GELU)
+    return launch_nj<EPI_GELU, 2, false, 4>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, KH * KW * Cin, cg, 0, gn, nonfinite_flag, st, what);
+  return launch_nj<EPI_BIAS, 2, false, 4>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, KH * KW * Cin, cg, 0, gn, nonfinite_flag, st, what);
 }
 
 // The library's own sticky flag (launches with nonfinite_flag == NULL): *flag = 1 when a stored value was inf / NaN since the

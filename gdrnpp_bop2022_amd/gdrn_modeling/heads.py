@@ -285,13 +285,16 @@ class ConvPnPNet(nn.Module):
         c0 = self.features[0]
         cache = c0.__dict__.setdefault("_gdrnpp_cache", {})
         tag = hip_layers.weight_tag(c0.weight)
-        hit = cache.get("w96_pk")
+        b, _, h, w_ = x96_cl.shape
+        x3 = hip_layers.use_x3(b * ((h + 2 - 3) // 2 + 1) * ((w_ + 2 - 3) // 2 + 1), c0.out_channels)   # three- / six-product kernel
+        key = "w96_pk_x3" if x3 else "w96_pk"
+        hit = cache.get(key)
         if hit is None or hit[0] != tag:
             w = c0.weight.detach()
             w96 = torch.zeros((w.shape[0], 96, 3, 3), dtype=w.dtype, device=w.device)
             w96[:, :69] = w
-            hit = (tag, hip_lib.pack_conv_weight_bf16x3(w96))
-            cache["w96_pk"] = hit
+            hit = (tag, (hip_lib.pack_conv_weight_f16x2 if x3 else hip_lib.pack_conv_weight_bf16x3)(w96))
+            cache[key] = hit
         x = hip_lib.conv2d_f32_split(x96_cl, hit[1], None, 3, 3, 2, 1)
         x = run_features(self.features[1:], x)
         return self._fc_tail(x)

@@ -137,6 +137,10 @@ def gemm_products() -> int:
     return _GEMM_PRODUCTS
 
 
+def use_x3(m: int, n: int, k_linear: int = 0) -> bool:
+    return _use_x3(m, n, k_linear)
+
+
 def _use_x3(m: int, n: int, k_linear: int = 0) -> bool:
     """Three-product kernel for an [m, n] result?  ``k_linear`` = K of a linear-form launch: its A operand is addressed with
     32-bit lane offsets (m * K * 4 bytes < 4 GiB, ~480 ROIs at stage 0); beyond that the six-product kernels take over."""
@@ -227,7 +231,9 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     if _conv_split_ok(conv, x):
         cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
         is3x3 = conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
-        x3 = is3x3 and _use_x3(x.shape[0] * x.shape[2] * x.shape[3], conv.out_channels)
+        ks, st, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        oh, ow = (x.shape[2] + 2 * pd - ks) // st + 1, (x.shape[3] + 2 * pd - ks) // st + 1
+        x3 = ks * ks <= 32 and _use_x3(x.shape[0] * oh * ow, conv.out_channels)
         w_pk = _packed_weight(cache, "w_pk", conv.weight, x3, hip_lib.pack_conv_weight_bf16x3, hip_lib.pack_conv_weight_f16x2)
         if is3x3:
             return hip_lib.conv3x3_f32_split(_cl(x), w_pk, conv.bias)

@@ -108,6 +108,7 @@ SIGNATURES = {
     "gdrnpp_pack_weight_f16x2": (c_int, [_P, _P, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split2": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "gdrnpp_conv3x3_f32_split2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "gdrnpp_conv2d_f32_split2": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "gdrnpp_split2_nonfinite": (c_int, [_P, c_int, _P]),
 }
 
@@ -849,13 +850,13 @@ def conv2d_f32_split(x_cl, weight_packed, bias, kh: int, kw: int, stride: int, p
     oh, ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
     out = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
     if fp16x2:
-        if (kh, kw, stride, pad) != (3, 3, 1, 1):
-            raise ValueError("the three-product convolution exists for 3x3 / stride 1 / pad 1 only")
+        if kh * kw > 32:
+            raise ValueError("the three-product convolution takes at most 32 taps")
         _count_x3()
         a2 = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
-              out.data_ptr(), None, n, h, w, cin, cout, 0, 1 if gelu else 0, _x3_flag().data_ptr(), _stream())
-        _check(_timed(_kind + X3, 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split2(*a2),
-                      4.0 * n * h * w * (cin + cout) + 4.0 * cout * 9 * cin), "gdrnpp_conv3x3_f32_split2")
+              out.data_ptr(), n, h, w, cin, cout, kh, kw, stride, pad, 1 if gelu else 0, _x3_flag().data_ptr(), _stream())
+        _check(_timed(_kind + X3, 2.0 * n * oh * ow * cout * kh * kw * cin, lambda: load().gdrnpp_conv2d_f32_split2(*a2),
+                      4.0 * n * (h * w * cin + oh * ow * cout) + 4.0 * cout * kh * kw * cin), "gdrnpp_conv2d_f32_split2")
         return out
     args = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
             out.data_ptr(), n, h, w, cin, cout, kh, kw, stride, pad, 1 if gelu else 0)

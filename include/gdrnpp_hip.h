@@ -453,6 +453,10 @@ int gdrnpp_linear_f32_split2(const float* A, const void* W_packed, const float* 
 int gdrnpp_conv3x3_f32_split2(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc, double* gn_partials,
                               int n_img, int H, int W, int Cin, int Cout, int groups, int epilogue, int* nonfinite_flag,
                               void* stream);
+/* any KH x KW / stride / zero-pad convolution with at most 32 taps (ConvNeXt's 2x2/2 downsamples, Patch-PnP's 3x3/2), epilogue 0 / 1 */
+int gdrnpp_conv2d_f32_split2(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc, int n_img, int H, int W,
+                             int Cin, int Cout, int KH, int KW, int stride, int pad, int epilogue, int* nonfinite_flag,
+                             void* stream);
 /* nonfinite_flag: device int the launch ORs 1 into when it stores an inf / NaN (the caller owns, zeroes and reads it — one per
  * stream / host thread keeps concurrent users apart); NULL = the library's own flag, read and reset by gdrnpp_split2_nonfinite. */
 int gdrnpp_split2_nonfinite(int* flag, int reset, void* stream);

@@ -141,6 +141,28 @@ def test_conv3x3_three_products_vs_fp64(hip, n, cin, cout, hw, gelu):
     assert e3 <= 1.3 * e6 + 4e-7, (e3, e6)
 
 
+@pytest.mark.parametrize("n,cin,cout,hw,k,stride,pad,gelu", [(8, 128, 256, 64, 2, 2, 0, False), (4, 96, 128, 64, 3, 2, 1, False),
+                                                         (3, 64, 128, 20, 3, 1, 0, True), (2, 32, 128, 17, 5, 2, 2, False)])
+def test_general_conv_three_products_vs_fp64(hip, n, cin, cout, hw, k, stride, pad, gelu):
+    """KH x KW / stride / zero-pad convolutions (ConvNeXt's 2x2/2 downsamples, Patch-PnP's 3x3/2, odd sizes with image borders)."""
+    torch.manual_seed(n + cin + k)
+    x = torch.randn(n, cin, hw, hw, device=DEV).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(cout, cin, k, k, device=DEV) * (k * k * cin) ** -0.5
+    b = torch.randn(cout, device=DEV)
+    hip.set_conv_splitk(False)
+    try:
+        out3 = hip.conv2d_f32_split(x, hip.pack_conv_weight_f16x2(w), b, k, k, stride, pad, gelu)
+        out6 = hip.conv2d_f32_split(x, hip.pack_conv_weight_bf16x3(w), b, k, k, stride, pad, gelu)
+    finally:
+        hip.set_conv_splitk(True)
+    want = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)
+    if gelu:
+        want = F.gelu(want)
+    assert out3.shape == want.shape
+    e3, e6 = (_amax(o.double() - want) / _amax(want) for o in (out3, out6))
+    assert e3 <= 1.3 * e6 + 4e-7, (e3, e6)
+
+
 def test_conv3x3_groupnorm_three_products_matches_six(hip):
     torch.manual_seed(5)
     n, c, hw, groups = 16, 256, 64, 32
@@ -221,6 +243,7 @@ def test_network_with_three_products_matches_reference_forward(hip, three_produc
         hip.set_launch_timer(None)
     kinds = [r[0] for r in timer.records]
     assert sum(k == "linear" + hip.X3 for k in kinds) == 72 and sum(k == "conv3x3" + hip.X3 for k in kinds) >= 5
+    assert sum(k == "conv" + hip.X3 for k in kinds) >= 4           # the three downsamples + Patch-PnP's strided convolutions
     assert sum(k == "deconv" + hip.X3 for k in kinds) == 1 and not hip.split2_nonfinite()
 
     def err(a, ref, scale=None):
