@@ -1,6 +1,7 @@
-// Three-product form of the split GEMM ("fp16x2"): the default of the ConvNeXt MLPs, the head's 3x3 convolutions and the
-// transposed-convolution GEMM where a launch has at least 256 tiles of 256x128 (hip_layers.set_gemm_products; entry points
-// gdrnpp_linear_f32_split2 / gdrnpp_conv3x3_f32_split2) — SURVEY.md §8 row a3.
+// Three-product form of the split GEMM ("fp16x2"): the default of the ConvNeXt MLPs, the convolutions of the head / downsample
+// layers / Patch-PnP and the transposed-convolution GEMM where a launch has at least 256 tiles of 256x128
+// (hip_layers.set_gemm_products; entry points gdrnpp_linear_f32_split2 / gdrnpp_conv3x3_f32_split2 / gdrnpp_conv2d_f32_split2)
+// — SURVEY.md §8 row a3.
 //
 // Numerical scheme.  Every fp32 operand is written as x = h + l + e with h = rn_f16(x), l = rn_f16(x - h) (the subtraction is
 // exact) and |e| <= 2^-22 |x| as long as l stays in the normal fp16 range (else |e| <= 2^-25 absolute): 22 significant bits in
@@ -20,16 +21,18 @@
 //   * activations are split as they are: |x| up to 65504 is representable, elements below 2^-2 lose l's low bits to the fp16
 //     subnormal spacing (absolute error 2^-25, i.e. still 2^-22 of any tensor whose scale is 2^-3 or more — LayerNorm /
 //     GroupNorm / GELU outputs).  An activation beyond 65504 becomes inf and the output non-finite: the epilogue checks every
-//     value it stores and raises a sticky device flag (gdrnpp_split2_nonfinite), on which the host side re-runs the step in the
-//     six-product form (engine.py) — the fast path is never silently wrong.
+//     value it stores and raises a sticky device flag (the launch's nonfinite_flag argument, one per stream on the Python side),
+//     on which the host side re-runs the step in the six-product form (engine.run_with_overflow_check) — never silently wrong.
 //
 // Kernel: the software-pipelined LDS-DMA kernel of gemm_split_pipe.hip with 24 instead of 48 MFMA slots per k-tile: block tile
 // 256x128x16, 4 waves stacked along M (2 x 4 MFMA tiles each), fp32 A by LDS-DMA into three 16 KB stages private to the waves,
 // pre-packed fp16 weight tiles (8 KB: [split][k-block][128][8]) by LDS-DMA into two stages, the split of k-tile t+1 (cvt_pk,
 // v_fma_mix_f32 residual, cvt_pk: 32 VALU operations) spread over the MFMA slots of k-tile t, both weight fragment sets read
 // just in time (l behind the barrier of the previous k-tile, h in slots 1 and 3), one barrier per k-tile behind slot 19.
-// 64 KB of dynamic LDS, two workgroups per CU.  Linear form and the 3x3 / stride 1 / pad 1 convolution (implicit im2col, k-tile
-// order of gemm_split.hpp), optional GroupNorm statistics in the epilogue (as gemm_split_glds_kernel<.., GNS>).
+// 64 KB of dynamic LDS, two workgroups per CU.  Linear form, the 3x3 / stride 1 / pad 1 convolution and the general K x K /
+// stride / pad convolution (implicit im2col, k-tile order of gemm_split.hpp), optional GroupNorm statistics in the epilogue (as
+// gemm_split_glds_kernel<.., GNS>).  -DGDRNPP2_TIMING_NO_{BREAD,SPLIT,SYNC,DMA}: timing-only builds (results invalid) behind
+// profiles/r03y_split2_kloop_dissection.txt.
 #include "gemm_split.hpp"
 
 namespace {
