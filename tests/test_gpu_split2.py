@@ -1,4 +1,4 @@
-"""-m gpu: the three-product ("fp16x2") form of the split GEMM — opt-in fast mode (csrc/gemm_split2_pipe.hip,
+"""-m gpu: the three-product ("fp16x2") form of the split GEMM — the default for large launches (csrc/gemm_split2_pipe.hip,
 hip_layers.set_gemm_products(3)).  What is pinned here:
   * the packed weight image is h + l = w * 2^e to 2^-22, with the scale in the trailer;
   * linear / conv3x3 (+ GroupNorm statistics) against fp64 at MLP / head shapes, every epilogue, ragged M, the panel walk, operands
