@@ -86,6 +86,11 @@ class GDRN_DoubleMask(nn.Module):
         self._sliced_pk = None  # cache of the packed, 128-row padded slices for the grouped split GEMM
         self.fused_head_tail = True   # all-NHWC head tail on the HIP path (False: baddbmm + torch ops, for A/B)
 
+    def load_state_dict(self, *args, **kwargs):
+        res = super().load_state_dict(*args, **kwargs)
+        hip_layers.reset_x3_calibration()     # new weights, new activation scales: the layers look at their inputs again
+        return res
+
     # ------------------------------------------------------------------------------------------
     def _sliced_out_layer(self, feat, roi_classes):
         """Per-ROI 70-channel output layer = the class-aware gather folded into the weights."""

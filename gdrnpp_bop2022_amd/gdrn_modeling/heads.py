@@ -286,7 +286,7 @@ class ConvPnPNet(nn.Module):
         cache = c0.__dict__.setdefault("_gdrnpp_cache", {})
         tag = hip_layers.weight_tag(c0.weight)
         b, _, h, w_ = x96_cl.shape
-        x3 = hip_layers.use_x3(b * ((h + 2 - 3) // 2 + 1) * ((w_ + 2 - 3) // 2 + 1), c0.out_channels)   # three- / six-product kernel
+        x3 = hip_layers.use_x3(b * ((h + 2 - 3) // 2 + 1) * ((w_ + 2 - 3) // 2 + 1), c0.out_channels, 0, cache, "conv96", x96_cl)   # three- / six-product kernel
         key = "w96_pk_x3" if x3 else "w96_pk"
         hit = cache.get(key)
         if hit is None or hit[0] != tag:

@@ -137,8 +137,36 @@ def gemm_products() -> int:
     return _GEMM_PRODUCTS
 
 
-def use_x3(m: int, n: int, k_linear: int = 0) -> bool:
-    return _use_x3(m, n, k_linear)
+def use_x3(m: int, n: int, k_linear: int = 0, cache: dict | None = None, key: str = "", x: torch.Tensor | None = None) -> bool:
+    return _use_x3(m, n, k_linear) and (x is None or x3_scale_ok(cache, key, x))
+
+
+# The one silent limit of the two-way fp16 split is on the small side: an activation tensor whose scale is below ~2^-4 loses the
+# low half of its elements to the fp16 subnormal spacing (absolute operand error 2^-25; csrc/gemm_split2_pipe.hip) — the large side
+# raises the overflow flag.  So every layer LOOKS at its input the first X3_CALIBRATION_CALLS times it is about to use a
+# three-product kernel (rms of the A operand: one reduction + read-back per layer and call, during warm-up only) and stays on the
+# six-product kernels if the tensor is too small (or not finite).  Trained GDRNPP layers feed LayerNorm / GroupNorm / GELU outputs
+# (scale ~1) and pass; reset_x3_calibration() forgets the decisions (e.g. after loading other weights).
+X3_CALIBRATION_CALLS = 2
+X3_MIN_RMS = 2.0 ** -4
+_X3_CALIBRATION_EPOCH = 0
+
+
+def reset_x3_calibration() -> None:
+    global _X3_CALIBRATION_EPOCH
+    _X3_CALIBRATION_EPOCH += 1
+
+
+def x3_scale_ok(cache: dict, key: str, x: torch.Tensor) -> bool:
+    st = cache.get("x3_calib_" + key)
+    if st is None or st[0] != _X3_CALIBRATION_EPOCH:
+        st = cache["x3_calib_" + key] = [_X3_CALIBRATION_EPOCH, 0, True]
+    if st[1] < X3_CALIBRATION_CALLS and st[2] and not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+        st[1] += 1
+        rms = float(x.detach().float().square().mean().sqrt())
+        if not rms >= X3_MIN_RMS:       # also catches NaN
+            st[2] = False
+    return st[2]
 
 
 def _use_x3(m: int, n: int, k_linear: int = 0) -> bool:
@@ -196,10 +224,11 @@ def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: 
           and c % 128 == 0)
     if ok and _MLP_GEMM == "split" and hip_lib.split_gemm_tiles(m, c) >= _LIBRARY_BELOW_TILES:
         # fewer than two output tiles per CU (small ROI counts at the deep stages): split K as well, or most of the chip idles
-        x3_1, x3_2 = _use_x3(m, 4 * c, c), _use_x3(m, c, 4 * c)
+        x3_1 = _use_x3(m, 4 * c, c) and x3_scale_ok(cache, "fc1", x_nhwc)
         f1 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, 4 * c) < _SPLITK_BELOW_TILES and not x3_1 else hip_lib.linear_f32_split
-        f2 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, c) < _SPLITK_BELOW_TILES and not x3_2 else hip_lib.linear_f32_split
         h = f1(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk", x3_1), mlp.fc1.bias, "gelu")
+        x3_2 = _use_x3(m, c, 4 * c) and x3_scale_ok(cache, "fc2", h)
+        f2 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, c) < _SPLITK_BELOW_TILES and not x3_2 else hip_lib.linear_f32_split
         y = f2(h, _packed(mlp.fc2, cache, "fc2_pk", x3_2), mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
         return y.view(x_nhwc.shape)
     return torch.addcmul(shortcut_nhwc, mlp(x_nhwc), gamma)
@@ -233,7 +262,7 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
         is3x3 = conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
         ks, st, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         oh, ow = (x.shape[2] + 2 * pd - ks) // st + 1, (x.shape[3] + 2 * pd - ks) // st + 1
-        x3 = ks * ks <= 32 and _use_x3(x.shape[0] * oh * ow, conv.out_channels)
+        x3 = ks * ks <= 32 and _use_x3(x.shape[0] * oh * ow, conv.out_channels) and x3_scale_ok(cache, "conv", x)
         w_pk = _packed_weight(cache, "w_pk", conv.weight, x3, hip_lib.pack_conv_weight_bf16x3, hip_lib.pack_conv_weight_f16x2)
         if is3x3:
             return hip_lib.conv3x3_f32_split(_cl(x), w_pk, conv.bias)
@@ -311,7 +340,7 @@ def conv_transpose2d(deconv: nn.ConvTranspose2d, x: torch.Tensor) -> torch.Tenso
             and deconv.dilation == (1, 1) and deconv.groups == 1 and deconv.in_channels % 32 == 0
             and deconv.out_channels % 4 == 0 and (ks * ks * deconv.out_channels) % 128 == 0):
         cache = deconv.__dict__.setdefault("_gdrnpp_cache", {})
-        x3 = _use_x3(x.shape[0] * x.shape[2] * x.shape[3], ks * ks * deconv.out_channels, deconv.in_channels)
+        x3 = _use_x3(x.shape[0] * x.shape[2] * x.shape[3], ks * ks * deconv.out_channels, deconv.in_channels) and x3_scale_ok(cache, "deconv", x)
         w_pk = _packed_weight(cache, "w_pk", deconv.weight, x3, hip_lib.pack_deconv_weight_bf16x3, hip_lib.pack_deconv_weight_f16x2)
         return hip_lib.conv_transpose2d_f32_split(_cl(x), w_pk, deconv.bias, ks, deconv.stride[0], deconv.padding[0],
                                                   deconv.output_padding[0])
@@ -338,7 +367,7 @@ def conv3x3_groupnorm_act(conv: nn.Conv2d, gn: nn.GroupNorm, act: nn.Module | No
             and (act is None or (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none"))):
         return None
     cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
-    x3 = _use_x3(x.shape[0] * x.shape[2] * x.shape[3], conv.out_channels)
+    x3 = _use_x3(x.shape[0] * x.shape[2] * x.shape[3], conv.out_channels) and x3_scale_ok(cache, "conv", x)
     w_pk = _packed_weight(cache, "w_pk", conv.weight, x3, hip_lib.pack_conv_weight_bf16x3, hip_lib.pack_conv_weight_f16x2)
     return hip_lib.conv3x3_groupnorm_act(_cl(x), w_pk, conv.bias, gn.weight, gn.bias, gn.num_groups, gn.eps,
                                          gelu=act is not None)

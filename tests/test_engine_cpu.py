@@ -367,3 +367,26 @@ def test_gemm_product_switch_and_overflow_give_up(monkeypatch):
         assert calls == [6] * engine.X3_OVERFLOW_STEPS_TO_GIVE_UP
     finally:
         hip_layers.set_gemm_products(3)
+
+
+def test_x3_scale_calibration_decides_per_layer():
+    """hip_layers.x3_scale_ok: a layer looks at the rms of its A operand the first X3_CALIBRATION_CALLS times; an operand below
+    2^-4 (or non-finite) keeps that layer on the six-product kernels, reset_x3_calibration() makes every layer look again."""
+    import torch
+
+    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers as hl
+
+    hl.reset_x3_calibration()
+    torch.manual_seed(0)
+    big, small = torch.randn(64, 32), torch.randn(64, 32) * 1e-3
+    c1, c2 = {}, {}
+    assert hl.x3_scale_ok(c1, "fc1", big) and hl.x3_scale_ok(c1, "fc1", big)
+    assert hl.x3_scale_ok(c1, "fc1", small)            # calibration over: the decision stands without another look
+    assert not hl.x3_scale_ok(c2, "fc1", small) and not hl.x3_scale_ok(c2, "fc1", big)
+    assert hl.x3_scale_ok(c2, "fc2", big)              # per layer key
+    assert not hl.x3_scale_ok({}, "conv", torch.full((4, 4), float("nan")))
+    hl.reset_x3_calibration()
+    assert hl.x3_scale_ok(c2, "fc1", big)              # looks again after a reset
+    # use_x3 folds the shape rule and the look together
+    assert hl.use_x3(128 * 4096, 512, 128, {}, "fc1", big) and not hl.use_x3(128 * 4096, 512, 128, {}, "fc1", small)
+    assert not hl.use_x3(4 * 4096, 128, 512, {}, "fc2", big)      # too few tiles: six products whatever the scale

@@ -340,3 +340,40 @@ def test_inference_step_needs_no_outer_no_grad(hip):
         hip.set_launch_timer(None)
     assert rec.shape == (NG.B, 16) and not rec.requires_grad
     assert sum(r[0] in ("linear", "linear_splitk", "linear_x3") for r in timer.records) == 74
+
+
+def test_small_scale_layer_input_keeps_that_layer_on_six_products(hip, three_products):
+    """The silent side of the fp16x2 range (operands below ~2^-4) is handled per layer: the first calls look at the A operand and a
+    layer fed with a tiny-scale tensor stays on the six-product kernels; its result is then as exact as ever."""
+    from gdrnpp_bop2022_amd.gdrn_modeling.backbones import Mlp
+
+    hip_layers = three_products
+    hip.SPLIT2_MIN_TILES = 1
+    torch.manual_seed(21)
+    c = 128
+    mlp = Mlp(c, 4 * c).cuda().eval()
+    gamma = torch.randn(c, device=DEV)
+    x = torch.randn(4, 32, 32, c, device=DEV)
+    sc = torch.randn(4, 32, 32, c, device=DEV)
+
+    def run(inp, cache):
+        timer = hip.LaunchTimer()
+        hip.set_launch_timer(timer)
+        try:
+            with torch.no_grad():
+                y = hip_layers.convnext_mlp(mlp, gamma, inp, sc, cache)
+        finally:
+            hip.set_launch_timer(None)
+        return y, [r[0] for r in timer.records]
+
+    hip_layers.reset_x3_calibration()
+    y, kinds = run(x, {})
+    assert kinds == ["linear" + hip.X3] * 2
+    tiny = x * 1e-3
+    y_t, kinds = run(tiny, {})
+    assert len(kinds) == 2 and all(k in ("linear", "linear_splitk") for k in kinds)      # six-product kernels (plain or split-K)
+    with torch.no_grad():
+        want = sc.double() + gamma.double() * mlp.double()(tiny.double())
+        mlp.float()
+    assert ((y_t.double() - want).abs().max() / want.abs().max()).item() < 5e-7
+    assert not hip.split2_nonfinite()
