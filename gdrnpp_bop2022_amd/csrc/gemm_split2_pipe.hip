@@ -21,8 +21,16 @@
 //   * activations are split as they are: |x| up to 65504 is representable, elements below 2^-2 lose l's low bits to the fp16
 //     subnormal spacing (absolute error 2^-25, i.e. still 2^-22 of any tensor whose scale is 2^-3 or more — LayerNorm /
 //     GroupNorm / GELU outputs).  An activation beyond 65504 becomes inf and the output non-finite: the epilogue checks every
-//     value it stores and raises a sticky device flag (the launch's nonfinite_flag argument, one per stream on the Python side),
-//     on which the host side re-runs the step in the six-product form (engine.run_with_overflow_check) — never silently wrong.
+//     value it stores and raises bit 0 of the launch's range word (the range_flag argument: one word per layer and stream on
+//     the Python side);
+//   * the small side is checked on every launch as well, per A row: the k-loop accumulates the sum of squares of the row's h
+//     halves (v_dot2c_f32_f16, 8 per k-tile and wave), and a row that is not all zero with rms below 2^-4 raises bit 1 — below
+//     that scale the 2^-25 absolute operand error of the subnormal l would exceed 2^-21 of the row's own output scale (zero-padded
+//     taps of a convolution count as zeros).  A non-finite A element makes the sum non-finite and raises bit 0.
+//   On either bit the host side re-runs the step in the six-product form and keeps the flagged layer there
+//   (engine.run_with_range_check) — never silently wrong, on either side of the range, on every launch;
+//   * weights: gdrnpp_pack_weight_f16x2 applies the same per-row test to the scaled weight rows (trailer word 3); such a layer
+//     is not eligible for this form (hip_layers._packed_weight).
 //
 // Kernel: the software-pipelined LDS-DMA kernel of gemm_split_pipe.hip with 24 instead of 48 MFMA slots per k-tile: block tile
 // 256x128x16, 4 waves stacked along M (2 x 4 MFMA tiles each), fp32 A by LDS-DMA into three 16 KB stages private to the waves,
@@ -46,7 +54,7 @@ constexpr int A_STAGE_B = 256 * BK * 4;        // fp32 A image of one k-tile: 16
 constexpr int W2_TILE_SLOTS = 2 * KB * BN;     // uint4 slots of one packed 128x16 fp16x2 weight tile
 constexpr int W2_TILE_B = W2_TILE_SLOTS * 16;  // 8 KB
 
-__device__ int g_split2_nonfinite;  // sticky: a stored value was inf / NaN (activation beyond the fp16 range, or non-finite input); used when a launch passes no flag of its own
+__device__ int g_split2_range_word;  // sticky range word (GDRNPP_SPLIT2_NONFINITE | GDRNPP_SPLIT2_SMALL_ROWS) of launches that pass no word of their own
 __device__ __attribute__((aligned(64))) float g_split2_zero_page[16];
 
 __device__ __forceinline__ void dma_s(unsigned voff, const void* sbase, unsigned lds_dst) {
@@ -79,6 +87,12 @@ __device__ __forceinline__ float residual(float x, unsigned hpk) {
   if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(x));
   else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(x));
   return r;
+}
+
+// s + (lo of hpk)^2 + (hi of hpk)^2: one v_dot2c_f32_f16 (row sums of squares of the range check)
+__device__ __forceinline__ float sumsq2(unsigned hpk, float s) {
+  const f16x2 v = __builtin_bit_cast(f16x2, hpk);
+  return __builtin_amdgcn_fdot2(v, v, s, false);
 }
 
 // One half of a wave's A tile for one k-tile: 32 rows x 16 k, 8 consecutive k of one row per lane.  x ~ h + l in 8 steps of two
@@ -138,7 +152,7 @@ __device__ __forceinline__ int weight_exp(unsigned amax_bits) {
 }
 
 // W f32[N][K] -> packed fp16 [N/128][K/16][2][2][128][8]; one thread per (row, k-block) = 8 consecutive k.
-// trailer (16 B behind the tiles): {amax bits, 2^-e, 2^e, 0}
+// trailer (16 B behind the tiles): {amax bits, 2^-e, 2^e, rows-below-range bit (weight_rows_range_kernel)}
 __global__ void pack_weight2_kernel(const float* __restrict__ W, uint4* __restrict__ packed, int N, int K) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int kbs = K / 8;
@@ -168,6 +182,28 @@ __global__ void pack_weight2_kernel(const float* __restrict__ W, uint4* __restri
   img[(1 * KB + kb) * BN + row] = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// one workgroup per weight row: a row that is not all zero whose SCALED rms is below 2^-4 (2^-17 of the tensor maximum: its low
+// halves are fp16 subnormals) raises trailer word 3 — the per-row test of the kernels' A side, applied to the other operand
+__global__ void weight_rows_range_kernel(const float* __restrict__ W, uint4* __restrict__ packed, int N, int K) {
+  unsigned* trailer = reinterpret_cast<unsigned*>(packed + (size_t)(N / BN) * (K / BK) * W2_TILE_SLOTS);
+  const float sc = __builtin_ldexpf(1.f, weight_exp(trailer[0]));
+  const float* row = W + (size_t)blockIdx.x * K;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const float v = row[k] * sc;
+    s = fmaf(v, v, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = (part[0] + part[1]) + (part[2] + part[3]);
+    if (s > 0.f && s < (float)K * 0x1p-8f) atomicOr(trailer + 3, 1u);
+  }
+}
+
 struct GnStats2 { double* part; int G; int tiles_per_img; };   // as GnStats of gemm_split.hip
 
 // CONV: 0 = linear (A row-major [M,K]), 1 = 3x3 / stride 1 / pad 1 convolution over an NHWC image (geometry folded at compile
@@ -181,7 +217,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
                                                                   const float* __restrict__ bias,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ resid, float* __restrict__ C,
-                                                                  int M, int N, int K, ConvGeom cg, int panel, GnStats2 gn, int* nonfinite) {
+                                                                  int M, int N, int K, ConvGeom cg, int panel, GnStats2 gn, int* range_flag) {
   constexpr int BNB = NJ * 32;                     // block columns
   constexpr int NWT = NJ / 4;                      // packed 128-column weight tiles per block
   constexpr int B_STAGE_B = NWT * W2_TILE_B;       // 8 / 16 KB
@@ -306,6 +342,10 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
   // fragment slot of column tile J, split plane P, relative to sBf (+ stage)
   auto bslot = [](int P, int J) { return (J >> 2) * W2_TILE_SLOTS + P * KB * BN + (J & 3) * 32; };
 
+  // range check: per lane the sum of squares of the h halves it has multiplied (row frow / frow + 32 of the wave, k-blocks fk),
+  // two accumulators per row half; -DGDRNPP2_NO_RANGE_CHECK: timing-only build without it
+  float ssq[4] = {0.f, 0.f, 0.f, 0.f};
+
   // One k-tile, NS = 6 NJ slots (slot S: product group G = S / (2 NJ) in the order h*l, l*h, h*h; row half I, column tile J).
   // cur: split A fragments of k-tile kt; nxt: receives the split of k-tile kt+1 (its raw first half is already in nxt[0].x).
   // fbL holds the weight split l of kt on entry (dead after slot 2 NJ - 1, refilled with the split l of kt+1 behind the
@@ -335,6 +375,13 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
         fbH[j0] = __builtin_bit_cast(f16x8, b[bslot(0, j0)]);
         fbH[j0 + 1] = __builtin_bit_cast(f16x8, b[bslot(0, j0 + 1)]);
       }
+#endif
+#ifndef GDRNPP2_NO_RANGE_CHECK
+      // sums of squares of cur's h halves in slots without split arithmetic (cur[..].h stays live through group h*h)
+      if constexpr (S == 0) { ssq[2] = sumsq2(cur[1].h[0], ssq[2]); ssq[3] = sumsq2(cur[1].h[1], ssq[3]); }
+      if constexpr (S == 2) { ssq[2] = sumsq2(cur[1].h[2], ssq[2]); ssq[3] = sumsq2(cur[1].h[3], ssq[3]); }
+      if constexpr (S == 11) { ssq[0] = sumsq2(cur[0].h[0], ssq[0]); ssq[1] = sumsq2(cur[0].h[1], ssq[1]); }
+      if constexpr (S == 12) { ssq[0] = sumsq2(cur[0].h[2], ssq[0]); ssq[1] = sumsq2(cur[0].h[3], ssq[1]); }
 #endif
       constexpr int S1 = NJ == 4 ? 13 : 20;   // first split slot of the second half (its raw read four slots earlier)
       if constexpr (S == S1 - 4) load_half(nxt[1], sa1, 1);
@@ -455,19 +502,33 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
       }
     }
   }
-  if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(nonfinite ? nonfinite : &g_split2_nonfinite, 1);
+  // range verdict of the wave's 64 A rows: lanes l and l ^ 32 hold the two k-block halves of rows frow and frow + 32
+  bool small = false;
+#ifndef GDRNPP2_NO_RANGE_CHECK
+  {
+    float s0 = ssq[0] + ssq[1], s1 = ssq[2] + ssq[3];
+    s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    const float thr = (float)K * 0x1p-8f;                         // rms 2^-4 over the K elements of the row
+    small = (s0 > 0.f && s0 < thr) || (s1 > 0.f && s1 < thr);
+    bad |= !(s0 < __builtin_inff()) || !(s1 < __builtin_inff());  // an inf / NaN element of A
+  }
+#endif
+  const int word = (__builtin_amdgcn_ballot_w64(bad) != 0 ? GDRNPP_SPLIT2_NONFINITE : 0) |
+                   (__builtin_amdgcn_ballot_w64(small) != 0 ? GDRNPP_SPLIT2_SMALL_ROWS : 0);
+  if (word && lane == 0) atomicOr(range_flag ? range_flag : &g_split2_range_word, word);
 }
 
 template <int EPI, int CONV, bool GNS, int NJ>
 int launch_nj(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
-              int K, ConvGeom cg, int panel, GnStats2 gn, int* nonfinite, hipStream_t st, const char* what) {
+              int K, ConvGeom cg, int panel, GnStats2 gn, int* range_flag, hipStream_t st, const char* what) {
   constexpr int lds_bytes = NA * A_STAGE_B + 2 * (NJ / 4) * W2_TILE_B;
   const int rc = gdrnpp::ensure_dynamic_lds((const void*)gemm_split2_pipe_kernel<EPI, CONV, GNS, NJ>, lds_bytes);
   if (rc) return rc;
   const long tiles = (long)((M + 255) / 256) * (N / (NJ * 32));
   GDRNPP_REQUIRE(tiles < (1l << 30), GDRNPP_ELIMIT, "%s: grid too large", what);
   hipLaunchKernelGGL((gemm_split2_pipe_kernel<EPI, CONV, GNS, NJ>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, A, Wp, bias, gamma,
-                     resid, C, M, N, K, cg, panel, gn, nonfinite);
+                     resid, C, M, N, K, cg, panel, gn, range_flag);
   return gdrnpp::check_launch(what);
 }
 
@@ -476,11 +537,11 @@ int launch_nj(const float* A, const uint4* Wp, const float* bias, const float* g
 // 189 us, stage-0 fc1 623 vs 533 us: one wave per SIMD has nobody to hide its LDS / DMA latencies behind)
 template <int EPI, int CONV, bool GNS>
 int launch_one(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
-               int K, ConvGeom cg, int panel, GnStats2 gn, int* nonfinite, hipStream_t st, const char* what) {
+               int K, ConvGeom cg, int panel, GnStats2 gn, int* range_flag, hipStream_t st, const char* what) {
   const int opt = gdrnpp::option_split2_wide();
   const bool wide = N % 256 == 0 && opt == 1;
-  if (wide) return launch_nj<EPI, CONV, GNS, 8>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, nonfinite, st, what);
-  return launch_nj<EPI, CONV, GNS, 4>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, nonfinite, st, what);
+  if (wide) return launch_nj<EPI, CONV, GNS, 8>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what);
+  return launch_nj<EPI, CONV, GNS, 4>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what);
 }
 
 }  // namespace
@@ -500,11 +561,12 @@ extern "C" int gdrnpp_pack_weight_f16x2(const float* W, void* packed, int N, int
   hipLaunchKernelGGL(amax_kernel, dim3((unsigned)min((n + 1023) / 1024, 1024l)), dim3(256), 0, st, W, n, trailer);
   const long threads = (long)N * (K / 8);
   hipLaunchKernelGGL(pack_weight2_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, (uint4*)packed, N, K);
+  hipLaunchKernelGGL(weight_rows_range_kernel, dim3((unsigned)N), dim3(256), 0, st, W, (uint4*)packed, N, K);   // behind the pack: it writes trailer[3] = 0
   return gdrnpp::check_launch("gdrnpp_pack_weight_f16x2");
 }
 
 extern "C" int gdrnpp_linear_f32_split2(const float* A, const void* W_packed, const float* bias, const float* gamma,
-                                        const float* resid, float* C, int M, int N, int K, int epilogue, int* nonfinite_flag,
+                                        const float* resid, float* C, int M, int N, int K, int epilogue, int* range_flag,
                                         void* stream) {
   GDRNPP_REQUIRE(A && W_packed && C, GDRNPP_EINVAL, "gdrnpp_linear_f32_split2: null pointer");
   GDRNPP_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % 32 == 0, GDRNPP_ELIMIT,
@@ -521,14 +583,14 @@ extern "C" int gdrnpp_linear_f32_split2(const float* A, const void* W_packed, co
   hipStream_t st = (hipStream_t)stream;
   const uint4* Wp = (const uint4*)W_packed;
   const char* what = "gdrnpp_linear_f32_split2";
-  if (epilogue == EPI_BIAS) return launch_one<EPI_BIAS, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, nonfinite_flag, st, what);
-  if (epilogue == EPI_GELU) return launch_one<EPI_GELU, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, nonfinite_flag, st, what);
-  return launch_one<EPI_SCALE_RES, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, nonfinite_flag, st, what);
+  if (epilogue == EPI_BIAS) return launch_one<EPI_BIAS, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what);
+  if (epilogue == EPI_GELU) return launch_one<EPI_GELU, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what);
+  return launch_one<EPI_SCALE_RES, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what);
 }
 
 extern "C" int gdrnpp_conv3x3_f32_split2(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                                          double* gn_partials, int n_img, int H, int W, int Cin, int Cout, int groups, int epilogue,
-                                         int* nonfinite_flag, void* stream) {
+                                         int* range_flag, void* stream) {
   GDRNPP_REQUIRE(x_nhwc && W_packed && y_nhwc, GDRNPP_EINVAL, "gdrnpp_conv3x3_f32_split2: null pointer");
   GDRNPP_REQUIRE(n_img > 0 && H > 0 && W > 0 && H < 32768 && W < 32768 && Cin > 0 && Cout > 0, GDRNPP_EINVAL,
                  "gdrnpp_conv3x3_f32_split2: bad shape");
@@ -545,23 +607,23 @@ extern "C" int gdrnpp_conv3x3_f32_split2(const float* x_nhwc, const void* W_pack
                    "gdrnpp_conv3x3_f32_split2: GroupNorm statistics need the plain epilogue, H*W %% 256 == 0 and 8 channels per group "
                    "(H*W=%d Cout=%d groups=%d)", H * W, Cout, groups);
     return launch_one<EPI_BIAS, 1, true>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, cg, 0,
-                                         GnStats2{gn_partials, groups, (H * W) / 256}, nonfinite_flag, st, what);
+                                         GnStats2{gn_partials, groups, (H * W) / 256}, range_flag, st, what);
   }
   const GnStats2 gn{nullptr, 0, 0};
   if (epilogue == EPI_GELU)
-    return launch_one<EPI_GELU, 1, false>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, cg, 0, gn, nonfinite_flag, st, what);
-  return launch_one<EPI_BIAS, 1, false>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, cg, 0, gn, nonfinite_flag, st, what);
+    return launch_one<EPI_GELU, 1, false>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, cg, 0, gn, range_flag, st, what);
+  return launch_one<EPI_BIAS, 1, false>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, 9 * Cin, cg, 0, gn, range_flag, st, what);
 }
 
 extern "C" int gdrnpp_conv2d_f32_split2(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc, int n_img,
                                         int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int epilogue,
-                                        int* nonfinite_flag, void* stream) {
+                                        int* range_flag, void* stream) {
   GDRNPP_REQUIRE(x_nhwc && W_packed && y_nhwc, GDRNPP_EINVAL, "gdrnpp_conv2d_f32_split2: null pointer");
   GDRNPP_REQUIRE(n_img > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && H < 32768 && W < 32768 && KH > 0 && KW > 0 && KH * KW <= 32 &&
                      stride > 0 && pad >= 0 && pad < KH && pad < KW,
                  GDRNPP_EINVAL, "gdrnpp_conv2d_f32_split2: bad shape (at most 32 taps)");
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1)
-    return gdrnpp_conv3x3_f32_split2(x_nhwc, W_packed, bias, y_nhwc, nullptr, n_img, H, W, Cin, Cout, 0, epilogue, nonfinite_flag, stream);
+    return gdrnpp_conv3x3_f32_split2(x_nhwc, W_packed, bias, y_nhwc, nullptr, n_img, H, W, Cin, Cout, 0, epilogue, range_flag, stream);
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   GDRNPP_REQUIRE(OH > 0 && OW > 0 && (OH - 1) * stride < H && (OW - 1) * stride < W, GDRNPP_EINVAL,
                  "gdrnpp_conv2d_f32_split2: empty output or anchor pixel outside the image");
@@ -575,23 +637,23 @@ extern "C" int gdrnpp_conv2d_f32_split2(const float* x_nhwc, const void* W_packe
   const uint4* Wp = (const uint4*)W_packed;
   const char* what = "gdrnpp_conv2d_f32_split2";
   if (epilogue == EPI_GELU)
-    return launch_nj<EPI_GELU, 2, false, 4>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, KH * KW * Cin, cg, 0, gn, nonfinite_flag, st, what);
-  return launch_nj<EPI_BIAS, 2, false, 4>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, KH * KW * Cin, cg, 0, gn, nonfinite_flag, st, what);
+    return launch_nj<EPI_GELU, 2, false, 4>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, KH * KW * Cin, cg, 0, gn, range_flag, st, what);
+  return launch_nj<EPI_BIAS, 2, false, 4>(x_nhwc, Wp, bias, nullptr, nullptr, y_nhwc, (int)M, Cout, KH * KW * Cin, cg, 0, gn, range_flag, st, what);
 }
 
-// The library's own sticky flag (launches with nonfinite_flag == NULL): *flag = 1 when a stored value was inf / NaN since the
-// last reset (synchronises the stream).  Callers running several streams / host threads pass a flag of their own per launch.
-extern "C" int gdrnpp_split2_nonfinite(int* flag, int reset, void* stream) {
-  GDRNPP_REQUIRE(flag, GDRNPP_EINVAL, "gdrnpp_split2_nonfinite: null pointer");
+// The library's own sticky range word (launches with range_flag == NULL): *word = the bits raised since the last reset
+// (synchronises the stream).  Callers running several streams / host threads / layers pass words of their own per launch.
+extern "C" int gdrnpp_split2_range_word(int* flag, int reset, void* stream) {
+  GDRNPP_REQUIRE(flag, GDRNPP_EINVAL, "gdrnpp_split2_range_word: null pointer");
   hipStream_t st = (hipStream_t)stream;
   int v = 0;
-  GDRNPP_HIP_TRY(hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(g_split2_nonfinite), sizeof(int), 0, hipMemcpyDeviceToHost, st));
+  GDRNPP_HIP_TRY(hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(g_split2_range_word), sizeof(int), 0, hipMemcpyDeviceToHost, st));
   GDRNPP_HIP_TRY(hipStreamSynchronize(st));
   if (reset && v) {
     const int zero = 0;
-    GDRNPP_HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_split2_nonfinite), &zero, sizeof(int), 0, hipMemcpyHostToDevice, st));
+    GDRNPP_HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_split2_range_word), &zero, sizeof(int), 0, hipMemcpyHostToDevice, st));
     GDRNPP_HIP_TRY(hipStreamSynchronize(st));
   }
-  *flag = v ? 1 : 0;
+  *flag = v;
   return 0;
 }

@@ -406,6 +406,59 @@ __global__ __launch_bounds__(256) void deconv_col2im_kernel(const float* __restr
   }
 }
 
+// The same gather with the GroupNorm statistics of its result taken on the way (the head's ConvTranspose2d is followed by
+// GroupNorm + GELU, top_down_doublemask_xyz_region_head.py:53-75): launch geometry, pixel partition and summation order of
+// gn_stats_kernel, so the partials [N, P, G, 2] — and with them the normalised tensor — are bitwise those of the two-pass path.
+__global__ __launch_bounds__(256) void deconv_col2im_gn_kernel(const float* __restrict__ cols, const float* __restrict__ bias,
+                                                               float* __restrict__ y, double* __restrict__ part, int H, int W,
+                                                               int C, int KS, int stride, int pad, int OH, int OW, int G, int P) {
+  extern __shared__ double sred[];  // [2][256]
+  const int Q = C >> 2, cpg = C / G, HW = OH * OW;
+  const int n = blockIdx.y, pc = blockIdx.x;
+  const int q = threadIdx.x % Q, row = threadIdx.x / Q, rows = blockDim.x / Q;
+  const int per = (HW + P - 1) / P;
+  const int p0 = pc * per, p1 = min(HW, p0 + per);
+  const float4 b4 = bias ? ld4(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  double s = 0.0, ss = 0.0;
+  for (int p = p0 + row; p < p1; p += rows) {
+    const int oy = p / OW, ox = p - oy * OW;
+    float4 a = b4;
+    for (int ky = 0; ky < KS; ++ky) {
+      const int ty = oy + pad - ky;
+      if (ty < 0 || ty % stride) continue;
+      const int iy = ty / stride;
+      if (iy >= H) continue;
+      for (int kx = 0; kx < KS; ++kx) {
+        const int tx = ox + pad - kx;
+        if (tx < 0 || tx % stride) continue;
+        const int ix = tx / stride;
+        if (ix >= W) continue;
+        const float4 v = ld4(cols + (((size_t)n * H + iy) * W + ix) * ((size_t)KS * KS * C) + (size_t)(ky * KS + kx) * C + 4 * q);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    }
+    st4(y + ((size_t)n * HW + p) * C + 4 * q, a);
+    s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+    ss += ((double)a.x * a.x + (double)a.y * a.y) + ((double)a.z * a.z + (double)a.w * a.w);
+  }
+  sred[threadIdx.x] = s;
+  sred[256 + threadIdx.x] = ss;
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    const int g = threadIdx.x, qpg = cpg >> 2;
+    double a = 0.0, c2 = 0.0;
+    for (int r = 0; r < rows; ++r)
+      for (int k = 0; k < qpg; ++k) {
+        const int t = r * Q + g * qpg + k;
+        a += sred[t];
+        c2 += sred[256 + t];
+      }
+    double* o = part + (((size_t)n * P + pc) * G + g) * 2;
+    o[0] = a;
+    o[1] = c2;
+  }
+}
+
 // --------------------------------------------------------------------------------------------------
 // GroupNorm (+ optional exact GELU), NHWC.  Pass A: per (sample, pixel chunk) fp64 partial sums per group,
 // written to a workspace [N, P, G, 2] (no atomics -> deterministic).  Pass B: every thread rebuilds mean/rstd of
@@ -855,6 +908,23 @@ int gdrnpp_deconv_col2im_nhwc(const float* cols, const float* bias, float* y, in
   hipLaunchKernelGGL(deconv_col2im_kernel, dim3((unsigned)(blocks < 65536 * 8 ? blocks : 65536 * 8)), dim3(256), 0,
                      (hipStream_t)stream, cols, bias, y, H, W, C, KS, stride, pad, OH, OW, total);
   return gdrnpp::check_launch("gdrnpp_deconv_col2im_nhwc");
+}
+
+int gdrnpp_deconv_col2im_gn_nhwc(const float* cols, const float* bias, float* y, double* gn_partials, int N, int H, int W, int C,
+                                 int KS, int stride, int pad, int out_pad, int G, void* stream) {
+  GDRNPP_REQUIRE(cols && y && gn_partials, GDRNPP_EINVAL, "gdrnpp_deconv_col2im_gn_nhwc: null pointer");
+  GDRNPP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && KS > 0 && stride > 0 && pad >= 0 && out_pad >= 0 &&
+                     out_pad < stride && G > 0 && C % G == 0,
+                 GDRNPP_EINVAL, "gdrnpp_deconv_col2im_gn_nhwc: bad shape");
+  const int OH = (H - 1) * stride - 2 * pad + KS + out_pad, OW = (W - 1) * stride - 2 * pad + KS + out_pad;
+  GDRNPP_REQUIRE(OH > 0 && OW > 0, GDRNPP_EINVAL, "gdrnpp_deconv_col2im_gn_nhwc: empty output");
+  const int cpg = C / G, Q = C / 4, HW = OH * OW;
+  GDRNPP_REQUIRE(cpg % 4 == 0 && Q <= 256 && 256 % Q == 0 && G <= 64 && N <= 65535, GDRNPP_ELIMIT,
+                 "gdrnpp_deconv_col2im_gn_nhwc: unsupported shape C=%d G=%d N=%d", C, G, N);
+  const int P = HW >= 1024 ? 64 : (HW >= 64 ? 8 : 1);      // = gdrnpp_groupnorm_workspace_bytes / gdrnpp_groupnorm_act_nhwc
+  hipLaunchKernelGGL(deconv_col2im_gn_kernel, dim3(P, N), dim3(256), sizeof(double) * 512, (hipStream_t)stream, cols, bias, y,
+                     gn_partials, H, W, C, KS, stride, pad, OH, OW, G, P);
+  return gdrnpp::check_launch("gdrnpp_deconv_col2im_gn_nhwc");
 }
 
 int gdrnpp_groupnorm_apply_nhwc(const float* x, const double* partials, int P, const float* gamma, const float* beta,

@@ -338,6 +338,33 @@ __global__ void pose_from_pred_kernel(const float* __restrict__ rot_in, const fl
   }
 }
 
+// Patch-PnP's output layers fc_r | fc_t (conv_pnp_net.py:99-101,178-182) for one ROI per wavefront: lane l multiplies the
+// elements k = l, l + 64, ... of the ROI's feature row with each of the rot_dim + 3 weight rows, the partial sums meet in a
+// fixed-order butterfly (deterministic).  K <= 1024, rot_dim <= 9.
+__global__ __launch_bounds__(64) void pnp_fc_heads_kernel(const float* __restrict__ x, const float* __restrict__ w_r,
+                                                          const float* __restrict__ b_r, const float* __restrict__ w_t,
+                                                          const float* __restrict__ b_t, float* __restrict__ rot_,
+                                                          float* __restrict__ t_, int K, int rot_dim) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  float xv[16];
+  const int nk = (K + 63) / 64;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) xv[j] = (j < nk && lane + 64 * j < K) ? x[(size_t)i * K + lane + 64 * j] : 0.f;
+  for (int r = 0; r < rot_dim + 3; ++r) {
+    const float* w = r < rot_dim ? w_r + (size_t)r * K : w_t + (size_t)(r - rot_dim) * K;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nk && lane + 64 * j < K) s = fmaf(xv[j], w[lane + 64 * j], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+      if (r < rot_dim) rot_[(size_t)i * rot_dim + r] = s + (b_r ? b_r[r] : 0.f);
+      else t_[(size_t)i * 3 + (r - rot_dim)] = s + (b_t ? b_t[r - rot_dim] : 0.f);
+    }
+  }
+}
+
 __global__ void zoom_K_kernel(const float* __restrict__ K, const float* __restrict__ centers,
                               const float* __restrict__ scales, float* __restrict__ Kc, int b, float out_res) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -416,6 +443,16 @@ int gdrnpp_pose_from_pred(const float* rot_in, int rot_mode, const float* t_, in
   hipLaunchKernelGGL(pose_from_pred_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot_in, t_, cams,
                      centers, whs, resize_ratios, rot, trans, b, t_mode, is_allo, rot_mode);
   return gdrnpp::check_launch("gdrnpp_pose_from_pred");
+}
+
+int gdrnpp_pnp_fc_heads(const float* x, const float* w_r, const float* b_r, const float* w_t, const float* b_t, float* rot_,
+                        float* t_, int b, int K, int rot_dim, void* stream) {
+  if (b == 0) return 0;
+  GDRNPP_REQUIRE(x && w_r && w_t && rot_ && t_, GDRNPP_EINVAL, "gdrnpp_pnp_fc_heads: null pointer");
+  GDRNPP_REQUIRE(b > 0 && K > 0 && K <= 1024 && rot_dim > 0 && rot_dim <= 9, GDRNPP_ELIMIT,
+                 "gdrnpp_pnp_fc_heads: b=%d K=%d (<= 1024) rot_dim=%d (<= 9)", b, K, rot_dim);
+  hipLaunchKernelGGL(pnp_fc_heads_kernel, dim3(b), dim3(64), 0, (hipStream_t)stream, x, w_r, b_r, w_t, b_t, rot_, t_, K, rot_dim);
+  return gdrnpp::check_launch("gdrnpp_pnp_fc_heads");
 }
 
 int gdrnpp_zoom_K(const float* K, const float* centers, const float* scales, float* K_crop, int b, float out_res,

@@ -203,24 +203,34 @@ def class_sorted_order(roi_cls):
     return np.argsort(np.asarray(roi_cls).reshape(-1), kind="stable")
 
 
-_PER_ROI_DETECTION_KEYS = ("bbox", "im_idx", "roi_cls", "score", "time")
+_GLOBAL_DETECTION_KEYS = ("extents",)     # per-class / per-dataset arrays of a detections dict: never permuted
 
 
 def sort_detections_by_class(detections: dict, roi_id_base: int = 0):
     """-> (detections with every per-ROI array permuted into class order, roi_id i32[n] = ``roi_id_base`` + the position the
-    ROI had before).  Sorting the DETECTIONS costs nothing on the device: the crop kernel simply reads its ROI parameters in
-    the new order, no ROI tensor is ever permuted."""
+    ROI had before).  Per-ROI = every array-like entry whose leading dimension is the number of ROIs (bbox, im_idx, roi_cls,
+    score, time, a per-ROI cam [n,3,3], detection / scene / image ids a caller carries along, ...); the per-class entries
+    (``extents``), a shared ``cam`` [3,3] and scalars pass through.  Sorting the DETECTIONS costs nothing on the device: the crop
+    kernel simply reads its ROI parameters in the new order, no ROI tensor is ever permuted."""
     import numpy as np
 
     order = class_sorted_order(np.asarray(detections["roi_cls"]))
     out = dict(detections)
     n = len(order)
-    for k in _PER_ROI_DETECTION_KEYS:
-        if k in detections:
-            out[k] = np.asarray(detections[k])[order]
-    cam = np.asarray(detections["cam"])
-    if cam.ndim == 3 and cam.shape[0] == n:
-        out["cam"] = cam[order]
+    for k, v in detections.items():
+        if k in _GLOBAL_DETECTION_KEYS or isinstance(v, (str, bytes)) or v is None:
+            continue
+        if isinstance(v, torch.Tensor):
+            if v.dim() >= 1 and v.shape[0] == n and not (k == "cam" and v.dim() == 2):
+                out[k] = v[torch.as_tensor(order, device=v.device)]
+            continue
+        if isinstance(v, (list, tuple)) and len(v) == n and not (k == "cam" and np.asarray(v).ndim == 2):
+            if all(isinstance(e, (str, bytes)) for e in v):
+                out[k] = [v[i] for i in order]
+                continue
+        arr = np.asarray(v)
+        if arr.ndim >= 1 and arr.shape[0] == n and not (k == "cam" and arr.ndim == 2):
+            out[k] = arr[order]
     return out, (roi_id_base + order).astype(np.int32)
 
 
@@ -233,46 +243,89 @@ def records_in_roi_order(rec: torch.Tensor) -> torch.Tensor:
 
 _X3_OVERFLOW_STEPS = 0          # steps of this process whose three-product kernels overflowed the fp16 range
 X3_OVERFLOW_STEPS_TO_GIVE_UP = 3
+_RANGE_RERUNS = 0               # steps repeated with six products (either side of the range); bench.py reports it
 
 
-def _six_product_rerun(run):
-    """Repeat a step with the six-product kernels after the three-product ones raised their non-finite flag.  A model whose
-    activations leave the fp16 range on every batch would pay for both attempts each time: after X3_OVERFLOW_STEPS_TO_GIVE_UP such
-    steps the process stays on six products (with a warning)."""
+def range_reruns() -> int:
+    return _RANGE_RERUNS
+
+
+def _note_range_words(words: dict) -> None:
+    """What a step's non-zero range words ({slot: word}, hip_lib.split2_range_words) change for the steps to come:
+      * every layer with rows below the range stays on the six-product kernels (hip_layers.demote_x3);
+      * of the layers reporting non-finite values the FIRST in launch order does (the others saw its inf / NaN pass through);
+      * a model whose activations overflow step after step is not paid for twice for ever: after X3_OVERFLOW_STEPS_TO_GIVE_UP
+        such steps the process stays on six products (with a warning)."""
     global _X3_OVERFLOW_STEPS
-    _X3_OVERFLOW_STEPS += 1
-    hip_layers.set_gemm_products(6)
-    try:
-        return run()
-    finally:
-        if _X3_OVERFLOW_STEPS < X3_OVERFLOW_STEPS_TO_GIVE_UP:
-            hip_layers.set_gemm_products(3)
-        else:
+    hip_layers.demote_x3({s_: w for s_, w in words.items() if w & hip_lib.X3_SMALL_ROWS})
+    over = sorted(s_ for s_, w in words.items() if w & hip_lib.X3_NONFINITE)
+    if over:
+        _X3_OVERFLOW_STEPS += 1
+        first = [s_ for s_ in over if s_ > 0][:1]
+        hip_layers.demote_x3({s_: hip_lib.X3_NONFINITE for s_ in first})
+        if _X3_OVERFLOW_STEPS >= X3_OVERFLOW_STEPS_TO_GIVE_UP and hip_layers.gemm_products() == 3:
             import warnings
+            hip_layers.set_gemm_products(6)
             warnings.warn(f"{_X3_OVERFLOW_STEPS} steps overflowed the fp16 range of the three-product GEMM kernels: staying on the "
                           "six-product kernels (hip_layers.set_gemm_products(3) switches back)")
 
 
-def run_with_overflow_check(run):
-    """``run()`` (a forward, or a whole step) under the contract of the three-product GEMM kernels: if any of them was launched
-    (hip_layers.gemm_products() == 3 and the batch is large enough) and raised the non-finite flag — an activation beyond the fp16
-    range — the work is repeated with the six-product kernels.  One 4-byte read-back + stream sync; under hipGraph capture the
-    check is the graph owner's (GraphedInference.replay)."""
+def _six_product_rerun(run, words: dict):
+    """Repeat a step with the six-product kernels after its three-product launches reported ``words``; the calling host thread
+    only (hip_layers.forced_gemm_products), other threads / streams keep their setting."""
+    global _RANGE_RERUNS
+    _RANGE_RERUNS += 1
+    _note_range_words(words)
+    with hip_layers.forced_gemm_products(6):
+        return run()
+
+
+class StepHandle:
+    """A launched step whose range words have not been looked at yet.  ``result()`` waits for the step (one event), reads the
+    words from pinned host memory and — if a three-product launch left the range — repeats the step with six products.  Between
+    launch and ``result()`` the host is free: launch the next step first and the check costs no device idle time."""
+
+    def __init__(self, run, out, host_words=None, event=None):
+        self._run, self._out, self._host, self._event = run, out, host_words, event
+
+    def result(self):
+        if self._event is not None:
+            self._event.synchronize()
+            words = hip_lib.range_words_of(self._host)
+            self._event = self._host = None
+            if words:
+                self._out = _six_product_rerun(self._run, words)
+        self._run = None
+        return self._out
+
+
+def launch_with_range_check(run) -> StepHandle:
+    """``run()`` (a forward, or a whole step) under the contract of the three-product GEMM kernels, without waiting: if any of
+    them was launched, the stream's range words are copied to pinned host memory behind the work (and cleared on the stream, so
+    the next step starts from zero) and an event marks the copy; ``StepHandle.result()`` does the rest.  Under hipGraph capture
+    the check is the graph owner's (GraphedInference.replay)."""
     n_x3 = hip_lib.x3_launch_count()
     out = run()
-    if hip_lib.x3_launch_count() != n_x3 and not torch.cuda.is_current_stream_capturing() and hip_lib.split2_nonfinite(reset=True):
-        out = _six_product_rerun(run)
-    return out
+    if hip_lib.x3_launch_count() == n_x3 or torch.cuda.is_current_stream_capturing():
+        return StepHandle(None, out)
+    words = hip_lib._x3_flags()
+    host = torch.empty(words.shape, dtype=words.dtype, pin_memory=True)
+    host.copy_(words, non_blocking=True)
+    words.zero_()
+    ev = torch.cuda.Event()
+    ev.record()
+    return StepHandle(run, out, host, ev)
 
 
-@torch.no_grad()
-def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor | None = None) -> torch.Tensor:
-    """One pass of the hot path over one batch of ROIs (the unit ``bench.py`` times).  ``roi_ids`` (or ``batch["roi_id"]``,
-    set by ``batch_data_test_gpu(sort_by_class=True)``) = the global index each record carries."""
-    if roi_ids is None:
-        roi_ids = batch.get("roi_id")
-    if batch["roi_img"].shape[0] == 0:            # empty shard (shard_range may give trailing ranks nothing): the caller
-        return torch.zeros((0, 16), dtype=torch.float32, device=batch["roi_img"].device)   # still reaches gather_records
+def run_with_range_check(run):
+    """The synchronous form: ``run()``, then its range check (one stream sync when three-product kernels were launched)."""
+    return launch_with_range_check(run).result()
+
+
+run_with_overflow_check = run_with_range_check     # the round-3 name
+
+
+def _step_closure(model, post: "GdrnHipPost", batch: dict, roi_ids):
     def run():
         out_dict = model(
             batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"], roi_whs=batch["roi_wh"],
@@ -280,9 +333,25 @@ def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor 
             roi_coord_2d=batch.get("roi_coord_2d"), roi_coord_2d_rel=batch.get("roi_coord_2d_rel"),
             roi_extents=batch.get("roi_extent"))
         return post.process(batch, out_dict, roi_ids)
+    return run
 
-    rec = run_with_overflow_check(run)
-    return rec
+
+@torch.no_grad()
+def inference_step_async(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor | None = None) -> StepHandle:
+    """Launch one pass of the hot path over one batch of ROIs and return without waiting for the device: ``.result()`` gives
+    the f32[b,16] records (after the range check of the three-product kernels).  ``batch`` must stay untouched until then."""
+    if roi_ids is None:
+        roi_ids = batch.get("roi_id")
+    if batch["roi_img"].shape[0] == 0:            # empty shard (shard_range may give trailing ranks nothing): the caller
+        return StepHandle(None, torch.zeros((0, 16), dtype=torch.float32, device=batch["roi_img"].device))   # still reaches gather_records
+    run = torch.no_grad()(_step_closure(model, post, batch, roi_ids))
+    return launch_with_range_check(run)
+
+
+def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor | None = None) -> torch.Tensor:
+    """One pass of the hot path over one batch of ROIs (the unit ``bench.py`` times).  ``roi_ids`` (or ``batch["roi_id"]``,
+    set by ``batch_data_test_gpu(sort_by_class=True)``) = the global index each record carries."""
+    return inference_step_async(model, post, batch, roi_ids).result()
 
 
 def gather_records(rec: torch.Tensor, n_local_max: int, group=None) -> torch.Tensor:
@@ -430,35 +499,55 @@ class GraphedInference:
     replayed per batch.  At the reference's own batch sizes (one image = a few to ~30 ROIs, gdrn_evaluator.py:702)
     the ≈260 launches of a step are launch-bound; a graph replay removes the per-launch host cost.  Shapes are
     fixed at capture time: batches are copied into static device buffers (pad the ROI dimension to the captured
-    size; padded rows are ordinary ROIs whose records the caller ignores)."""
+    size; padded rows are ordinary ROIs whose records the caller ignores).
+
+    Three-product kernels inside the graph write their range words to a buffer the graph owns; ``replay`` reads it after every
+    replay (one 4 KB read-back).  When a layer left the range the step is repeated eagerly with six products, its records are
+    copied into the static output, the layer is demoted and the graph is captured again with it on the six-product kernels —
+    so a flagged layer is paid for once, not on every replay."""
 
     def __init__(self, model, post: GdrnHipPost, example_batch: dict, roi_ids: torch.Tensor | None = None,
                  warmup: int = 3):
         self.model, self.post = model, post
         self.static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in example_batch.items()}
         self.roi_ids = roi_ids.clone() if roi_ids is not None else None
+        self.captures = 0
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # MIOpen find, hipFuncSetAttribute, allocator warm-up happen outside capture
-            for _ in range(max(warmup, 1)):
+        with torch.cuda.stream(side):  # MIOpen find, hipFuncSetAttribute, allocator warm-up, weight packing and the first
+            for _ in range(max(warmup, 1)):   # range verdicts (demotions) happen outside capture
                 inference_step(model, post, self.static, self.roi_ids)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self.x3_flag = torch.zeros((hip_lib.X3_SLOTS,), dtype=torch.int32, device=self.static["roi_img"].device)   # the graph's own range words
+        self._capture()
+
+    @torch.no_grad()
+    def _capture(self):
+        run = _step_closure(self.model, self.post, self.static, self.roi_ids)
         self.graph = torch.cuda.CUDAGraph()
         n_x3 = hip_lib.x3_launch_count()
-        self.x3_flag = torch.zeros((1,), dtype=torch.int32, device=self.static["roi_img"].device)   # the graph's own overflow flag
+        self.x3_flag.zero_()
+        torch.cuda.synchronize()
         with hip_lib.x3_flag_scope(self.x3_flag), torch.cuda.graph(self.graph):
-            self.records = inference_step(model, post, self.static, self.roi_ids)
+            self.records = run()
         self.uses_x3 = hip_lib.x3_launch_count() != n_x3     # the captured step holds three-product kernels
+        self._demoted_at_capture = hip_layers.x3_demoted()
+        self._products_at_capture = hip_layers.gemm_products()
+        self.captures += 1
 
     @torch.no_grad()
     def replay(self) -> torch.Tensor:
-        """Replay on the static buffers; with three-product kernels in the graph their non-finite flag is checked (one sync) and
-        the step repeated eagerly with six products when it is up."""
+        """Replay on the static buffers, then the range check of the graph's three-product kernels."""
+        if self.uses_x3 and (hip_layers.x3_demoted() != self._demoted_at_capture or hip_layers.gemm_products() != self._products_at_capture):
+            self._capture()        # another step demoted a layer this graph still runs on three products
         self.graph.replay()
-        if self.uses_x3 and bool(self.x3_flag.item()):
-            self.x3_flag.zero_()
-            return _six_product_rerun(lambda: inference_step(self.model, self.post, self.static, self.roi_ids))
+        if self.uses_x3:
+            words = hip_lib.range_words_of(self.x3_flag.cpu())
+            if words:
+                rec = _six_product_rerun(_step_closure(self.model, self.post, self.static, self.roi_ids), words)
+                self._capture()
+                self.records.copy_(rec)
         return self.records
 
     @torch.no_grad()

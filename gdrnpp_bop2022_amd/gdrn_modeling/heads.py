@@ -111,6 +111,15 @@ def run_features(features, x):
                     continue
             x = hip_layers.conv2d(layer, x)
         elif isinstance(layer, nn.ConvTranspose2d):
+            gn = features[i + 1] if i + 1 < n else None
+            if isinstance(gn, nn.GroupNorm):   # deconv -> GN (-> exact GELU): statistics from the col2im gather
+                nxt = features[i + 2] if i + 2 < n else None
+                gelu = nxt if isinstance(nxt, nn.GELU) and getattr(nxt, "approximate", "none") == "none" else None
+                y = hip_layers.conv_transpose2d_groupnorm_act(layer, gn, gelu, x)
+                if y is not None:
+                    x = y
+                    i += 3 if gelu is not None else 2
+                    continue
             x = hip_layers.conv_transpose2d(layer, x)
         else:
             x = layer(x)
@@ -266,9 +275,12 @@ class ConvPnPNet(nn.Module):
 
     def _fc_tail(self, x):
         x = x.flatten(2).flatten(1)  # NCHW order, like the reference (weights of fc1 depend on it)
-        x = self.act(hip_layers.linear(self.fc1, x))
-        x = self.act(hip_layers.linear(self.fc2, x))
-        return self.fc_r(x), self.fc_t(x)
+        if isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none":
+            x = hip_layers.linear(self.fc2, hip_layers.linear(self.fc1, x, gelu=True), gelu=True)   # GELU in the GEMM epilogues
+        else:
+            x = self.act(hip_layers.linear(self.fc1, x))
+            x = self.act(hip_layers.linear(self.fc2, x))
+        return hip_layers.pnp_fc_heads(self.fc_r, self.fc_t, x)
 
     # ---- NHWC entry used by the fused head tail (hip_lib.head_tail_nhwc) ------------------------------------------------
     def accepts_prepared_input(self) -> bool:
@@ -284,18 +296,15 @@ class ConvPnPNet(nn.Module):
         input channels on the implicit-GEMM split kernel, the rest as ``forward``."""
         c0 = self.features[0]
         cache = c0.__dict__.setdefault("_gdrnpp_cache", {})
-        tag = hip_layers.weight_tag(c0.weight)
-        b, _, h, w_ = x96_cl.shape
-        x3 = hip_layers.use_x3(b * ((h + 2 - 3) // 2 + 1) * ((w_ + 2 - 3) // 2 + 1), c0.out_channels, 0, cache, "conv96", x96_cl)   # three- / six-product kernel
-        key = "w96_pk_x3" if x3 else "w96_pk"
-        hit = cache.get(key)
-        if hit is None or hit[0] != tag:
-            w = c0.weight.detach()
-            w96 = torch.zeros((w.shape[0], 96, 3, 3), dtype=w.dtype, device=w.device)
-            w96[:, :69] = w
-            hit = (tag, (hip_lib.pack_conv_weight_f16x2 if x3 else hip_lib.pack_conv_weight_bf16x3)(w96))
-            cache[key] = hit
-        x = hip_lib.conv2d_f32_split(x96_cl, hit[1], None, 3, 3, 2, 1)
+        def w96(w):
+            out = torch.zeros((w.shape[0], 96, 3, 3), dtype=w.dtype, device=w.device)
+            out[:, :69] = w
+            return out
+
+        # always the six-product kernel: the input (metres, [0, 1) coordinates, softmax weights) is not a normalised tensor and sits
+        # below the range of the three-product form at most pixels (its range word would say so on the first step)
+        w_pk = hip_layers._packed_weight(cache, "w96_pk", c0.weight, lambda w: hip_lib.pack_conv_weight_bf16x3(w96(w)))
+        x = hip_lib.conv2d_f32_split(x96_cl, w_pk, None, 3, 3, 2, 1)
         x = run_features(self.features[1:], x)
         return self._fc_tail(x)
 

@@ -3,6 +3,8 @@
 or ``set_enabled(False)`` for A/B measurements).  Same math as the PyTorch operators, different summation order."""
 from __future__ import annotations
 
+import threading
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -120,10 +122,13 @@ _LIBRARY_BELOW_TILES = 0    # A/B switch: blocks whose fc2 has fewer 128x128 out
 #      result is as close as the six-product form and closer than hipBLASLt's fp32 GEMM on the same operands (the fp32
 #      accumulation chain dominates all three; tools/split2_error_probe.py, profiles/r03y_split2_accuracy.txt), and the
 #      network outputs sit at the same 6e-6 from the reference's recorded forward as with six products or the vendor fp32
-#      kernels — for half the matrix-pipe work.  An activation beyond the fp16 range (65504) turns the outputs non-finite and
-#      raises hip_lib.split2_nonfinite(): engine.inference_step then repeats the step with 6.
+#      kernels — for half the matrix-pipe work.  The form has a RANGE: every launch checks both sides of it on the device and
+#      reports in the range word of its layer (hip_lib.split2_range_words) — an activation beyond 65504, or an A row whose rms is
+#      below 2^-4 (low halves in the fp16 subnormals).  engine.run_with_range_check then repeats the step with 6 and keeps the
+#      flagged layers on 6 (demote_x3), so the outputs are fp32-level on EVERY batch, not on the ones somebody looked at.
 #   6: bf16x3 operand split, exact to 2^-26, everywhere.
 _GEMM_PRODUCTS = 3
+_TLS = threading.local()     # .forced: products forced for the calling host thread (the six-product repeat of a flagged step)
 
 
 def set_gemm_products(n: int) -> None:
@@ -134,54 +139,98 @@ def set_gemm_products(n: int) -> None:
 
 
 def gemm_products() -> int:
-    return _GEMM_PRODUCTS
+    forced = getattr(_TLS, "forced", None)
+    return _GEMM_PRODUCTS if forced is None else forced
 
 
-def use_x3(m: int, n: int, k_linear: int = 0, cache: dict | None = None, key: str = "", x: torch.Tensor | None = None) -> bool:
-    return _use_x3(m, n, k_linear) and (x is None or x3_scale_ok(cache, key, x))
+class forced_gemm_products:
+    """``with forced_gemm_products(6):`` — the calling host thread runs every split GEMM with that many products, other threads
+    (streams) keep the process setting."""
+
+    def __init__(self, n: int):
+        if n not in (3, 6):
+            raise ValueError(f"gemm products must be 6 or 3, got {n!r}")
+        self.n = n
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "forced", None)
+        _TLS.forced = self.n
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.forced = self.prev
+        return False
 
 
-# The one silent limit of the two-way fp16 split is on the small side: an activation tensor whose scale is below ~2^-4 loses the
-# low half of its elements to the fp16 subnormal spacing (absolute operand error 2^-25; csrc/gemm_split2_pipe.hip) — the large side
-# raises the overflow flag.  So every layer LOOKS at its input the first X3_CALIBRATION_CALLS times it is about to use a
-# three-product kernel (rms of the A operand: one reduction + read-back per layer and call, during warm-up only) and stays on the
-# six-product kernels if the tensor is too small (or not finite).  Trained GDRNPP layers feed LayerNorm / GroupNorm / GELU outputs
-# (scale ~1) and pass; reset_x3_calibration() forgets the decisions (e.g. after loading other weights).
-X3_CALIBRATION_CALLS = 2
-X3_MIN_RMS = 2.0 ** -4
-_X3_CALIBRATION_EPOCH = 0
+# ---- which layers run the three-product kernels ----------------------------------------------------------------------------
+# A layer = (the module's cache dict, a key).  It gets a range-word slot at its first three-product launch (slots follow launch
+# order within a model) and loses the three-product form for good — until the weights change — when a launch of it reported
+# rows below the range, or when it was the first layer of a step to overflow.
+_X3_NEXT_SLOT = 1            # slot 0: launches that name no layer
+_X3_DEMOTED = {}             # slot -> range word that demoted it
+_X3_EPOCH = 0                # bumped by reset_x3_demotions: slots handed out before it are forgotten
 
 
-def reset_x3_calibration() -> None:
-    global _X3_CALIBRATION_EPOCH
-    _X3_CALIBRATION_EPOCH += 1
+def x3_slot(cache: dict, key: str) -> int:
+    global _X3_NEXT_SLOT
+    st = cache.get("x3_slot_" + key)
+    if st is None or st[0] != _X3_EPOCH:
+        st = cache["x3_slot_" + key] = (_X3_EPOCH, min(_X3_NEXT_SLOT, hip_lib.X3_SLOTS - 1))   # beyond the buffer: layers share the last slot
+        _X3_NEXT_SLOT += 1
+    return st[1]
 
 
-def x3_scale_ok(cache: dict, key: str, x: torch.Tensor) -> bool:
-    st = cache.get("x3_calib_" + key)
-    if st is None or st[0] != _X3_CALIBRATION_EPOCH:
-        st = cache["x3_calib_" + key] = [_X3_CALIBRATION_EPOCH, 0, True]
-    if st[1] < X3_CALIBRATION_CALLS and st[2] and not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
-        st[1] += 1
-        rms = float(x.detach().float().square().mean().sqrt())
-        if not rms >= X3_MIN_RMS:       # also catches NaN
-            st[2] = False
-    return st[2]
+def demote_x3(words: dict) -> None:
+    """Keep the layers of ``words`` ({slot: range word}) on the six-product kernels from now on."""
+    for slot, word in words.items():
+        if slot > 0:
+            _X3_DEMOTED[int(slot)] = _X3_DEMOTED.get(int(slot), 0) | int(word)
+
+
+def x3_demoted() -> dict:
+    return dict(_X3_DEMOTED)
+
+
+def reset_x3_demotions() -> None:
+    """Forget the demotions and the slot numbering (new weights: new activation scales)."""
+    global _X3_EPOCH, _X3_NEXT_SLOT
+    _X3_EPOCH += 1
+    _X3_NEXT_SLOT = 1
+    _X3_DEMOTED.clear()
+
+
+reset_x3_calibration = reset_x3_demotions    # the name GDRN_DoubleMask.load_state_dict has always called
 
 
 def _use_x3(m: int, n: int, k_linear: int = 0) -> bool:
     """Three-product kernel for an [m, n] result?  ``k_linear`` = K of a linear-form launch: its A operand is addressed with
     32-bit lane offsets (m * K * 4 bytes < 4 GiB, ~480 ROIs at stage 0); beyond that the six-product kernels take over."""
-    return _GEMM_PRODUCTS == 3 and hip_lib.split2_tiles_ok(m, n) and m * k_linear * 4 < (1 << 32)
+    return gemm_products() == 3 and hip_lib.split2_tiles_ok(m, n) and m * k_linear * 4 < (1 << 32)
 
 
-def _packed_weight(cache: dict, key: str, weight: torch.Tensor, x3: bool, pack6, pack3) -> torch.Tensor:
-    """Packed split image of ``weight`` in the six- (key) or three-product (key + "_x3") format, rebuilt when the weight changes."""
-    key = key + "_x3" if x3 else key
+def x3_for(cache: dict, key: str, weight: torch.Tensor, pack3, m: int, n: int, k_linear: int = 0):
+    """-> (packed three-product weight or None, range-word slot).  None = this launch runs the six-product kernel: the shape is
+    outside the three-product kernels, the layer was demoted, or its weight has rows below the range (checked once per weight
+    by the pack kernel)."""
+    if not _use_x3(m, n, k_linear):
+        return None, 0
+    slot = x3_slot(cache, key)
+    if slot in _X3_DEMOTED:
+        return None, slot
+    tag = weight_tag(weight)
+    hit = cache.get(key + "_pk_x3")
+    if hit is None or hit[0] != tag:
+        packed = pack3(weight.detach())
+        hit = cache[key + "_pk_x3"] = (tag, packed, hip_lib.packed_rows_in_range(packed))
+    return (hit[1] if hit[2] else None), slot
+
+
+def _packed_weight(cache: dict, key: str, weight: torch.Tensor, pack6) -> torch.Tensor:
+    """Packed six-product split image of ``weight``, rebuilt when the weight changes."""
     tag = weight_tag(weight)
     hit = cache.get(key)
     if hit is None or hit[0] != tag:
-        hit = (tag, (pack3 if x3 else pack6)(weight.detach()))
+        hit = (tag, pack6(weight.detach()))
         cache[key] = hit
     return hit[1]
 
@@ -210,8 +259,8 @@ def set_fused_mlp(flag: bool) -> None:
     set_mlp_gemm("split" if flag else "torch")
 
 
-def _packed(linear: nn.Linear, cache: dict, key: str, x3: bool = False) -> torch.Tensor:
-    return _packed_weight(cache, key, linear.weight, x3, hip_lib.pack_weight_bf16x3, hip_lib.pack_weight_f16x2)
+def _packed(linear: nn.Linear, cache: dict, key: str) -> torch.Tensor:
+    return _packed_weight(cache, key, linear.weight, hip_lib.pack_weight_bf16x3)
 
 
 def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: torch.Tensor, cache: dict) -> torch.Tensor:
@@ -224,12 +273,18 @@ def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: 
           and c % 128 == 0)
     if ok and _MLP_GEMM == "split" and hip_lib.split_gemm_tiles(m, c) >= _LIBRARY_BELOW_TILES:
         # fewer than two output tiles per CU (small ROI counts at the deep stages): split K as well, or most of the chip idles
-        x3_1 = _use_x3(m, 4 * c, c) and x3_scale_ok(cache, "fc1", x_nhwc)
-        f1 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, 4 * c) < _SPLITK_BELOW_TILES and not x3_1 else hip_lib.linear_f32_split
-        h = f1(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk", x3_1), mlp.fc1.bias, "gelu")
-        x3_2 = _use_x3(m, c, 4 * c) and x3_scale_ok(cache, "fc2", h)
-        f2 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, c) < _SPLITK_BELOW_TILES and not x3_2 else hip_lib.linear_f32_split
-        y = f2(h, _packed(mlp.fc2, cache, "fc2_pk", x3_2), mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
+        w3, slot = x3_for(cache, "fc1", mlp.fc1.weight, hip_lib.pack_weight_f16x2, m, 4 * c, c)
+        if w3 is not None:
+            h = hip_lib.linear_f32_split(x_nhwc.view(m, c), w3, mlp.fc1.bias, "gelu", x3_slot=slot)
+        else:
+            f1 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, 4 * c) < _SPLITK_BELOW_TILES else hip_lib.linear_f32_split
+            h = f1(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk"), mlp.fc1.bias, "gelu")
+        w3, slot = x3_for(cache, "fc2", mlp.fc2.weight, hip_lib.pack_weight_f16x2, m, c, 4 * c)
+        if w3 is not None:
+            y = hip_lib.linear_f32_split(h, w3, mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c), x3_slot=slot)
+        else:
+            f2 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, c) < _SPLITK_BELOW_TILES else hip_lib.linear_f32_split
+            y = f2(h, _packed(mlp.fc2, cache, "fc2_pk"), mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
         return y.view(x_nhwc.shape)
     return torch.addcmul(shortcut_nhwc, mlp(x_nhwc), gamma)
 
@@ -262,12 +317,14 @@ def conv2d(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
         is3x3 = conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
         ks, st, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         oh, ow = (x.shape[2] + 2 * pd - ks) // st + 1, (x.shape[3] + 2 * pd - ks) // st + 1
-        x3 = ks * ks <= 32 and _use_x3(x.shape[0] * oh * ow, conv.out_channels) and x3_scale_ok(cache, "conv", x)
-        w_pk = _packed_weight(cache, "w_pk", conv.weight, x3, hip_lib.pack_conv_weight_bf16x3, hip_lib.pack_conv_weight_f16x2)
+        w_pk, slot = (x3_for(cache, "conv", conv.weight, hip_lib.pack_conv_weight_f16x2, x.shape[0] * oh * ow, conv.out_channels)
+                      if ks * ks <= 32 else (None, 0))
+        if w_pk is None:
+            w_pk = _packed_weight(cache, "w_pk", conv.weight, hip_lib.pack_conv_weight_bf16x3)
         if is3x3:
-            return hip_lib.conv3x3_f32_split(_cl(x), w_pk, conv.bias)
+            return hip_lib.conv3x3_f32_split(_cl(x), w_pk, conv.bias, x3_slot=slot)
         return hip_lib.conv2d_f32_split(_cl(x), w_pk, conv.bias, conv.kernel_size[0], conv.kernel_size[1], conv.stride[0],
-                                       conv.padding[0])
+                                       conv.padding[0], x3_slot=slot)
     return conv(x)
 
 
@@ -330,21 +387,48 @@ def conv_bn_act(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool
     return torch.relu_(y) if relu else y
 
 
-def conv_transpose2d(deconv: nn.ConvTranspose2d, x: torch.Tensor) -> torch.Tensor:
-    """nn.ConvTranspose2d forward; the head's square-kernel / stride-2 form with Cin % 32 == 0 and KS*KS*Cout % 128 == 0
-    runs as split GEMM + col2im gather (``hip_lib.conv_transpose2d_f32_split``), everything else in MIOpen."""
+def _deconv_split_ok(deconv, x) -> bool:
     ks = deconv.kernel_size[0]
-    if (_CONV_SPLIT and _MLP_GEMM == "split" and enabled_for(x) and deconv.kernel_size[0] == deconv.kernel_size[1]
+    return (_CONV_SPLIT and _MLP_GEMM == "split" and isinstance(deconv, nn.ConvTranspose2d) and enabled_for(x)
+            and deconv.kernel_size[0] == deconv.kernel_size[1]
             and deconv.stride[0] == deconv.stride[1] and deconv.padding[0] == deconv.padding[1]
             and deconv.output_padding[0] == deconv.output_padding[1] and deconv.output_padding[0] < deconv.stride[0]
             and deconv.dilation == (1, 1) and deconv.groups == 1 and deconv.in_channels % 32 == 0
-            and deconv.out_channels % 4 == 0 and (ks * ks * deconv.out_channels) % 128 == 0):
-        cache = deconv.__dict__.setdefault("_gdrnpp_cache", {})
-        x3 = _use_x3(x.shape[0] * x.shape[2] * x.shape[3], ks * ks * deconv.out_channels, deconv.in_channels) and x3_scale_ok(cache, "deconv", x)
-        w_pk = _packed_weight(cache, "w_pk", deconv.weight, x3, hip_lib.pack_deconv_weight_bf16x3, hip_lib.pack_deconv_weight_f16x2)
-        return hip_lib.conv_transpose2d_f32_split(_cl(x), w_pk, deconv.bias, ks, deconv.stride[0], deconv.padding[0],
-                                                  deconv.output_padding[0])
+            and deconv.out_channels % 4 == 0 and (ks * ks * deconv.out_channels) % 128 == 0)
+
+
+def _deconv_weight(deconv, x):
+    """-> (packed GEMM weight of the transposed convolution in the three- or six-product format, range-word slot)."""
+    ks = deconv.kernel_size[0]
+    cache = deconv.__dict__.setdefault("_gdrnpp_cache", {})
+    w_pk, slot = x3_for(cache, "deconv", deconv.weight, hip_lib.pack_deconv_weight_f16x2, x.shape[0] * x.shape[2] * x.shape[3],
+                        ks * ks * deconv.out_channels, deconv.in_channels)
+    if w_pk is None:
+        w_pk = _packed_weight(cache, "w_pk", deconv.weight, hip_lib.pack_deconv_weight_bf16x3)
+    return w_pk, slot
+
+
+def conv_transpose2d(deconv: nn.ConvTranspose2d, x: torch.Tensor) -> torch.Tensor:
+    """nn.ConvTranspose2d forward; the head's square-kernel / stride-2 form with Cin % 32 == 0 and KS*KS*Cout % 128 == 0
+    runs as split GEMM + col2im gather (``hip_lib.conv_transpose2d_f32_split``), everything else in MIOpen."""
+    if _deconv_split_ok(deconv, x):
+        w_pk, slot = _deconv_weight(deconv, x)
+        return hip_lib.conv_transpose2d_f32_split(_cl(x), w_pk, deconv.bias, deconv.kernel_size[0], deconv.stride[0], deconv.padding[0],
+                                                  deconv.output_padding[0], x3_slot=slot)
     return deconv(x)
+
+
+def conv_transpose2d_groupnorm_act(deconv: nn.ConvTranspose2d, gn: nn.GroupNorm, act: nn.Module | None, x: torch.Tensor):
+    """The head's [ConvTranspose2d, GroupNorm(, GELU)] triple with the GroupNorm statistics taken by the col2im gather
+    (``hip_lib.conv_transpose2d_groupnorm_act``).  Returns None when the layers are outside that form; the caller then runs them
+    one by one."""
+    if not (_CONV_GN_FUSED and _deconv_split_ok(deconv, x) and isinstance(gn, nn.GroupNorm) and gn.num_channels == deconv.out_channels
+            and _gn_ok(gn, x) and (act is None or (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none"))):
+        return None
+    w_pk, slot = _deconv_weight(deconv, x)
+    return hip_lib.conv_transpose2d_groupnorm_act(_cl(x), w_pk, deconv.bias, deconv.kernel_size[0], deconv.stride[0], deconv.padding[0],
+                                                  deconv.output_padding[0], gn.weight, gn.bias, gn.num_groups, gn.eps,
+                                                  gelu=act is not None, x3_slot=slot)
 
 
 _CONV_GN_FUSED = True
@@ -367,18 +451,27 @@ def conv3x3_groupnorm_act(conv: nn.Conv2d, gn: nn.GroupNorm, act: nn.Module | No
             and (act is None or (isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none"))):
         return None
     cache = conv.__dict__.setdefault("_gdrnpp_cache", {})
-    x3 = _use_x3(x.shape[0] * x.shape[2] * x.shape[3], conv.out_channels) and x3_scale_ok(cache, "conv", x)
-    w_pk = _packed_weight(cache, "w_pk", conv.weight, x3, hip_lib.pack_conv_weight_bf16x3, hip_lib.pack_conv_weight_f16x2)
+    w_pk, slot = x3_for(cache, "conv", conv.weight, hip_lib.pack_conv_weight_f16x2, x.shape[0] * x.shape[2] * x.shape[3], conv.out_channels)
+    if w_pk is None:
+        w_pk = _packed_weight(cache, "w_pk", conv.weight, hip_lib.pack_conv_weight_bf16x3)
     return hip_lib.conv3x3_groupnorm_act(_cl(x), w_pk, conv.bias, gn.weight, gn.bias, gn.num_groups, gn.eps,
-                                         gelu=act is not None)
+                                         gelu=act is not None, x3_slot=slot)
 
 
-def linear(fc: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+def linear(fc: nn.Linear, x: torch.Tensor, gelu: bool = False) -> torch.Tensor:
     """nn.Linear on a [M, K] activation with few rows and a long K (Patch-PnP fc1: 8192 -> 1024 on one row per ROI):
     hipBLASLt picks a 256x16 macro-tile for it and streams the 33 MB weight at ~70 GB/s (0.49 ms at 128 ROIs); the split-K
     form of the split GEMM spreads K over 64 workgroups per output tile."""
     if (_MLP_GEMM == "split" and enabled_for(x) and x.dim() == 2 and x.is_contiguous() and fc.out_features % 128 == 0
             and fc.in_features % 32 == 0 and fc.in_features >= 1024 and x.shape[0] <= 1024):
         cache = fc.__dict__.setdefault("_gdrnpp_cache", {})
-        return hip_lib.linear_f32_splitk(x, _packed(fc, cache, "w_pk"), fc.bias)
-    return fc(x)
+        return hip_lib.linear_f32_splitk(x, _packed(fc, cache, "w_pk"), fc.bias, "gelu" if gelu else "none")
+    return F.gelu(fc(x)) if gelu else fc(x)
+
+
+def pnp_fc_heads(fc_r: nn.Linear, fc_t: nn.Linear, x: torch.Tensor):
+    """(fc_r(x), fc_t(x)) of Patch-PnP in one HIP launch instead of two library GEMMs (conv_pnp_net.py:99-101,178-182)."""
+    if (enabled_for(x) and _MLP_GEMM == "split" and x.dim() == 2 and x.is_contiguous() and fc_r.in_features == fc_t.in_features <= 1024
+            and fc_r.out_features <= 9 and fc_t.out_features == 3):
+        return hip_lib.pnp_fc_heads(x, fc_r.weight.detach().contiguous(), fc_r.bias, fc_t.weight.detach().contiguous(), fc_t.bias)
+    return fc_r(x), fc_t(x)

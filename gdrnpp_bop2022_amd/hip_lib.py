@@ -101,6 +101,8 @@ SIGNATURES = {
     "gdrnpp_groupnorm_act_nhwc": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "gdrnpp_bias_act_nhwc": (c_int, [_P, _P, _P, _P, ctypes.c_long, c_int, c_int, _P]),
     "gdrnpp_deconv_col2im_nhwc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_deconv_col2im_gn_nhwc": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "gdrnpp_pnp_fc_heads": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gdrnpp_conv3x3_gnstats_partials": (c_int, [c_int, c_int]),
     "gdrnpp_conv3x3_f32_split_gnstats": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_groupnorm_apply_nhwc": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
@@ -109,7 +111,7 @@ SIGNATURES = {
     "gdrnpp_linear_f32_split2": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "gdrnpp_conv3x3_f32_split2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "gdrnpp_conv2d_f32_split2": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
-    "gdrnpp_split2_nonfinite": (c_int, [_P, c_int, _P]),
+    "gdrnpp_split2_range_word": (c_int, [_P, c_int, _P]),
 }
 
 
@@ -633,6 +635,13 @@ def pack_weight_f16x2(weight):
     return packed
 
 
+def packed_rows_in_range(packed) -> bool:
+    """False when gdrnpp_pack_weight_f16x2 found a non-zero weight row whose scaled rms is below 2^-4 (trailer word 3): the layer
+    belongs on the six-product kernels.  One 16-byte read-back, done once per packed weight (hip_layers caches it)."""
+    trailer = packed._gdrnpp_base[packed.numel() * 2:].view(torch.int32)
+    return int(trailer[3].item()) == 0
+
+
 def unpack_weight_f16x2(packed):
     """For tests: (fp16[2, N, K] planes h / l of the SCALED weight, 2^-e) of a pack_weight_f16x2 result."""
     tn, tk = packed.shape[:2]
@@ -655,29 +664,40 @@ def split2_tiles_ok(m: int, n: int) -> bool:
     return n % 128 == 0 and ((m + 255) // 256) * (n // 128) >= SPLIT2_MIN_TILES
 
 
-_X3_FLAGS = {}   # (device index, stream handle) -> i32[1] device tensor the three-product launches of that stream OR into
+# Range words of the three-product launches (include/gdrnpp_hip.h: GDRNPP_SPLIT2_NONFINITE | GDRNPP_SPLIT2_SMALL_ROWS).  Every
+# (device, stream) owns one i32[X3_SLOTS] device buffer; a launch ORs its word into the entry of its LAYER (slot numbers are
+# handed out by hip_layers.x3_slot, slot 0 = launches that name no layer), so that the reader knows which layer left the range.
+X3_SLOTS = 1024
+X3_NONFINITE, X3_SMALL_ROWS = 1, 2
+_X3_FLAGS = {}   # (device index, stream handle) -> i32[X3_SLOTS]
 
 
-def _x3_flag():
-    """The non-finite flag of the current device + stream: launches pass it to the kernels, split2_nonfinite() reads it.  One per
-    stream, so host threads / streams running independent steps do not consume each other's overflow."""
+def _x3_flags():
+    """The range words of the current device + stream (or of the enclosing x3_flag_scope)."""
     if _X3_FLAG_OVERRIDE is not None:
         return _X3_FLAG_OVERRIDE
     key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     f = _X3_FLAGS.get(key)
     if f is None:
-        f = _X3_FLAGS[key] = torch.zeros((1,), dtype=torch.int32, device=f"cuda:{key[0]}")
+        f = _X3_FLAGS[key] = torch.zeros((X3_SLOTS,), dtype=torch.int32, device=f"cuda:{key[0]}")
     return f
+
+
+def _x3_flag_ptr(slot: int) -> int:
+    f = _x3_flags()
+    return f.data_ptr() + 4 * (slot if 0 <= slot < f.numel() else 0)
 
 
 _X3_FLAG_OVERRIDE = None
 
 
 class x3_flag_scope:
-    """``with x3_flag_scope(flag):`` — three-product launches inside record into ``flag`` (i32[1] device tensor) instead of the
-    current stream's: a captured hipGraph must write to a flag its owner can read after every replay (engine.GraphedInference)."""
+    """``with x3_flag_scope(words):`` — three-product launches inside record into ``words`` (i32[X3_SLOTS] device tensor) instead of
+    the current stream's: a captured hipGraph must write to words its owner can read after every replay (engine.GraphedInference)."""
 
     def __init__(self, flag):
+        if flag.dtype != torch.int32 or not flag.is_cuda or flag.numel() < 1:
+            raise ValueError("x3_flag_scope needs an int32 device tensor")
         self.flag = flag
 
     def __enter__(self):
@@ -691,15 +711,27 @@ class x3_flag_scope:
         return False
 
 
-def split2_nonfinite(reset: bool = True) -> bool:
-    """True when a three-product kernel launched on the current stream stored an inf / NaN since the last reset (an activation
-    beyond the fp16 range, or a non-finite input): the caller repeats the work with the six-product kernels.  Synchronises the
-    current stream (4-byte read-back)."""
-    f = _x3_flag()
-    up = bool(f.item())
-    if up and reset:
+def range_words_of(host_words) -> dict:
+    """{slot: word} of the non-zero entries of a host copy of a range-word buffer."""
+    nz = torch.nonzero(host_words).reshape(-1).tolist()
+    return {int(i): int(host_words[i]) for i in nz}
+
+
+def split2_range_words(reset: bool = True) -> dict:
+    """{slot: word} of the layers whose three-product launches on the current stream left the fp16x2 range since the last reset
+    (empty dict: all inside).  Synchronises the current stream (one X3_SLOTS * 4 byte read-back)."""
+    f = _x3_flags()
+    words = range_words_of(f.cpu())
+    if words and reset:
         f.zero_()
-    return up
+    return words
+
+
+def split2_nonfinite(reset: bool = True) -> bool:
+    """True when a three-product kernel launched on the current stream raised ANY bit of its range word since the last reset:
+    a stored value / an A element was inf or NaN (activation beyond the fp16 range), or an A row sat below the range (rms < 2^-4).
+    The caller repeats the work with the six-product kernels.  Synchronises the current stream."""
+    return bool(split2_range_words(reset))
 
 
 def unpack_weight_bf16x3(packed):
@@ -723,7 +755,7 @@ def _count_x3():
 X3 = "_x3"   # LaunchTimer kind suffix of the three-product (fp16x2) kernels: 3 instead of 6 MFMA flops per fp32-equivalent flop
 
 
-def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None, _kind: str = "linear"):
+def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None, _kind: str = "linear", x3_slot: int = 0):
     """out = epilogue(x2d @ W^T + bias) with the weight given as pack_weight_bf16x3(weight); runs on the bf16 matrix cores
     with six partial products per fp32 product (fp32-accurate, see csrc/gemm_split.hip)."""
     m, k = x2d.shape
@@ -737,7 +769,7 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
             _dev(bias, torch.float32, "bias") if bias is not None else None,
             _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
             _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
-            {"none": 0, "gelu": 1, "scale_res": 2}[epilogue]) + ((_x3_flag().data_ptr(),) if fp16x2 else ()) + (_stream(),)
+            {"none": 0, "gelu": 1, "scale_res": 2}[epilogue]) + ((_x3_flag_ptr(x3_slot),) if fp16x2 else ()) + (_stream(),)
     nbytes = 4.0 * m * k + (4.0 if fp16x2 else 6.0) * n * k + 4.0 * m * n * (2 if epilogue == "scale_res" else 1)
     if fp16x2:
         _count_x3()
@@ -836,7 +868,8 @@ def set_conv_splitk(flag: bool) -> None:
     _CONV_SPLITK = bool(flag)
 
 
-def conv2d_f32_split(x_cl, weight_packed, bias, kh: int, kw: int, stride: int, pad: int, gelu: bool = False, _kind: str = "conv"):
+def conv2d_f32_split(x_cl, weight_packed, bias, kh: int, kw: int, stride: int, pad: int, gelu: bool = False, _kind: str = "conv",
+                     x3_slot: int = 0):
     """KHxKW / stride / zero-pad convolution of a channels_last tensor [N,Cin,H,W] on the bf16 matrix cores (fp32-accurate
     split GEMM, implicit im2col) -> channels_last [N,Cout,OH,OW]."""
     n, cin, h, w = x_cl.shape
@@ -854,7 +887,7 @@ def conv2d_f32_split(x_cl, weight_packed, bias, kh: int, kw: int, stride: int, p
             raise ValueError("the three-product convolution takes at most 32 taps")
         _count_x3()
         a2 = (x_cl.data_ptr(), weight_packed.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
-              out.data_ptr(), n, h, w, cin, cout, kh, kw, stride, pad, 1 if gelu else 0, _x3_flag().data_ptr(), _stream())
+              out.data_ptr(), n, h, w, cin, cout, kh, kw, stride, pad, 1 if gelu else 0, _x3_flag_ptr(x3_slot), _stream())
         _check(_timed(_kind + X3, 2.0 * n * oh * ow * cout * kh * kw * cin, lambda: load().gdrnpp_conv2d_f32_split2(*a2),
                       4.0 * n * (h * w * cin + oh * ow * cout) + 4.0 * cout * kh * kw * cin), "gdrnpp_conv2d_f32_split2")
         return out
@@ -872,10 +905,10 @@ def conv2d_f32_split(x_cl, weight_packed, bias, kh: int, kw: int, stride: int, p
     return out
 
 
-def conv3x3_f32_split(x_cl, weight_packed, bias, gelu: bool = False):
+def conv3x3_f32_split(x_cl, weight_packed, bias, gelu: bool = False, x3_slot: int = 0):
     """3x3 / stride 1 / pad 1 convolution of a channels_last tensor [N,Cin,H,W] on the bf16 matrix cores (fp32-accurate
     split GEMM, implicit im2col) -> channels_last [N,Cout,H,W] (gdrnpp_conv3x3_f32_split = the general entry with 3, 3, 1, 1)."""
-    return conv2d_f32_split(x_cl, weight_packed, bias, 3, 3, 1, 1, gelu, _kind="conv3x3")
+    return conv2d_f32_split(x_cl, weight_packed, bias, 3, 3, 1, 1, gelu, _kind="conv3x3", x3_slot=x3_slot)
 
 
 def bias_act_nhwc_(x_cl, bias, resid=None, relu: bool = True):
@@ -904,14 +937,14 @@ def pack_deconv_weight_f16x2(weight):
     return pack_weight_f16x2(weight.detach().permute(2, 3, 1, 0).reshape(kh * kw * cout, cin).contiguous())
 
 
-def conv_transpose2d_f32_split(x_cl, weight_packed, bias, ks: int, stride: int, pad: int, out_pad: int):
+def conv_transpose2d_f32_split(x_cl, weight_packed, bias, ks: int, stride: int, pad: int, out_pad: int, x3_slot: int = 0):
     """nn.ConvTranspose2d of a channels_last tensor [N,Cin,H,W] as split GEMM + col2im gather -> channels_last
     [N,Cout,OH,OW] (``weight_packed`` from pack_deconv_weight_bf16x3)."""
     n, cin, h, w = x_cl.shape
     if not x_cl.is_contiguous(memory_format=torch.channels_last) or x_cl.dtype != torch.float32 or not x_cl.is_cuda:
         raise ValueError("conv_transpose2d_f32_split expects a float32 channels_last device tensor")
     cout = weight_packed.shape[0] * 128 // (ks * ks)
-    cols = linear_f32_split(x_cl.permute(0, 2, 3, 1).reshape(n * h * w, cin), weight_packed, None, _kind="deconv")
+    cols = linear_f32_split(x_cl.permute(0, 2, 3, 1).reshape(n * h * w, cin), weight_packed, None, _kind="deconv", x3_slot=x3_slot)
     oh, ow = (h - 1) * stride - 2 * pad + ks + out_pad, (w - 1) * stride - 2 * pad + ks + out_pad
     y = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
     _check(load().gdrnpp_deconv_col2im_nhwc(cols.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
@@ -920,7 +953,46 @@ def conv_transpose2d_f32_split(x_cl, weight_packed, bias, ks: int, stride: int, 
     return y
 
 
-def conv3x3_groupnorm_act(x_cl, weight_packed, bias, gamma, beta, groups: int, eps: float = 1e-5, gelu: bool = False):
+def conv_transpose2d_groupnorm_act(x_cl, weight_packed, bias, ks: int, stride: int, pad: int, out_pad: int, gamma, beta, groups: int,
+                                   eps: float = 1e-5, gelu: bool = False, x3_slot: int = 0):
+    """nn.ConvTranspose2d -> GroupNorm(groups) [-> GELU] of a channels_last tensor: split GEMM, then the col2im gather leaves the
+    GroupNorm partial sums (``gdrnpp_deconv_col2im_gn_nhwc``) and the norm is one more pass (``gdrnpp_groupnorm_apply_nhwc``) —
+    bitwise the result of conv_transpose2d_f32_split + groupnorm_act, one launch fewer."""
+    n, cin, h, w = x_cl.shape
+    if not x_cl.is_contiguous(memory_format=torch.channels_last) or x_cl.dtype != torch.float32 or not x_cl.is_cuda:
+        raise ValueError("conv_transpose2d_groupnorm_act expects a float32 channels_last device tensor")
+    cout = weight_packed.shape[0] * 128 // (ks * ks)
+    cols = linear_f32_split(x_cl.permute(0, 2, 3, 1).reshape(n * h * w, cin), weight_packed, None, _kind="deconv", x3_slot=x3_slot)
+    oh, ow = (h - 1) * stride - 2 * pad + ks + out_pad, (w - 1) * stride - 2 * pad + ks + out_pad
+    y = torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x_cl.device, memory_format=torch.channels_last)
+    nbytes = load().gdrnpp_groupnorm_workspace_bytes(n, oh * ow, groups)
+    P = nbytes // (16 * n * groups)
+    part = torch.empty((n, P, groups, 2), dtype=torch.float64, device=x_cl.device)
+    _check(load().gdrnpp_deconv_col2im_gn_nhwc(cols.data_ptr(), _dev(bias, torch.float32, "bias") if bias is not None else None,
+                                               y.data_ptr(), part.data_ptr(), n, h, w, cout, ks, stride, pad, out_pad, groups, _stream()),
+           "gdrnpp_deconv_col2im_gn_nhwc")
+    out = torch.empty_like(y)
+    a2 = (y.data_ptr(), part.data_ptr(), P, _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"),
+          out.data_ptr(), n, oh * ow, cout, groups, float(eps), 1 if gelu else 0, _stream())
+    _check(_timed("hbm:groupnorm_apply", 0.0, lambda: load().gdrnpp_groupnorm_apply_nhwc(*a2), 8.0 * y.numel()),
+           "gdrnpp_groupnorm_apply_nhwc")
+    return out
+
+
+def pnp_fc_heads(x, w_r, b_r, w_t, b_t):
+    """Patch-PnP's output layers in one launch (``gdrnpp_pnp_fc_heads``): x f32[b,K] -> (fc_r(x) f32[b,rot_dim], fc_t(x) f32[b,3])."""
+    b, k = x.shape
+    rot_dim = w_r.shape[0]
+    rot_ = torch.empty((b, rot_dim), dtype=torch.float32, device=x.device)
+    t_ = torch.empty((b, 3), dtype=torch.float32, device=x.device)
+    _check(load().gdrnpp_pnp_fc_heads(_dev(x, torch.float32, "x"), _dev(w_r, torch.float32, "w_r"),
+                                      _dev(b_r, torch.float32, "b_r") if b_r is not None else None, _dev(w_t, torch.float32, "w_t"),
+                                      _dev(b_t, torch.float32, "b_t") if b_t is not None else None, rot_.data_ptr(), t_.data_ptr(),
+                                      b, k, rot_dim, _stream()), "gdrnpp_pnp_fc_heads")
+    return rot_, t_
+
+
+def conv3x3_groupnorm_act(x_cl, weight_packed, bias, gamma, beta, groups: int, eps: float = 1e-5, gelu: bool = False, x3_slot: int = 0):
     """conv3x3 (stride 1, pad 1) -> GroupNorm(groups) [-> GELU] of a channels_last tensor: the convolution's epilogue
     leaves the GroupNorm partial sums, the norm is one more pass (``gdrnpp_conv3x3_f32_split_gnstats`` +
     ``gdrnpp_groupnorm_apply_nhwc``).  Returns None when the shape is outside the fused form (H*W % 256, 8 channels
@@ -943,7 +1015,7 @@ def conv3x3_groupnorm_act(x_cl, weight_packed, bias, gamma, beta, groups: int, e
     nbytes = 4.0 * n * h * w * (cin + cout) + (4.0 if fp16x2 else 6.0) * cout * 9 * cin
     if fp16x2:
         _count_x3()
-        a3 = args[:4] + (part.data_ptr(), n, h, w, cin, cout, groups, 0, _x3_flag().data_ptr(), _stream())
+        a3 = args[:4] + (part.data_ptr(), n, h, w, cin, cout, groups, 0, _x3_flag_ptr(x3_slot), _stream())
         _check(_timed("conv3x3" + X3, 2.0 * n * h * w * cout * 9 * cin, lambda: load().gdrnpp_conv3x3_f32_split2(*a3), nbytes),
                "gdrnpp_conv3x3_f32_split2")
     else:

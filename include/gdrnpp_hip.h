@@ -217,6 +217,13 @@ int gdrnpp_pose_from_pred(const float* rot_in, int rot_mode, const float* t_, in
                           const float* centers, const float* whs, const float* resize_ratios, float* rot, float* trans,
                           int b, int is_allo, void* stream);
 
+/* Patch-PnP's two output layers in one launch (row a3.3): rot_ = fc_r(x), t_ = fc_t(x) of ConvPnPNet.forward,
+ * core/gdrn_modeling/models/heads/conv_pnp_net.py:99-101,178-182 (two nn.Linear on the same [b,256] feature).
+ * x f32[b,K] (K <= 1024), w_r f32[rot_dim,K] (rot_dim <= 9), b_r f32[rot_dim] | NULL, w_t f32[3,K], b_t f32[3] | NULL
+ * -> rot_ f32[b,rot_dim], t_ f32[b,3]; fp32 fma chains, one wavefront per ROI, fixed summation order. */
+int gdrnpp_pnp_fc_heads(const float* x, const float* w_r, const float* b_r, const float* w_t, const float* b_t, float* rot_,
+                        float* t_, int b, int K, int rot_dim, void* stream);
+
 /* ---- crop-resize intrinsics (a8.2) — camera_geometry.py:6-21 --------------
  * K f32[b,9], centers f32[b,2], scales f32[b] -> K_crop f32[b,9],
  * with crop_xy = center - scale/2 and ratio = out_res/scale
@@ -422,6 +429,12 @@ int gdrnpp_bias_act_nhwc(const float* x, const float* bias, const float* resid, 
                          void* stream);
 int gdrnpp_deconv_col2im_nhwc(const float* cols, const float* bias, float* y, int N, int H, int W, int C, int KS,
                               int stride, int pad, int out_pad, void* stream);
+/* the same gather + the GroupNorm(G) statistics of its result (the head's ConvTranspose2d -> GroupNorm -> GELU,
+ * top_down_doublemask_xyz_region_head.py:53-75): gn_partials f64[N, P, G, 2] with P = gdrnpp_groupnorm_workspace_bytes(N, OH*OW, G)
+ * / (16 N G), bitwise what gdrnpp_groupnorm_act_nhwc's own statistics pass writes; follow with gdrnpp_groupnorm_apply_nhwc.
+ * (C / G) % 4 == 0, C / 4 divides 256, G <= 64. */
+int gdrnpp_deconv_col2im_gn_nhwc(const float* cols, const float* bias, float* y, double* gn_partials, int N, int H, int W, int C,
+                                 int KS, int stride, int pad, int out_pad, int G, void* stream);
 int gdrnpp_conv3x3_gnstats_partials(int H, int W);
 int gdrnpp_conv3x3_f32_split_gnstats(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,
                                      double* gn_partials, int n_img, int H, int W, int Cin, int Cout, int groups,
@@ -438,10 +451,14 @@ int gdrnpp_groupnorm_apply_nhwc(const float* x, const double* partials, int P, c
  * of two when they are packed
  * (gdrnpp_pack_weight_f16x2: W f32[N][K] -> fp16 [N/128][K/16][2][2][128][8] + a 16-byte trailer holding the scale,
  * gdrnpp_pack_weight_f16x2_bytes(N, K) bytes; conv weights reordered to [Cout][ky][kx][Cin] first, as for bf16x3), activations
- * are split as they are: one beyond the fp16 range (65504) makes the output non-finite, which the epilogues detect on every
- * value they store -> a sticky device flag (nonfinite_flag argument, or the library's own behind gdrnpp_split2_nonfinite); the caller
- * then repeats the work in the six-product form (engine.inference_step does).  Activation tensors whose scale is below 2^-3 lose
- * low bits to the fp16 subnormal spacing (absolute operand error 2^-25).
+ * are split as they are.  Both sides of the fp16 range are checked by every launch and reported in its RANGE WORD (range_flag
+ * argument, or the library's own word behind gdrnpp_split2_range_word):
+ *   GDRNPP_SPLIT2_NONFINITE   an activation beyond 65504 (or a non-finite input): a stored value or an A element was inf / NaN;
+ *   GDRNPP_SPLIT2_SMALL_ROWS  an A row that is not all zero has rms below 2^-4 over its K elements: the low halves fall into the
+ *                             fp16 subnormal spacing (absolute operand error 2^-25), i.e. more than 2^-21 of that row's output.
+ * On either bit the caller repeats the work in the six-product form (engine.inference_step does, and keeps the flagged layer
+ * there).  gdrnpp_pack_weight_f16x2 applies the small-rows test to the scaled weight rows and leaves the verdict in the trailer
+ * (word 3 of the 16 bytes behind the tiles: 1 = some non-zero row is below range; such a weight belongs on the six-product form).
  * gdrnpp_linear_f32_split2: as gdrnpp_linear_f32_split (N % 128 == 0, K % 32 == 0, any M, M*K*4 < 4 GiB).
  * gdrnpp_conv3x3_f32_split2: 3x3 / stride 1 / pad 1 convolution over NHWC (Cin % 32 == 0, Cout % 128 == 0), epilogue 0 / 1
  * (bias / bias + GELU); gn_partials != NULL additionally writes the GroupNorm partials of gdrnpp_conv3x3_f32_split_gnstats
@@ -449,17 +466,20 @@ int gdrnpp_groupnorm_apply_nhwc(const float* x, const double* partials, int P, c
 size_t gdrnpp_pack_weight_f16x2_bytes(int N, int K);
 int gdrnpp_pack_weight_f16x2(const float* W, void* packed, int N, int K, void* stream);
 int gdrnpp_linear_f32_split2(const float* A, const void* W_packed, const float* bias, const float* gamma, const float* resid,
-                             float* C, int M, int N, int K, int epilogue, int* nonfinite_flag, void* stream);
+                             float* C, int M, int N, int K, int epilogue, int* range_flag, void* stream);
 int gdrnpp_conv3x3_f32_split2(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc, double* gn_partials,
-                              int n_img, int H, int W, int Cin, int Cout, int groups, int epilogue, int* nonfinite_flag,
+                              int n_img, int H, int W, int Cin, int Cout, int groups, int epilogue, int* range_flag,
                               void* stream);
 /* any KH x KW / stride / zero-pad convolution with at most 32 taps (ConvNeXt's 2x2/2 downsamples, Patch-PnP's 3x3/2), epilogue 0 / 1 */
 int gdrnpp_conv2d_f32_split2(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc, int n_img, int H, int W,
-                             int Cin, int Cout, int KH, int KW, int stride, int pad, int epilogue, int* nonfinite_flag,
+                             int Cin, int Cout, int KH, int KW, int stride, int pad, int epilogue, int* range_flag,
                              void* stream);
-/* nonfinite_flag: device int the launch ORs 1 into when it stores an inf / NaN (the caller owns, zeroes and reads it — one per
- * stream / host thread keeps concurrent users apart); NULL = the library's own flag, read and reset by gdrnpp_split2_nonfinite. */
-int gdrnpp_split2_nonfinite(int* flag, int reset, void* stream);
+/* range_flag: device int the launch ORs its range word into (the caller owns, zeroes and reads it — one per layer and stream
+ * tells the caller WHICH layer left the range and keeps concurrent users apart); NULL = the library's own word, read (*word) and
+ * optionally reset by gdrnpp_split2_range_word (synchronises the stream). */
+#define GDRNPP_SPLIT2_NONFINITE 1
+#define GDRNPP_SPLIT2_SMALL_ROWS 2
+int gdrnpp_split2_range_word(int* word, int reset, void* stream);
 
 /* ---- depth-to-flow (SURVEY §8b boundary "flow") — replaces the flow_cuda torch extension,
  * core/csrc/flow/src/flow_cuda.cpp:30-47 (kernel flow_cuda_kernel.cu:33-64).

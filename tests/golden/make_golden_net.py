@@ -54,7 +54,7 @@ CONFIGS = {
 SO_CONFIGS = {
     "ycbvso": "configs/gdrn/ycbvSO/convnext_AugCosyAAEGray_DMask_amodalClipBox_ycbv/002_master_chef_can.py",
 }
-from tests.netgolden import SEED, net_detections, net_image, norm_alias  # noqa: E402
+from tests.netgolden import SEED, net_detections, net_detections_b128, net_image, norm_alias  # noqa: E402
 
 
 def jsonable(o):
@@ -145,6 +145,57 @@ def main(configs=None):
         print("wrote", f"net_golden_{ds}.npz")
 
 
+def record_b128(datasets=("ycbv", "tless"), b=128):
+    """The reference's forward at the BENCHMARK's batch (BASELINE configs[2]: YCB-V, 128 ROIs; configs[3]: one rank's 128-ROI
+    shard of T-LESS): every class of the dataset occurs (roi_cls = i mod C, unsorted).  To stay at ~1 MB per fixture the maps are
+    stored sub-sampled (every 4th pixel of every ROI; region logits on a 4 x 4 grid + the full arg-max image); R, t and the
+    Patch-PnP outputs are stored for all ROIs.  -> net_golden_<ds>_b128.npz"""
+    torch.set_num_threads(os.cpu_count())
+    torch.set_grad_enabled(False)
+    hip_layers.set_enabled(False)
+    from core.gdrn_modeling.models import GDRN_double_mask as REFM
+    from core.gdrn_modeling.models import net_factory
+
+    net_factory.BACKBONES["timm/convnext_base"] = lambda model_name=None, **kw: create_backbone(type="timm/" + model_name, **kw)
+    for ds in datasets:
+        raw = _refimport.load_ref_config(CONFIGS[ds])
+        cfg = Config(raw)
+        cfg.MODEL.DEVICE = "cpu"
+        cfg.MODEL.POSE_NET.BACKBONE.INIT_CFG.pretrained = False
+        cfg.TEST.USE_DEPTH_REFINE = True
+        cfg.SOLVER.BASE_LR = cfg.SOLVER.OPTIMIZER_CFG["lr"]
+        model, opt = REFM.build_model_optimizer(cfg, is_test=True)
+        assert opt is None and type(model).__module__ == "core.gdrn_modeling.models.GDRN_double_mask"
+        model.eval()
+        sd = model.state_dict()
+        model.load_state_dict(S.seeded_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], SEED, alias=norm_alias), strict=True)
+        C = cfg.MODEL.POSE_NET.NUM_CLASSES
+        x, det = net_image(b), net_detections_b128(C, b)
+        T = torch.from_numpy
+        grab = {}
+        model.pnp_net.register_forward_hook(lambda m, i, o: grab.update(pred_rot_=o[0].clone(), pred_t_=o[1].clone()))
+        out = model(T(x), roi_classes=T(det["roi_cls"]), roi_cams=T(det["roi_cam"]), roi_whs=T(det["roi_wh"]),
+                    roi_centers=T(det["roi_center"]), resize_ratios=T(det["resize_ratio"]),
+                    roi_coord_2d=T(S.coord2d_roi(det["roi_center"], det["scale"])), roi_extents=T(det["roi_extent"]), do_loss=False)
+        region = out["region"].numpy()
+        rec = dict(
+            cfg_json=json.dumps(jsonable({k: raw[k] for k in ("MODEL", "TEST", "INPUT")})),
+            head_keys=json.dumps([[k, list(v.shape)] for k, v in sd.items() if not k.startswith("backbone.")]),
+            roi_cls=det["roi_cls"], roi_cam=det["roi_cam"], roi_wh=det["roi_wh"], roi_center=det["roi_center"],
+            resize_ratio=det["resize_ratio"], scale=det["scale"], roi_extent=det["roi_extent"],
+            pred_rot_=grab["pred_rot_"].numpy(), pred_t_=grab["pred_t_"].numpy(), rot=out["rot"].numpy(), trans=out["trans"].numpy(),
+            region_sub=np.ascontiguousarray(region[:, :, 5::16, 9::16]), region_argmax=region.argmax(1).astype(np.uint8),
+            region_absmax=np.float32(np.abs(region).max()))
+        for k in ("mask", "full_mask", "coor_x", "coor_y", "coor_z"):
+            m = out[k].numpy()
+            rec[k + "_sub"] = np.ascontiguousarray(m[:, :, ::4, 1::4])
+            rec[k + "_absmax"] = np.float32(np.abs(m).max())
+        for k in ("mask_sub", "coor_x_sub", "rot", "trans", "pred_rot_", "pred_t_"):
+            print(ds, "b128", k, rec[k].shape, float(np.abs(rec[k]).mean()), float(np.abs(rec[k]).max()))
+        np.savez_compressed(os.path.join(HERE, f"net_golden_{ds}_b128.npz"), **rec)
+        print("wrote", f"net_golden_{ds}_b128.npz")
+
+
 def record_resnet34():
     """BASELINE configs[0]: models/GDRN.py built from configs/_base_/gdrn_base.py (NUM_CLASSES=1 for the single LM-O object;
     the base file's 13 gives the same graph — nothing in it is class-aware), 32 ROIs = the batch of configs[0].
@@ -202,7 +253,9 @@ def record_resnet34():
 
 
 if __name__ == "__main__":
-    if "--resnet34-only" in sys.argv:
+    if "--b128-only" in sys.argv:
+        record_b128()
+    elif "--resnet34-only" in sys.argv:
         torch.set_num_threads(os.cpu_count())
         torch.set_grad_enabled(False)
         hip_layers.set_enabled(False)
@@ -212,3 +265,4 @@ if __name__ == "__main__":
     else:
         main()
         record_resnet34()
+        record_b128()

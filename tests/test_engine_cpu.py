@@ -332,9 +332,11 @@ def test_class_sorted_shards_gather_and_restore_roi_order_gloo_world2(n_total):
     assert np.array_equal(rec[:, 13], np.random.default_rng(11).integers(0, 5, n_total))
 
 
-def test_gemm_product_switch_and_overflow_give_up(monkeypatch):
+def test_gemm_product_switch_and_range_word_policy(monkeypatch):
     """Host logic of the three-product mode (no GPU): the switch validates its argument, launches are eligible from 256 tiles of
-    256 x 128 on, and a process whose steps keep overflowing the fp16 range settles on six products after three of them."""
+    256 x 128 on; a step's range words demote the layers with rows below the range and the FIRST overflowing layer, the repeat
+    runs with six products for the calling thread only, and a process whose steps keep overflowing settles on six products."""
+    import threading
     import warnings
 
     import pytest
@@ -350,43 +352,76 @@ def test_gemm_product_switch_and_overflow_give_up(monkeypatch):
     # linear form: the A operand must stay below 4 GiB (32-bit lane offsets) — 128 ROIs of stage-0 fc2 do, 600 do not
     assert hip_layers._use_x3(128 * 4096, 128, 512) and not hip_layers._use_x3(600 * 4096, 128, 512)
     assert hip_layers._use_x3(600 * 4096, 256)            # convolutions address per pixel: no such limit
-    calls = []
+    seen = []
 
     def run():
-        calls.append(hip_layers.gemm_products())
+        seen.append(hip_layers.gemm_products())
+        other = []
+        t = threading.Thread(target=lambda: other.append(hip_layers.gemm_products()))
+        t.start()
+        t.join()
+        seen.append(other[0])
         return "rec"
 
+    hip_layers.reset_x3_demotions()
     monkeypatch.setattr(engine, "_X3_OVERFLOW_STEPS", 0)
+    S, NF = hip_lib.X3_SMALL_ROWS, hip_lib.X3_NONFINITE
     try:
-        for i in range(engine.X3_OVERFLOW_STEPS_TO_GIVE_UP - 1):
-            assert engine._six_product_rerun(run) == "rec" and hip_layers.gemm_products() == 3
+        # rows below the range in layers 5 and 9; non-finite values from layer 7 on (8 and 9 saw them pass through)
+        assert engine._six_product_rerun(run, {5: S, 7: NF, 8: NF, 9: NF | S}) == "rec"
+        assert seen == [6, 3]                              # six products for this thread, the process setting for the others
+        assert hip_layers.gemm_products() == 3 and hip_layers.x3_demoted() == {5: S, 7: NF, 9: NF | S}
+        assert engine._X3_OVERFLOW_STEPS == 1
+        engine._six_product_rerun(run, {0: S})             # slot 0 = launches that named no layer: repeated, nothing to demote
+        assert hip_layers.x3_demoted() == {5: S, 7: NF, 9: NF | S} and engine._X3_OVERFLOW_STEPS == 1
+        engine._six_product_rerun(run, {8: NF})
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
-            assert engine._six_product_rerun(run) == "rec"
+            engine._six_product_rerun(run, {11: NF})
         assert hip_layers.gemm_products() == 6 and any("six-product" in str(x.message) for x in w)
-        assert calls == [6] * engine.X3_OVERFLOW_STEPS_TO_GIVE_UP
+        assert set(hip_layers.x3_demoted()) == {5, 7, 8, 9, 11}
     finally:
         hip_layers.set_gemm_products(3)
+        hip_layers.reset_x3_demotions()
 
 
-def test_x3_scale_calibration_decides_per_layer():
-    """hip_layers.x3_scale_ok: a layer looks at the rms of its A operand the first X3_CALIBRATION_CALLS times; an operand below
-    2^-4 (or non-finite) keeps that layer on the six-product kernels, reset_x3_calibration() makes every layer look again."""
+def test_x3_layers_get_slots_and_lose_the_form_when_demoted(monkeypatch):
+    """hip_layers.x3_for: a layer (module cache, key) gets its range-word slot at the first eligible launch (launch order), runs
+    the three-product kernel until it is demoted or its packed weight reports rows below the range, and reset_x3_demotions()
+    forgets both (new weights).  No device: the pack and its verdict are stubbed."""
     import torch
 
+    from gdrnpp_bop2022_amd import hip_lib
     from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers as hl
 
-    hl.reset_x3_calibration()
-    torch.manual_seed(0)
-    big, small = torch.randn(64, 32), torch.randn(64, 32) * 1e-3
+    hl.reset_x3_demotions()
+    verdict = {"ok": True}
+    monkeypatch.setattr(hip_lib, "packed_rows_in_range", lambda packed: verdict["ok"])
+    packs = []
+
+    def pack3(w):
+        packs.append(1)
+        return ("packed", len(packs))
+
+    w = torch.zeros(512, 128)
     c1, c2 = {}, {}
-    assert hl.x3_scale_ok(c1, "fc1", big) and hl.x3_scale_ok(c1, "fc1", big)
-    assert hl.x3_scale_ok(c1, "fc1", small)            # calibration over: the decision stands without another look
-    assert not hl.x3_scale_ok(c2, "fc1", small) and not hl.x3_scale_ok(c2, "fc1", big)
-    assert hl.x3_scale_ok(c2, "fc2", big)              # per layer key
-    assert not hl.x3_scale_ok({}, "conv", torch.full((4, 4), float("nan")))
-    hl.reset_x3_calibration()
-    assert hl.x3_scale_ok(c2, "fc1", big)              # looks again after a reset
-    # use_x3 folds the shape rule and the look together
-    assert hl.use_x3(128 * 4096, 512, 128, {}, "fc1", big) and not hl.use_x3(128 * 4096, 512, 128, {}, "fc1", small)
-    assert not hl.use_x3(4 * 4096, 128, 512, {}, "fc2", big)      # too few tiles: six products whatever the scale
+    big = (128 * 4096, 512, 128)
+    try:
+        p, s1 = hl.x3_for(c1, "fc1", w, pack3, *big)
+        assert p == ("packed", 1) and s1 == 1
+        assert hl.x3_for(c1, "fc1", w, pack3, *big) == (("packed", 1), 1) and len(packs) == 1     # cached
+        assert hl.x3_for(c2, "fc1", w, pack3, *big)[1] == 2 and hl.x3_for(c1, "fc2", w, pack3, *big)[1] == 3
+        assert hl.x3_for({}, "fc2", w, pack3, 4 * 4096, 128, 512) == (None, 0)                   # too few tiles: no slot spent
+        hl.demote_x3({2: hip_lib.X3_SMALL_ROWS})
+        assert hl.x3_for(c2, "fc1", w, pack3, *big) == (None, 2) and hl.x3_for(c1, "fc1", w, pack3, *big)[0] is not None
+        with hl.forced_gemm_products(6):
+            assert hl.x3_for(c1, "fc1", w, pack3, *big) == (None, 0)
+        w.add_(1.0)                                         # in-place weight update: packed again, verdict read again
+        verdict["ok"] = False
+        assert hl.x3_for(c1, "fc1", w, pack3, *big) == (None, 1) and len(packs) == 4
+        hl.reset_x3_demotions()
+        verdict["ok"] = True
+        w.add_(1.0)
+        assert hl.x3_for(c2, "fc1", w, pack3, *big)[1] == 1 and hl.x3_demoted() == {}
+    finally:
+        hl.reset_x3_demotions()

@@ -160,3 +160,44 @@ def test_resnet34_hip_path_matches_reference_forward_4_rois(resnet_model):
     assert _err(o["region"][:, :, 1::8, 2::8], fx["region_sub"][:4], float(fx["region_absmax"])) <= 1e-4
     assert np.abs(o["rot"] - fx["rot"][:4]).max() <= 1e-4
     assert np.abs(o["trans"] - fx["trans"][:4]).max() <= 1e-4 * max(1.0, np.abs(fx["trans"]).max())
+
+
+# ---- the benchmark's batch: BASELINE configs[2] (YCB-V, 128 ROIs) and one rank's 128-ROI shard of configs[3] (T-LESS) ----------
+@pytest.mark.parametrize("ds", ["ycbv", "tless"])
+def test_default_path_matches_reference_forward_at_128_rois(hip, ds):
+    """The library's DEFAULT configuration (three-product split GEMMs where the launch is large enough, as bench.py times it)
+    against GDRN_DoubleMask.forward of the reference recorded at 128 ROIs with every class of the dataset present
+    (net_golden_<ds>_b128.npz, tests/golden/make_golden_net.py record_b128): R / t / Patch-PnP outputs of ALL 128 ROIs and the
+    stored sub-sampling of all their maps, tolerances of BASELINE.json's north_star; no layer leaves the three-product range."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
+
+    assert hip_layers.gemm_products() == 3 and hip_layers.mlp_gemm() == "split"
+    fx = NG.load_fixture(ds + "_b128")
+    b = fx["rot"].shape[0]
+    assert b == 128 and len(set(fx["roi_cls"].tolist())) == fx["cfg"]["MODEL"]["POSE_NET"]["NUM_CLASSES"]
+    cfg = get_cfg(NG.cfg_name(ds), opts=["TEST.USE_DEPTH_REFINE=True"])
+    model, _ = build_model_optimizer(cfg)
+    model.load_state_dict(NG.seeded_reference_state_dict(model, fx), strict=True)
+    x = torch.from_numpy(NG.net_image(b)).cuda()
+    kw = NG.forward_kwargs(fx, "cuda")
+    timer = hip.LaunchTimer()
+    hip.set_launch_timer(timer)
+    try:
+        with torch.no_grad():
+            out = model(x, **kw)
+            rot_, t_, _ = model.forward_maps(x, kw["roi_classes"], kw["roi_coord_2d"], None, kw["roi_extents"])
+    finally:
+        hip.set_launch_timer(None)
+    words = hip.split2_range_words()
+    kinds = [r[0] for r in timer.records]
+    assert sum(k == "linear" + hip.X3 for k in kinds) == 2 * 72, "the ConvNeXt MLPs did not run on the three-product kernels"
+    assert words == {}, f"three-product launches left their range: {words}"
+    o = {k: v.float().cpu().numpy() for k, v in out.items()}
+    for k in ("mask", "full_mask", "coor_x", "coor_y", "coor_z"):
+        assert _err(o[k][:, :, ::4, 1::4], fx[k + "_sub"], float(fx[k + "_absmax"])) <= 1e-4, k
+    assert _err(o["region"][:, :, 5::16, 9::16], fx["region_sub"], float(fx["region_absmax"])) <= 1e-4
+    assert (o["region"].argmax(1) == fx["region_argmax"]).mean() > 0.999
+    assert np.abs(rot_.cpu().numpy() - fx["pred_rot_"]).max() <= 1e-4 * max(1.0, np.abs(fx["pred_rot_"]).max())
+    assert np.abs(t_.cpu().numpy() - fx["pred_t_"]).max() <= 1e-4 * max(1.0, np.abs(fx["pred_t_"]).max())
+    assert np.abs(o["rot"] - fx["rot"]).max() <= 1e-4
+    assert np.abs(o["trans"] - fx["trans"]).max() <= 1e-4 * max(1.0, np.abs(fx["trans"]).max())

@@ -556,3 +556,73 @@ def test_pipelined_128_row_kernel_is_bitwise_equal_to_the_256_row_kernel(hip, m,
         finally:
             hip.set_option("split_gemm_mi4", -1)
         assert torch.isfinite(small).all() and torch.equal(small, big), epi
+
+
+@pytest.mark.parametrize("ks,pad,out_pad", [(3, 1, 1), (4, 1, 0), (2, 0, 0)])
+@pytest.mark.parametrize("n,h,w,cin,cout,groups,bias,gelu", [(5, 8, 8, 1024, 256, 32, False, True), (3, 5, 7, 64, 128, 32, True, False),
+                                                          (2, 16, 16, 128, 256, 32, False, True)])
+def test_conv_transpose2d_groupnorm_fused_is_bitwise_the_two_pass_result(hip, ks, pad, out_pad, n, h, w, cin, cout, groups, bias, gelu):
+    """ConvTranspose2d -> GroupNorm (-> GELU) with the statistics taken by the col2im gather (gdrnpp_deconv_col2im_gn_nhwc): the
+    partials are those of gdrnpp_groupnorm_act_nhwc's own statistics pass (same partition, same order), so the result equals
+    conv_transpose2d_f32_split + groupnorm_act bit for bit; and both sit at fp32 rounding from the fp64 layers."""
+    torch.manual_seed(ks + n + cout)
+    x = torch.randn(n, cin, h, w, device="cuda").contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(cin, cout, ks, ks, device="cuda") * cin ** -0.5
+    b = torch.randn(cout, device="cuda") if bias else None
+    gw, gb = torch.randn(cout, device="cuda"), torch.randn(cout, device="cuda")
+    pk = hip.pack_deconv_weight_bf16x3(wt)
+    fused = hip.conv_transpose2d_groupnorm_act(x, pk, b, ks, 2, pad, out_pad, gw, gb, groups, 1e-5, gelu=gelu)
+    two = hip.groupnorm_act(hip.conv_transpose2d_f32_split(x, pk, b, ks, 2, pad, out_pad), gw, gb, groups, 1e-5, gelu=gelu)
+    assert fused.is_contiguous(memory_format=torch.channels_last) and torch.equal(fused, two)
+    ref = F.group_norm(F.conv_transpose2d(x.double(), wt.double(), None if b is None else b.double(), stride=2, padding=pad,
+                                          output_padding=out_pad), groups, gw.double(), gb.double(), 1e-5)
+    if gelu:
+        ref = F.gelu(ref)
+    assert ((fused.double() - ref).abs().max() / ref.abs().max()).item() < 5e-6
+
+
+@pytest.mark.parametrize("b,k,rot_dim", [(128, 256, 6), (1, 256, 4), (7, 1000, 3), (33, 64, 9)])
+def test_pnp_fc_heads_vs_fp64(hip, b, k, rot_dim):
+    """fc_r | fc_t of Patch-PnP in one launch (conv_pnp_net.py:99-101,178-182) against the two nn.Linear in fp64, and against
+    torch's fp32 layers at fp32 rounding."""
+    torch.manual_seed(b + k)
+    x = torch.randn(b, k, device="cuda")
+    fc_r, fc_t = torch.nn.Linear(k, rot_dim).cuda(), torch.nn.Linear(k, 3).cuda()
+    with torch.no_grad():
+        fc_t.bias.add_(1.5)
+        r, t = hip.pnp_fc_heads(x, fc_r.weight, fc_r.bias, fc_t.weight, fc_t.bias)
+        r64, t64 = fc_r.double()(x.double()), fc_t.double()(x.double())
+    assert r.shape == (b, rot_dim) and t.shape == (b, 3)
+    assert (r.double() - r64).abs().max().item() < 2e-6 * max(1.0, r64.abs().max().item())
+    assert (t.double() - t64).abs().max().item() < 2e-6 * max(1.0, t64.abs().max().item())
+    r0, t0 = hip.pnp_fc_heads(x, fc_r.weight.float(), None, fc_t.weight.float(), None)     # bias is optional
+    assert (r0.double() + fc_r.bias.double() - r64).abs().max().item() < 2e-6 * max(1.0, r64.abs().max().item())
+
+
+def test_patch_pnp_tail_runs_on_this_library(hip):
+    """The GDRNPP Patch-PnP tail (fc1 -> GELU -> fc2 -> GELU -> fc_r | fc_t) leaves no vendor-library launch: two split-K GEMMs with
+    the GELU in their epilogues + gdrnpp_pnp_fc_heads; same numbers as the module graph."""
+    from gdrnpp_bop2022_amd.gdrn_modeling.heads import ConvPnPNet
+    torch.manual_seed(4)
+    net = ConvPnPNet(nIn=69, featdim=128, rot_dim=6, num_regions=64, act="gelu").cuda().eval()
+    for m in (net.fc1, net.fc2, net.fc_r, net.fc_t):
+        torch.nn.init.normal_(m.weight, 0.0, m.in_features ** -0.5)
+        torch.nn.init.normal_(m.bias, 0.0, 0.3)
+    feat = torch.randn(128, 128, 8, 8, device="cuda")
+    timer = hip.LaunchTimer()
+    hip.set_launch_timer(timer)
+    try:
+        with torch.no_grad(), torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            r, t = net._fc_tail(feat)
+            torch.cuda.synchronize()
+    finally:
+        hip.set_launch_timer(None)
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    assert [k for k in (rec[0] for rec in timer.records)] == ["linear_splitk", "linear_splitk"]
+    assert not [n for n in names if n.startswith("Cijk") or "Gelu" in n or "gelu" in n], names
+    with torch.no_grad():
+        x = feat.flatten(1).double()
+        h = F.gelu(net.fc2.double()(F.gelu(net.fc1.double()(x))))
+        r64, t64 = net.fc_r.double()(h), net.fc_t.double()(h)
+    assert (r.double() - r64).abs().max().item() < 5e-6 * r64.abs().max().item()
+    assert (t.double() - t64).abs().max().item() < 5e-6 * max(1.0, t64.abs().max().item())

@@ -6,8 +6,10 @@ hip_layers.set_gemm_products(3)).  What is pinned here:
     3e-6 of the output scale at K = 128 .. 4096, six products 5e-7 .. 3e-6, hipBLASLt fp32 6e-7 .. 4e-6 on the same operands;
     the operand representation alone (fp64 evaluation of the same three products) contributes 1.3e-7 .. 2.2e-7
     (tools/split2_error_probe.py).  Bars: <= 1.3 x six products + 4e-7 and <= the library's fp32 GEMM + 1e-7;
-  * the documented limit: a tensor at scale 1e-3 loses l to the fp16 subnormal spacing (2^-25 absolute) — still below 1e-4;
-  * an activation beyond the fp16 range raises the sticky flag, and engine.inference_step then repeats the step with six products;
+  * the range of the form, checked by every launch on both sides: a tensor at scale 1e-3 loses l to the fp16 subnormal spacing
+    (2^-25 absolute) and raises the SMALL_ROWS bit of the launch's range word, an activation beyond 65504 the NONFINITE bit; the
+    same test on the weight rows at pack time; engine.inference_step then repeats the step with six products (records bit-equal to
+    the six-product mode) and keeps the flagged layer there — also when the first batches were healthy, also under a hipGraph;
   * the whole network with three products against the REFERENCE's recorded outputs (tolerances of BASELINE.json's north_star:
     maps 1e-4 of scale, R / t 1e-4) and against the six-product path at 128 ROIs."""
 import numpy as np
@@ -44,6 +46,13 @@ def test_packed_image_is_the_scaled_weight_to_22_bits(hip):
     ws = w.double() * 2.0 ** e
     assert torch.equal(planes[0], ws.float().half())
     assert torch.equal(planes[1], (ws - planes[0].double()).float().half())
+    # rows verdict of the pack kernel: all-zero rows are fine, a non-zero row 2^-17 below the tensor maximum is not
+    assert hip.packed_rows_in_range(pk)
+    w[9] = 0.0
+    assert hip.packed_rows_in_range(hip.pack_weight_f16x2(w))
+    w[9] *= 0.0
+    w[9, 3] = 0.7 * 2.0 ** -15
+    assert not hip.packed_rows_in_range(hip.pack_weight_f16x2(w))
 
 
 @pytest.mark.parametrize("m,k,n,epi", [(4096, 128, 512, "gelu"), (4096, 512, 128, "scale_res"), (1000, 2048, 512, "scale_res"),
@@ -113,16 +122,40 @@ def test_wide_block_tiles_are_bitwise_equal(hip, m, k, n, epi):
     assert torch.equal(ys[0], ys[1])
 
 
-def test_small_scale_activations_degrade_as_documented(hip):
-    """A tensor at scale 1e-3: l falls into the fp16 subnormal range, absolute operand error 2^-25 -> ~1e-5 relative — the stated
-    limit of the mode (LayerNorm / GroupNorm / GELU outputs sit at scale 1); still inside the 1e-4 tolerance of the path."""
+def test_small_scale_activations_raise_the_small_rows_bit(hip):
+    """A tensor at scale 1e-3: l falls into the fp16 subnormal range, absolute operand error 2^-25 -> ~1e-5 relative — outside what
+    the mode promises, and the launch says so (SMALL_ROWS); rows that are entirely zero are exact and raise nothing; one small row
+    among healthy ones raises the bit; the conv forms judge their im2col rows."""
     torch.manual_seed(2)
     m, k, n = 2048, 512, 256
-    x, w = torch.randn(m, k, device=DEV) * 1e-3, torch.randn(n, k, device=DEV) * k ** -0.5
-    out3 = hip.linear_f32_split(x, hip.pack_weight_f16x2(w), None)
-    want = x.double() @ w.double().t()
+    x, w = torch.randn(m, k, device=DEV), torch.randn(n, k, device=DEV) * k ** -0.5
+    pk = hip.pack_weight_f16x2(w)
+    hip.linear_f32_split(x, pk, None)
+    assert hip.split2_range_words() == {}
+    out3 = hip.linear_f32_split(x * 1e-3, pk, None)
+    want = (x * 1e-3).double() @ w.double().t()
     e3 = _amax(out3.double() - want) / _amax(want)
     assert 5e-7 < e3 < 4e-5, e3
+    assert hip.split2_range_words() == {0: hip.X3_SMALL_ROWS} and hip.split2_range_words() == {}
+    x[100:300] = 0.0                                     # zero rows (padding): exact, no word
+    hip.linear_f32_split(x, pk, None)
+    assert hip.split2_range_words() == {}
+    x[1999] *= 0.03                                      # rms 0.03 < 2^-4 in ONE row of the last tile
+    hip.linear_f32_split(x, pk, None, x3_slot=17)
+    assert hip.split2_range_words() == {17: hip.X3_SMALL_ROWS}
+    x[1999] *= 3.0                                       # rms 0.09: inside
+    hip.linear_f32_split(x, pk, None, x3_slot=17)
+    assert hip.split2_range_words() == {}
+    # ragged M: the rows behind M are copies of the last row, never a verdict of their own
+    hip.linear_f32_split(x[:1000], pk, None)
+    assert hip.split2_range_words() == {}
+    xc = torch.randn(4, 64, 32, 32, device=DEV).contiguous(memory_format=torch.channels_last)
+    pkc = hip.pack_conv_weight_f16x2(torch.randn(128, 64, 3, 3, device=DEV) * (9 * 64) ** -0.5)
+    hip.conv3x3_f32_split(xc, pkc, None, x3_slot=5)      # corner pixels see 4 of 9 taps: rms 2/3, still inside
+    assert hip.split2_range_words() == {}
+    xc[2, :, 10:20, 10:20] *= 0.01                       # a patch of tiny pixels in one image
+    hip.conv3x3_f32_split(xc, pkc, None, x3_slot=5)
+    assert hip.split2_range_words() == {5: hip.X3_SMALL_ROWS}
 
 
 @pytest.mark.parametrize("n,cin,cout,hw,gelu", [(4, 256, 256, 64, False), (6, 256, 256, 32, True), (3, 96, 128, 16, False)])
@@ -178,20 +211,23 @@ def test_conv3x3_groupnorm_three_products_matches_six(hip):
     assert e3 <= 1.3 * e6 + 4e-7 and e6 <= 3e-6, (e3, e6)
 
 
-def test_overflow_raises_the_sticky_flag(hip):
+def test_overflow_raises_the_nonfinite_bit(hip):
     torch.manual_seed(3)
     x, w = torch.randn(512, 64, device=DEV), torch.randn(128, 64, device=DEV)
     pk = hip.pack_weight_f16x2(w)
     hip.linear_f32_split(x, pk, None)
     assert not hip.split2_nonfinite()
     x[17, 5] = 7.0e4                                   # beyond fp16: h = inf
-    out = hip.linear_f32_split(x, pk, None)
+    out = hip.linear_f32_split(x, pk, None, x3_slot=3)
     assert not torch.isfinite(out[17]).all()
-    assert hip.split2_nonfinite(reset=False) and hip.split2_nonfinite() and not hip.split2_nonfinite()
+    assert hip.split2_range_words(reset=False) == {3: hip.X3_NONFINITE} and hip.split2_nonfinite() and not hip.split2_nonfinite()
     x[17, 5] = 6.5e4                                   # the largest binade still works
     out = hip.linear_f32_split(x, pk, None)
     assert torch.isfinite(out).all() and not hip.split2_nonfinite()
-    # flags are per stream: an overflow on a side stream is not consumed by (and does not leak into) the current one
+    x[17, 5] = float("nan")                            # non-finite input: same bit (the A side is judged by its own row sums)
+    hip.linear_f32_split(x, pk, None)
+    assert hip.split2_range_words() == {0: hip.X3_NONFINITE}
+    # words are per stream: an overflow on a side stream is not consumed by (and does not leak into) the current one
     x[17, 5] = 7.0e4
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -202,25 +238,33 @@ def test_overflow_raises_the_sticky_flag(hip):
     assert not hip.split2_nonfinite()
     with torch.cuda.stream(side):
         assert hip.split2_nonfinite() and not hip.split2_nonfinite()
-    # C ABI with nonfinite_flag = NULL: the library's own flag
+    # C ABI with range_flag = NULL: the library's own word
     import ctypes
     out = torch.empty(512, 128, device=DEV)
     lib = hip.load()
     args = (x.data_ptr(), pk.data_ptr(), None, None, None, out.data_ptr(), 512, 128, 64, 0, None, None)
     assert lib.gdrnpp_linear_f32_split2(*args) == 0
     f = ctypes.c_int(0)
-    assert lib.gdrnpp_split2_nonfinite(ctypes.byref(f), 1, None) == 0 and f.value == 1
-    assert lib.gdrnpp_split2_nonfinite(ctypes.byref(f), 1, None) == 0 and f.value == 0
+    assert lib.gdrnpp_split2_range_word(ctypes.byref(f), 1, None) == 0 and f.value == hip.X3_NONFINITE
+    assert lib.gdrnpp_split2_range_word(ctypes.byref(f), 1, None) == 0 and f.value == 0
+    x[17] = 1e-3
+    x[17, 5] = 1e-3
+    assert lib.gdrnpp_linear_f32_split2(*args) == 0
+    assert lib.gdrnpp_split2_range_word(ctypes.byref(f), 1, None) == 0 and f.value == hip.X3_SMALL_ROWS
 
 
 @pytest.fixture()
 def three_products(hip):
-    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine, hip_layers
+    old_products, old_tiles = hip_layers.gemm_products(), hip.SPLIT2_MIN_TILES
     hip_layers.set_gemm_products(3)
-    old = hip.SPLIT2_MIN_TILES
+    hip_layers.reset_x3_demotions()
+    engine._X3_OVERFLOW_STEPS = 0
     yield hip_layers
-    hip_layers.set_gemm_products(6)
-    hip.SPLIT2_MIN_TILES = old
+    hip_layers.set_gemm_products(old_products)          # what the session ran before (the library default: 3)
+    hip.SPLIT2_MIN_TILES = old_tiles
+    hip_layers.reset_x3_demotions()
+    engine._X3_OVERFLOW_STEPS = 0
 
 
 @pytest.mark.parametrize("ds", ["ycbv", "ycbvso"])
@@ -244,7 +288,8 @@ def test_network_with_three_products_matches_reference_forward(hip, three_produc
     kinds = [r[0] for r in timer.records]
     assert sum(k == "linear" + hip.X3 for k in kinds) == 72 and sum(k == "conv3x3" + hip.X3 for k in kinds) >= 5
     assert sum(k == "conv" + hip.X3 for k in kinds) >= 4           # the three downsamples + Patch-PnP's strided convolutions
-    assert sum(k == "deconv" + hip.X3 for k in kinds) == 1 and not hip.split2_nonfinite()
+    words = hip.split2_range_words()
+    assert sum(k == "deconv" + hip.X3 for k in kinds) == 1 and words == {}, f"range words {words}"
 
     def err(a, ref, scale=None):
         a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
@@ -257,65 +302,119 @@ def test_network_with_three_products_matches_reference_forward(hip, three_produc
     assert np.abs(out["trans"] - fx["trans"]).max() <= 1e-4 * max(1.0, np.abs(fx["trans"]).max())
 
 
-def test_headline_batch_three_vs_six_products_and_retry(hip, three_products):
-    """128 ROIs (the shapes bench.py times): maps / poses of the two modes agree far inside the 1e-4 tolerance; with an fc1 bias that
-    pushes the hidden tensor beyond the fp16 range the flag rises and engine.inference_step returns the six-product result."""
+def _headline_model_and_batch(hip, seed=7):
     from gdrnpp_bop2022_amd import synthetic as S
     from gdrnpp_bop2022_amd.gdrn_modeling import engine
     from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
     from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
 
-    hip_layers = three_products
     cfg = get_cfg("ycbv_convnext_a6", opts=["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"])
     model, _ = build_model_optimizer(cfg)
     sd = model.state_dict()
-    model.load_state_dict(S.seeded_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], 7), strict=True)
+    model.load_state_dict(S.seeded_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], seed), strict=True)
     b = 128
     x = torch.from_numpy(NG.net_image(b)).cuda()
     det = NG.net_detections(21, b)
     fx = dict(roi_cls=det["roi_cls"], roi_cam=det["roi_cam"], roi_wh=det["roi_wh"], roi_center=det["roi_center"],
               resize_ratio=det["resize_ratio"], scale=det["scale"], roi_extent=det["roi_extent"])
     kw = NG.forward_kwargs(fx, "cuda")
+    # records straight from the network pose (no refine, no PnP)
+    post = engine.GdrnHipPost(get_cfg("ycbv_convnext_a6"))
+    batch = dict(roi_img=x, roi_cls=kw["roi_classes"], roi_cam=kw["roi_cams"], roi_wh=kw["roi_whs"], roi_center=kw["roi_centers"],
+                 resize_ratio=kw["resize_ratios"], roi_coord_2d=kw["roi_coord_2d"], roi_extent=kw["roi_extents"])
+    return model, post, batch, x, kw
+
+
+def _six(hip_layers, fn):
+    with hip_layers.forced_gemm_products(6):
+        return fn()
+
+
+def test_headline_batch_three_vs_six_products_and_overflow_retry(hip, three_products):
+    """128 ROIs (the shapes bench.py times): maps / poses of the two modes agree far inside the 1e-4 tolerance and no layer leaves
+    the range; with an fc1 bias that pushes the hidden tensor beyond the fp16 range the consuming fc2 raises NONFINITE,
+    engine.inference_step returns the six-product result and from then on runs THAT layer on six products (no second repeat)."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+
+    hip_layers = three_products
+    model, post, batch, x, kw = _headline_model_and_batch(hip)
     with torch.no_grad():
         o3 = model(x, **kw)
-        assert not hip.split2_nonfinite()
-        hip_layers.set_gemm_products(6)
-        o6 = model(x, **kw)
-        hip_layers.set_gemm_products(3)
+        assert hip.split2_range_words() == {}, "a layer of the seeded headline model left the three-product range"
+        o6 = _six(hip_layers, lambda: model(x, **kw))
     for k in ("mask", "full_mask", "coor_x", "coor_y", "coor_z", "region"):
         a, r = o3[k].float(), o6[k].float()
         assert ((a - r).abs().max() / r.abs().max()).item() <= 2e-5, k
     assert (o3["rot"] - o6["rot"]).abs().max().item() <= 1e-4          # north_star tolerance
     assert (o3["trans"] - o6["trans"]).abs().max().item() <= 1e-4 * max(1.0, o6["trans"].abs().max().item())
 
-    # overflow -> flag -> retry (records straight from the network pose: no refine, no PnP)
-    post = engine.GdrnHipPost(get_cfg("ycbv_convnext_a6"))
-    batch = dict(roi_img=x, roi_cls=kw["roi_classes"], roi_cam=kw["roi_cams"], roi_wh=kw["roi_whs"], roi_center=kw["roi_centers"],
-                 resize_ratio=kw["resize_ratios"], roi_coord_2d=kw["roi_coord_2d"], roi_extent=kw["roi_extents"])
     with torch.no_grad():
         model.backbone.stages_2.blocks[5].mlp.fc1.bias[7] = 9.0e4      # GELU(9e4) = 9e4 > 65504 in the fc2 input
-        hip_layers.set_gemm_products(6)
-        want = engine.inference_step(model, post, batch)
-        hip_layers.set_gemm_products(3)
+        want = _six(hip_layers, lambda: engine.inference_step(model, post, batch))
         model(x, **kw)
-        assert hip.split2_nonfinite(reset=True)          # the plain forward trips the flag ...
+        words = hip.split2_range_words()
+        assert words and all(w_ & hip.X3_NONFINITE for w_ in words.values())     # the plain forward trips the word ...
+        reruns = engine.range_reruns()
         got = engine.inference_step(model, post, batch)  # ... and the step repeats itself with six products
-    assert hip_layers.gemm_products() == 3 and not hip.split2_nonfinite()
+    assert hip_layers.gemm_products() == 3 and hip.split2_range_words() == {} and engine.range_reruns() == reruns + 1
     assert torch.isfinite(got).all() and torch.equal(got, want)
-    # a model that overflows on every batch is not paid for twice for ever: after the third such step the process stays on six
-    with torch.no_grad(), pytest.warns(UserWarning, match="staying on the six-product"):
-        for _ in range(engine.X3_OVERFLOW_STEPS_TO_GIVE_UP - engine._X3_OVERFLOW_STEPS):
-            got = engine.inference_step(model, post, batch)
-    assert hip_layers.gemm_products() == 6 and torch.equal(got, want)
+    assert list(hip_layers.x3_demoted()) == [min(words)] and engine._X3_OVERFLOW_STEPS == 1     # the first layer that saw the inf
+    with torch.no_grad():
+        again = engine.inference_step(model, post, batch)               # that fc2 now runs on six products: nothing to repeat
+    assert engine.range_reruns() == reruns + 1 and torch.isfinite(again).all()
+    assert (again[:, :12] - want[:, :12]).abs().max().item() <= 1e-3     # (a 9e4 outlier in front of a LayerNorm: sane, not parity)
+    # the same through a captured hipGraph built from scratch: the eager warm-up step trips, demotes, and the capture holds the mix
+    hip_layers.reset_x3_demotions()
     engine._X3_OVERFLOW_STEPS = 0
-    # the same through a captured hipGraph: the graph owns its flag and checks it after every replay
-    hip_layers.set_gemm_products(3)
     with torch.no_grad():
         g = engine.GraphedInference(model, post, batch, warmup=1)
-        assert g.uses_x3 and engine._X3_OVERFLOW_STEPS == 1       # (the eager warm-up step overflowed and repeated itself)
+        assert g.uses_x3 and g.captures == 1 and len(hip_layers.x3_demoted()) == 1
         got = g.replay()
-    assert torch.equal(got, want) and engine._X3_OVERFLOW_STEPS == 2 and hip_layers.gemm_products() == 3
-    engine._X3_OVERFLOW_STEPS = 0
+    assert g.captures == 1 and engine.range_reruns() == reruns + 2 and torch.isfinite(got).all()
+    assert (got[:, :12] - want[:, :12]).abs().max().item() <= 1e-3
+
+
+def test_third_batch_leaves_the_range_on_the_small_side(hip, three_products):
+    """Batches 1 and 2 are healthy; before batch 3 ONE layer's input shrinks to the 1e-3 scale (its LayerNorm affine is scaled in
+    place — no load_state_dict, nothing that resets anything): the launch reports SMALL_ROWS, the step's records are bit-equal to
+    the six-product mode, the layer stays on six products afterwards; the same under GraphedInference, which captures again."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+
+    hip_layers = three_products
+    model, post, batch, x, kw = _headline_model_and_batch(hip, seed=11)
+    blk = model.backbone.stages_2.blocks[9]
+    with torch.no_grad():
+        reruns = engine.range_reruns()
+        for _ in range(2):
+            rec = engine.inference_step(model, post, batch)
+        assert engine.range_reruns() == reruns and hip_layers.x3_demoted() == {} and torch.isfinite(rec).all()
+        g = engine.GraphedInference(model, post, batch, warmup=1)
+        assert g.uses_x3 and g.captures == 1 and torch.equal(g.replay(), rec)
+        blk.norm.weight.mul_(1e-3)
+        blk.norm.bias.mul_(1e-3)
+        want = _six(hip_layers, lambda: engine.inference_step(model, post, batch))
+        got = engine.inference_step(model, post, batch)
+        assert engine.range_reruns() == reruns + 1 and torch.equal(got, want)
+        demoted = hip_layers.x3_demoted()      # the block's fc1 (and its fc2 when GELU(bias) is as small: seeded biases are 0.1 u)
+        assert 1 <= len(demoted) <= 2 and set(demoted.values()) == {hip.X3_SMALL_ROWS}
+        again = engine.inference_step(model, post, batch)
+        assert engine.range_reruns() == reruns + 1 and (again[:, :12] - want[:, :12]).abs().max().item() <= 1e-4
+        # the graph was captured before the change and still holds the layer's three-product kernel: it sees the demotion and
+        # captures again before replaying
+        got_g = g.replay()
+        assert g.captures == 2 and torch.equal(got_g, again) and engine.range_reruns() == reruns + 1
+        # ... and a graph whose own replay trips: forget the demotion, capture afresh with healthy weights, shrink, replay
+        blk.norm.weight.mul_(1e3)
+        blk.norm.bias.mul_(1e3)
+        hip_layers.reset_x3_demotions()
+        g2 = engine.GraphedInference(model, post, batch, warmup=1)
+        assert g2.captures == 1 and hip_layers.x3_demoted() == {}
+        blk.norm.weight.mul_(1e-3)
+        blk.norm.bias.mul_(1e-3)
+        got_g2 = g2.replay()
+        assert g2.captures == 2 and engine.range_reruns() == reruns + 2 and len(hip_layers.x3_demoted()) == len(demoted)
+        assert torch.equal(got_g2, want)
+        assert torch.equal(g2.replay(), again) and g2.captures == 2
 
 
 def test_inference_step_needs_no_outer_no_grad(hip):
@@ -342,9 +441,10 @@ def test_inference_step_needs_no_outer_no_grad(hip):
     assert sum(r[0] in ("linear", "linear_splitk", "linear_x3") for r in timer.records) == 74
 
 
-def test_small_scale_layer_input_keeps_that_layer_on_six_products(hip, three_products):
-    """The silent side of the fp16x2 range (operands below ~2^-4) is handled per layer: the first calls look at the A operand and a
-    layer fed with a tiny-scale tensor stays on the six-product kernels; its result is then as exact as ever."""
+def test_small_scale_layer_input_moves_that_layer_to_six_products(hip, three_products):
+    """The small side of the fp16x2 range is handled per layer and per launch: a layer fed with a tiny-scale tensor reports it, the
+    work is repeated with six products (as exact as ever) and the layer stays there; its healthy sibling keeps three products."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
     from gdrnpp_bop2022_amd.gdrn_modeling.backbones import Mlp
 
     hip_layers = three_products
@@ -352,28 +452,34 @@ def test_small_scale_layer_input_keeps_that_layer_on_six_products(hip, three_pro
     torch.manual_seed(21)
     c = 128
     mlp = Mlp(c, 4 * c).cuda().eval()
+    with torch.no_grad():
+        mlp.fc1.bias.add_(1.0)            # the hidden tensor (fc2's input) stays at scale ~1 whatever fc1's input is
     gamma = torch.randn(c, device=DEV)
     x = torch.randn(4, 32, 32, c, device=DEV)
     sc = torch.randn(4, 32, 32, c, device=DEV)
+    cache = {}
 
-    def run(inp, cache):
+    def run(inp):
         timer = hip.LaunchTimer()
         hip.set_launch_timer(timer)
         try:
             with torch.no_grad():
-                y = hip_layers.convnext_mlp(mlp, gamma, inp, sc, cache)
+                y = engine.run_with_range_check(lambda: hip_layers.convnext_mlp(mlp, gamma, inp, sc, cache))
         finally:
             hip.set_launch_timer(None)
         return y, [r[0] for r in timer.records]
 
-    hip_layers.reset_x3_calibration()
-    y, kinds = run(x, {})
-    assert kinds == ["linear" + hip.X3] * 2
+    y, kinds = run(x)
+    assert kinds == ["linear" + hip.X3] * 2 and hip_layers.x3_demoted() == {}
     tiny = x * 1e-3
-    y_t, kinds = run(tiny, {})
-    assert len(kinds) == 2 and all(k in ("linear", "linear_splitk") for k in kinds)      # six-product kernels (plain or split-K)
+    y_t, kinds = run(tiny)
+    assert kinds[:2] == ["linear" + hip.X3] * 2 and len(kinds) == 4 and all(k in ("linear", "linear_splitk") for k in kinds[2:])
     with torch.no_grad():
         want = sc.double() + gamma.double() * mlp.double()(tiny.double())
         mlp.float()
     assert ((y_t.double() - want).abs().max() / want.abs().max()).item() < 5e-7
-    assert not hip.split2_nonfinite()
+    assert list(hip_layers.x3_demoted().values()) == [hip.X3_SMALL_ROWS]
+    y_t2, kinds = run(tiny)               # fc1 on six products, fc2 still on three; nothing to repeat
+    assert len(kinds) == 2 and kinds[0] in ("linear", "linear_splitk") and kinds[1] == "linear" + hip.X3
+    assert ((y_t2.double() - want).abs().max() / want.abs().max()).item() < 2e-6
+    assert hip.split2_range_words() == {}

@@ -285,3 +285,32 @@ def test_resnet34_pytorch_graph_reproduces_reference_outputs(resnet_case):
         hip_layers.set_enabled(True)
         torch.set_grad_enabled(True)
     check_resnet34_outputs(fx, {k: v.numpy() for k, v in maps.items()}, rot6.numpy(), t3.numpy(), 2e-5, 5e-5)
+
+
+# ---- the benchmark-size fixtures (128 ROIs, every class): CPU check of a few of their ROIs ----------------------------------
+@pytest.mark.parametrize("ds", ["ycbv", "tless"])
+def test_b128_fixture_rois_match_the_cpu_graph(ds):
+    """net_golden_<ds>_b128.npz holds GDRN_DoubleMask.forward of the reference at 128 ROIs (all of them compared on the GPU,
+    tests/test_gpu_net_golden.py).  Here: the fixture is what it claims — five of its ROIs (first, last, three in between) through
+    this repo's plain-PyTorch graph on the same seeded parameters reproduce the recorded rows (eval mode: a ROI's outputs do not
+    depend on its batch), every class of the dataset occurs, and roi_cls is the i mod C pattern the generator documents."""
+    fx = NG.load_fixture(ds + "_b128")
+    C = fx["cfg"]["MODEL"]["POSE_NET"]["NUM_CLASSES"]
+    assert fx["rot"].shape == (128, 3, 3) and np.array_equal(fx["roi_cls"], np.arange(128) % C)
+    cfg = get_cfg(NG.cfg_name(ds), opts=["TEST.USE_DEPTH_REFINE=True", "MODEL.DEVICE=cpu"])
+    model, _ = build_model_optimizer(cfg)
+    model.load_state_dict(NG.seeded_reference_state_dict(model, fx), strict=True)
+    sel = np.array([0, 37, 64, 90, 127])
+    x = torch.from_numpy(NG.net_image(128)[sel])
+    kw = {k: v[torch.from_numpy(sel)] for k, v in NG.forward_kwargs(fx, "cpu").items()}
+    hip_layers.set_enabled(False)
+    try:
+        with torch.no_grad():
+            rot6, t3, maps = model.forward_maps(x, kw["roi_classes"], kw["roi_coord_2d"], None, kw["roi_extents"])
+    finally:
+        hip_layers.set_enabled(True)
+    for k in ("mask", "full_mask", "coor_x", "coor_y", "coor_z"):
+        _close(maps[k].numpy()[:, :, ::4, 1::4], fx[k + "_sub"][sel], 2e-5, scale=float(fx[k + "_absmax"]))
+    _close(maps["region"].numpy()[:, :, 5::16, 9::16], fx["region_sub"][sel], 2e-5, scale=float(fx["region_absmax"]))
+    _close(rot6.numpy(), fx["pred_rot_"][sel], 5e-5, scale=float(np.abs(fx["pred_rot_"]).max()))
+    _close(t3.numpy(), fx["pred_t_"][sel], 5e-5, scale=float(np.abs(fx["pred_t_"]).max()))
