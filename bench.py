@@ -5,7 +5,8 @@ One "step" = one call of the product entry point ``engine.inference_step`` on on
 resident in HBM (+ the one collective of the path when N > 1):
     GDRN_Net forward (ConvNeXt-B + geometry head + Patch-PnP, fp32)  ->  K_crop  ->  fast depth refine
     (render + compare, 2 iterations, HIP)  ->  pose records  ->  (N>1) one RCCL all-gather of the f32[n,16] records.
-Two distinct batches per model alternate step by step.  Timing = the reference's protocol (gdrn_evaluator.py:697-706,
+Two distinct batches per model alternate step by step; a step's records are resolved (range check of the three-product GEMM
+kernels, engine.StepHandle) after the NEXT step has been launched, all of them inside the timed region.  Timing = the reference's protocol (gdrn_evaluator.py:697-706,
 748-750): host perf_counter, device synchronised (and ranks barriered) on both sides, warm-up steps discarded, MAX over ranks.
 
 Workloads (``--workload``; index into BASELINE.json ``configs``):
@@ -14,6 +15,8 @@ Workloads (``--workload``; index into BASELINE.json ``configs``):
   rgb                      configs[1]  YCB-V convnext_a6, 64 ROIs, RGB-only Patch-PnP
   lmo_upnp                 configs[0]  LM-O ape, 32 ROIs, ResNet-34 forward + uncertainty-PnP (9 keypoints per ROI, HIP LM)
   bop7                     configs[4]  BOP-7 mixed stream (lmo/ycbv/tless/icbin/hb/itodd/tudl models cycled per step) + refine
+  stream                   (configs[2] fed the reference's way) a stream of 480x640 images with 3-30 detections each, packed by
+                           engine.RoiStreamScheduler into steps of exactly 128 ROIs, GPU crop inside the step: ROIs/s AND images/s
 
 Multi-GPU: ``python bench.py --gpus N`` spawns N ranks by itself (one process per GPU, RCCL); under
 ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` it joins the launcher's ranks instead.
@@ -66,6 +69,9 @@ WORKLOADS = {  # name -> (index into BASELINE.json configs, cfg names, ROIs per 
     "bop7": (4, [f"{d}_convnext_a6" for d in ("lmo", "ycbv", "tless", "icbin", "hb", "itodd", "tudl")], 128, True,
              "BOP-7 mixed stream (lmo/ycbv/tless/icbin/hb/itodd/tudl convnext_a6 models cycled per step) + fast depth refine"),
     # not a BASELINE.json config (index None): the class-agnostic head of the reference's single-object config families
+    # not a BASELINE.json config of its own: configs[2]'s model fed by an image stream through the ROI packer
+    "stream": (None, ["ycbv_convnext_a6"], 128, True,
+               "YCB-V convnext_a6 + fast depth refine on a stream of 480x640 images (3-30 detections each) packed into 128-ROI steps, GPU crop in the step"),
     "ycbv_so": (None, ["ycbv_convnext_so"], 128, True,
                 "YCB-V single-object convnext (configs/gdrn/ycbvSO/*, class-agnostic head) + fast depth refine"),
 }
@@ -197,18 +203,25 @@ def worker(args):
         state = build_state(args, cfg_names, refine, wname, b, rank, dev, lo)
         step = state["step"]
 
-    def run_step(i):
-        return gather_records(step(i), b)
+    launch = state["launch"] if state is not None else (lambda i: (lambda: step(i)))
 
-    for i in range(max(args.warmup, 1) * len(cfg_names) * 2):   # MIOpen find, weight packing, both batches of every model
-        run_step(i)
+    def run_steps(n):
+        """n steps, each resolved (range check + gather) after the next one has been launched."""
+        rec, prev = None, None
+        for i in range(n):
+            cur = launch(i)
+            if prev is not None:
+                rec = gather_records(prev(), b)
+            prev = cur
+        return gather_records(prev(), b)
+
+    run_steps(max(args.warmup, 1) * len(cfg_names) * 2)   # MIOpen find, weight packing, first range verdicts, both batches of every model
     sync()
     if world > 1:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        rec = run_step(i)
+    rec = run_steps(args.steps)
     sync()
     if world > 1:
         dist.barrier()
@@ -221,7 +234,10 @@ def worker(args):
 
     # the gathered block holds every ROI id of the iteration exactly once, on every rank
     ids = rec[:, 14][rec[:, 15] > 0.5].to(torch.int64).cpu().numpy()
-    assert len(ids) == n_global and np.array_equal(np.sort(ids), np.arange(n_global)), "gathered records: ROI ids not a permutation"
+    if wname == "stream":     # stream ids keep counting: the last step holds n_global distinct consecutive ids per rank block
+        assert len(ids) == n_global and len(set(ids.tolist())) == n_global, "gathered records: ROI ids not distinct"
+    else:
+        assert len(ids) == n_global and np.array_equal(np.sort(ids), np.arange(n_global)), "gathered records: ROI ids not a permutation"
 
     gather_ms = None
     if world > 1:                                           # the collective alone, after the timed region
@@ -250,7 +266,11 @@ def worker(args):
         line = {
             "metric": metric, "value": n_global * args.steps / dt, "unit": "ROIs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32",   # fp32 in, fp32 accumulate, fp32 out; operand splits: config.gemm_products
+            "vs_baseline": None, "dtype": "f32",   # fp32 in, fp32 accumulate, fp32 out; how the operands enter the matrix cores:
+            "arithmetic": (("fp16x2 operand split (22 bits) on the fp16 matrix cores, fp32 accumulate; range checked per launch on both sides, "
+                            "out-of-range layers repeated / kept on the exact bf16x3 form" if args.gemm_products == 3 else
+                            "bf16x3 exact operand split (six partial products) on the bf16 matrix cores, fp32 accumulate")
+                           if args.mlp_gemm == "split" else "fp32 vendor kernels (hipBLASLt / MIOpen)"),
             "data": "synthetic (seeded ROIs sorted by class within the rank, two alternating batches per model, ellipsoid meshes "
                     "2562V/5120F, " + ("PyTorch default-init weights" if args.random_init else
                                         "seeded O(1) parameters = synthetic.seeded_state_dict, the parity tests' set") +
@@ -258,7 +278,7 @@ def worker(args):
             "config": {
                 "workload": f"{label}, batch={b} ROIs/GPU" + (f", {n_global} ROIs per iteration over {world} ranks" if world > 1 else ""),
                 "baseline_config_index": cfg_no, "workload_key": wname, "global_batch": n_global, "rois_per_gpu": b,
-                "roi_prep_on_gpu": bool(args.with_crop), "hipgraph": bool(args.graph), "input_res": 256, "output_res": 64,
+                "roi_prep_on_gpu": bool(args.with_crop) or wname == "stream", "hipgraph": bool(args.graph), "input_res": 256, "output_res": 64,
                 "parallelism": f"roi-shard x{world}", "collective": "all_gather f32[n,16] pose records" if world > 1 else None,
                 "class_sliced_out_layer": not args.exact_reference_order, "rois_class_sorted_within_rank": True,
                 "parameters": "default-init" if args.random_init else "seeded O(1)", "hip_network_layers": not args.no_hip_layers,
@@ -267,14 +287,19 @@ def worker(args):
                                   "(22 significant bits), three partial products; measured error against fp64 = that of the six-product "
                                   "bf16x3 form and below hipBLASLt's fp32 GEMM on the same operands, network outputs at the same distance "
                                   "from the reference's recorded forward (profiles/r03y_split2_accuracy.txt, tests/test_gpu_split2.py); "
-                                  "fp16-range overflow detected per step and repeated with six products; six_product_mode = the same "
-                                  "steps with the exact form" if args.gemm_products == 3 else
+                                  "both sides of the fp16x2 range checked on the device by every launch (range word per layer), a flagged step is "
+                                  "repeated with six products and the layer kept there; six_product_mode = the same steps with the exact form"
+                                  if args.gemm_products == 3 else
                                   "fp32 operands split exactly into three bf16 values, six partial products, fp32 accumulation (exact to 2^-26)"),
-                "library_options": args.opt, "timed_entry_point": "engine.inference_step + engine.gather_records",
+                "library_options": args.opt,
+                "timed_entry_point": ("engine.RoiStreamScheduler.launch_next (GPU crop + inference_step_async) + engine.gather_records"
+                                      if wname == "stream" else "engine.inference_step_async / StepHandle.result + engine.gather_records"),
                 "stub_step": bool(args.stub_step)},
             "gather_ms": gather_ms,
         }
         line.update(extras)
+        if "stream" in line:
+            line["stream"]["images_per_s"] = line["value"] / line["stream"]["rois_per_image_mean"]
         line.setdefault("roofline", None)
         line.setdefault("cpu_baseline", None)
         print(json.dumps(line), flush=True)
@@ -287,7 +312,8 @@ def worker(args):
 def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
     from gdrnpp_bop2022_amd import hip_lib
     from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
-    from gdrnpp_bop2022_amd.gdrn_modeling.engine import GdrnHipPost, GraphedInference, inference_step
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine as E
+    from gdrnpp_bop2022_amd.gdrn_modeling.engine import GdrnHipPost, GraphedInference, inference_step, inference_step_async
     from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
 
     hip_lib.load()
@@ -365,6 +391,28 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         models.append(dict(cfg=cfg, model=model, post=post, batches=[p[0] for p in pair], dets=[p[1] for p in pair],
                            K_crops=[p[2] for p in pair], meshes=meshes, verts=verts, faces=faces, C=C, graphs={}))
 
+    stream = None
+    if wname == "stream":
+        # the reference's feed: one image at a time (data_loader.py:901, batch_size = 1), 3-30 detections each.  64 distinct images
+        # + detections resident in HBM, cycled; every pushed image gets a fresh key, ROI ids keep counting (per-rank id block).
+        import itertools
+        m0 = models[0]
+        rng = np.random.default_rng(20220925 + 17 + rank)
+        g = torch.Generator(device=dev).manual_seed(20220925 + rank)
+        pool = []
+        for _ in range(64):
+            n = int(rng.integers(3, 31))
+            det = S.make_detections(n, m0["C"], ext, rng)
+            x1y1 = det["roi_center"] - det["roi_wh"] / 2
+            pool.append((torch.randint(0, 256, (S.IM_H, S.IM_W, 3), dtype=torch.uint8, device=dev, generator=g),
+                         torch.rand((S.IM_H, S.IM_W), device=dev, generator=g) + 0.3,
+                         dict(bbox=np.concatenate([x1y1, x1y1 + det["roi_wh"]], 1).astype(np.float32), roi_cls=det["roi_cls"],
+                              score=det["score"], cam=S.YCBV_K.astype(np.float32), extents=ext)))
+        counter = itertools.count()
+        feeder = ((next(counter), im, dp, dt_) for im, dp, dt_ in itertools.cycle(pool))
+        sched = E.RoiStreamScheduler(m0["cfg"], m0["model"], m0["post"], rois_per_step=b, roi_id_base=lo)
+        stream = dict(sched=sched, feeder=feeder, counter=counter, rois_per_image=float(np.mean([len(p[2]["roi_cls"]) for p in pool])))
+
     upnp = None
     if wname == "lmo_upnp":   # PVNet-style pose of config 1: 8 FPS keypoints + centre, noisy projections, cov^-1/2 weights
         m0 = models[0]
@@ -393,45 +441,72 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         return dict(bt, roi_img=roi_img, roi_coord_2d=roi_c2d)
 
     @torch.no_grad()
-    def step(i):
+    def launch(i):
+        """Launch step i, return the callable that resolves it (-> records f32[b,16])."""
         m = models[i % len(models)]
         k = (i // len(models)) % 2
+        if stream is not None:
+            return stream["sched"].launch_next(stream["feeder"])
         if args.graph and not args.with_crop and upnp is None:
             if k not in m["graphs"]:
                 m["graphs"][k] = GraphedInference(m["model"], m["post"], m["batches"][k], m["batches"][k]["roi_id"])
-            return m["graphs"][k].replay()   # inputs already live in the graph's static buffers (resident in HBM)
-        rec = inference_step(m["model"], m["post"], prepared(m, k))     # records carry batch["roi_id"]
-        if upnp is not None:
+            rec = m["graphs"][k].replay()   # inputs already live in the graph's static buffers (resident in HBM)
+            return lambda: rec
+        h = inference_step_async(m["model"], m["post"], prepared(m, k))     # records carry batch["roi_id"]
+        if upnp is None:
+            return h.result
+
+        def resolve():
+            rec = h.result()
             u = upnp[k]
             rt = hip_lib.uncertainty_pnp_batched(u["p2"], u["p3"], u["w"], u["K"], u["init"])
             rec[:, 9:12] = rt[:, 3:6].float()   # the PVNet-style pose replaces the direct translation in the records
-        return rec
+            return rec
+        return resolve
+
+    def step(i):
+        return launch(i)()
+
+    def run_pipelined(n):
+        prev = None
+        for i in range(n):
+            cur = launch(i)
+            if prev is not None:
+                prev()
+            prev = cur
+        return prev()
 
     def other_mode_line(products, steps, n_rois, sync):
         try:
             hip_layers.set_gemm_products(products)
-            hip_lib.split2_nonfinite(reset=True)
-            for i in range(2 * len(models) * 2):
-                step(i)
+            hip_lib.split2_range_words(reset=True)
+            reruns0 = E.range_reruns()
+            run_pipelined(max(args.warmup, 3) * len(models) * 2)      # the same warm-up as the headline's
             sync()
             t0 = time.perf_counter()
-            for i in range(steps):
-                step(i)
+            run_pipelined(steps)
             sync()
             dt = time.perf_counter() - t0
             return {"gemm_products": products, "value": n_rois * steps / dt, "unit": "ROIs/s", "ms_per_step": dt / steps * 1e3,
-                    "steps": steps, "nonfinite_flag_after": bool(hip_lib.split2_nonfinite(reset=True)),
+                    "steps": steps, "range_reruns": E.range_reruns() - reruns0,
                     "note": ("hip_layers.set_gemm_products(6): every split GEMM on the six-product bf16x3 kernels (exact to 2^-26)"
                              if products == 6 else
                              "hip_layers.set_gemm_products(3): ConvNeXt MLPs / 3x3 convolutions / deconv GEMM on the fp16x2 three-product "
-                             "kernels; the per-step overflow check (4-byte read-back + sync) is inside the timing")}
+                             "kernels; the per-step range check is inside the timing")}
         except Exception as e:  # the headline line must not depend on the extra measurement
             return {"gemm_products": products, "error": repr(e)}
         finally:
             hip_layers.set_gemm_products(args.gemm_products)
 
     def measure_after(do_cpu):
-        out = {}
+        out = {"range_check": {"steps_repeated_with_six_products": E.range_reruns(),
+                               "layers_kept_on_six_products": len(hip_layers.x3_demoted()),
+                               "note": "whole process (warm-up included): a layer whose A rows sat below 2^-4 rms or that overflowed "
+                                       "the fp16 range is repeated once and then stays on the bf16x3 kernels"}}
+        if stream is not None:
+            out["stream"] = {"images_per_s": None, "rois_per_image_mean": stream["rois_per_image"],
+                             "images_pushed": next(stream["counter"]), "rois_per_step": b,
+                             "note": "value / rois_per_image_mean = images per second; ROI-granular packing, an image's ROIs may straddle two steps"}
         m = models[0]
         bt, det, K_crop, cfg = m["batches"][0], m["dets"][0], m["K_crops"][0], m["cfg"]
 
@@ -474,10 +549,19 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                 rs = [r for r in hbm_records if r[0] == kind]
                 t_k = sum(r[2].elapsed_time(r[3]) for r in rs)
                 gbs = sum(r[4] for r in rs) / (t_k * 1e-3) / 1e9
-                hbm_rooflines.append(dict(kernel=kind[4:], bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
-                                          frac=gbs / HBM_PEAK_GBS, traffic=None, launch_ms=t_k / len(rs),
-                                          launches_per_step=len(rs) / args.steps, ms_per_step=t_k / args.steps,
-                                          bytes_per_launch=sum(r[4] for r in rs) / len(rs)))
+                entry = dict(kernel=kind[4:], bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=gbs / HBM_PEAK_GBS, traffic=None, launch_ms=t_k / len(rs),
+                             launches_per_step=len(rs) / args.steps, ms_per_step=t_k / args.steps,
+                             bytes_per_launch=sum(r[4] for r in rs) / len(rs))
+                if kind == "hbm:dwconv7_ln":
+                    # 49 taps x 2 flops per element on the vector ALUs (+ ~10 for the LayerNorm): the kernel is bound by its fp32 FMA
+                    # stream, not by the bytes it moves (profiles/r03_dwconv_dissection.txt) — report it against the VALU peak
+                    fl = sum(r[4] for r in rs) / 8.0 * (2.0 * 49.0 + 10.0)
+                    tf = fl / (t_k * 1e-3) / 1e12
+                    entry.update(bound="valu", achieved=tf, peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / F32_MFMA_PEAK_TFLOPS,
+                                 flops_per_launch=fl / len(rs), hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
+                                 note="fp32 vector peak 157.3 TFLOP/s (MI355X_MICROARCH.md); hbm_* = the same launches against the HBM roofline")
+                hbm_rooflines.append(entry)
             if gemm_records:
                 fl = sum(r[1] for r in gemm_records)
                 ms_all = sum(r[2].elapsed_time(r[3]) for r in gemm_records)
@@ -559,7 +643,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                 out["cpu_baseline"] = dict(value=None, error=r.stderr[-400:])
         return out
 
-    return dict(step=step, measure_after=measure_after, other_mode_line=other_mode_line)
+    return dict(step=step, launch=launch, measure_after=measure_after, other_mode_line=other_mode_line)
 
 
 if __name__ == "__main__":

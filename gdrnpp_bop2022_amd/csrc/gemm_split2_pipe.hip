@@ -128,6 +128,25 @@ struct HalfSplit2 {
   }
 };
 
+#ifdef GDRNPP2_A_DIRECT
+// Experiment (profiles/r04_a_direct.txt): the fp32 A rows of the linear form go from global memory straight to the VGPRs that
+// feed the split — no LDS round trip (the A stages are private to their wave, LDS buys them only asynchrony).  A lane loads the
+// 8 consecutive k of its MFMA operand row: two global_load_dwordx4 per half and k-tile, issued ONE k-tile ahead of the split
+// (slots 4 / 5 of k-tile kt for k-tile kt + 2), landing in the x registers the split of k-tile kt + 1 has left.  The data is
+// valid only behind wait_x<N> (s_waitcnt vmcnt with the registers tied to the statement).
+__device__ __forceinline__ void gload_x(float (&x)[8], unsigned voff, const void* sbase) {
+  f32x4v a, b;
+  asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
+               : "=&v"(a), "=&v"(b) : "v"(voff), "s"(sbase) : "memory");
+  x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3];
+  x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+}
+template <int N>
+__device__ __forceinline__ void wait_x(float (&x)[8]) {
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "n"(N) : "memory");
+}
+#endif
+
 // W f32[N][K] -> max |w| (bits of a non-negative float order like unsigned integers)
 __global__ void amax_kernel(const float* __restrict__ W, long n, unsigned* __restrict__ out) {
   float m = 0.f;
@@ -334,6 +353,16 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
   const int aslot0 = 4 * lrow0 + ((2 * fk) ^ g0), aslot1 = 4 * lrow0 + ((2 * fk + 1) ^ g0);
   const uint4* const sA = smem;
   const uint4* const sBf = smem + NA * (A_STAGE_B / 16) + fk * BN + frow;
+#ifdef GDRNPP2_A_DIRECT
+  constexpr bool ADIR = CONV == 0;     // linear form only
+  const unsigned gvoff0 = (unsigned)min(m0 + lrow0, M - 1) * (unsigned)(K * 4) + (unsigned)(fk * 32);
+  const unsigned gvoff1 = (unsigned)min(m0 + lrow0 + 32, M - 1) * (unsigned)(K * 4) + (unsigned)(fk * 32);
+  auto gload_half = [&](HalfSplit2& hs, int kt, int half) {
+    gload_x(hs.x, half ? gvoff1 : gvoff0, reinterpret_cast<const char*>(A) + (size_t)min(kt, nk - 1) * (BK * 4));
+  };
+#else
+  constexpr bool ADIR = false;
+#endif
 
   auto load_half = [&](HalfSplit2& hs, int stage, int half) {
     hs.load(sA + stage * (A_STAGE_B / 16) + half * 128, aslot0, aslot1);
@@ -344,7 +373,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
 
   // range check: per lane the sum of squares of the h halves it has multiplied (row frow / frow + 32 of the wave, k-blocks fk),
   // two accumulators per row half; -DGDRNPP2_NO_RANGE_CHECK: timing-only build without it
-  float ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] float ssq[4] = {0.f, 0.f, 0.f, 0.f};
 
   // One k-tile, NS = 6 NJ slots (slot S: product group G = S / (2 NJ) in the order h*l, l*h, h*h; row half I, column tile J).
   // cur: split A fragments of k-tile kt; nxt: receives the split of k-tile kt+1 (its raw first half is already in nxt[0].x).
@@ -367,7 +396,18 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
       // weight DMA of k-tile kt+1, then A DMA of k-tile kt+NA (the A pieces are the newest four loads at the wait)
 #ifndef GDRNPP2_TIMING_NO_DMA
       if constexpr (S % 2 == 0 && S < 2 * NBP) dma_b(kt_b, sb_wr, std::integral_constant<int, S / 2>{});
-      if constexpr (S % 2 == 0 && S >= 2 * NBP && S < 2 * NBP + 8) dma_a(kt_a, sa_wr_b, std::integral_constant<int, (S - 2 * NBP) / 2>{});
+      if constexpr (!ADIR && S % 2 == 0 && S >= 2 * NBP && S < 2 * NBP + 8) dma_a(kt_a, sa_wr_b, std::integral_constant<int, (S - 2 * NBP) / 2>{});
+#endif
+#ifdef GDRNPP2_A_DIRECT
+      if constexpr (ADIR) {
+        // raw A of k-tile kt + 2 into the x registers cur has left (its split finished in the previous k-tile); issue order
+        // per k-tile: weight pieces (slots 0, 2), then these four loads — so the waits below leave exactly the right tail:
+        if constexpr (S == 2 * NBP) gload_half(cur[0], kt + 2, 0);
+        if constexpr (S == 2 * NBP + 1) gload_half(cur[1], kt + 2, 1);
+        if constexpr (S == 3) wait_x<2 + NBP>(nxt[0].x);    // behind: nxt[1]'s two loads + this k-tile's weight pieces
+        constexpr int S1d = NJ == 4 ? 13 : 20;
+        if constexpr (S == S1d) wait_x<NBP + 4>(nxt[1].x);  // behind: weight pieces + the four loads of k-tile kt + 2
+      }
 #endif
 #ifndef GDRNPP2_TIMING_NO_BREAD   // timing-only builds (results invalid)
       if constexpr (S % 2 == 1 && S < NJ) {   // weight split h of kt
@@ -384,7 +424,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
       if constexpr (S == 12) { ssq[0] = sumsq2(cur[0].h[2], ssq[0]); ssq[1] = sumsq2(cur[0].h[3], ssq[1]); }
 #endif
       constexpr int S1 = NJ == 4 ? 13 : 20;   // first split slot of the second half (its raw read four slots earlier)
-      if constexpr (S == S1 - 4) load_half(nxt[1], sa1, 1);
+      if constexpr (!ADIR && S == S1 - 4) load_half(nxt[1], sa1, 1);
       // split of the next k-tile: first half in slots 3..10, second half in slots S1..S1+7
 #ifndef GDRNPP2_TIMING_NO_SPLIT
       if constexpr (S >= 3 && S < 11) nxt[0].template step<S - 3>();
@@ -411,26 +451,39 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
         fbL[j0 + 1] = __builtin_bit_cast(f16x8, bn[bslot(1, j0 + 1)]);
       }
 #endif
-      if constexpr (S == SB + NJ / 2 + 1) load_half(cur[0], sa2, 0);
+      if constexpr (!ADIR && S == SB + NJ / 2 + 1) load_half(cur[0], sa2, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
 
   // ---- prologue: k-tiles 0 .. 2 of A and k-tile 0 of the weights; split k-tile 0; first fragments of the loop
-  static_for<0, 4>([&](auto c) { dma_a(0, 0u, c); });
-  static_for<0, NBP>([&](auto c) { dma_b(0, 0u, c); });
-  static_for<0, 4>([&](auto c) { dma_a(min(1, nk - 1), (unsigned)A_STAGE_B, c); });
-  static_for<0, 4>([&](auto c) { dma_a(min(2, nk - 1), 2u * A_STAGE_B, c); });
-  wait_vmcnt<4>();
-  __builtin_amdgcn_s_barrier();
   HalfSplit2 f0[2], f1[2];
   f16x8 fbL[NJ], fbH[NJ];
-  load_half(f0[0], 0, 0);
-  load_half(f0[1], 0, 1);
+  if constexpr (!ADIR) {
+    static_for<0, 4>([&](auto c) { dma_a(0, 0u, c); });
+    static_for<0, NBP>([&](auto c) { dma_b(0, 0u, c); });
+    static_for<0, 4>([&](auto c) { dma_a(min(1, nk - 1), (unsigned)A_STAGE_B, c); });
+    static_for<0, 4>([&](auto c) { dma_a(min(2, nk - 1), 2u * A_STAGE_B, c); });
+    wait_vmcnt<4>();
+    __builtin_amdgcn_s_barrier();
+    load_half(f0[0], 0, 0);
+    load_half(f0[1], 0, 1);
+  } else {
+#ifdef GDRNPP2_A_DIRECT
+    static_for<0, NBP>([&](auto c) { dma_b(0, 0u, c); });
+    gload_half(f0[0], 0, 0);
+    gload_half(f0[1], 0, 1);
+    gload_half(f1[0], 1, 0);
+    gload_half(f1[1], 1, 1);
+    wait_x<4>(f0[0].x);
+    wait_x<4>(f0[1].x);
+    __builtin_amdgcn_s_barrier();
+#endif
+  }
   static_for<0, 8>([&](auto s) { f0[0].template step<decltype(s)::value>(); f0[1].template step<decltype(s)::value>(); });
 #pragma unroll
   for (int j = 0; j < NJ; ++j) fbL[j] = __builtin_bit_cast(f16x8, sBf[bslot(1, j)]);
-  load_half(f1[0], 1, 0);
+  if constexpr (!ADIR) load_half(f1[0], 1, 0);
 
   // ---- main loop, two k-tiles per trip (nk is even: K % 32 == 0)
   int sa = 0;  // kt % NA

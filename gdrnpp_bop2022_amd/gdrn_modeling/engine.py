@@ -639,13 +639,16 @@ def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, dev
     {"bbox": [n,4] xyxy, "im_idx": [n], "roi_cls": [n], "score": [n], "cam": [n,3,3] or [3,3], "extents": [C,3]}.
     Returns the batch dict ``GDRN_Net.forward`` / ``GdrnHipPost`` consume (all tensors on the device).
     ``sort_by_class``: ROIs are laid out in class order and ``batch["roi_id"]`` = ``roi_id_base`` + the
-    detection's original position, which ``inference_step`` writes into the records (``records_in_roi_order`` restores it)."""
+    detection's original position (or the caller's ``detections["roi_id"]``), which ``inference_step`` writes into the records
+    (``records_in_roi_order`` restores it)."""
     import numpy as np
 
     dev = device or images.device
     roi_id = None
     if sort_by_class:
         detections, roi_id = sort_detections_by_class(detections, roi_id_base)
+    if "roi_id" in detections:        # the caller's own ids (RoiStreamScheduler: global stream ids), permuted with the rest
+        roi_id = np.asarray(detections["roi_id"], np.int32)
     net_cfg = cfg.MODEL.POSE_NET
     n_im, H, W, _ = images.shape
     r = rois_from_detections(detections["bbox"], H, W, cfg.INPUT.DZI_PAD_SCALE, net_cfg.OUTPUT_RES)
@@ -678,3 +681,205 @@ def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, dev
         wh = torch.tensor([float(W), float(H)], dtype=torch.float64, device=dev).view(1, 2, 1, 1)
         batch["roi_coord_2d_rel"] = ((centers64.view(n, 2, 1, 1) - roi_c2d.double() * wh) / scales64.view(n, 1, 1, 1)).float()
     return batch
+
+
+# --------------------------------------------------------------------------------------------------
+# ROI packing: the reference's image loop (one image per forward, gdrn_evaluator.py:702, data_loader.py:901 batch_size=1)
+# feeds the network 3-30 ROIs at a time; the kernels of this library reach their rate from ~128 ROIs per step on.  The packer
+# sits between the two: ROIs of consecutive images are dealt into steps of EXACTLY ``rois_per_step`` (an image's ROIs may
+# straddle two steps), every ROI carries a stream-wide id into its record, and records are dealt back to their images.
+# --------------------------------------------------------------------------------------------------
+class RoiPacker:
+    """Host-side bookkeeping of the packing (no device, no tensors): which ROI of which image goes into which step, and which
+    images are complete once a step's records are back.  ROI ids wrap at 2^24 (they travel as float32 in the records)."""
+
+    ID_WRAP = 1 << 24
+
+    def __init__(self, rois_per_step: int, roi_id_base: int = 0):
+        import collections
+
+        if rois_per_step < 1:
+            raise ValueError("rois_per_step must be positive")
+        self.rois_per_step = int(rois_per_step)
+        self._queue = collections.deque()      # [key, n, next local index] of images with ROIs not yet dealt into a step
+        self._pending = 0
+        self._next_id = int(roi_id_base) % self.ID_WRAP
+        self._where = {}                       # roi id -> (key, local index) of ROIs dealt into a step whose records are not back
+        self._open = {}                        # key -> [n, records f32[n,16], number still missing]
+        self._done = []
+
+    def add_image(self, key, n_rois: int) -> None:
+        import numpy as np
+
+        if key in self._open:
+            raise KeyError(f"image key {key!r} is already in flight")
+        n = int(n_rois)
+        if n == 0:
+            self._done.append((key, np.zeros((0, 16), np.float32)))      # the reference skips images without detections
+            return
+        self._open[key] = [n, np.full((n, 16), np.nan, np.float32), n]
+        self._queue.append([key, n, 0])
+        self._pending += n
+
+    @property
+    def pending(self) -> int:
+        return self._pending
+
+    def ready(self) -> bool:
+        return self._pending >= self.rois_per_step
+
+    def next_pack(self, flush: bool = False):
+        """-> [(key, local indices i64[k], roi ids i32[k]), ...] covering exactly ``rois_per_step`` ROIs in arrival order (fewer
+        only with ``flush`` = the tail of the stream), or None when there is nothing to launch yet."""
+        import numpy as np
+
+        if self._pending == 0 or (not flush and not self.ready()):
+            return None
+        want = min(self.rois_per_step, self._pending)
+        pack = []
+        while want > 0:
+            ent = self._queue[0]
+            key, n, nxt = ent
+            k = min(want, n - nxt)
+            local = np.arange(nxt, nxt + k, dtype=np.int64)
+            ids = ((self._next_id + np.arange(k, dtype=np.int64)) % self.ID_WRAP).astype(np.int32)
+            for j, i in zip(local.tolist(), ids.tolist()):
+                self._where[i] = (key, j)
+            self._next_id = (self._next_id + k) % self.ID_WRAP
+            pack.append((key, local, ids))
+            ent[2] += k
+            if ent[2] == n:
+                self._queue.popleft()
+            want -= k
+            self._pending -= k
+        return pack
+
+    def last_roi_dealt(self, key) -> bool:
+        """True once every ROI of image ``key`` has been dealt into a step (its pixels are no longer needed)."""
+        return all(e[0] != key for e in self._queue)
+
+    def deliver(self, records) -> None:
+        """Records f32[m,16] of one step (any order, padding rows with valid = 0 ignored) -> their images."""
+        import numpy as np
+
+        rec = np.asarray(records, np.float32).reshape(-1, 16)
+        for r in rec[rec[:, 15] > 0.5]:
+            key, j = self._where.pop(int(r[14]))
+            ent = self._open[key]
+            ent[1][j] = r
+            ent[2] -= 1
+            if ent[2] == 0:
+                self._done.append((key, ent[1]))
+                del self._open[key]
+
+    def pop_completed(self):
+        """-> [(key, records f32[n,16] in the image's own detection order), ...] of the images completed since the last call."""
+        done, self._done = self._done, []
+        return done
+
+
+class RoiStreamScheduler:
+    """detections -> pose records for a STREAM of images, at the step size the kernels want.
+
+        push(key, image u8[H,W,3] (device, BGR), depth f32[H,W] | None, detections)      one image and its detections
+          -> the packer deals ROIs into steps of exactly ``rois_per_step``; every full step is launched at once:
+             GPU crop (gdrnpp_crop_resize_roi, ROIs class-sorted within the step) -> inference_step_async
+          -> steps are resolved one launch late (the range check of the three-product kernels and the 8 KB record copy never
+             stall the device), their records dealt back to the images
+          -> returns the images that became complete: [(key, records f32[n,16] in detection order, seconds since push)]
+        flush()  launches the tail (a short step) and returns everything still open.
+
+    ``detections`` = the dict of ``batch_data_test_gpu`` for ONE image (bbox [n,4] xyxy, roi_cls [n], score [n], cam [3,3],
+    extents [C,3]).  All images of a stream share H x W (a BOP dataset's resolution)."""
+
+    def __init__(self, cfg, model, post: GdrnHipPost, rois_per_step: int = 128, max_in_flight: int = 2, roi_id_base: int = 0):
+        import collections
+
+        self.cfg, self.model, self.post = cfg, model, post
+        self.packer = RoiPacker(rois_per_step, roi_id_base)
+        self.max_in_flight = max(1, int(max_in_flight))
+        self._images = {}                       # key -> (image, depth, detections, arrival time)
+        self._arrival = {}
+        self._in_flight = collections.deque()   # (StepHandle, batch) — the batch stays alive for a six-product repeat
+        self.steps_launched = 0
+
+    # -- one step ----------------------------------------------------------------------------------
+    def _launch(self, pack) -> None:
+        import numpy as np
+
+        def per_roi(key, loc, name, dtype, default=None):
+            d = self._images[key][2]
+            a = np.asarray(d[name] if name in d else default(len(d["roi_cls"])), dtype)
+            return a.reshape((len(d["roi_cls"]),) + a.shape[1:])[loc]
+
+        def cams(key, loc):
+            c = np.asarray(self._images[key][2]["cam"], np.float32)
+            return np.broadcast_to(c, (len(loc), 3, 3)) if c.ndim == 2 else c[loc]
+
+        keys = [k for k, _, _ in pack]
+        images = torch.stack([self._images[k][0] for k in keys])
+        depths = torch.stack([self._images[k][1] for k in keys]) if self._images[keys[0]][1] is not None else None
+        det = dict(
+            bbox=np.concatenate([per_roi(k, loc, "bbox", np.float32) for k, loc, _ in pack]),
+            roi_cls=np.concatenate([per_roi(k, loc, "roi_cls", np.int64) for k, loc, _ in pack]),
+            score=np.concatenate([per_roi(k, loc, "score", np.float32, np.ones) for k, loc, _ in pack]),
+            im_idx=np.concatenate([np.full(len(loc), i, np.int64) for i, (_, loc, _) in enumerate(pack)]),
+            roi_id=np.concatenate([ids for _, _, ids in pack]),
+            cam=np.concatenate([cams(k, loc) for k, loc, _ in pack]),
+            extents=self._images[keys[0]][2]["extents"])
+        batch = batch_data_test_gpu(self.cfg, images, depths, det, sort_by_class=True)
+        self._in_flight.append((inference_step_async(self.model, self.post, batch), batch))
+        self.steps_launched += 1
+        for k in keys:                          # pixels are only read by the crop kernel just enqueued
+            if self.packer.last_roi_dealt(k):
+                del self._images[k]
+
+    def _resolve_oldest(self):
+        handle, _batch = self._in_flight.popleft()
+        rec = handle.result()
+        self.packer.deliver(rec.cpu().numpy())
+        return rec
+
+    def _finished(self):
+        import time
+
+        now = time.perf_counter()
+        return [(k, r, now - self._arrival.pop(k)) for k, r in self.packer.pop_completed()]
+
+    def _admit(self, key, image, depth, detections) -> None:
+        import time
+
+        self._arrival[key] = time.perf_counter()
+        if len(detections["roi_cls"]):
+            self._images[key] = (image, depth, detections)
+        self.packer.add_image(key, len(detections["roi_cls"]))
+
+    # -- the stream --------------------------------------------------------------------------------
+    def push(self, key, image: torch.Tensor, depth, detections: dict):
+        self._admit(key, image, depth, detections)
+        while self.packer.ready():
+            self._launch(self.packer.next_pack())
+            while len(self._in_flight) > self.max_in_flight:
+                self._resolve_oldest()
+        return self._finished()
+
+    def launch_next(self, feeder):
+        """bench.py's step: pull (key, image, depth, detections) tuples from ``feeder`` until one more step is launched;
+        returns a callable that resolves the OLDEST step in flight (-> its records f32[rois_per_step,16] on the device).  Call
+        it one launch late and the host never waits for the device."""
+        while not self.packer.ready():
+            self._admit(*next(feeder))
+        self._launch(self.packer.next_pack())
+
+        def resolve():
+            rec = self._resolve_oldest()
+            self._finished()
+            return rec
+        return resolve
+
+    def flush(self):
+        while self.packer.pending:
+            self._launch(self.packer.next_pack(flush=True))
+        while self._in_flight:
+            self._resolve_oldest()
+        return self._finished()

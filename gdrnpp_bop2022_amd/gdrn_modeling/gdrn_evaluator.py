@@ -26,7 +26,7 @@ import torch
 import torch.distributed as dist
 
 from .. import hip_lib
-from .engine import BOP_CSV_HEADER, GdrnHipPost, run_with_overflow_check, save_bop_csv
+from .engine import BOP_CSV_HEADER, GdrnHipPost, run_with_range_check, save_bop_csv
 
 logger = logging.getLogger(__name__)
 
@@ -178,10 +178,35 @@ class GDRN_Evaluator:
         return {}
 
 
-def gdrn_inference_on_dataset(cfg, model, data_loader, evaluator, amp_test=False):
+def packed_loader(data_loader, pack_rois: int):
+    """The reference's loader yields ONE image per iteration (data_loader.py:901-950, batch_size = 1: a list with one per-image
+    dict of pre-cropped ROIs); this pools consecutive items until they hold at least ``pack_rois`` ROIs and yields the pooled
+    list — the same list-of-per-image-dicts protocol, so ``batch_data_test`` / ``GDRN_Evaluator.process`` take it unchanged and
+    every record keeps its image.  (Image-granular: the crops come ready-made per image.  engine.RoiStreamScheduler packs
+    ROI-granular, with the crops made on the GPU.)"""
+    pool, n = [], 0
+    for inputs in data_loader:
+        inputs = inputs if isinstance(inputs, list) else [inputs]
+        pool += inputs
+        n += sum(len(d["roi_cls"]) for d in inputs)
+        if n >= pack_rois:
+            yield pool
+            pool, n = [], 0
+    if pool:
+        yield pool
+
+
+def gdrn_inference_on_dataset(cfg, model, data_loader, evaluator, amp_test=False, pack_rois: int = 0):
     """gdrn_evaluator.py:668-809: the inference loop with the reference's timing protocol — host ``perf_counter``, device
     synchronise before the clock stops, the first ``min(5, total - 1)`` iterations discarded — returning
-    ``evaluator.evaluate()`` (or ``{}``).  ``stats`` of the run are left on ``gdrn_inference_on_dataset.last_stats``."""
+    ``evaluator.evaluate()`` (or ``{}``).  ``stats`` of the run are left on ``gdrn_inference_on_dataset.last_stats``.
+
+    ``pack_rois`` > 0 (this build's addition; 0 = the reference's one image per forward): consecutive images are pooled until
+    they hold that many ROIs (``packed_loader``) — at 128 the kernels run at the rate bench.py reports instead of the
+    3-30-ROI rate.  Records, their order and the csv are unchanged; the time charged to an image is the time of the step that
+    carried it, exactly as the reference charges every image of a batch the batch's time (:748-760)."""
+    if pack_rois:
+        data_loader = list(packed_loader(data_loader, int(pack_rois)))
     # TEST.AMP_TEST (gdrn_evaluator.py:736-747: ``with autocast(enabled=amp_test)`` around the forward).  The HIP network
     # layers of this library are fp32 computations (the parity configuration, common_base.py:219); under AMP the forward runs
     # as the plain PyTorch module graph inside ``torch.autocast`` — the reference's own mixed-precision path — and the outputs
@@ -215,8 +240,8 @@ def gdrn_inference_on_dataset(cfg, model, data_loader, evaluator, amp_test=False
                 hip_layers.set_enabled(False)
             try:
                 with torch.autocast("cuda", dtype=torch.float16, enabled=bool(amp_test) and dev.type == "cuda"):
-                    # (three-product GEMM kernels: an fp16-range overflow repeats the forward with six products)
-                    out_dict = run_with_overflow_check(lambda: model(
+                    # (three-product GEMM kernels: a layer outside their range repeats the forward with six products)
+                    out_dict = run_with_range_check(lambda: model(
                         batch["roi_img"], roi_classes=batch["roi_cls"], roi_cams=batch["roi_cam"], roi_whs=batch["roi_wh"],
                         roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"],
                         roi_coord_2d=batch.get("roi_coord_2d", None), roi_coord_2d_rel=batch.get("roi_coord_2d_rel", None),

@@ -425,3 +425,106 @@ def test_x3_layers_get_slots_and_lose_the_form_when_demoted(monkeypatch):
         assert hl.x3_for(c2, "fc1", w, pack3, *big)[1] == 1 and hl.x3_demoted() == {}
     finally:
         hl.reset_x3_demotions()
+
+
+# ---- ROI packing: the reference's one-image-per-forward stream dealt into steps of exactly P ROIs ------------------------------
+def test_roi_packer_deals_exact_steps_and_returns_records_to_their_images():
+    rng = np.random.default_rng(1)
+    P = 16
+    pk = engine.RoiPacker(P, roi_id_base=engine.RoiPacker.ID_WRAP - 40)       # the ids wrap (float32-exact range) mid-stream
+    counts = rng.integers(0, 12, 40).tolist()
+    packs, order = [], []
+    for key, n in enumerate(counts):
+        pk.add_image(key, n)
+        if n:
+            with pytest.raises(KeyError):
+                pk.add_image(key, n)                      # a key cannot be in flight twice
+        while pk.ready():
+            packs.append(pk.next_pack())
+    assert pk.next_pack() is None and 0 <= pk.pending < P
+    tail = pk.next_pack(flush=True)
+    if tail:
+        packs.append(tail)
+    assert pk.pending == 0 and pk.next_pack(flush=True) is None
+    sizes = [sum(len(loc) for _, loc, _ in p) for p in packs]
+    assert all(s == P for s in sizes[:-1]) and sum(sizes) == sum(counts)
+    # arrival order is kept: flattening the packs enumerates (image, local index) in stream order
+    flat = [(k, j) for p in packs for k, loc, _ in p for j in loc.tolist()]
+    assert flat == [(k, j) for k, n in enumerate(counts) for j in range(n)]
+    ids = np.concatenate([i for p in packs for _, _, i in p])
+    assert len(set(ids.tolist())) == len(ids) and ids.max() < engine.RoiPacker.ID_WRAP and ids.min() == 0
+    # steps come back in any order, rows in any order (class-sorted in the step), padding rows are ignored
+    done = dict(pk.pop_completed())                                          # the images without detections
+    assert sorted(done) == [k for k, n in enumerate(counts) if n == 0] and all(r.shape == (0, 16) for r in done.values())
+    for p in packs[::-1]:
+        ids_p = np.concatenate([i for _, _, i in p])
+        rec = np.zeros((len(ids_p) + 3, 16), np.float32)
+        rec[:len(ids_p), 14], rec[:len(ids_p), 15] = ids_p, 1.0
+        rec[:len(ids_p), 0] = [1000 * k + j for k, loc, _ in p for j in loc.tolist()]
+        pk.deliver(rec[rng.permutation(len(rec))])
+        done.update(pk.pop_completed())
+    assert sorted(done) == list(range(len(counts)))
+    for k, n in enumerate(counts):
+        assert done[k].shape == (n, 16) and done[k][:, 0].tolist() == [1000 * k + j for j in range(n)]
+
+
+def test_packed_loader_pools_images_until_the_step_is_full():
+    from gdrnpp_bop2022_amd.gdrn_modeling.gdrn_evaluator import packed_loader
+    counts = [3, 30, 12, 0, 25, 29, 30, 7, 1]
+    loader = [[dict(roi_cls=list(range(n)), tag=i)] for i, n in enumerate(counts)]
+    packs = list(packed_loader(loader, 64))
+    assert [[d["tag"] for d in p] for p in packs] == [[0, 1, 2, 3, 4], [5, 6, 7], [8]]
+    assert [sum(len(d["roi_cls"]) for d in p) for p in packs] == [70, 66, 1]
+    assert [[d["tag"] for d in p] for p in packed_loader(loader, 1)] == [[0], [1], [2], [3, 4], [5], [6], [7], [8]]
+
+
+def _packed_stream_worker(rank, world, port, ret):
+    """Each rank runs its own image stream (InferenceSampler shards IMAGES), packs it into steps of P ROIs, and every step ends
+    in the path's one collective; the step itself is a host stub that emits the records of the ROIs it was given."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P, n_steps = 8, 5
+    rng = np.random.default_rng(100 + rank)
+    pk = engine.RoiPacker(P, roi_id_base=rank * 100000)                      # disjoint id ranges per rank
+    seen, gathered, key = {}, [], 0
+    for _ in range(n_steps):
+        while not pk.ready():
+            n = int(rng.integers(0, 6))
+            pk.add_image((rank, key), n)
+            seen[(rank, key)] = n
+            key += 1
+        pack = pk.next_pack()
+        cls = rng.integers(0, 4, P)
+        ids = np.concatenate([i for _, _, i in pack])
+        order = engine.class_sorted_order(cls)                               # the step runs its ROIs in class order
+        rec = torch.zeros((P, 16))
+        rec[:, 14] = torch.from_numpy(ids[order].astype(np.float32))
+        rec[:, 13] = torch.from_numpy(cls[order].astype(np.float32))
+        rec[:, 12] = rec[:, 14] * 0.5
+        rec[:, 15] = 1.0
+        allrec = engine.gather_records(rec, P)                               # [world * P, 16], same on every rank
+        gathered.append(allrec.numpy())
+        mine = allrec[(allrec[:, 14] >= rank * 100000) & (allrec[:, 14] < (rank + 1) * 100000)]
+        pk.deliver(mine.numpy())
+    done = {k: r for k, r in pk.pop_completed()}
+    ret[rank] = (np.stack(gathered), {k: r[:, 12].tolist() for k, r in done.items()}, seen, pk.pending)
+    dist.destroy_process_group()
+
+
+def test_packed_streams_shard_gather_and_restore_gloo_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_packed_stream_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    (g0, done0, seen0, pend0), (g1, done1, seen1, pend1) = ret[0], ret[1]
+    assert np.array_equal(g0, g1) and g0.shape == (5, 16, 16)                # every step gathered 2 x 8 records, identical everywhere
+    for rank, (done, seen, pend) in enumerate(((done0, seen0, pend0), (done1, seen1, pend1))):
+        n_done = sum(len(v) for v in done.values())
+        assert n_done + pend <= 5 * 8 and n_done >= 5 * 8 - pend - 5         # all but the images straddling the last step
+        for k, vals in done.items():
+            assert k[0] == rank and len(vals) == seen[k]
+        ids = sorted(v * 2 for vals in done.values() for v in vals)
+        assert ids == sorted(set(ids)) and all(rank * 100000 <= i < (rank + 1) * 100000 for i in ids)
+    rec = engine.records_in_roi_order(torch.from_numpy(g0.reshape(-1, 16))).numpy()
+    assert (np.diff(rec[:, 14]) > 0).all() and len(rec) == 2 * 5 * 8

@@ -99,3 +99,47 @@ def test_inference_loop_protocol(hip, tmp_path):
     for p, (R, t) in zip(ev._predictions, fp32):
         assert np.abs(np.array(p["R"]) - np.array(R)).max() < 5e-2
         assert np.isfinite(p["t"]).all()
+
+
+def test_inference_loop_with_roi_packing_keeps_records_and_order(hip, tmp_path):
+    """gdrn_inference_on_dataset(pack_rois=N): consecutive one-image loader items pooled into steps of >= N ROIs — same records in
+    the same order as the reference's one-image-per-forward schedule (R / t within the path's tolerance: other kernels serve the
+    larger step), every image of a step charged the step's time, csv written as before."""
+    from gdrnpp_bop2022_amd import synthetic as S
+
+    cfg = get_cfg("ycbv_convnext_a6", opts=["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"])
+    names = [f"obj_{i:02d}" for i in range(21)]
+    rng = np.random.default_rng(4)
+    verts, faces, ext = S.make_models(21, rng, 2)
+    ev = GDRN_Evaluator(cfg, "ycbv_test", False, str(tmp_path), obj_names=names, obj2id={n: i + 1 for i, n in enumerate(names)},
+                        meshes=hip_lib.MeshSet(verts, faces, DEV))
+    torch.manual_seed(0)
+    model, _ = build_model_optimizer(cfg)
+    model.load_state_dict(S.seeded_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], 3), strict=True)
+    with torch.no_grad():
+        model.pnp_net.fc_t.bias.copy_(torch.tensor([0.0, 0.0, 1.5 * float(S.YCBV_K[0, 0]) * 0.19 / 64.0]))
+    loader = []
+    for im, n in enumerate([3, 7, 1, 9, 4, 6, 2, 8, 5, 3, 4, 6]):
+        det = S.make_detections(n, 21, ext, rng)
+        T = torch.from_numpy
+        loader.append([dict(
+            roi_img=torch.rand(n, 3, 256, 256), roi_cls=T(det["roi_cls"]), cam=T(det["roi_cam"]), roi_wh=T(det["roi_wh"]),
+            bbox_center=T(det["roi_center"]), resize_ratio=T(det["resize_ratio"]), scale=T(det["scale"]), score=T(det["score"]),
+            roi_coord_2d=T(S.coord2d_roi(det["roi_center"], det["scale"])), roi_extent=T(det["roi_extent"]),
+            roi_depth=torch.rand(n, 1, 256, 256) + 0.5, scene_im_id=[f"50/{im}"] * n, time=torch.full((n,), 0.01))])
+    assert gdrn_inference_on_dataset(cfg, model, loader, ev) == {}
+    plain = [dict(p) for p in ev._predictions]
+    assert gdrn_inference_on_dataset(cfg, model, loader, ev, pack_rois=16) == {}
+    st = gdrn_inference_on_dataset.last_stats
+    assert st["iters"] == 3 and st["warmup_iters"] == 2                      # 58 ROIs in steps of >= 16: 20 + 20 + 18
+    packed = ev._predictions
+    assert len(packed) == len(plain) == 58
+    for p, q in zip(packed, plain):
+        assert (p["scene_id"], p["im_id"], p["obj_id"], p["score"]) == (q["scene_id"], q["im_id"], q["obj_id"], q["score"])
+        assert np.abs(np.array(p["R"]) - np.array(q["R"])).max() <= 1e-4
+        assert np.abs(np.array(p["t"]) - np.array(q["t"])).max() <= 1e-4 * 1000.0          # mm
+    by_im = {}
+    for p in packed:
+        by_im.setdefault(p["im_id"], set()).add(p["time"])
+    assert all(len(v) == 1 for v in by_im.values())
+    assert len(open(tmp_path / "ycbv-convnext-a6-iter0_ycbv-test.csv").read().strip().split("\n")) == 59

@@ -1,0 +1,94 @@
+"""-m gpu: ROI packing between the reference's image loop and the step size the kernels want (engine.RoiStreamScheduler,
+gdrn_evaluator.packed_loader).  A stream of images with 0 .. 30 detections each goes through the scheduler in steps of exactly
+P ROIs (GPU crop -> forward -> depth refine -> records, resolved one launch late); every image gets the records the same image
+gets when it is run on its own (the reference's schedule) — within the path's tolerance, since a lone image runs the
+small-batch kernels (six products, split-K) and a packed step the large-batch ones."""
+import numpy as np
+import pytest
+import torch
+
+from gdrnpp_bop2022_amd import hip_lib, synthetic as S
+from gdrnpp_bop2022_amd.gdrn_modeling import engine
+from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def setup(hip):
+    cfg = get_cfg("ycbv_convnext_a6", opts=["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"])
+    torch.manual_seed(0)
+    model, _ = build_model_optimizer(cfg)
+    model.load_state_dict(S.seeded_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], 5), strict=True)
+    with torch.no_grad():
+        model.pnp_net.fc_t.bias.copy_(torch.tensor([0.0, 0.0, 1.5 * float(S.YCBV_K[0, 0]) * 0.19 / 64.0]))
+    rng = np.random.default_rng(9)
+    verts, faces, ext = S.make_models(21, rng, 2)
+    post = engine.GdrnHipPost(cfg, hip_lib.MeshSet(verts, faces, DEV))
+    g = torch.Generator(device=DEV).manual_seed(1)
+    stream = []
+    for i, n in enumerate([5, 0, 30, 17, 3, 22, 9, 30, 11, 1]):
+        det = S.make_detections(max(n, 1), 21, ext, rng)
+        x1y1 = det["roi_center"] - det["roi_wh"] / 2
+        d = dict(bbox=np.concatenate([x1y1, x1y1 + det["roi_wh"]], 1).astype(np.float32)[:n], roi_cls=det["roi_cls"][:n],
+                 score=det["score"][:n], cam=S.YCBV_K.astype(np.float32), extents=ext)
+        img = torch.randint(0, 256, (S.IM_H, S.IM_W, 3), dtype=torch.uint8, device=DEV, generator=g)
+        dep = torch.rand((S.IM_H, S.IM_W), device=DEV, generator=g) + 0.5
+        stream.append((f"48/{i}", img, dep, d))
+    return cfg, model, post, stream
+
+
+def _alone(cfg, model, post, img, dep, det):
+    if len(det["roi_cls"]) == 0:
+        return np.zeros((0, 16), np.float32)
+    batch = engine.batch_data_test_gpu(cfg, img[None], dep[None], dict(det, im_idx=np.zeros(len(det["roi_cls"]), np.int64)))
+    return engine.inference_step(model, post, batch, torch.arange(len(det["roi_cls"]), dtype=torch.int32, device=DEV)).cpu().numpy()
+
+
+@pytest.mark.parametrize("P,in_flight", [(32, 2), (48, 1)])
+def test_stream_scheduler_returns_every_image_its_own_records(setup, P, in_flight):
+    cfg, model, post, stream = setup
+    sch = engine.RoiStreamScheduler(cfg, model, post, rois_per_step=P, max_in_flight=in_flight)
+    out = {}
+    for key, img, dep, det in stream:
+        for k, rec, sec in sch.push(key, img, dep, det):
+            assert k not in out and sec >= 0.0
+            out[k] = rec
+    for k, rec, sec in sch.flush():
+        out[k] = rec
+    total = sum(len(d["roi_cls"]) for _, _, _, d in stream)
+    assert sorted(out) == sorted(k for k, _, _, _ in stream) and sch.steps_launched == -(-total // P)
+    for key, img, dep, det in stream:
+        n = len(det["roi_cls"])
+        rec = out[key]
+        assert rec.shape == (n, 16)
+        if n == 0:
+            continue
+        want = _alone(cfg, model, post, img, dep, det)
+        assert np.array_equal(rec[:, 13], det["roi_cls"].astype(np.float32)) and np.array_equal(rec[:, 12], det["score"])
+        assert (rec[:, 15] == 1).all() and np.isfinite(rec).all()
+        assert np.abs(rec[:, :9] - want[:, :9]).max() <= 1e-4, key                    # R
+        assert np.abs(rec[:, 9:12] - want[:, 9:12]).max() <= 1e-4, key               # t (metres)
+
+
+def test_launch_next_runs_exact_steps_and_resolves_one_launch_late(setup):
+    """bench.py's use: launch_next(feeder) launches exactly one full step per call; resolving it a call later returns that
+    step's [P,16] records with every stream id exactly once."""
+    import itertools
+
+    cfg, model, post, stream = setup
+    P = 32
+    sch = engine.RoiStreamScheduler(cfg, model, post, rois_per_step=P)
+    counter = itertools.count()
+    feeder = ((f"{k}#{next(counter)}", i, d, det) for k, i, d, det in itertools.cycle(stream))
+    pending, ids = None, []
+    for _ in range(5):
+        res = sch.launch_next(feeder)
+        if pending is not None:
+            ids.append(pending().cpu().numpy()[:, 14])
+        pending = res
+    ids.append(pending().cpu().numpy()[:, 14])
+    assert sch.steps_launched == 5
+    assert np.array_equal(np.sort(np.concatenate(ids)), np.arange(5 * P))
