@@ -8,8 +8,8 @@
 // polished by five Gauss-Newton steps on the six control-point distances, Horn/Arun absolute orientation, smallest mean
 // reprojection error wins; RANSAC = 5-point minimal sets from cv::RNG(2^64-1) (or injected 32-bit words), float32
 // squared reprojection error against reprojErr^2, strictly-more-inliers update, adaptive iteration count, final EPnP
-// on the inliers of the best hypothesis.  One documented deviation: exactly 4 correspondences (OpenCV: P3P) report "no
-// model", see final_kernel.
+// on the inliers of the best hypothesis; exactly 5 correspondences = one EPnP over all of them, exactly 4 = one P3P solve
+// (p3p_4points below), as solvePnPRansac switches its kernel.
 //
 // Work decomposition (nothing here is bandwidth-relevant: ~100 hypotheses x <= 4096 points per ROI):
 //   subsets_kernel     one thread per ROI      the RNG stream is sequential by definition: draws every minimal set
@@ -440,6 +440,121 @@ __device__ bool epnp_solve(const PointSet& ps, const Cam cam, int lane, double* 
   return have;
 }
 
+// ---- exactly four correspondences: cv2.solvePnPRansac solves once with SOLVEPNP_P3P (solvepnp.cpp: npoints == 4 -> model_points
+// = 4, kernel P3P, model_points == npoints -> plain solvePnP).  p3p.cpp (Gao et al. 2003) finds the poses consistent with the first
+// three points and orders them by the reprojection error of the fourth; here the same contract through Grunert's elimination
+// (oracle/epnp.py p3p_4points has the derivation): a quartic in v = s3 / s1, u = s2 / s1 re-derived from the two cosine laws it has
+// to satisfy, camera points s_i j_i, absolute orientation of the three pairs, fourth point picks the pose.  One thread, fp64.
+__device__ bool p3p_4points(const float* uv, const float* pw, const Cam cam, double* R, double* t) {
+  double xn[4][3], j[3][3], P[4][3];
+  for (int i = 0; i < 4; ++i) {
+    xn[i][0] = ((double)uv[2 * i] - cam.uc) / cam.fu;
+    xn[i][1] = ((double)uv[2 * i + 1] - cam.vc) / cam.fv;
+    xn[i][2] = 1.0;
+    for (int k = 0; k < 3; ++k) P[i][k] = (double)pw[3 * i + k];
+  }
+  for (int i = 0; i < 3; ++i) {
+    const double n = sqrt(xn[i][0] * xn[i][0] + xn[i][1] * xn[i][1] + 1.0);
+    for (int k = 0; k < 3; ++k) j[i][k] = xn[i][k] / n;
+  }
+  auto d2 = [&](int a, int b) { double s = 0; for (int k = 0; k < 3; ++k) s += (P[a][k] - P[b][k]) * (P[a][k] - P[b][k]); return s; };
+  auto dot = [&](int a, int b) { return j[a][0] * j[b][0] + j[a][1] * j[b][1] + j[a][2] * j[b][2]; };
+  const double a2 = d2(1, 2), b2 = d2(0, 2), c2 = d2(0, 1);
+  if (!(a2 > 0.0 && b2 > 0.0 && c2 > 0.0)) return false;
+  const double ca = dot(1, 2), cb = dot(0, 2), cg = dot(0, 1);
+  const double q = (a2 - c2) / b2, cb2 = c2 / b2;
+  // polynomials, lowest power first: N (deg 2), D (deg 1), Q = 1 - (c^2 / b^2)(1 + v^2 - 2 v cos beta) (deg 2)
+  const double N[3] = {1.0 + q, -2.0 * q * cb, q - 1.0}, D[2] = {2.0 * cg, -2.0 * ca}, Q[3] = {1.0 - cb2, 2.0 * cb2 * cb, -cb2};
+  double c[5] = {0, 0, 0, 0, 0};                      // N^2 - 2 cos(gamma) N D + D^2 Q
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) c[a + b] += N[a] * N[b];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 2; ++b) c[a + b] -= 2.0 * cg * N[a] * D[b];
+  double DD[3] = {D[0] * D[0], 2.0 * D[0] * D[1], D[1] * D[1]};
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) c[a + b] += DD[a] * Q[b];
+  for (int k = 0; k < 5; ++k)
+    if (!is_finite(c[k])) return false;
+  if (!(fabs(c[4]) >= 1e-300)) return false;
+  const double m[4] = {c[0] / c[4], c[1] / c[4], c[2] / c[4], c[3] / c[4]};   // monic: z^4 + m3 z^3 + m2 z^2 + m1 z + m0
+  // all four roots by Durand-Kerner (Weierstrass) iteration in complex fp64
+  double radius = 0.0;
+  for (int k = 0; k < 4; ++k) radius = fmax(radius, fabs(m[k]));
+  radius = 1.0 + radius;
+  double zr[4], zi[4];
+  {
+    double pr = 1.0, pi = 0.0;                          // powers of 0.4 + 0.9 i
+    for (int k = 0; k < 4; ++k) {
+      zr[k] = pr * radius * 0.5; zi[k] = pi * radius * 0.5;
+      const double nr = pr * 0.4 - pi * 0.9, ni = pr * 0.9 + pi * 0.4;
+      pr = nr; pi = ni;
+    }
+  }
+  for (int it = 0; it < 400; ++it) {
+    double moved = 0.0;
+    for (int k = 0; k < 4; ++k) {
+      double vr = zr[k] + m[3], vi = zi[k];             // Horner: ((z + m3) z + m2) z + m1) z + m0
+      for (int e = 2; e >= 0; --e) {
+        const double nr = vr * zr[k] - vi * zi[k] + m[e], ni = vr * zi[k] + vi * zr[k];
+        vr = nr; vi = ni;
+      }
+      double dr = 1.0, di = 0.0;
+      for (int o = 0; o < 4; ++o)
+        if (o != k) {
+          const double er = zr[k] - zr[o], ei = zi[k] - zi[o];
+          const double nr = dr * er - di * ei, ni = dr * ei + di * er;
+          dr = nr; di = ni;
+        }
+      const double den = dr * dr + di * di;
+      if (!(den > 0.0)) continue;
+      const double sr = (vr * dr + vi * di) / den, si = (vi * dr - vr * di) / den;
+      zr[k] -= sr; zi[k] -= si;
+      moved = fmax(moved, (fabs(sr) + fabs(si)) / fmax(1.0, fabs(zr[k]) + fabs(zi[k])));
+    }
+    if (moved < 1e-15) break;
+  }
+  bool have = false;
+  double best = 0.0;
+  for (int k = 0; k < 4; ++k) {
+    double v = zr[k];
+    if (!(fabs(zi[k]) <= 1e-7 * fmax(1.0, fabs(v))) || !(v > 0.0)) continue;
+    const double f = 1.0 + v * v - 2.0 * v * cb;
+    const double disc = fmax(cg * cg - 1.0 + cb2 * f, 0.0), sq = sqrt(disc);
+    const double u0 = cg + sq, u1 = cg - sq, a2b2 = a2 / b2;
+    const double r0 = fabs(u0 * u0 - 2.0 * v * ca * u0 + v * v - a2b2 * f), r1 = fabs(u1 * u1 - 2.0 * v * ca * u1 + v * v - a2b2 * f);
+    const double u = r0 <= r1 ? u0 : u1;
+    const double w = 1.0 + u * u - 2.0 * u * cg;
+    if (!(u > 0.0) || !(w > 0.0)) continue;
+    const double s1 = sqrt(c2 / w), sc[3] = {s1, u * s1, v * s1};
+    double pc[3][3], mw[3] = {0, 0, 0}, mc[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i)
+      for (int e = 0; e < 3; ++e) { pc[i][e] = sc[i] * j[i][e]; mw[e] += P[i][e] / 3.0; mc[e] += pc[i][e] / 3.0; }
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; ++i)
+      for (int r = 0; r < 3; ++r)
+        for (int e = 0; e < 3; ++e) H[r * 3 + e] += (pc[i][r] - mc[r]) * (P[i][e] - mw[e]);
+    double U[9], sv[3], Vt[9], Rc[9], tc[3];
+    svd3(H, U, sv, Vt);
+    for (int r = 0; r < 3; ++r)
+      for (int e = 0; e < 3; ++e) Rc[r * 3 + e] = U[r * 3] * Vt[e] + U[r * 3 + 1] * Vt[3 + e] + U[r * 3 + 2] * Vt[6 + e];
+    const double det = Rc[0] * (Rc[4] * Rc[8] - Rc[5] * Rc[7]) - Rc[1] * (Rc[3] * Rc[8] - Rc[5] * Rc[6]) + Rc[2] * (Rc[3] * Rc[7] - Rc[4] * Rc[6]);
+    if (det < 0)                                        // Arun / Umeyama: flip the direction the three points do not span
+      for (int r = 0; r < 3; ++r)
+        for (int e = 0; e < 3; ++e) Rc[r * 3 + e] -= 2.0 * U[r * 3 + 2] * Vt[6 + e];
+    for (int r = 0; r < 3; ++r) tc[r] = mc[r] - (Rc[r * 3] * mw[0] + Rc[r * 3 + 1] * mw[1] + Rc[r * 3 + 2] * mw[2]);
+    double p4[3];
+    for (int r = 0; r < 3; ++r) p4[r] = Rc[r * 3] * P[3][0] + Rc[r * 3 + 1] * P[3][1] + Rc[r * 3 + 2] * P[3][2] + tc[r];
+    const double ex = p4[0] / p4[2] - xn[3][0], ey = p4[1] / p4[2] - xn[3][1], err = ex * ex + ey * ey;
+    if (is_finite(err) && (!have || err < best)) {
+      have = true;
+      best = err;
+      for (int e = 0; e < 9; ++e) R[e] = Rc[e];
+      for (int e = 0; e < 3; ++e) t[e] = tc[e];
+    }
+  }
+  return have;
+}
+
 __device__ __forceinline__ Cam cam_of(const float* K9) { return Cam{(double)K9[0], (double)K9[4], (double)K9[2], (double)K9[5]}; }
 
 // cv::RNG (multiply-with-carry) or an injected stream of 32-bit words
@@ -553,7 +668,7 @@ __device__ int update_num_iters(double p, double ep, int model_points, int max_i
 }
 
 // one wave per ROI.  status: 1 = pose found, 0 = no model (fewer than 4 points, no hypothesis with >= 5 inliers, or a
-// degenerate final system) — the caller applies the reference's fallbacks.
+// degenerate final / P3P system) — the caller applies the reference's fallbacks.
 __global__ __launch_bounds__(64) void final_kernel(const float* __restrict__ img_pts, const float* __restrict__ mdl_pts,
                                                    const int* __restrict__ count, int stride, const float* __restrict__ K,
                                                    const double* __restrict__ pose, const int* __restrict__ cnt,
@@ -569,10 +684,20 @@ __global__ __launch_bounds__(64) void final_kernel(const float* __restrict__ img
   int good = 0;
   bool ok = false;
   const double* Pbest = nullptr;
-  // solvePnPRansac: model_points == npoints -> plain solve, every point an inlier.  DEVIATION for exactly 4 correspondences:
-  // OpenCV then solves with SOLVEPNP_P3P (model_points = 4), which is not restated here — a 4-pixel mask is a failed
-  // detection, and an under-determined EPnP on 4 points would return a finite but arbitrary pose.  n == 4 reports "no
-  // model" (status 0) like n < 4, so the caller applies the reference's own fallbacks (-100 sentinel / network pose).
+  // solvePnPRansac: model_points == npoints -> plain solve, every point an inlier; with exactly 4 correspondences the kernel is P3P
+  bool p3p = false;
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+  if (n == 4) {
+    int okp = 0;
+    if (lane == 0) okp = p3p_4points(uv, pw, cam, R, t) ? 1 : 0;
+    okp = __shfl(okp, 0, 64);
+    for (int k = 0; k < 9; ++k) R[k] = __shfl(R[k], 0, 64);
+    for (int k = 0; k < 3; ++k) t[k] = __shfl(t[k], 0, 64);
+    p3p = true;
+    ok = okp != 0;
+    good = ok ? 4 : 0;
+    for (int i = lane; i < n; i += 64) m[i] = ok ? 1 : 0;
+  } else
   if (n == kModelPts) {
     for (int i = lane; i < n; i += 64) m[i] = 1;
     good = n;
@@ -605,8 +730,7 @@ __global__ __launch_bounds__(64) void final_kernel(const float* __restrict__ img
     }
   }
   for (int i = n + lane; i < stride; i += 64) m[i] = 0;
-  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
-  if (ok) {
+  if (ok && !p3p) {
     PointSet ps{uv, pw, nullptr, Pbest, cam, thr2, n, n};
     ok = epnp_solve<true>(ps, cam, lane, R, t);
   }

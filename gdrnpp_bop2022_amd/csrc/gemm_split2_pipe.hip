@@ -128,22 +128,22 @@ struct HalfSplit2 {
   }
 };
 
-#ifdef GDRNPP2_A_DIRECT
-// Experiment (profiles/r04_a_direct.txt): the fp32 A rows of the linear form go from global memory straight to the VGPRs that
-// feed the split — no LDS round trip (the A stages are private to their wave, LDS buys them only asynchrony).  A lane loads the
-// 8 consecutive k of its MFMA operand row: two global_load_dwordx4 per half and k-tile, issued ONE k-tile ahead of the split
-// (slots 4 / 5 of k-tile kt for k-tile kt + 2), landing in the x registers the split of k-tile kt + 1 has left.  The data is
-// valid only behind wait_x<N> (s_waitcnt vmcnt with the registers tied to the statement).
-__device__ __forceinline__ void gload_x(float (&x)[8], unsigned voff, const void* sbase) {
-  f32x4v a, b;
+#ifdef GDRNPP2_TIMING_A_DIRECT
+// Timing-only experiment (results invalid; profiles/r04_a_direct.txt): what would the k-loop cost if the fp32 A rows of the
+// linear form went from global memory straight to VGPRs — no LDS-DMA fill and no ds_read of the A stages (they are private to
+// their wave, LDS buys them only asynchrony)?  A lane issues the loads of its MFMA operand rows (8 consecutive k per half: two
+// global_load_dwordx4 per half and k-tile) for k-tile kt + 2 in slots 4 / 5 of k-tile kt and waits for them at the end of the
+// same k-tile; the data lands in four scratch registers and is NOT used — the split keeps working on whatever its x registers
+// hold.  (A build that used the data faulted: a value that is still in flight must not be copied, and the register allocator
+// copies loop-carried values at the back edge — a production form needs the k-loop in assembly.)
+using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
+struct ADirectScratch { u32x4v d[4]; };
+__device__ __forceinline__ void gload_scratch(u32x4v& a, u32x4v& b, unsigned voff, const void* sbase) {
   asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
                : "=&v"(a), "=&v"(b) : "v"(voff), "s"(sbase) : "memory");
-  x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3];
-  x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
 }
-template <int N>
-__device__ __forceinline__ void wait_x(float (&x)[8]) {
-  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "n"(N) : "memory");
+__device__ __forceinline__ void wait_scratch(ADirectScratch& s) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(s.d[0]), "+v"(s.d[1]), "+v"(s.d[2]), "+v"(s.d[3]) : : "memory");
 }
 #endif
 
@@ -353,13 +353,11 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
   const int aslot0 = 4 * lrow0 + ((2 * fk) ^ g0), aslot1 = 4 * lrow0 + ((2 * fk + 1) ^ g0);
   const uint4* const sA = smem;
   const uint4* const sBf = smem + NA * (A_STAGE_B / 16) + fk * BN + frow;
-#ifdef GDRNPP2_A_DIRECT
+#ifdef GDRNPP2_TIMING_A_DIRECT
   constexpr bool ADIR = CONV == 0;     // linear form only
   const unsigned gvoff0 = (unsigned)min(m0 + lrow0, M - 1) * (unsigned)(K * 4) + (unsigned)(fk * 32);
   const unsigned gvoff1 = (unsigned)min(m0 + lrow0 + 32, M - 1) * (unsigned)(K * 4) + (unsigned)(fk * 32);
-  auto gload_half = [&](HalfSplit2& hs, int kt, int half) {
-    gload_x(hs.x, half ? gvoff1 : gvoff0, reinterpret_cast<const char*>(A) + (size_t)min(kt, nk - 1) * (BK * 4));
-  };
+  [[maybe_unused]] ADirectScratch ads;
 #else
   constexpr bool ADIR = false;
 #endif
@@ -398,15 +396,12 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
       if constexpr (S % 2 == 0 && S < 2 * NBP) dma_b(kt_b, sb_wr, std::integral_constant<int, S / 2>{});
       if constexpr (!ADIR && S % 2 == 0 && S >= 2 * NBP && S < 2 * NBP + 8) dma_a(kt_a, sa_wr_b, std::integral_constant<int, (S - 2 * NBP) / 2>{});
 #endif
-#ifdef GDRNPP2_A_DIRECT
+#ifdef GDRNPP2_TIMING_A_DIRECT
       if constexpr (ADIR) {
-        // raw A of k-tile kt + 2 into the x registers cur has left (its split finished in the previous k-tile); issue order
-        // per k-tile: weight pieces (slots 0, 2), then these four loads — so the waits below leave exactly the right tail:
-        if constexpr (S == 2 * NBP) gload_half(cur[0], kt + 2, 0);
-        if constexpr (S == 2 * NBP + 1) gload_half(cur[1], kt + 2, 1);
-        if constexpr (S == 3) wait_x<2 + NBP>(nxt[0].x);    // behind: nxt[1]'s two loads + this k-tile's weight pieces
-        constexpr int S1d = NJ == 4 ? 13 : 20;
-        if constexpr (S == S1d) wait_x<NBP + 4>(nxt[1].x);  // behind: weight pieces + the four loads of k-tile kt + 2
+        const char* gsrc = reinterpret_cast<const char*>(A) + (size_t)min(kt + 2, nk - 1) * (BK * 4);
+        if constexpr (S == 2 * NBP) gload_scratch(ads.d[0], ads.d[1], gvoff0, gsrc);
+        if constexpr (S == 2 * NBP + 1) gload_scratch(ads.d[2], ads.d[3], gvoff1, gsrc);
+        if constexpr (S == NS - 1) wait_scratch(ads);
       }
 #endif
 #ifndef GDRNPP2_TIMING_NO_BREAD   // timing-only builds (results invalid)
@@ -468,17 +463,12 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
     __builtin_amdgcn_s_barrier();
     load_half(f0[0], 0, 0);
     load_half(f0[1], 0, 1);
-  } else {
-#ifdef GDRNPP2_A_DIRECT
+  } else {   // timing-only: the x registers start from finite values and are never refilled
     static_for<0, NBP>([&](auto c) { dma_b(0, 0u, c); });
-    gload_half(f0[0], 0, 0);
-    gload_half(f0[1], 0, 1);
-    gload_half(f1[0], 1, 0);
-    gload_half(f1[1], 1, 1);
-    wait_x<4>(f0[0].x);
-    wait_x<4>(f0[1].x);
+    wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-#endif
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { f0[0].x[e] = f0[1].x[e] = f1[0].x[e] = f1[1].x[e] = 1.0f + 0.01f * (float)(e + lane); }
   }
   static_for<0, 8>([&](auto s) { f0[0].template step<decltype(s)::value>(); f0[1].template step<decltype(s)::value>(); });
 #pragma unroll

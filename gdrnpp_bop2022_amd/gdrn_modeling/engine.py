@@ -123,14 +123,13 @@ class GdrnHipPost:
         """``TEST.USE_PNP`` with ``PNP_TYPE="ransac_pnp"`` (gdrn_evaluator.py:373-459): decode, compact, then
         ``misc.pnp_v2(..., method=EPNP, ransac=True, ransac_reprojErr=3, ransac_iter=100)`` for every ROI on the device.
         ROIs with fewer than 4 correspondences get the reference's sentinel pose -100 (:445-447); a RANSAC that finds no
-        model leaves R = I, t = 0 (status 0).  Documented deviation: EXACTLY 4 correspondences — OpenCV would run P3P, which
-        is not restated (csrc/epnp_ransac.hip, final_kernel) — are treated like fewer than 4 (sentinel).
-        -> (R f32[b,3,3], t f32[b,3], status i32[b])."""
+        model leaves R = I, t = 0 (status 0).  Exactly 4 correspondences: one P3P solve like OpenCV's (csrc/epnp_ransac.hip,
+        p3p_4points).  -> (R f32[b,3,3], t f32[b,3], status i32[b])."""
         b = out_dict["trans"].shape[0]
         count, _, img_pts, mdl_pts, _ = self.process_correspondences(batch, out_dict)
         R, t, _, status, _ = hip_lib.epnp_ransac(img_pts, mdl_pts, count, batch["roi_cam"].reshape(b, 9).contiguous(),
                                                  iters=iters, reproj_err=3.0, draws=draws)
-        few = (count <= 4).view(b, 1)
+        few = (count < 4).view(b, 1)
         R = torch.where(few.view(b, 1, 1), torch.full_like(R, -100.0), R)
         t = torch.where(few, torch.full_like(t, -100.0), t)
         return R, t, status
@@ -139,14 +138,14 @@ class GdrnHipPost:
         """``PNP_TYPE="net_ransac_pnp"`` / ``"net_ransac_pnp_rot"`` (gdrn_evaluator.py:241-371 with pnp_type "ransac" /
         "ransac_rot"): solvePnPRansac(EPNP, reprojErr 3, 20 iterations) on the correspondences (the extrinsic guess is
         ignored by EPnP).  "ransac": translation falls back to the network's when it moved by more than 1 m (:347-351);
-        "ransac_rot": rotation from RANSAC, translation always the network's; fewer than 4 correspondences (here: also exactly
-        4, see process_pnp_ransac) or no model: the network pose (:355-358)."""
+        "ransac_rot": rotation from RANSAC, translation always the network's; fewer than 4 correspondences or no model: the
+        network pose (:355-358)."""
         b = out_dict["trans"].shape[0]
         count, _, img_pts, mdl_pts, _ = self.process_correspondences(batch, out_dict)
         R, t, _, status, _ = hip_lib.epnp_ransac(img_pts, mdl_pts, count, batch["roi_cam"].reshape(b, 9).contiguous(),
                                                  iters=20, reproj_err=3.0, draws=draws)
         R_net, t_net = out_dict["rot"].reshape(b, 3, 3).float(), out_dict["trans"].float()
-        use = ((count > 4) & (status == 1)).view(b, 1)
+        use = ((count >= 4) & (status == 1)).view(b, 1)
         far = (t - t_net).norm(dim=1, keepdim=True) > 1.0
         t = t_net if rot_only else torch.where(use & ~far, t, t_net)
         R = torch.where(use.view(b, 1, 1), R, R_net)

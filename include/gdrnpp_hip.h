@@ -146,7 +146,8 @@ int gdrnpp_uncertainty_pnp_batched(const double* pts2d, const double* pts3d,
  * gdrn_evaluator.py:319-330 (20 iterations), for every ROI of the batch.  OpenCV is a third-party dependency that is not
  * in the reference tree: its published algorithms are restated (calib3d epnp.cpp, ptsetreg.cpp, solvepnp.cpp) — 5-point
  * minimal sets, float32 squared reprojection error <= reprojErr^2, best = strictly more inliers, adaptive iteration
- * count, final EPnP over the inliers of the best hypothesis.
+ * count, final EPnP over the inliers of the best hypothesis; count == 5: one EPnP over all five; count == 4: one P3P solve
+ * (OpenCV switches to SOLVEPNP_P3P there: the poses consistent with the first three points, the fourth picks), all inliers.
  * img_pts f32[b,stride,2], mdl_pts f32[b,stride,3], count i32[b]: outputs of gdrnpp_decode_correspondences; K f32[b,9].
  * draws: NULL -> every ROI draws from cv::RNG(2^64-1) like OpenCV does; else u32[b,n_draws] words consumed in order
  * (index = word % count, redrawn while it repeats), n_draws >= 5*iters.

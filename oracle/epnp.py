@@ -16,6 +16,13 @@ The arithmetic lives in OpenCV (calib3d), a third-party dependency that is NOT u
   reprojection error in float32 against reprojErr^2, best = strictly more inliers, adaptive iteration count
   (``RANSACUpdateNumIters``, confidence 0.99), final EPnP on all inliers of the best model —
 
+* exactly four correspondences: solvePnPRansac switches its kernel to SOLVEPNP_P3P and solves once with all four
+  (solvepnp.cpp: ``npoints == 4 -> model_points = 4, ransac_kernel_method = SOLVEPNP_P3P; model_points == npoints -> solvePnP``).
+  calib3d's p3p.cpp (Gao, Hou, Tang, Chang, PAMI 2003) finds the up-to-four poses consistent with the FIRST THREE points and
+  orders them by the reprojection error of the fourth; the first is returned.  ``p3p_4points`` restates that contract with
+  Grunert's elimination (Haralick et al., "Review and analysis of solutions of the three point perspective pose estimation
+  problem", IJCV 1994): the P3P solution set does not depend on the elimination used, so both pick the same pose —
+
 and is anchored on closed-form properties instead of golden vectors: exact correspondences recover the pose they were
 projected with; with outliers the inlier set is the set of uncontaminated points.  The dense linear algebra uses LAPACK
 (np.linalg), an implementation independent of the device code.
@@ -234,13 +241,78 @@ def update_num_iters(p, ep, model_points, max_iters):
     return int(np.rint(num / denom))
 
 
+def p3p_4points(pw, uv, K):
+    """cv2.solvePnP(flags=SOLVEPNP_P3P) on exactly four correspondences -> (R, t) or None.
+
+    Unit bearings j_i of the first three image points, model distances a = |P2 P3|, b = |P1 P3|, c = |P1 P2|, cosines
+    alpha = (j2, j3), beta = (j1, j3), gamma = (j1, j2).  With camera distances s2 = u s1, s3 = v s1 the three cosine laws give
+        u = N(v) / D(v),  N = (q - 1) v^2 - 2 q cos(beta) v + 1 + q,  D = 2 (cos(gamma) - v cos(alpha)),  q = (a^2 - c^2) / b^2
+    and, substituted into  u^2 - 2 cos(gamma) u + 1 = (c^2 / b^2)(1 + v^2 - 2 v cos(beta)),  the quartic
+        N^2 - 2 cos(gamma) N D + D^2 (1 - (c^2 / b^2)(1 + v^2 - 2 v cos(beta))) = 0   in v.
+    Every real root v > 0 with u > 0 (u re-derived from the two cosine laws it has to satisfy, see below) gives s1 = c / sqrt(1 + u^2 - 2 u cos(gamma)) and the camera points s_i j_i; the rigid motion
+    model -> camera follows by absolute orientation (Arun).  The candidate with the smallest reprojection error of the FOURTH
+    point (normalised image coordinates, like p3p.cpp) wins."""
+    pw = np.asarray(pw, np.float64).reshape(4, 3)
+    uv = np.asarray(uv, np.float64).reshape(4, 2)
+    K = np.asarray(K, np.float64).reshape(3, 3)
+    xn = np.stack([(uv[:, 0] - K[0, 2]) / K[0, 0], (uv[:, 1] - K[1, 2]) / K[1, 1], np.ones(4)], 1)
+    j = xn[:3] / np.linalg.norm(xn[:3], axis=1, keepdims=True)
+    a2, b2, c2 = np.sum((pw[1] - pw[2]) ** 2), np.sum((pw[0] - pw[2]) ** 2), np.sum((pw[0] - pw[1]) ** 2)
+    if min(a2, b2, c2) <= 0.0:
+        return None
+    ca, cb, cg = j[1] @ j[2], j[0] @ j[2], j[0] @ j[1]
+    q = (a2 - c2) / b2
+    N = np.array([q - 1.0, -2.0 * q * cb, 1.0 + q])                     # highest power first (np.poly convention)
+    D = np.array([-2.0 * ca, 2.0 * cg])
+    Q = np.array([-c2 / b2, 2.0 * (c2 / b2) * cb, 1.0 - c2 / b2])        # 1 - (c^2 / b^2)(1 + v^2 - 2 v cos beta)
+    quartic = np.polyadd(np.polysub(np.polymul(N, N), 2.0 * cg * np.polymul(N, D)), np.polymul(np.polymul(D, D), Q))
+    if not np.all(np.isfinite(quartic)) or abs(quartic[0]) < 1e-300:
+        return None
+    best = None
+    for v in np.roots(quartic):
+        if abs(v.imag) > 1e-7 * max(1.0, abs(v.real)) or v.real <= 0.0:
+            continue
+        v = v.real
+        # u from the quadratic  u^2 - 2 cos(gamma) u + 1 = (c^2 / b^2) f,  f = 1 + v^2 - 2 v cos(beta)  (N / D is 0 / 0 when the
+        # object subtends a small angle: cos(gamma) ~ v cos(alpha)); of its two roots the one that also satisfies
+        # u^2 - 2 v cos(alpha) u + v^2 = (a^2 / b^2) f
+        f = 1.0 + v * v - 2.0 * v * cb
+        disc = max(cg * cg - 1.0 + (c2 / b2) * f, 0.0)
+        cand = [cg + np.sqrt(disc), cg - np.sqrt(disc)]
+        u = min(cand, key=lambda x: abs(x * x - 2.0 * v * ca * x + v * v - (a2 / b2) * f))
+        w = 1.0 + u * u - 2.0 * u * cg
+        if u <= 0.0 or w <= 0.0:
+            continue
+        s1 = np.sqrt(c2 / w)
+        pc = np.stack([s1 * j[0], u * s1 * j[1], v * s1 * j[2]])
+        # absolute orientation of the three pairs (Arun): pc = R pw + t
+        mw, mc = pw[:3].mean(0), pc.mean(0)
+        H = (pc - mc).T @ (pw[:3] - mw)
+        U, _, Vt = np.linalg.svd(H)
+        R = U @ Vt
+        if np.linalg.det(R) < 0:
+            U[:, 2] = -U[:, 2]
+            R = U @ Vt
+        t = mc - R @ mw
+        p4 = R @ pw[3] + t
+        err = (p4[0] / p4[2] - xn[3, 0]) ** 2 + (p4[1] / p4[2] - xn[3, 1]) ** 2
+        if np.isfinite(err) and (best is None or err < best[0]):
+            best = (err, R, t)
+    return None if best is None else (best[1], best[2])
+
+
 def solve_pnp_ransac_epnp(pw, uv, K, reproj_err=3.0, iters=100, confidence=0.99, rng_next=None):
     """-> (ok, R, t, inlier_mask bool[n]).  ``rng_next`` yields 32-bit words (default: cv::RNG seeded like OpenCV)."""
     pw32, uv32 = np.asarray(pw, np.float32), np.asarray(uv, np.float32)      # solvePnPRansac converts to CV_32F
     K = np.asarray(K, np.float64)
     n = len(pw32)
-    if n <= 4:      # n == 4: OpenCV solves with P3P (model_points = 4), not restated — product and oracle report "no model"
+    if n < 4:
         return False, np.eye(3), np.zeros(3), np.zeros(n, bool)
+    if n == 4:      # model_points = 4, kernel P3P, model_points == npoints: one solve with all four, every point an inlier
+        sol = p3p_4points(pw32, uv32, K)
+        if sol is None:
+            return False, np.eye(3), np.zeros(3), np.zeros(n, bool)
+        return True, sol[0], sol[1], np.ones(n, bool)
     model_points = 5
     if n == model_points:
         sol = epnp(pw32, uv32, K)

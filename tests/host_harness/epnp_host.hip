@@ -6,6 +6,7 @@
 __host__ static inline double __shfl_xor(double v, int, int) { return v; }
 __host__ static inline int __shfl_xor(int v, int, int) { return v; }
 __host__ static inline int __shfl(int v, int, int) { return v; }
+__host__ static inline double __shfl(double v, int, int) { return v; }
 #undef __device__
 #define __device__ __attribute__((host)) __attribute__((device))
 #include EPNP_SOURCE
@@ -14,4 +15,8 @@ extern "C" int host_epnp(const float* uv, const float* pw, int n, const float* K
   Cam cam = Cam{(double)K9[0], (double)K9[4], (double)K9[2], (double)K9[5]};
   PointSet ps{uv, pw, nullptr, nullptr, cam, 0.f, n, n};
   return epnp_solve<false>(ps, cam, 0, R, t) ? 1 : 0;
+}
+extern "C" int host_p3p(const float* uv, const float* pw, const float* K9, double* R, double* t) {
+  Cam cam = Cam{(double)K9[0], (double)K9[4], (double)K9[2], (double)K9[5]};
+  return p3p_4points(uv, pw, cam, R, t) ? 1 : 0;
 }

@@ -57,14 +57,34 @@ def test_ransac_inlier_set_is_the_uncontaminated_points():
     ok, Re, te, mask = E.solve_pnp_ransac_epnp(pw, uv, K)
     assert ok and np.array_equal(mask, ~bad)
     assert np.abs(Re - R).max() < 2e-3 and np.abs(te - t).max() < 2e-3
-    # fewer than 4 points: no model; exactly 4 (OpenCV: P3P, not restated): no model either — the documented deviation,
-    # pinned here and on the device (test_gpu_epnp counts include 4); exactly 5: plain EPnP
+    # fewer than 4 points: no model; exactly 4: one P3P solve, every point an inlier (solvepnp.cpp: model_points == npoints);
+    # exactly 5: plain EPnP
     assert not E.solve_pnp_ransac_epnp(pw[:3], uv[:3], K)[0]
-    ok4, R4, t4, m4 = E.solve_pnp_ransac_epnp(pw[:4], uv[:4], K)
-    assert not ok4 and np.array_equal(R4, np.eye(3)) and not t4.any() and not m4.any()
+    R4t, t4t, pw4, uv4, _ = _case(rng, 4)
+    ok4, R4, t4, m4 = E.solve_pnp_ransac_epnp(pw4, uv4, K)
+    assert ok4 and m4.all() and np.abs(R4 - R4t).max() < 1e-3 and np.abs(t4 - t4t).max() < 1e-3     # float32 image points
     R5, t5, pw5, uv5, _ = _case(rng, 5)
     ok, Re, te, mask = E.solve_pnp_ransac_epnp(pw5, uv5, K)
     assert ok and mask.all() and np.abs(te - t5).max() < 1e-4
+
+
+def test_p3p_recovers_exact_poses_and_picks_by_the_fourth_point():
+    """p3p_4points (cv2.solvePnP(SOLVEPNP_P3P) on four correspondences): exact projections give back the pose they were made
+    with (float64 inputs: 1e-6 but for the clustered-root configurations P3P is ill-conditioned in — then the pose still
+    re-projects all four points to a tenth of a pixel); a fourth point that belongs to ANOTHER of the P3P solutions flips
+    the choice."""
+    rng = np.random.default_rng(7)
+    errs, reproj = [], []
+    for _ in range(400):
+        R, t, pw, uv, _ = _case(rng, 4)
+        Re, te = E.p3p_4points(pw, uv, K)
+        errs.append(max(np.abs(Re - R).max(), np.abs(te - t).max()))
+        pc = pw @ Re.T + te
+        reproj.append(np.abs(pc[:, :2] / pc[:, 2:] * [K[0, 0], K[1, 1]] + [K[0, 2], K[1, 2]] - uv).max())
+        assert abs(np.linalg.det(Re) - 1.0) < 1e-9
+    errs = np.array(errs)
+    assert np.median(errs) < 1e-8 and (errs < 1e-6).mean() > 0.97 and max(reproj) < 0.1 and np.median(reproj) < 1e-6
+    assert E.p3p_4points(np.zeros((4, 3)), np.zeros((4, 2)), K) is None                                  # coincident points
 
 
 def test_device_epnp_math_compiled_for_the_host_equals_the_oracle(tmp_path):
@@ -101,3 +121,22 @@ def test_device_epnp_math_compiled_for_the_host_equals_the_oracle(tmp_path):
         assert bool(ok) == (sol is not None)
         if sol is not None:
             assert np.abs(Rh.reshape(3, 3) - sol[0]).max() < 1e-7 and np.abs(th - sol[1]).max() < 1e-7, (trial, n)
+    # the P3P of exactly four correspondences (Durand-Kerner quartic roots + Jacobi SVD on the device side, np.roots + LAPACK in
+    # the oracle): the same pose wherever the quartic's roots are separated; always a pose that re-projects the four points
+    close = 0
+    for trial in range(200):
+        R, t, pw, uv, _ = _case(rng, 4, noise=0.0 if trial % 2 else 0.3)
+        uv = uv.astype(np.float32)
+        pw = pw.astype(np.float32)
+        Rh, th = np.zeros(9), np.zeros(3)
+        ok = lib.host_p3p(uv.ctypes.data_as(fp), pw.ctypes.data_as(fp), K32.ctypes.data_as(fp), Rh.ctypes.data_as(dp), th.ctypes.data_as(dp))
+        sol = E.p3p_4points(pw, uv, K)
+        assert bool(ok) == (sol is not None), trial
+        if sol is None:
+            continue
+        Rh = Rh.reshape(3, 3)
+        close += int(np.abs(Rh - sol[0]).max() < 1e-6 and np.abs(th - sol[1]).max() < 1e-6)
+        pc = pw[:3].astype(np.float64) @ Rh.T + th                                                       # its three defining points
+        px = pc[:, :2] / pc[:, 2:] * [K[0, 0], K[1, 1]] + [K[0, 2], K[1, 2]]
+        assert np.abs(px - uv[:3]).max() < 1e-2 and abs(np.linalg.det(Rh) - 1.0) < 1e-9, trial
+    assert close >= 190, close

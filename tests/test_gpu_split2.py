@@ -390,8 +390,10 @@ def test_third_batch_leaves_the_range_on_the_small_side(hip, three_products):
         assert engine.range_reruns() == reruns and hip_layers.x3_demoted() == {} and torch.isfinite(rec).all()
         g = engine.GraphedInference(model, post, batch, warmup=1)
         assert g.uses_x3 and g.captures == 1 and torch.equal(g.replay(), rec)
-        blk.norm.weight.mul_(1e-3)
-        blk.norm.bias.mul_(1e-3)
+        w_ok, b_ok = blk.norm.weight.clone(), blk.norm.bias.clone()
+        w_tiny, b_tiny = w_ok * 1e-3, b_ok * 1e-3
+        blk.norm.weight.copy_(w_tiny)
+        blk.norm.bias.copy_(b_tiny)
         want = _six(hip_layers, lambda: engine.inference_step(model, post, batch))
         got = engine.inference_step(model, post, batch)
         assert engine.range_reruns() == reruns + 1 and torch.equal(got, want)
@@ -404,13 +406,13 @@ def test_third_batch_leaves_the_range_on_the_small_side(hip, three_products):
         got_g = g.replay()
         assert g.captures == 2 and torch.equal(got_g, again) and engine.range_reruns() == reruns + 1
         # ... and a graph whose own replay trips: forget the demotion, capture afresh with healthy weights, shrink, replay
-        blk.norm.weight.mul_(1e3)
-        blk.norm.bias.mul_(1e3)
+        blk.norm.weight.copy_(w_ok)
+        blk.norm.bias.copy_(b_ok)
         hip_layers.reset_x3_demotions()
         g2 = engine.GraphedInference(model, post, batch, warmup=1)
         assert g2.captures == 1 and hip_layers.x3_demoted() == {}
-        blk.norm.weight.mul_(1e-3)
-        blk.norm.bias.mul_(1e-3)
+        blk.norm.weight.copy_(w_tiny)
+        blk.norm.bias.copy_(b_tiny)
         got_g2 = g2.replay()
         assert g2.captures == 2 and engine.range_reruns() == reruns + 2 and len(hip_layers.x3_demoted()) == len(demoted)
         assert torch.equal(got_g2, want)

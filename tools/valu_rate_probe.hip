@@ -4,6 +4,9 @@
 //   fma      v_fma_f32      acc, a, b, acc           (1 FMA per lane and instruction)
 //   pk       v_pk_fma_f32   acc2, a2, b2, acc2       (2 FMAs per lane and instruction)
 //   pk_bcast v_pk_fma_f32 with the b operand the same register pair in every instruction (a weight held in registers)
+//   pk_alt2  ... the b operand alternating between two pairs (the kernel's pattern: wv.xy, wv.zw, wv.xy, ...)
+//   pk_run8  ... the b operand changing every 8 instructions, the a operand sliding by one pair per instruction (a kx tap of
+//            dwconv: acc[j] += row[j + kx] * w for j = 0..7)
 // at 1, 2 and 4 waves per SIMD.  Build: hipcc --offload-arch=gfx950 -O3 tools/valu_rate_probe.hip -o _ab/valu_rate_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,7 +23,7 @@ __global__ __launch_bounds__(256) void probe(float* out, float seed) {
   for (int i = 0; i < 32; ++i) acc[i] = f2{seed * i, seed + i};
 #pragma unroll
   for (int i = 0; i < 8; ++i) a[i] = f2{1.0f + seed * i, 1.0f - seed * i};
-  f2 b = f2{seed, -seed};
+  f2 b = f2{seed, -seed}, b2 = f2{-seed, seed * 2};
   for (int it = 0; it < kIters; ++it) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
@@ -29,8 +32,12 @@ __global__ __launch_bounds__(256) void probe(float* out, float seed) {
                      : "+v"(acc[i].x), "+v"(acc[i].y) : "v"(a[i & 7].x), "v"(a[(i + 1) & 7].x), "v"(a[i & 7].y), "v"(a[(i + 1) & 7].y));
       } else if constexpr (MODE == 1) {   // packed, all three operands distinct register pairs
         asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i & 7]), "v"(a[(i + 3) & 7]));
-      } else {                            // packed, one operand the same pair throughout
+      } else if constexpr (MODE == 2) {   // packed, one operand the same pair throughout
         asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i & 7]), "v"(b));
+      } else if constexpr (MODE == 3) {   // packed, the shared operand alternates between two pairs
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i & 7]), "v"(i & 1 ? b : b2));
+      } else {                            // runs of 8 with one weight pair, the other operand sliding
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[(i + (i >> 3)) & 7]), "v"((i >> 3) & 1 ? b : b2));
       }
     }
   }
@@ -72,5 +79,7 @@ int main() {
   run<0>("fma", d_out, cus);
   run<1>("pk", d_out, cus);
   run<2>("pk_bcast", d_out, cus);
+  run<3>("pk_alt2", d_out, cus);
+  run<4>("pk_run8", d_out, cus);
   return 0;
 }
