@@ -412,11 +412,18 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
       }
 #endif
 #ifndef GDRNPP2_NO_RANGE_CHECK
-      // sums of squares of cur's h halves in slots without split arithmetic (cur[..].h stays live through group h*h)
-      if constexpr (S == 0) { ssq[2] = sumsq2(cur[1].h[0], ssq[2]); ssq[3] = sumsq2(cur[1].h[1], ssq[3]); }
-      if constexpr (S == 2) { ssq[2] = sumsq2(cur[1].h[2], ssq[2]); ssq[3] = sumsq2(cur[1].h[3], ssq[3]); }
-      if constexpr (S == 11) { ssq[0] = sumsq2(cur[0].h[0], ssq[0]); ssq[1] = sumsq2(cur[0].h[1], ssq[1]); }
-      if constexpr (S == 12) { ssq[0] = sumsq2(cur[0].h[2], ssq[0]); ssq[1] = sumsq2(cur[0].h[3], ssq[1]); }
+      // sums of squares of cur's h halves in slots without split arithmetic (cur[..].h stays live through group h*h);
+      // -DGDRNPP2_RC_SLOTS=a,b,c,d moves the four pairs for A/B timing (profiles/r04c_range_check_slots.txt)
+#ifndef GDRNPP2_RC_SLOTS
+#define GDRNPP2_RC_SLOTS 0, 2, 11, 12
+#endif
+      {
+        constexpr int rc[4] = {GDRNPP2_RC_SLOTS};
+        if constexpr (S == rc[0]) { ssq[2] = sumsq2(cur[1].h[0], ssq[2]); ssq[3] = sumsq2(cur[1].h[1], ssq[3]); }
+        if constexpr (S == rc[1]) { ssq[2] = sumsq2(cur[1].h[2], ssq[2]); ssq[3] = sumsq2(cur[1].h[3], ssq[3]); }
+        if constexpr (S == rc[2]) { ssq[0] = sumsq2(cur[0].h[0], ssq[0]); ssq[1] = sumsq2(cur[0].h[1], ssq[1]); }
+        if constexpr (S == rc[3]) { ssq[0] = sumsq2(cur[0].h[2], ssq[0]); ssq[1] = sumsq2(cur[0].h[3], ssq[1]); }
+      }
 #endif
       constexpr int S1 = NJ == 4 ? 13 : 20;   // first split slot of the second half (its raw read four slots earlier)
       if constexpr (!ADIR && S == S1 - 4) load_half(nxt[1], sa1, 1);

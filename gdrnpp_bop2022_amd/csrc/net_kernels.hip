@@ -551,6 +551,60 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// GroupNorm (+ GELU) of SMALL images in one launch (Patch-PnP's 32x32 / 16x16 / 8x8 x 128-channel maps: the two-pass form spent a
+// launch on ~8 us of statistics): one 1024-thread workgroup per image, pass 1 = fp64 sums per thread and an LDS gather per group,
+// pass 2 = normalise the same elements again (the image, <= 1 MB, comes back from L2).
+template <bool GELU>
+__global__ __launch_bounds__(1024) void gn_small_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y, int HW, int C, int G,
+                                                        float eps) {
+  extern __shared__ double sred[];  // [2][1024]
+  __shared__ float s_mean[64], s_rstd[64];
+  const int Q = C >> 2, cpg = C / G;
+  const int n = blockIdx.x;
+  const int q = threadIdx.x % Q, row = threadIdx.x / Q, rows = blockDim.x / Q;
+  const float* xb = x + (size_t)n * HW * C + 4 * q;
+  float* yb = y + (size_t)n * HW * C + 4 * q;
+  double s = 0.0, ss = 0.0;
+  for (int p = row; p < HW; p += rows) {
+    const float4 v = ld4(xb + (size_t)p * C);
+    s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    ss += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+  }
+  sred[threadIdx.x] = s;
+  sred[1024 + threadIdx.x] = ss;
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    const int g = threadIdx.x, qpg = cpg >> 2;
+    double a = 0.0, c2 = 0.0;
+    for (int r = 0; r < rows; ++r)
+      for (int k = 0; k < qpg; ++k) {
+        const int t = r * Q + g * qpg + k;
+        a += sred[t];
+        c2 += sred[1024 + t];
+      }
+    const double cnt = (double)HW * cpg, m = a / cnt;
+    double var = c2 / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    s_mean[g] = (float)m;
+    s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int g = (4 * q) / cpg;
+  const float m = s_mean[g], r = s_rstd[g];
+  const float4 ga = ld4(gamma + 4 * q), be = ld4(beta + 4 * q);
+  for (int p = row; p < HW; p += rows) {
+    float4 w = ld4(xb + (size_t)p * C);
+    w.x = (w.x - m) * r * ga.x + be.x;
+    w.y = (w.y - m) * r * ga.y + be.y;
+    w.z = (w.z - m) * r * ga.z + be.z;
+    w.w = (w.w - m) * r * ga.w + be.w;
+    if (GELU) { w.x = gelu_erf(w.x); w.y = gelu_erf(w.y); w.z = gelu_erf(w.z); w.w = gelu_erf(w.w); }
+    st4(yb + (size_t)p * C, w);
+  }
+}
+
+
 // --------------------------------------------------------------------------------------------------
 // LayerNorm over C of an NHWC tensor (timm LayerNorm2d of the ConvNeXt stem / downsample layers).  One thread holds one
 // channel quad of LN_PIX pixels (all loads issued before the first reduction); the C/4 lanes of a pixel are
@@ -867,6 +921,13 @@ int gdrnpp_groupnorm_act_nhwc(const float* x, const float* gamma, const float* b
                  "gdrnpp_groupnorm_act_nhwc: unsupported shape C=%d G=%d N=%d", C, G, N);
   const int P = HW >= 1024 ? 64 : (HW >= 64 ? 8 : 1);
   hipStream_t st = (hipStream_t)stream;
+  if ((size_t)HW * C * 4 <= (1u << 20) && x != y) {     // small images: statistics + normalisation in one launch
+    if (act_gelu)
+      hipLaunchKernelGGL(gn_small_kernel<true>, dim3(N), dim3(1024), sizeof(double) * 2048, st, x, gamma, beta, y, HW, C, G, eps);
+    else
+      hipLaunchKernelGGL(gn_small_kernel<false>, dim3(N), dim3(1024), sizeof(double) * 2048, st, x, gamma, beta, y, HW, C, G, eps);
+    return gdrnpp::check_launch("gdrnpp_groupnorm_act_nhwc");
+  }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(P, N), dim3(256), sizeof(double) * 512, st, x, (double*)workspace, HW, C, G,
                      P);
   const long total = (long)HW * Q;

@@ -236,17 +236,16 @@ __global__ __launch_bounds__(kRegThreads) void decode_corr_reg_kernel(
 //           quaternion_lf.qexp then quat2mat_torch), 4 = Lie vector / angle-axis (3 values: lie_algebra.lie_vec_to_rot)
 // t_mode:   0 = centroid_z with relative z (SITE), 1 = centroid_z with absolute z, 2 = centroid_z_abs (absolute 2-d centre
 //           and z: pose_from_pred_centroid_z_abs.py:44-76), 3 = trans (the head's output IS the translation: pose_from_pred.py:25-27)
-__global__ void pose_from_pred_kernel(const float* __restrict__ rot_in, const float* __restrict__ t_,
-                                      const float* __restrict__ cams, const float* __restrict__ centers,
-                                      const float* __restrict__ whs, const float* __restrict__ resize_ratios,
-                                      float* __restrict__ rot, float* __restrict__ trans, int b, int t_mode,
-                                      int is_allo, int rot_mode) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b) return;
+// rot_in / t_: the ROI's OWN rows of the head outputs (already offset); the other arrays are indexed by the ROI number i
+__device__ void pose_from_pred_one(const float* rot_in, const float* t_,
+                                   const float* __restrict__ cams, const float* __restrict__ centers,
+                                   const float* __restrict__ whs, const float* __restrict__ resize_ratios,
+                                   float* __restrict__ rot, float* __restrict__ trans, int i, int t_mode,
+                                   int is_allo, int rot_mode) {
   float Ra[9];
   if (rot_mode == 0) {
     // rot6d_to_mat_batch (rot_reps.py:34-55): x = normalize(a), z = normalize(x X b), y = z X x; columns (x,y,z)
-    const float* d6 = rot_in + 6 * (size_t)i;
+    const float* d6 = rot_in;
     float ax = d6[0], ay = d6[1], az = d6[2], bx = d6[3], by = d6[4], bz = d6[5];
     float na = fmaxf(sqrtf((ax * ax + ay * ay) + az * az), 1e-12f);  // F.normalize eps
     float x0 = ax / na, x1 = ay / na, x2 = az / na;
@@ -258,11 +257,11 @@ __global__ void pose_from_pred_kernel(const float* __restrict__ rot_in, const fl
   } else if (rot_mode == 1 || rot_mode == 3) {
     float q[4];
     if (rot_mode == 1) {
-      for (int k = 0; k < 4; ++k) q[k] = rot_in[4 * (size_t)i + k];
+      for (int k = 0; k < 4; ++k) q[k] = rot_in[k];
     } else {
       // quaternion_lf.qexp on a 3-vector (core/utils/quaternion_lf.py:294-318): s = 0, theta = |v|, exp(q) = (cos theta,
       // sin theta / max(theta, 1e-8) * v); get_rot_mat feeds it to quat2mat_torch (model_utils.py:350-352)
-      const float* v = rot_in + 3 * (size_t)i;
+      const float* v = rot_in;
       const float theta = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
       const float k = 1.0f / fmaxf(theta, 1e-8f) * sinf(theta);
       q[0] = cosf(theta); q[1] = k * v[0]; q[2] = k * v[1]; q[3] = k * v[2];
@@ -278,7 +277,7 @@ __global__ void pose_from_pred_kernel(const float* __restrict__ rot_in, const fl
   } else if (rot_mode == 4) {
     // lie_algebra.lie_vec_to_rot (core/utils/lie_algebra.py:7-77, kornia's angle_axis_to_rotation_matrix): Rodrigues with the
     // axis divided by (theta + 1e-6); theta^2 <= 1e-6 takes the first-order form I + [r]x
-    const float* v = rot_in + 3 * (size_t)i;
+    const float* v = rot_in;
     const float rx = v[0], ry = v[1], rz = v[2];
     const float theta2 = (rx * rx + ry * ry) + rz * rz;
     if (theta2 > 1e-6f) {
@@ -292,18 +291,18 @@ __global__ void pose_from_pred_kernel(const float* __restrict__ rot_in, const fl
       Ra[0] = 1.f; Ra[1] = -rz; Ra[2] = ry; Ra[3] = rz; Ra[4] = 1.f; Ra[5] = -rx; Ra[6] = -ry; Ra[7] = rx; Ra[8] = 1.f;
     }
   } else {
-    for (int k = 0; k < 9; ++k) Ra[k] = rot_in[9 * (size_t)i + k];
+    for (int k = 0; k < 9; ++k) Ra[k] = rot_in[k];
   }
 
   // pose_from_predictions_test (pose_from_pred_centroid_z.py:73-110 and its _abs / plain-translation siblings), fp32 like torch
   const float* K = cams + 9 * (size_t)i;
   float tx, ty, z;
   if (t_mode == 3) {
-    tx = t_[3 * i]; ty = t_[3 * i + 1]; z = t_[3 * i + 2];
+    tx = t_[0]; ty = t_[1]; z = t_[2];
   } else {
-    const float cxp = t_mode == 2 ? t_[3 * i] : t_[3 * i] * whs[2 * i] + centers[2 * i];
-    const float cyp = t_mode == 2 ? t_[3 * i + 1] : t_[3 * i + 1] * whs[2 * i + 1] + centers[2 * i + 1];
-    z = (t_mode == 0) ? t_[3 * i + 2] * resize_ratios[i] : t_[3 * i + 2];
+    const float cxp = t_mode == 2 ? t_[0] : t_[0] * whs[2 * i] + centers[2 * i];
+    const float cyp = t_mode == 2 ? t_[1] : t_[1] * whs[2 * i + 1] + centers[2 * i + 1];
+    z = (t_mode == 0) ? t_[2] * resize_ratios[i] : t_[2];
     tx = z * (cxp - K[2]) / K[0];
     ty = z * (cyp - K[5]) / K[4];
   }
@@ -338,18 +337,32 @@ __global__ void pose_from_pred_kernel(const float* __restrict__ rot_in, const fl
   }
 }
 
+__global__ void pose_from_pred_kernel(const float* __restrict__ rot_in, const float* __restrict__ t_,
+                                      const float* __restrict__ cams, const float* __restrict__ centers,
+                                      const float* __restrict__ whs, const float* __restrict__ resize_ratios,
+                                      float* __restrict__ rot, float* __restrict__ trans, int b, int t_mode,
+                                      int is_allo, int rot_mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b) return;
+  const int rdim = rot_mode == 0 ? 6 : (rot_mode == 1 ? 4 : (rot_mode == 2 ? 9 : 3));
+  pose_from_pred_one(rot_in + (size_t)rdim * i, t_ + 3 * (size_t)i, cams, centers, whs, resize_ratios, rot, trans, i, t_mode, is_allo, rot_mode);
+}
+
 // Patch-PnP's output layers fc_r | fc_t (conv_pnp_net.py:99-101,178-182) for one ROI per wavefront: lane l multiplies the
 // elements k = l, l + 64, ... of the ROI's feature row with each of the rot_dim + 3 weight rows, the partial sums meet in a
-// fixed-order butterfly (deterministic).  K <= 1024, rot_dim <= 9.
+// fixed-order butterfly (deterministic).  K <= 1024, rot_dim <= 9.  PoseArgs.rot != NULL: lane 0 goes on to the pose of its ROI
+// (pose_from_pred_one on the values it has just written) — the network's last launch.
+struct PoseArgs { const float* cams; const float* centers; const float* whs; const float* resize_ratios; float* rot; float* trans; int t_mode, is_allo, rot_mode; };
 __global__ __launch_bounds__(64) void pnp_fc_heads_kernel(const float* __restrict__ x, const float* __restrict__ w_r,
                                                           const float* __restrict__ b_r, const float* __restrict__ w_t,
                                                           const float* __restrict__ b_t, float* __restrict__ rot_,
-                                                          float* __restrict__ t_, int K, int rot_dim) {
+                                                          float* __restrict__ t_, int K, int rot_dim, PoseArgs pa) {
   const int i = blockIdx.x, lane = threadIdx.x;
   float xv[16];
   const int nk = (K + 63) / 64;
 #pragma unroll
   for (int j = 0; j < 16; ++j) xv[j] = (j < nk && lane + 64 * j < K) ? x[(size_t)i * K + lane + 64 * j] : 0.f;
+  float outv[12];
   for (int r = 0; r < rot_dim + 3; ++r) {
     const float* w = r < rot_dim ? w_r + (size_t)r * K : w_t + (size_t)(r - rot_dim) * K;
     float s = 0.f;
@@ -358,11 +371,15 @@ __global__ __launch_bounds__(64) void pnp_fc_heads_kernel(const float* __restric
       if (j < nk && lane + 64 * j < K) s = fmaf(xv[j], w[lane + 64 * j], s);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s += r < rot_dim ? (b_r ? b_r[r] : 0.f) : (b_t ? b_t[r - rot_dim] : 0.f);
+    outv[r] = s;
     if (lane == 0) {
-      if (r < rot_dim) rot_[(size_t)i * rot_dim + r] = s + (b_r ? b_r[r] : 0.f);
-      else t_[(size_t)i * 3 + (r - rot_dim)] = s + (b_t ? b_t[r - rot_dim] : 0.f);
+      if (r < rot_dim) rot_[(size_t)i * rot_dim + r] = s;
+      else t_[(size_t)i * 3 + (r - rot_dim)] = s;
     }
   }
+  if (pa.rot && lane == 0)     // the pose from the values this lane holds in registers
+    pose_from_pred_one(outv, outv + rot_dim, pa.cams, pa.centers, pa.whs, pa.resize_ratios, pa.rot, pa.trans, i, pa.t_mode, pa.is_allo, pa.rot_mode);
 }
 
 __global__ void zoom_K_kernel(const float* __restrict__ K, const float* __restrict__ centers,
@@ -451,8 +468,24 @@ int gdrnpp_pnp_fc_heads(const float* x, const float* w_r, const float* b_r, cons
   GDRNPP_REQUIRE(x && w_r && w_t && rot_ && t_, GDRNPP_EINVAL, "gdrnpp_pnp_fc_heads: null pointer");
   GDRNPP_REQUIRE(b > 0 && K > 0 && K <= 1024 && rot_dim > 0 && rot_dim <= 9, GDRNPP_ELIMIT,
                  "gdrnpp_pnp_fc_heads: b=%d K=%d (<= 1024) rot_dim=%d (<= 9)", b, K, rot_dim);
-  hipLaunchKernelGGL(pnp_fc_heads_kernel, dim3(b), dim3(64), 0, (hipStream_t)stream, x, w_r, b_r, w_t, b_t, rot_, t_, K, rot_dim);
+  hipLaunchKernelGGL(pnp_fc_heads_kernel, dim3(b), dim3(64), 0, (hipStream_t)stream, x, w_r, b_r, w_t, b_t, rot_, t_, K, rot_dim,
+                     PoseArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0});
   return gdrnpp::check_launch("gdrnpp_pnp_fc_heads");
+}
+
+int gdrnpp_pnp_fc_heads_pose(const float* x, const float* w_r, const float* b_r, const float* w_t, const float* b_t, float* rot_,
+                             float* t_, int b, int K, int rot_mode, int t_mode, const float* cams, const float* centers,
+                             const float* whs, const float* resize_ratios, float* rot, float* trans, int is_allo, void* stream) {
+  if (b == 0) return 0;
+  GDRNPP_REQUIRE(x && w_r && w_t && rot_ && t_ && cams && rot && trans, GDRNPP_EINVAL, "gdrnpp_pnp_fc_heads_pose: null pointer");
+  GDRNPP_REQUIRE(b > 0 && K > 0 && K <= 1024 && rot_mode >= 0 && rot_mode <= 4 && t_mode >= 0 && t_mode <= 3, GDRNPP_EINVAL,
+                 "gdrnpp_pnp_fc_heads_pose: b=%d K=%d rot_mode=%d t_mode=%d", b, K, rot_mode, t_mode);
+  GDRNPP_REQUIRE(t_mode >= 2 || (centers && whs && (t_mode == 1 || resize_ratios)), GDRNPP_EINVAL,
+                 "gdrnpp_pnp_fc_heads_pose: centroid_z needs centers, whs (and resize_ratios for relative z)");
+  const int rot_dim = rot_mode == 0 ? 6 : (rot_mode == 1 ? 4 : (rot_mode == 2 ? 9 : 3));
+  hipLaunchKernelGGL(pnp_fc_heads_kernel, dim3(b), dim3(64), 0, (hipStream_t)stream, x, w_r, b_r, w_t, b_t, rot_, t_, K, rot_dim,
+                     PoseArgs{cams, centers, whs, resize_ratios, rot, trans, t_mode, is_allo, rot_mode});
+  return gdrnpp::check_launch("gdrnpp_pnp_fc_heads_pose");
 }
 
 int gdrnpp_zoom_K(const float* K, const float* centers, const float* scales, float* K_crop, int b, float out_res,

@@ -125,7 +125,7 @@ class GDRN_DoubleMask(nn.Module):
                 and feat.shape[1] % 32 == 0 and (feat.shape[2] * feat.shape[3]) % 256 == 0
                 and feat.shape[0] * feat.shape[2] * feat.shape[3] * feat.shape[1] * 4 < (1 << 32))
 
-    def _fused_tail(self, feat, roi_classes, coord2d, roi_extents):
+    def _fused_tail(self, feat, roi_classes, coord2d, roi_extents, pose=None):
         """feat [B,256,64,64] (channels_last) -> Patch-PnP outputs and the maps of out_dict, without leaving NHWC:
         one grouped GEMM launch (each ROI's 4096 rows against the 70-channel weight slice of its class, padded to one 128-wide
         tile), one kernel for [xyz * extent | coord2d | region softmax] + the map planes, Patch-PnP's first convolution with
@@ -148,7 +148,7 @@ class GDRN_DoubleMask(nn.Module):
         out = hip_lib.linear_f32_split_grouped(x2d, w_pk, b128, roi_classes.to(torch.int32), h * wd, n_store=(n70 + 3) // 4 * 4)
         pnp_in, planes = hip_lib.head_tail_nhwc(out, coord2d.contiguous(), roi_extents.contiguous().float(), self.double_mask)
         x96 = pnp_in.view(bs, h, wd, 96).permute(0, 3, 1, 2)        # [B,96,H,W] channels_last view
-        pred_rot_, pred_t_ = self.pnp_net.forward_prepared(x96)
+        pred_rot_, pred_t_ = self.pnp_net.forward_prepared(x96, pose)
         planes = planes.view(planes.shape[0], bs, 1, h, wd)
         k = 2 if self.double_mask else 1
         maps = {"mask": planes[0], "coor_x": planes[k], "coor_y": planes[k + 1], "coor_z": planes[k + 2],
@@ -157,8 +157,9 @@ class GDRN_DoubleMask(nn.Module):
             maps["full_mask"] = planes[1]
         return pred_rot_, pred_t_, maps
 
-    def forward_maps(self, x, roi_classes=None, roi_coord_2d=None, roi_coord_2d_rel=None, roi_extents=None):
-        """Everything of ``forward`` up to the Patch-PnP outputs: pure PyTorch (also runs on CPU)."""
+    def forward_maps(self, x, roi_classes=None, roi_coord_2d=None, roi_coord_2d_rel=None, roi_extents=None, pose=None):
+        """Everything of ``forward`` up to the Patch-PnP outputs: pure PyTorch (also runs on CPU).  ``pose``: the pose request of
+        ``forward`` (hip_layers.pnp_fc_heads): on the HIP path Patch-PnP's last launch also produces the pose."""
         cfg = self.cfg
         net_cfg = cfg.MODEL.POSE_NET
         g_head_cfg = net_cfg.GEO_HEAD
@@ -182,7 +183,7 @@ class GDRN_DoubleMask(nn.Module):
             feat = self.geo_head_net.trunk(conv_feat)
             coord2d = roi_coord_2d_rel if pnp_net_cfg.WITH_2D_COORD and pnp_net_cfg.COORD_2D_TYPE == "rel" else roi_coord_2d
             if self._fused_tail_ok(x, feat, sel, coord2d, roi_extents):
-                return self._fused_tail(feat, sel, coord2d, roi_extents)
+                return self._fused_tail(feat, sel, coord2d, roi_extents, pose)
             if self.class_aware:
                 vis_mask, full_mask, coor_x, coor_y, coor_z, region = self._sliced_out_layer(feat, sel)
                 sliced = True
@@ -226,7 +227,7 @@ class GDRN_DoubleMask(nn.Module):
             mask_atten = get_mask_prob(vis_mask, net_cfg.LOSS_CFG.MASK_LOSS_TYPE)
         region_atten = region_softmax if pnp_net_cfg.REGION_ATTENTION else None
         pred_rot_, pred_t_ = self.pnp_net(coor_feat, region=region_atten, extents=roi_extents,
-                                          mask_attention=mask_atten)
+                                          mask_attention=mask_atten, **({"pose": pose} if pose is not None else {}))
 
         maps = {"mask": vis_mask, "coor_x": coor_x, "coor_y": coor_y, "coor_z": coor_z, "region": region}
         if full_mask is not None:
@@ -242,9 +243,8 @@ class GDRN_DoubleMask(nn.Module):
         cfg = self.cfg
         pnp_net_cfg = cfg.MODEL.POSE_NET.PNP_NET
         bs = x.shape[0]
-        pred_rot_, pred_t_, maps = self.forward_maps(x, roi_classes, roi_coord_2d, roi_coord_2d_rel, roi_extents)
-
-        # ---- rot6d -> R, centroid/z -> t, allo -> ego: one HIP kernel, no host sync --------------------------
+        # ---- rot6d -> R, centroid/z -> t, allo -> ego on the device, no host sync: in Patch-PnP's last launch on the HIP path
+        # (gdrnpp_pnp_fc_heads_pose), else one kernel of its own (gdrnpp_pose_from_pred) ------------------------------------------
         rot_type = pnp_net_cfg.ROT_TYPE          # get_rot_mat (model_utils.py:347-359) + the three TRANS_TYPE branches (:162-200)
         if rot_type in ("allo_rot6d", "ego_rot6d"):
             rot_mode = "rot6d"
@@ -266,11 +266,16 @@ class GDRN_DoubleMask(nn.Module):
         else:
             raise ValueError(f"Unknown trans type: {trans_type}")
         need_roi = trans_type == "centroid_z"
-        pred_ego_rot, pred_trans = hip_lib.pose_from_pred(
-            pred_rot_.float().contiguous(), pred_t_.float().contiguous(), roi_cams.reshape(bs, 9).contiguous(),
-            roi_centers.contiguous() if need_roi else None, roi_whs.contiguous() if need_roi else None,
-            resize_ratios.reshape(bs).contiguous() if need_roi and t_mode == "centroid_z_rel" else None,
-            rot_mode=rot_mode, t_mode=t_mode, is_allo="allo" in rot_type)
+        pose = dict(cams=roi_cams.reshape(bs, 9).contiguous().float(), centers=roi_centers.contiguous().float() if need_roi else None,
+                    whs=roi_whs.contiguous().float() if need_roi else None,
+                    resize_ratios=resize_ratios.reshape(bs).contiguous().float() if need_roi and t_mode == "centroid_z_rel" else None,
+                    rot_mode=rot_mode, t_mode=t_mode, is_allo="allo" in rot_type)
+        pred_rot_, pred_t_, maps = self.forward_maps(x, roi_classes, roi_coord_2d, roi_coord_2d_rel, roi_extents,
+                                                     pose if x.is_cuda else None)
+        if "result" in pose:
+            pred_ego_rot, pred_trans = pose.pop("result")
+        else:
+            pred_ego_rot, pred_trans = hip_lib.pose_from_pred(pred_rot_.float().contiguous(), pred_t_.float().contiguous(), **pose)
 
         out_dict = {"rot": pred_ego_rot, "trans": pred_trans}
         if cfg.TEST.USE_PNP or cfg.TEST.SAVE_RESULTS_ONLY or cfg.TEST.USE_DEPTH_REFINE:

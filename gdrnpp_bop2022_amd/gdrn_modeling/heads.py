@@ -261,7 +261,7 @@ class ConvPnPNet(nn.Module):
         _normal_init(self.fc_r, 0.01)
         _normal_init(self.fc_t, 0.01)
 
-    def forward(self, coor_feat, region=None, extents=None, mask_attention=None):
+    def forward(self, coor_feat, region=None, extents=None, mask_attention=None, pose=None):
         bs, in_c, fh, fw = coor_feat.shape
         if in_c in (3, 5) and self.denormalize_by_extent and extents is not None:
             coor_feat[:, :3] = (coor_feat[:, :3] - 0.5) * extents.view(bs, 3, 1, 1)  # in place, like :130-131
@@ -271,16 +271,16 @@ class ConvPnPNet(nn.Module):
         elif self.mask_attention_type == "concat":
             x = torch.cat([x, mask_attention], dim=1)
         x = run_features(self.features, x)
-        return self._fc_tail(x)
+        return self._fc_tail(x, pose)
 
-    def _fc_tail(self, x):
+    def _fc_tail(self, x, pose=None):
         x = x.flatten(2).flatten(1)  # NCHW order, like the reference (weights of fc1 depend on it)
         if isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none":
             x = hip_layers.linear(self.fc2, hip_layers.linear(self.fc1, x, gelu=True), gelu=True)   # GELU in the GEMM epilogues
         else:
             x = self.act(hip_layers.linear(self.fc1, x))
             x = self.act(hip_layers.linear(self.fc2, x))
-        return hip_layers.pnp_fc_heads(self.fc_r, self.fc_t, x)
+        return hip_layers.pnp_fc_heads(self.fc_r, self.fc_t, x, pose)
 
     # ---- NHWC entry used by the fused head tail (hip_lib.head_tail_nhwc) ------------------------------------------------
     def accepts_prepared_input(self) -> bool:
@@ -291,7 +291,7 @@ class ConvPnPNet(nn.Module):
                 and c0.stride == (2, 2) and c0.padding == (1, 1) and c0.bias is None and self.mask_attention_type == "none"
                 and self.denormalize_by_extent)
 
-    def forward_prepared(self, x96_cl):
+    def forward_prepared(self, x96_cl, pose=None):
         """``x96_cl``: [B, 96, H, W] channels_last, channels 69..95 zero.  First convolution with its weight zero-padded to 96
         input channels on the implicit-GEMM split kernel, the rest as ``forward``."""
         c0 = self.features[0]
@@ -306,7 +306,7 @@ class ConvPnPNet(nn.Module):
         w_pk = hip_layers._packed_weight(cache, "w96_pk", c0.weight, lambda w: hip_lib.pack_conv_weight_bf16x3(w96(w)))
         x = hip_lib.conv2d_f32_split(x96_cl, w_pk, None, 3, 3, 2, 1)
         x = run_features(self.features[1:], x)
-        return self._fc_tail(x)
+        return self._fc_tail(x, pose)
 
 
 HEADS = {

@@ -469,9 +469,17 @@ def linear(fc: nn.Linear, x: torch.Tensor, gelu: bool = False) -> torch.Tensor:
     return F.gelu(fc(x)) if gelu else fc(x)
 
 
-def pnp_fc_heads(fc_r: nn.Linear, fc_t: nn.Linear, x: torch.Tensor):
-    """(fc_r(x), fc_t(x)) of Patch-PnP in one HIP launch instead of two library GEMMs (conv_pnp_net.py:99-101,178-182)."""
+def pnp_fc_heads(fc_r: nn.Linear, fc_t: nn.Linear, x: torch.Tensor, pose: dict | None = None):
+    """(fc_r(x), fc_t(x)) of Patch-PnP in one HIP launch instead of two library GEMMs (conv_pnp_net.py:99-101,178-182).
+    ``pose`` (the keyword arguments of ``hip_lib.pose_from_pred`` after its two head tensors): the same launch also turns them
+    into the pose and leaves ``pose["result"] = (R_ego, trans)``."""
     if (enabled_for(x) and _MLP_GEMM == "split" and x.dim() == 2 and x.is_contiguous() and fc_r.in_features == fc_t.in_features <= 1024
             and fc_r.out_features <= 9 and fc_t.out_features == 3):
-        return hip_lib.pnp_fc_heads(x, fc_r.weight.detach().contiguous(), fc_r.bias, fc_t.weight.detach().contiguous(), fc_t.bias)
+        w_r, w_t = fc_r.weight.detach().contiguous(), fc_t.weight.detach().contiguous()
+        if pose is not None and fc_r.out_features == {"rot6d": 6, "quat": 4, "mat": 9, "log_quat": 3, "lie_vec": 3}[pose["rot_mode"]]:
+            kw = {k: v for k, v in pose.items() if k != "result"}
+            rot_, t_, R, trans = hip_lib.pnp_fc_heads_pose(x, w_r, fc_r.bias, w_t, fc_t.bias, **kw)
+            pose["result"] = (R, trans)
+            return rot_, t_
+        return hip_lib.pnp_fc_heads(x, w_r, fc_r.bias, w_t, fc_t.bias)
     return fc_r(x), fc_t(x)

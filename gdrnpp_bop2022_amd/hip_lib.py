@@ -103,6 +103,7 @@ SIGNATURES = {
     "gdrnpp_deconv_col2im_nhwc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_deconv_col2im_gn_nhwc": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_pnp_fc_heads": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "gdrnpp_pnp_fc_heads_pose": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "gdrnpp_conv3x3_gnstats_partials": (c_int, [c_int, c_int]),
     "gdrnpp_conv3x3_f32_split_gnstats": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_groupnorm_apply_nhwc": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
@@ -990,6 +991,32 @@ def pnp_fc_heads(x, w_r, b_r, w_t, b_t):
                                       _dev(b_t, torch.float32, "b_t") if b_t is not None else None, rot_.data_ptr(), t_.data_ptr(),
                                       b, k, rot_dim, _stream()), "gdrnpp_pnp_fc_heads")
     return rot_, t_
+
+
+ROT_MODES = {"rot6d": 0, "quat": 1, "mat": 2, "log_quat": 3, "lie_vec": 4}
+T_MODES = {"centroid_z_rel": 0, "centroid_z_abs_z": 1, "centroid_z_abs": 2, "trans": 3}
+
+
+def pnp_fc_heads_pose(x, w_r, b_r, w_t, b_t, cams, centers=None, whs=None, resize_ratios=None, rot_mode: str = "rot6d",
+                      t_mode: str = "centroid_z_rel", is_allo: bool = True):
+    """``pnp_fc_heads`` + ``pose_from_pred`` in one launch (``gdrnpp_pnp_fc_heads_pose``) -> (rot_ f32[b,rot_dim], t_ f32[b,3],
+    R_ego f32[b,3,3], trans f32[b,3])."""
+    b, k = x.shape
+    rot_dim = w_r.shape[0]
+    if rot_dim != {0: 6, 1: 4, 2: 9, 3: 3, 4: 3}[ROT_MODES[rot_mode]]:
+        raise ValueError(f"fc_r has {rot_dim} outputs, rot_mode {rot_mode!r} needs another count")
+    dev = x.device
+    rot_ = torch.empty((b, rot_dim), dtype=torch.float32, device=dev)
+    t_ = torch.empty((b, 3), dtype=torch.float32, device=dev)
+    rot = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
+    trans = torch.empty((b, 3), dtype=torch.float32, device=dev)
+    opt = lambda v, n: _dev(v, torch.float32, n) if v is not None else None  # noqa: E731
+    _check(load().gdrnpp_pnp_fc_heads_pose(
+        _dev(x, torch.float32, "x"), _dev(w_r, torch.float32, "w_r"), opt(b_r, "b_r"), _dev(w_t, torch.float32, "w_t"), opt(b_t, "b_t"),
+        rot_.data_ptr(), t_.data_ptr(), b, k, ROT_MODES[rot_mode], T_MODES[t_mode], _dev(cams, torch.float32, "cams"), opt(centers, "centers"),
+        opt(whs, "whs"), opt(resize_ratios, "resize_ratios"), rot.data_ptr(), trans.data_ptr(), 1 if is_allo else 0, _stream()),
+        "gdrnpp_pnp_fc_heads_pose")
+    return rot_, t_, rot, trans
 
 
 def conv3x3_groupnorm_act(x_cl, weight_packed, bias, gamma, beta, groups: int, eps: float = 1e-5, gelu: bool = False, x3_slot: int = 0):

@@ -224,6 +224,12 @@ int gdrnpp_pose_from_pred(const float* rot_in, int rot_mode, const float* t_, in
  * -> rot_ f32[b,rot_dim], t_ f32[b,3]; fp32 fma chains, one wavefront per ROI, fixed summation order. */
 int gdrnpp_pnp_fc_heads(const float* x, const float* w_r, const float* b_r, const float* w_t, const float* b_t, float* rot_,
                         float* t_, int b, int K, int rot_dim, void* stream);
+/* the same launch followed, per ROI, by gdrnpp_pose_from_pred on the values just computed (GDRN_double_mask.py:162-200 behind
+ * conv_pnp_net.py:178-182): the network's last kernel.  rot_dim follows from rot_mode (6 / 4 / 9 / 3 / 3); rot_ f32[b,rot_dim] and
+ * t_ f32[b,3] are written as well (forward returns them to the losses / tests).  Pose arguments as gdrnpp_pose_from_pred. */
+int gdrnpp_pnp_fc_heads_pose(const float* x, const float* w_r, const float* b_r, const float* w_t, const float* b_t, float* rot_,
+                             float* t_, int b, int K, int rot_mode, int t_mode, const float* cams, const float* centers,
+                             const float* whs, const float* resize_ratios, float* rot, float* trans, int is_allo, void* stream);
 
 /* ---- crop-resize intrinsics (a8.2) — camera_geometry.py:6-21 --------------
  * K f32[b,9], centers f32[b,2], scales f32[b] -> K_crop f32[b,9],

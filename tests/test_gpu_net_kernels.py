@@ -626,3 +626,28 @@ def test_patch_pnp_tail_runs_on_this_library(hip):
         r64, t64 = net.fc_r.double()(h), net.fc_t.double()(h)
     assert (r.double() - r64).abs().max().item() < 5e-6 * r64.abs().max().item()
     assert (t.double() - t64).abs().max().item() < 5e-6 * max(1.0, t64.abs().max().item())
+
+
+@pytest.mark.parametrize("rot_mode,t_mode,allo", [("rot6d", "centroid_z_rel", True), ("quat", "trans", False), ("lie_vec", "centroid_z_abs", True),
+                                                  ("log_quat", "centroid_z_abs_z", True)])
+def test_pnp_fc_heads_pose_equals_the_two_launches(hip, rot_mode, t_mode, allo):
+    """gdrnpp_pnp_fc_heads_pose = gdrnpp_pnp_fc_heads followed by gdrnpp_pose_from_pred, bit for bit, for the ROT_TYPE / TRANS_TYPE
+    families of GDRN_double_mask.py:162-200."""
+    torch.manual_seed(3)
+    b, k = 37, 256
+    rot_dim = {"rot6d": 6, "quat": 4, "log_quat": 3, "lie_vec": 3}[rot_mode]
+    x = torch.randn(b, k, device="cuda")
+    w_r, b_r = torch.randn(rot_dim, k, device="cuda") * 0.1, torch.randn(rot_dim, device="cuda")
+    w_t, b_t = torch.randn(3, k, device="cuda") * 0.05, torch.tensor([0.0, 0.0, 1.2], device="cuda")
+    cams = torch.tensor([[1066.8, 0, 312.9, 0, 1067.5, 241.3, 0, 0, 1.0]], device="cuda").repeat(b, 1)
+    centers = torch.rand(b, 2, device="cuda") * 400 + 100
+    whs = torch.rand(b, 2, device="cuda") * 100 + 40
+    rr = torch.rand(b, device="cuda") * 0.5 + 0.2
+    need = t_mode.startswith("centroid_z") and t_mode != "centroid_z_abs"
+    kw = dict(centers=centers if need else None, whs=whs if need else None, resize_ratios=rr if t_mode == "centroid_z_rel" else None,
+              rot_mode=rot_mode, t_mode=t_mode, is_allo=allo)
+    r1, t1 = hip.pnp_fc_heads(x, w_r, b_r, w_t, b_t)
+    R1, T1 = hip.pose_from_pred(r1, t1, cams, **kw)
+    r2, t2, R2, T2 = hip.pnp_fc_heads_pose(x, w_r, b_r, w_t, b_t, cams, **kw)
+    assert torch.equal(r1, r2) and torch.equal(t1, t2) and torch.equal(R1, R2) and torch.equal(T1, T2)
+    assert torch.isfinite(R2).all() and (R2 @ R2.transpose(1, 2) - torch.eye(3, device="cuda")).abs().max().item() < 1e-5
