@@ -205,14 +205,19 @@ def gdrn_inference_on_dataset(cfg, model, data_loader, evaluator, amp_test=False
     they hold that many ROIs (``packed_loader``) — at 128 the kernels run at the rate bench.py reports instead of the
     3-30-ROI rate.  Records, their order and the csv are unchanged; the time charged to an image is the time of the step that
     carried it, exactly as the reference charges every image of a batch the batch's time (:748-760)."""
+    lookahead = None
     if pack_rois:
-        data_loader = list(packed_loader(data_loader, int(pack_rois)))
+        # packs are formed lazily (a dataset's worth of pre-cropped ROIs must not be held in memory); the warm-up rule
+        # min(5, total - 1) needs to know whether at least six iterations exist: look that far ahead, no further
+        packs = packed_loader(data_loader, int(pack_rois))
+        lookahead = list(itertools.islice(packs, 6))
+        data_loader = itertools.chain(lookahead, packs)
     # TEST.AMP_TEST (gdrn_evaluator.py:736-747: ``with autocast(enabled=amp_test)`` around the forward).  The HIP network
     # layers of this library are fp32 computations (the parity configuration, common_base.py:219); under AMP the forward runs
     # as the plain PyTorch module graph inside ``torch.autocast`` — the reference's own mixed-precision path — and the outputs
     # are cast back to fp32 for the HIP post-processing.
     from . import hip_layers
-    total = len(data_loader)
+    total = len(lookahead) if lookahead is not None else len(data_loader)
     evaluator.reset()
     num_warmup = min(5, total - 1)
     start_time = time.perf_counter()
@@ -223,6 +228,7 @@ def gdrn_inference_on_dataset(cfg, model, data_loader, evaluator, amp_test=False
     n_rois = 0
     with torch.no_grad():
         for idx, inputs in enumerate(data_loader):
+            total = max(total, idx + 1)
             if idx == num_warmup:
                 start_time = time.perf_counter()
                 total_compute_time = total_process_time = 0.0
