@@ -41,13 +41,11 @@
 // stride / pad convolution (implicit im2col, k-tile order of gemm_split.hpp), optional GroupNorm statistics in the epilogue (as
 // gemm_split_glds_kernel<.., GNS>).  -DGDRNPP2_TIMING_NO_{BREAD,SPLIT,SYNC,DMA}: timing-only builds (results invalid) behind
 // profiles/r03y_split2_kloop_dissection.txt.
-#include "gemm_split.hpp"
+#include "split2_common.hpp"
 
 namespace {
 
-using namespace gdrnpp::splitgemm;
-using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
-using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using namespace gdrnpp::split2;
 
 constexpr int NA = 3;                          // A stages: the A DMA runs two k-tiles ahead
 constexpr int A_STAGE_B = 256 * BK * 4;        // fp32 A image of one k-tile: 16 KB
@@ -56,44 +54,6 @@ constexpr int W2_TILE_B = W2_TILE_SLOTS * 16;  // 8 KB
 
 __device__ int g_split2_range_word;  // sticky range word (GDRNPP_SPLIT2_NONFINITE | GDRNPP_SPLIT2_SMALL_ROWS) of launches that pass no word of their own
 __device__ __attribute__((aligned(64))) float g_split2_zero_page[16];
-
-__device__ __forceinline__ void dma_s(unsigned voff, const void* sbase, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
-               : "memory");
-}
-__device__ __forceinline__ void dma_v(const void* gsrc, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-template <int I, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < E) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, E>(f);
-  }
-}
-
-__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-}
-// x - f32(half HI of hpk), exact: one v_fma_mix_f32 (f16 source read in place, no v_cvt_f32_f16 in front of the subtraction)
-template <int HI>
-__device__ __forceinline__ float residual(float x, unsigned hpk) {
-  float r;
-  if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(x));
-  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(x));
-  return r;
-}
-
-// s + (lo of hpk)^2 + (hi of hpk)^2: one v_dot2c_f32_f16 (row sums of squares of the range check)
-__device__ __forceinline__ float sumsq2(unsigned hpk, float s) {
-  const f16x2 v = __builtin_bit_cast(f16x2, hpk);
-  return __builtin_amdgcn_fdot2(v, v, s, false);
-}
 
 // One half of a wave's A tile for one k-tile: 32 rows x 16 k, 8 consecutive k of one row per lane.  x ~ h + l in 8 steps of two
 // VALU operations (the residual overwrites x).
@@ -147,29 +107,6 @@ __device__ __forceinline__ void wait_scratch(ADirectScratch& s) {
 }
 #endif
 
-// W f32[N][K] -> max |w| (bits of a non-negative float order like unsigned integers)
-__global__ void amax_kernel(const float* __restrict__ W, long n, unsigned* __restrict__ out) {
-  float m = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float a = fabsf(W[i]);
-    m = (a > m || a != a) ? a : m;   // a NaN weight poisons the maximum (and with it every product, as it must)
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float t = __shfl_xor(m, o, 64);
-    m = (t > m || t != t) ? t : m;
-  }
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
-}
-
-// power-of-two scale of a weight tensor: max|w| * 2^e in [2^13, 2^14) (fp16: h = rn(x) cannot overflow, l of a typical weight
-// stays normal); e clamped so that 2^e and 2^-e are normal fp32
-__device__ __forceinline__ int weight_exp(unsigned amax_bits) {
-  const int ex = (int)((amax_bits >> 23) & 0xffu) - 127;   // floor(log2 amax) for normal amax; zero / subnormal -> -127
-  const int e = 13 - ex;
-  return amax_bits == 0u ? 0 : max(-110, min(110, e));
-}
-
 // W f32[N][K] -> packed fp16 [N/128][K/16][2][2][128][8]; one thread per (row, k-block) = 8 consecutive k.
 // trailer (16 B behind the tiles): {amax bits, 2^-e, 2^e, rows-below-range bit (weight_rows_range_kernel)}
 __global__ void pack_weight2_kernel(const float* __restrict__ W, uint4* __restrict__ packed, int N, int K) {
@@ -199,28 +136,6 @@ __global__ void pack_weight2_kernel(const float* __restrict__ W, uint4* __restri
   uint4* img = packed + ((size_t)tn * (K / BK) + tk) * W2_TILE_SLOTS;
   img[(0 * KB + kb) * BN + row] = make_uint4(h[0], h[1], h[2], h[3]);
   img[(1 * KB + kb) * BN + row] = make_uint4(l[0], l[1], l[2], l[3]);
-}
-
-// one workgroup per weight row: a row that is not all zero whose SCALED rms is below 2^-4 (2^-17 of the tensor maximum: its low
-// halves are fp16 subnormals) raises trailer word 3 — the per-row test of the kernels' A side, applied to the other operand
-__global__ void weight_rows_range_kernel(const float* __restrict__ W, uint4* __restrict__ packed, int N, int K) {
-  unsigned* trailer = reinterpret_cast<unsigned*>(packed + (size_t)(N / BN) * (K / BK) * W2_TILE_SLOTS);
-  const float sc = __builtin_ldexpf(1.f, weight_exp(trailer[0]));
-  const float* row = W + (size_t)blockIdx.x * K;
-  float s = 0.f;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const float v = row[k] * sc;
-    s = fmaf(v, v, s);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  __shared__ float part[4];
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    s = (part[0] + part[1]) + (part[2] + part[3]);
-    if (s > 0.f && s < (float)K * 0x1p-8f) atomicOr(trailer + 3, 1u);
-  }
 }
 
 struct GnStats2 { double* part; int G; int tiles_per_img; };   // as GnStats of gemm_split.hip
@@ -611,7 +526,7 @@ extern "C" int gdrnpp_pack_weight_f16x2(const float* W, void* packed, int N, int
   hipLaunchKernelGGL(amax_kernel, dim3((unsigned)min((n + 1023) / 1024, 1024l)), dim3(256), 0, st, W, n, trailer);
   const long threads = (long)N * (K / 8);
   hipLaunchKernelGGL(pack_weight2_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, (uint4*)packed, N, K);
-  hipLaunchKernelGGL(weight_rows_range_kernel, dim3((unsigned)N), dim3(256), 0, st, W, (uint4*)packed, N, K);   // behind the pack: it writes trailer[3] = 0
+  hipLaunchKernelGGL(weight_rows_range_kernel, dim3((unsigned)N), dim3(256), 0, st, W, trailer, trailer + 3, K);   // behind the pack: it writes trailer[3] = 0
   return gdrnpp::check_launch("gdrnpp_pack_weight_f16x2");
 }
 

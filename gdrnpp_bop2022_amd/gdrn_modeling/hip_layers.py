@@ -263,6 +263,33 @@ def _packed(linear: nn.Linear, cache: dict, key: str) -> torch.Tensor:
     return _packed_weight(cache, key, linear.weight, hip_lib.pack_weight_bf16x3)
 
 
+_FUSED_MLP = True
+_FUSED_MLP_MIN_ROWS = 256 * 256     # one workgroup (256 pixels) per CU at least
+
+
+def set_fused_mlp_x3(flag: bool) -> None:
+    """A/B switch: False runs the stage-0 ConvNeXt MLPs as two three-product launches again."""
+    global _FUSED_MLP
+    _FUSED_MLP = bool(flag)
+
+
+def _fused_mlp_weights(mlp, cache: dict, m: int, c: int):
+    """-> (packed image, fc1 slot, fc2 slot) when this block can run ``hip_lib.convnext_mlp_f32_fused``: the shape the kernel exists
+    for, enough rows to fill the chip, both layers eligible for the three-product form (not demoted, weight rows in range)."""
+    if not (_FUSED_MLP and gemm_products() == 3 and m >= _FUSED_MLP_MIN_ROWS and hip_lib.mlp_fused_supported(c, 4 * c)
+            and m * c * 4 < (1 << 32)):
+        return None
+    s1, s2 = x3_slot(cache, "fc1"), x3_slot(cache, "fc2")
+    if s1 in _X3_DEMOTED or s2 in _X3_DEMOTED:
+        return None
+    tag = weight_tag(mlp.fc1.weight, mlp.fc2.weight)
+    hit = cache.get("mlp_fused_pk")
+    if hit is None or hit[0] != tag:
+        packed = hip_lib.pack_mlp_fused_f16x2(mlp.fc1.weight.detach().contiguous(), mlp.fc2.weight.detach().contiguous())
+        hit = cache["mlp_fused_pk"] = (tag, packed, all(hip_lib.mlp_fused_rows_in_range(packed)))
+    return (hit[1], s1, s2) if hit[2] else None
+
+
 def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: torch.Tensor, cache: dict) -> torch.Tensor:
     """timm ConvNeXtBlock tail on NHWC tensors: shortcut + gamma * fc2(gelu(fc1(x))).  On the GPU both Linear layers
     run in the library's own GEMM with the exact-erf GELU and the layer-scale/residual fused into the epilogues
@@ -272,6 +299,11 @@ def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: 
     ok = (_MLP_GEMM != "torch" and enabled_for(x_nhwc) and x_nhwc.is_contiguous() and shortcut_nhwc.is_contiguous()
           and c % 128 == 0)
     if ok and _MLP_GEMM == "split" and hip_lib.split_gemm_tiles(m, c) >= _LIBRARY_BELOW_TILES:
+        fused = _fused_mlp_weights(mlp, cache, m, c)
+        if fused is not None:     # stage 0 (C = 128): fc1 + GELU + fc2 + layer scale + residual in one launch, no hidden tensor in HBM
+            y = hip_lib.convnext_mlp_f32_fused(x_nhwc.view(m, c), fused[0], mlp.fc1.bias, mlp.fc2.bias, gamma, shortcut_nhwc.view(m, c),
+                                               fused[1], fused[2])
+            return y.view(x_nhwc.shape)
         # fewer than two output tiles per CU (small ROI counts at the deep stages): split K as well, or most of the chip idles
         w3, slot = x3_for(cache, "fc1", mlp.fc1.weight, hip_lib.pack_weight_f16x2, m, 4 * c, c)
         if w3 is not None:

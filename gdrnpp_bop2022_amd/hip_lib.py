@@ -113,6 +113,9 @@ SIGNATURES = {
     "gdrnpp_conv3x3_f32_split2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "gdrnpp_conv2d_f32_split2": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "gdrnpp_split2_range_word": (c_int, [_P, c_int, _P]),
+    "gdrnpp_pack_mlp_fused_f16x2_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "gdrnpp_pack_mlp_fused_f16x2": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "gdrnpp_convnext_mlp_f32_fused": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
 }
 
 
@@ -634,6 +637,46 @@ def pack_weight_f16x2(weight):
     packed = buf[:n * k * 4].view(torch.float16).view(n // 128, k // 16, 2, 2, 128, 8)
     packed._gdrnpp_base = buf
     return packed
+
+
+def mlp_fused_supported(c: int, hidden: int) -> bool:
+    return load().gdrnpp_pack_mlp_fused_f16x2_bytes(int(c), int(hidden)) > 0
+
+
+def pack_mlp_fused_f16x2(w1, w2):
+    """fc1.weight f32[hidden,C], fc2.weight f32[C,hidden] -> the packed image of ``convnext_mlp_f32_fused`` (u8 buffer: per hidden
+    tile of 32 the fp16 h / l fragments of both layers in LDS order + a 32-byte trailer with the two power-of-two scales)."""
+    hidden, c = w1.shape
+    if tuple(w2.shape) != (c, hidden):
+        raise ValueError("pack_mlp_fused_f16x2: fc2.weight must be [C, hidden] for fc1.weight [hidden, C]")
+    nbytes = load().gdrnpp_pack_mlp_fused_f16x2_bytes(c, hidden)
+    if nbytes == 0:
+        raise ValueError(f"the fused MLP exists for C = 128, hidden = 512, not {c} / {hidden}")
+    buf = torch.empty((nbytes,), dtype=torch.uint8, device=w1.device)
+    _check(load().gdrnpp_pack_mlp_fused_f16x2(_dev(w1, torch.float32, "w1"), _dev(w2, torch.float32, "w2"), buf.data_ptr(), c, hidden,
+                                              _stream()), "gdrnpp_pack_mlp_fused_f16x2")
+    return buf
+
+
+def mlp_fused_rows_in_range(packed_buf) -> tuple:
+    """(fc1 ok, fc2 ok): False when the pack kernel found a non-zero weight row of that layer below the three-product range."""
+    tr = packed_buf[-32:].view(torch.int32).cpu()
+    return int(tr[3]) == 0, int(tr[7]) == 0
+
+
+def convnext_mlp_f32_fused(x2d, packed_buf, b1, b2, gamma, resid, slot_fc1: int = 0, slot_fc2: int = 0):
+    """y = resid + gamma * fc2(gelu(fc1(x))) in one launch (``gdrnpp_convnext_mlp_f32_fused``, three-product form, C = 128)."""
+    m, c = x2d.shape
+    hidden = b1.shape[0]
+    y = torch.empty((m, c), dtype=torch.float32, device=x2d.device)
+    _count_x3()
+    args = (_dev(x2d, torch.float32, "x"), packed_buf.data_ptr(), _dev(b1, torch.float32, "b1"), _dev(b2, torch.float32, "b2"),
+            _dev(gamma, torch.float32, "gamma"), _dev(resid, torch.float32, "resid"), y.data_ptr(), m, c, hidden,
+            _x3_flag_ptr(slot_fc1), _x3_flag_ptr(slot_fc2), _stream())
+    nbytes = 4.0 * m * c * 3 + 8.0 * c * hidden       # x + residual + y, both weights once
+    _check(_timed("mlp_fused" + X3, 4.0 * m * c * hidden, lambda: load().gdrnpp_convnext_mlp_f32_fused(*args), nbytes),
+           "gdrnpp_convnext_mlp_f32_fused")
+    return y
 
 
 def packed_rows_in_range(packed) -> bool:

@@ -52,6 +52,7 @@ const char* gdrnpp_last_error(void);
  *   "split_gemm_mi4"   -1 / 0 / 1   tile height by tile count (default) / force 128 rows / force 256 rows
  *   "dwconv_tile"      -1 / 0 / 1 / 2   output pixels per thread of the depthwise 7x7 kernel: by launch size (default: 2x8 at
  *                                   the headline batch, 2x4 / 1x4 when a launch has too few tiles for the chip) / force 2x8 / 2x4 / 1x4
+ *   "mlp_fused_pipe"   0 / 1       fused stage-0 MLP (gdrnpp_convnext_mlp_f32_fused): software-pipelined tile loop (default 1) or the plain loop (A/B switch)
  *   "split2_wide"      0 / 1       three-product kernels (gdrnpp_*_split2): 256x256 block tiles whenever N % 256 == 0 (A/B switch,
  *                                   default 0: bitwise identical and measured slower than 256x128)
  * unknown name -> GDRNPP_EINVAL. */
@@ -481,6 +482,21 @@ int gdrnpp_conv3x3_f32_split2(const float* x_nhwc, const void* W_packed, const f
 int gdrnpp_conv2d_f32_split2(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc, int n_img, int H, int W,
                              int Cin, int Cout, int KH, int KW, int stride, int pad, int epilogue, int* range_flag,
                              void* stream);
+/* ConvNeXt block tail  y = resid + gamma * fc2(gelu(fc1(x)))  (timm ConvNeXtBlock.forward behind conv_dw + norm; the reference's
+ * backbone module, core/utils/timm_utils.py:34) for the shallow stage (C = 128, hidden = 512) in ONE launch, three-product form:
+ * the hidden tensor never reaches HBM (csrc/gemm_mlp_fused.hip: everything computed transposed, x rows split once and held in
+ * registers, the GELU'd accumulator tile IS the second GEMM's operand, weights streamed through LDS once per 256 pixels).
+ * W_packed: gdrnpp_pack_mlp_fused_f16x2(fc1.weight f32[512,128], fc2.weight f32[128,512]) — gdrnpp_pack_mlp_fused_f16x2_bytes(C,
+ * hidden) bytes (0 = shape not supported); 32-byte trailer behind the tiles {amax1, 2^-e1, 2^e1, rows1, amax2, 2^-e2, 2^e2, rows2}
+ * (rows* = 1: a non-zero weight row of that layer is below the range, the layer belongs on the six-product form).
+ * x, resid, y f32[M,C] row-major (NHWC pixels); b1 f32[hidden], b2 / gamma f32[C].  range_flag_fc1 / _fc2: the range words of the
+ * two layers, both required (x rows are judged into the first, hidden rows and stored values into the second).  Results equal
+ * gdrnpp_linear_f32_split2(gelu) + gdrnpp_linear_f32_split2(scale_res) to fp32 rounding (other k order), not bit for bit. */
+size_t gdrnpp_pack_mlp_fused_f16x2_bytes(int C, int hidden);
+int gdrnpp_pack_mlp_fused_f16x2(const float* W1, const float* W2, void* packed, int C, int hidden, void* stream);
+int gdrnpp_convnext_mlp_f32_fused(const float* x, const void* W_packed, const float* b1, const float* b2, const float* gamma,
+                                  const float* resid, float* y, int M, int C, int hidden, int* range_flag_fc1, int* range_flag_fc2,
+                                  void* stream);
 /* range_flag: device int the launch ORs its range word into (the caller owns, zeroes and reads it — one per layer and stream
  * tells the caller WHICH layer left the range and keeps concurrent users apart); NULL = the library's own word, read (*word) and
  * optionally reset by gdrnpp_split2_range_word (synchronises the stream). */

@@ -14,7 +14,7 @@ while [ $# -gt 0 ]; do
   f=$1; flags=$2; shift 2
   base=${f%.hip}
   extra=""
-  case $base in gemm_split_pipe|gemm_split2_pipe) extra="-fno-slp-vectorize";; esac
+  case $base in gemm_split_pipe|gemm_split2_pipe|gemm_mlp_fused) extra="-fno-slp-vectorize";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value \
       $extra $flags -c $C/$f -o $R/_ab/$name/$base.o
   over[$base]=1
