@@ -56,14 +56,17 @@ __device__ int g_split2_range_word;  // sticky range word (GDRNPP_SPLIT2_NONFINI
 __device__ __attribute__((aligned(64))) float g_split2_zero_page[16];
 
 // One half of a wave's A tile for one k-tile: 32 rows x 16 k, 8 consecutive k of one row per lane.  x ~ h + l in 8 steps of two
-// VALU operations (the residual overwrites x).
-struct HalfSplit2 {
-  float x[8];
+// VALU operations (the residual overwrites x).  APRE: A is an "f16x2 rows" tensor (split2_common.hpp) — the two 16-byte chunks the
+// lane reads ARE its h and l fragments, there is nothing to split.
+template <bool APRE>
+struct HalfSplit2T {
+  float x[APRE ? 1 : 8];
   unsigned h[4], l[4];
 
   template <int S>
   __device__ __forceinline__ void step() {
-    if constexpr (S < 2) {
+    if constexpr (APRE) {
+    } else if constexpr (S < 2) {
       h[2 * S] = cvt_pk_f16(x[4 * S], x[4 * S + 1]);
       h[2 * S + 1] = cvt_pk_f16(x[4 * S + 2], x[4 * S + 3]);
     } else if constexpr (S < 6) {
@@ -77,9 +80,15 @@ struct HalfSplit2 {
     }
   }
   __device__ __forceinline__ void load(const uint4* lds, int slot0, int slot1) {
-    const float4 a = __builtin_bit_cast(float4, lds[slot0]), b = __builtin_bit_cast(float4, lds[slot1]);
-    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
-    x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    if constexpr (APRE) {
+      const uint4 a = lds[slot0], b = lds[slot1];
+      h[0] = a.x; h[1] = a.y; h[2] = a.z; h[3] = a.w;
+      l[0] = b.x; l[1] = b.y; l[2] = b.z; l[3] = b.w;
+    } else {
+      const float4 a = __builtin_bit_cast(float4, lds[slot0]), b = __builtin_bit_cast(float4, lds[slot1]);
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+      x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    }
   }
   template <int SPLIT>
   __device__ __forceinline__ f16x8 frag() const {
@@ -146,12 +155,15 @@ struct GnStats2 { double* part; int G; int tiles_per_img; };   // as GnStats of 
 // NJ: 32-column MFMA tiles per wave.  4: block tile 256 x 128, 24 slots per k-tile, 64 KB LDS, two workgroups per CU.
 //     8: block tile 256 x 256 (two packed weight tiles side by side), 48 slots per k-tile, 256 accumulator registers — one wave
 //     per SIMD, 80 KB LDS, one workgroup per CU: per MFMA half the A traffic (LDS-DMA, raw fragment reads, split arithmetic) of NJ = 4.
-template <int EPI, int CONV, bool GNS, int NJ>
+// APRE: A is an "f16x2 rows" tensor (linear form only).  c_rows (run time): C is written as one (bias / GELU epilogues).
+template <int EPI, int CONV, bool GNS, int NJ, bool APRE = false>
 __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(const float* __restrict__ A, const uint4* __restrict__ Wp,
                                                                   const float* __restrict__ bias,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ resid, float* __restrict__ C,
-                                                                  int M, int N, int K, ConvGeom cg, int panel, GnStats2 gn, int* range_flag) {
+                                                                  int M, int N, int K, ConvGeom cg, int panel, GnStats2 gn, int* range_flag, int c_rows) {
+  static_assert(!APRE || CONV == 0, "f16x2-rows A: linear form only");
+  using HalfSplit2 = HalfSplit2T<APRE>;
   constexpr int BNB = NJ * 32;                     // block columns
   constexpr int NWT = NJ / 4;                      // packed 128-column weight tiles per block
   constexpr int B_STAGE_B = NWT * W2_TILE_B;       // 8 / 16 KB
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
       }
 #endif
       constexpr int S1 = NJ == 4 ? 13 : 20;   // first split slot of the second half (its raw read four slots earlier)
-      if constexpr (!ADIR && S == S1 - 4) load_half(nxt[1], sa1, 1);
+      if constexpr (!ADIR && S == S1 - 4) load_half(nxt[1], sa1, 1);   // APRE: nxt[1].h / .l directly (dead since the previous k-tile)
       // split of the next k-tile: first half in slots 3..10, second half in slots S1..S1+7
 #ifndef GDRNPP2_TIMING_NO_SPLIT
       if constexpr (S >= 3 && S < 11) nxt[0].template step<S - 3>();
@@ -361,14 +373,16 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
       }
       // behind the barrier: weight split l of k-tile kt+1 (fbL is dead since slot 7) and the raw first half of k-tile kt+2
       // (cur[0] is nxt[0] of the next k-tile; only cur[0].h / .l are still in use)
+      // (APRE: the A read goes first — it IS the operand of slot 0 of the next k-tile, cur[0].h / .l are dead since slots 4 NJ + NJ - 1 / 3 NJ - 1)
+      constexpr int SL = APRE ? SB + 1 : SB;         // slot before the first weight read
 #ifndef GDRNPP2_TIMING_NO_BREAD
-      if constexpr (S > SB && S <= SB + NJ / 2) {
-        constexpr int j0 = 2 * (S - SB - 1);
+      if constexpr (S > SL && S <= SL + NJ / 2) {
+        constexpr int j0 = 2 * (S - SL - 1);
         fbL[j0] = __builtin_bit_cast(f16x8, bn[bslot(1, j0)]);
         fbL[j0 + 1] = __builtin_bit_cast(f16x8, bn[bslot(1, j0 + 1)]);
       }
 #endif
-      if constexpr (!ADIR && S == SB + NJ / 2 + 1) load_half(cur[0], sa2, 0);
+      if constexpr (!ADIR && S == (APRE ? SB + 1 : SB + NJ / 2 + 1)) load_half(cur[0], sa2, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -449,7 +463,13 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
         constexpr unsigned kInfNan = 0x203u;   // v_cmp_class_f32: signalling / quiet NaN, -inf, +inf
         bad |= __builtin_amdgcn_class(v.x, kInfNan) | __builtin_amdgcn_class(v.y, kInfNan) |
                __builtin_amdgcn_class(v.z, kInfNan) | __builtin_amdgcn_class(v.w, kInfNan);
-        { const f32x4v t4 = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t4, reinterpret_cast<f32x4v*>(C + off)); }
+        if (EPI != EPI_SCALE_RES && c_rows) {   // lanes 2k / 2k + 1 hold columns 8k .. 8k + 3 / 8k + 4 .. 8k + 7 of the same row
+          const uint4 o = f16x2_rows_quad(v.x, v.y, v.z, v.w, lane & 1);
+          const f32x4v t4 = {__uint_as_float(o.x), __uint_as_float(o.y), __uint_as_float(o.z), __uint_as_float(o.w)};
+          __builtin_nontemporal_store(t4, reinterpret_cast<f32x4v*>(C + off));
+        } else {
+          const f32x4v t4 = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t4, reinterpret_cast<f32x4v*>(C + off));
+        }
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
     }
@@ -484,16 +504,16 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
   if (word && lane == 0) atomicOr(range_flag ? range_flag : &g_split2_range_word, word);
 }
 
-template <int EPI, int CONV, bool GNS, int NJ>
+template <int EPI, int CONV, bool GNS, int NJ, bool APRE = false>
 int launch_nj(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
-              int K, ConvGeom cg, int panel, GnStats2 gn, int* range_flag, hipStream_t st, const char* what) {
+              int K, ConvGeom cg, int panel, GnStats2 gn, int* range_flag, hipStream_t st, const char* what, int c_rows = 0) {
   constexpr int lds_bytes = NA * A_STAGE_B + 2 * (NJ / 4) * W2_TILE_B;
-  const int rc = gdrnpp::ensure_dynamic_lds((const void*)gemm_split2_pipe_kernel<EPI, CONV, GNS, NJ>, lds_bytes);
+  const int rc = gdrnpp::ensure_dynamic_lds((const void*)gemm_split2_pipe_kernel<EPI, CONV, GNS, NJ, APRE>, lds_bytes);
   if (rc) return rc;
   const long tiles = (long)((M + 255) / 256) * (N / (NJ * 32));
   GDRNPP_REQUIRE(tiles < (1l << 30), GDRNPP_ELIMIT, "%s: grid too large", what);
-  hipLaunchKernelGGL((gemm_split2_pipe_kernel<EPI, CONV, GNS, NJ>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, A, Wp, bias, gamma,
-                     resid, C, M, N, K, cg, panel, gn, range_flag);
+  hipLaunchKernelGGL((gemm_split2_pipe_kernel<EPI, CONV, GNS, NJ, APRE>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, A, Wp, bias, gamma,
+                     resid, C, M, N, K, cg, panel, gn, range_flag, c_rows);
   return gdrnpp::check_launch(what);
 }
 
@@ -502,11 +522,14 @@ int launch_nj(const float* A, const uint4* Wp, const float* bias, const float* g
 // 189 us, stage-0 fc1 623 vs 533 us: one wave per SIMD has nobody to hide its LDS / DMA latencies behind)
 template <int EPI, int CONV, bool GNS>
 int launch_one(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
-               int K, ConvGeom cg, int panel, GnStats2 gn, int* range_flag, hipStream_t st, const char* what) {
+               int K, ConvGeom cg, int panel, GnStats2 gn, int* range_flag, hipStream_t st, const char* what, int a_rows = 0, int c_rows = 0) {
+  if constexpr (CONV == 0 && EPI != EPI_BIAS) {   // the f16x2-rows forms exist for the two MLP layers (GELU / scale + residual)
+    if (a_rows) return launch_nj<EPI, CONV, GNS, 4, true>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what, c_rows);
+  }
   const int opt = gdrnpp::option_split2_wide();
   const bool wide = N % 256 == 0 && opt == 1;
-  if (wide) return launch_nj<EPI, CONV, GNS, 8>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what);
-  return launch_nj<EPI, CONV, GNS, 4>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what);
+  if (wide) return launch_nj<EPI, CONV, GNS, 8>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what, c_rows);
+  return launch_nj<EPI, CONV, GNS, 4>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what, c_rows);
 }
 
 }  // namespace
@@ -530,9 +553,9 @@ extern "C" int gdrnpp_pack_weight_f16x2(const float* W, void* packed, int N, int
   return gdrnpp::check_launch("gdrnpp_pack_weight_f16x2");
 }
 
-extern "C" int gdrnpp_linear_f32_split2(const float* A, const void* W_packed, const float* bias, const float* gamma,
-                                        const float* resid, float* C, int M, int N, int K, int epilogue, int* range_flag,
-                                        void* stream) {
+extern "C" int gdrnpp_linear_f32_split2_rows(const float* A, const void* W_packed, const float* bias, const float* gamma,
+                                             const float* resid, float* C, int M, int N, int K, int epilogue, int rows,
+                                             int* range_flag, void* stream) {
   GDRNPP_REQUIRE(A && W_packed && C, GDRNPP_EINVAL, "gdrnpp_linear_f32_split2: null pointer");
   GDRNPP_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % 32 == 0, GDRNPP_ELIMIT,
                  "gdrnpp_linear_f32_split2: N=%d K=%d must be multiples of %d/32 (M=%d is free)", N, K, BN, M);
@@ -541,6 +564,11 @@ extern "C" int gdrnpp_linear_f32_split2(const float* A, const void* W_packed, co
   GDRNPP_REQUIRE(epilogue >= 0 && epilogue <= 2, GDRNPP_EINVAL, "gdrnpp_linear_f32_split2: epilogue=%d", epilogue);
   GDRNPP_REQUIRE(epilogue != EPI_SCALE_RES || (gamma && resid), GDRNPP_EINVAL,
                  "gdrnpp_linear_f32_split2: scale+residual epilogue needs gamma and resid");
+  GDRNPP_REQUIRE((rows & ~(GDRNPP_A_F16X2_ROWS | GDRNPP_C_F16X2_ROWS)) == 0, GDRNPP_EINVAL, "gdrnpp_linear_f32_split2_rows: rows=%d", rows);
+  GDRNPP_REQUIRE(!(rows & GDRNPP_C_F16X2_ROWS) || epilogue != EPI_SCALE_RES, GDRNPP_EINVAL,
+                 "gdrnpp_linear_f32_split2_rows: the scale+residual epilogue writes fp32");
+  GDRNPP_REQUIRE(!(rows & GDRNPP_A_F16X2_ROWS) || epilogue != EPI_BIAS, GDRNPP_ELIMIT,
+                 "gdrnpp_linear_f32_split2_rows: an f16x2-rows A needs the GELU or the scale+residual epilogue (the two MLP layers)");
   // wide layers walk the tiles in panels (gemm_split_pipe.hip: launch_split_pipe); the fp16x2 image is 4 bytes per weight
   const int panel = (N / BN >= 8 && (long)N * K * 4 > (2l << 20)) ? gdrnpp::option_split_gemm_panel() : 0;
   const ConvGeom cg{0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -548,9 +576,16 @@ extern "C" int gdrnpp_linear_f32_split2(const float* A, const void* W_packed, co
   hipStream_t st = (hipStream_t)stream;
   const uint4* Wp = (const uint4*)W_packed;
   const char* what = "gdrnpp_linear_f32_split2";
-  if (epilogue == EPI_BIAS) return launch_one<EPI_BIAS, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what);
-  if (epilogue == EPI_GELU) return launch_one<EPI_GELU, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what);
-  return launch_one<EPI_SCALE_RES, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what);
+  const int ar = rows & GDRNPP_A_F16X2_ROWS, cr = (rows & GDRNPP_C_F16X2_ROWS) ? 1 : 0;
+  if (epilogue == EPI_BIAS) return launch_one<EPI_BIAS, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what, 0, cr);
+  if (epilogue == EPI_GELU) return launch_one<EPI_GELU, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what, ar, cr);
+  return launch_one<EPI_SCALE_RES, 0, false>(A, Wp, bias, gamma, resid, C, M, N, K, cg, panel, gn, range_flag, st, what, ar, 0);
+}
+
+extern "C" int gdrnpp_linear_f32_split2(const float* A, const void* W_packed, const float* bias, const float* gamma,
+                                        const float* resid, float* C, int M, int N, int K, int epilogue, int* range_flag,
+                                        void* stream) {
+  return gdrnpp_linear_f32_split2_rows(A, W_packed, bias, gamma, resid, C, M, N, K, epilogue, 0, range_flag, stream);
 }
 
 extern "C" int gdrnpp_conv3x3_f32_split2(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc,

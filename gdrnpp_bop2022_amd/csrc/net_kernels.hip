@@ -13,6 +13,7 @@
 // fp32 math as the PyTorch operators (exact erf GELU, biased variance, eps inside the sqrt); summation
 // order differs, so parity is a tolerance (1e-5 rel, tests/test_gpu_net_kernels.py), not bit equality.
 #include "common.hpp"
+#include "split2_common.hpp"
 #include <mutex>
 
 namespace {
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DW_WPE))) v
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ ln_w,
                                                          const float* __restrict__ ln_b, float* __restrict__ y, int N,
-                                                         int H, int W, int C, float eps, int buf_rows) {
+                                                         int H, int W, int C, float eps, int buf_rows, int y_rows) {
   __shared__ float red[TH * TW * 8];  // FUSE_LN: per-wave partials when a pixel spans several waves
   extern __shared__ float4 wlds[];    // LDS_W: [49][C/4]
   const f4* wldsv = reinterpret_cast<const f4*>(wlds);
@@ -295,10 +296,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DW_WPE))) v
 #pragma unroll
       for (int j = 0; j < TW; ++j) {
         const int oy = ty0 + i, ox = tx0 + j;
+        f4 o = acc[i][j];
+        if (y_rows) {   // "f16x2 rows" output (split2_common.hpp): threads q = 2k / 2k + 1 of a pixel are neighbouring lanes
+          const uint4 u = gdrnpp::split2::f16x2_rows_quad(o.x, o.y, o.z, o.w, q & 1);
+          o = f4{__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+        }
 #if DW_NT_STORE
-        if (oy < H && ox < W) __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f4*>(yn + ((size_t)oy * W + ox) * C));
+        if (oy < H && ox < W) __builtin_nontemporal_store(o, reinterpret_cast<f4*>(yn + ((size_t)oy * W + ox) * C));
 #else
-        if (oy < H && ox < W) *reinterpret_cast<f4*>(yn + ((size_t)oy * W + ox) * C) = acc[i][j];
+        if (oy < H && ox < W) *reinterpret_cast<f4*>(yn + ((size_t)oy * W + ox) * C) = o;
 #endif
       }
   }
@@ -794,7 +800,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
 
 template <int TH, int TW>
 int launch_dwconv(const float* x, const float* w49c, const float* bias, const float* ln_w, const float* ln_b, float* y, int N,
-                  int H, int W, int C, float eps, hipStream_t st) {
+                  int H, int W, int C, float eps, int y_rows, hipStream_t st) {
   const int Q = C / 4;
   const long n_tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
   // buffer-load rows need the image (n) and tile row of a wave to be uniform: one tile per wave or more (Q >= 64), or the
@@ -836,10 +842,10 @@ int launch_dwconv(const float* x, const float* w49c, const float* bias, const fl
     if (blocks > n_groups) blocks = n_groups;
     if (fuse) {
       hipLaunchKernelGGL((dwconv7_ln_kernel<true, true, TH, TW>), dim3((unsigned)blocks), dim3(threads), wbytes, st, x, w49c, bias,
-                         ln_w, ln_b, y, N, H, W, C, eps, buf_rows);
+                         ln_w, ln_b, y, N, H, W, C, eps, buf_rows, y_rows);
     } else {
       hipLaunchKernelGGL((dwconv7_ln_kernel<false, true, TH, TW>), dim3((unsigned)blocks), dim3(threads), wbytes, st, x, w49c, bias,
-                         nullptr, nullptr, y, N, H, W, C, eps, buf_rows);
+                         nullptr, nullptr, y, N, H, W, C, eps, buf_rows, y_rows);
     }
   } else {
     const int tiles_per_block = 256 / Q;
@@ -847,10 +853,10 @@ int launch_dwconv(const float* x, const float* w49c, const float* bias, const fl
     GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "gdrnpp_dwconv7x7_ln_nhwc: grid too large");
     if (fuse) {
       hipLaunchKernelGGL((dwconv7_ln_kernel<true, false, TH, TW>), dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias, ln_w,
-                         ln_b, y, N, H, W, C, eps, buf_rows);
+                         ln_b, y, N, H, W, C, eps, buf_rows, y_rows);
     } else {
       hipLaunchKernelGGL((dwconv7_ln_kernel<false, false, TH, TW>), dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias,
-                         nullptr, nullptr, y, N, H, W, C, eps, buf_rows);
+                         nullptr, nullptr, y, N, H, W, C, eps, buf_rows, y_rows);
     }
   }
   return gdrnpp::check_launch("gdrnpp_dwconv7x7_ln_nhwc");
@@ -864,7 +870,13 @@ extern "C" {
 
 int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bias, const float* ln_w,
                              const float* ln_b, float* y, int N, int H, int W, int C, float eps, void* stream) {
+  return gdrnpp_dwconv7x7_ln_nhwc_rows(x, w49c, bias, ln_w, ln_b, y, N, H, W, C, eps, 0, stream);
+}
+
+int gdrnpp_dwconv7x7_ln_nhwc_rows(const float* x, const float* w49c, const float* bias, const float* ln_w,
+                                  const float* ln_b, float* y, int N, int H, int W, int C, float eps, int y_rows, void* stream) {
   GDRNPP_REQUIRE(x && w49c && bias && y, GDRNPP_EINVAL, "gdrnpp_dwconv7x7_ln_nhwc: null pointer");
+  GDRNPP_REQUIRE(!y_rows || C % 8 == 0, GDRNPP_ELIMIT, "gdrnpp_dwconv7x7_ln_nhwc_rows: the f16x2-rows output needs C %% 8 == 0 (C=%d)", C);
   GDRNPP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, GDRNPP_EINVAL, "gdrnpp_dwconv7x7_ln_nhwc: N=%d H=%d W=%d C=%d", N,
                  H, W, C);
   GDRNPP_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, GDRNPP_ELIMIT,
@@ -876,9 +888,9 @@ int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bia
   const int force = gdrnpp::option_dwconv_tile();
   int cfg = waves_of(2, 8) >= 1536.0 ? 0 : (waves_of(2, 4) >= 1536.0 ? 1 : 2);
   if (force >= 0 && force <= 2) cfg = force;
-  if (cfg == 0) return launch_dwconv<2, 8>(x, w49c, bias, ln_w, ln_b, y, N, H, W, C, eps, (hipStream_t)stream);
-  if (cfg == 1) return launch_dwconv<2, 4>(x, w49c, bias, ln_w, ln_b, y, N, H, W, C, eps, (hipStream_t)stream);
-  return launch_dwconv<1, 4>(x, w49c, bias, ln_w, ln_b, y, N, H, W, C, eps, (hipStream_t)stream);
+  if (cfg == 0) return launch_dwconv<2, 8>(x, w49c, bias, ln_w, ln_b, y, N, H, W, C, eps, y_rows ? 1 : 0, (hipStream_t)stream);
+  if (cfg == 1) return launch_dwconv<2, 4>(x, w49c, bias, ln_w, ln_b, y, N, H, W, C, eps, y_rows ? 1 : 0, (hipStream_t)stream);
+  return launch_dwconv<1, 4>(x, w49c, bias, ln_w, ln_b, y, N, H, W, C, eps, y_rows ? 1 : 0, (hipStream_t)stream);
 }
 
 int gdrnpp_layernorm_nhwc(const float* x, const float* weight, const float* bias, float* y, long n_pix, int C,

@@ -47,6 +47,21 @@ __device__ __forceinline__ float sumsq2(unsigned hpk, float s) {
   return __builtin_amdgcn_fdot2(v, v, s, false);
 }
 
+// "f16x2 rows": an activation tensor f32[M][K] in which every aligned group of 8 consecutive elements of a row is replaced, in the
+// same 32 bytes, by its 8 fp16 h halves followed by its 8 fp16 l halves — the split the k-loop of gemm_split2_pipe.hip otherwise
+// repeats per k-tile AND per column tile (K = 512, N = 2048: sixteen times per element).  A producer whose lanes 2k / 2k + 1 hold
+// values 0..3 / 4..7 of a group (float4 per lane, row-major) writes it with one quad exchange: each lane stores the returned 16
+// bytes where its float4 would have gone.  Same cvt_pk / v_fma_mix / cvt_pk as HalfSplit2::step: bit-identical operands.
+// Must be called by both lanes of a pair (DPP reads the neighbour's registers).
+__device__ __forceinline__ uint4 f16x2_rows_quad(float x, float y, float z, float w, bool odd) {
+  const unsigned h01 = cvt_pk_f16(x, y), h23 = cvt_pk_f16(z, w);
+  const unsigned l01 = cvt_pk_f16(residual<0>(x, h01), residual<1>(y, h01)), l23 = cvt_pk_f16(residual<0>(z, h23), residual<1>(w, h23));
+  const unsigned g0 = odd ? h01 : l01, g1 = odd ? h23 : l23;          // what the neighbour needs
+  const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)g0, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: lane ^ 1
+  const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)g1, 0xB1, 0xF, 0xF, true);
+  return odd ? make_uint4(r0, r1, l01, l23) : make_uint4(h01, h23, r0, r1);
+}
+
 // power-of-two scale of a weight tensor: max|w| * 2^e in [2^13, 2^14) (fp16: h = rn(x) cannot overflow, l of a typical weight
 // stays normal); e clamped so that 2^e and 2^-e are normal fp32
 __device__ __forceinline__ int weight_exp(unsigned amax_bits) {

@@ -54,9 +54,10 @@ class ConvNeXtBlock(nn.Module):
 
     def forward(self, x):
         shortcut = x
-        x = hip_layers.dwconv_ln(self.conv_dw, self.norm, x, self._cache)  # NHWC view, LayerNorm applied
+        rows = hip_layers.mlp_takes_rows(self.mlp, self.conv_dw, x, self._cache)   # fc1's operand handed over already split (HIP path)
+        x = hip_layers.dwconv_ln(self.conv_dw, self.norm, x, self._cache, y_rows=rows)  # NHWC view, LayerNorm applied
         # Mlp + layer scale + residual: shortcut + gamma * fc2(gelu(fc1(x)))  (timm: x.mul(gamma); drop_path(x) + shortcut)
-        x = hip_layers.convnext_mlp(self.mlp, self.gamma, x, shortcut.permute(0, 2, 3, 1), self._cache)
+        x = hip_layers.convnext_mlp(self.mlp, self.gamma, x, shortcut.permute(0, 2, 3, 1), self._cache, a_rows=rows)
         return x.permute(0, 3, 1, 2)
 
 

@@ -87,18 +87,26 @@ def stem(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
     return ln(conv(x.contiguous(memory_format=torch.channels_last)))
 
 
-def dwconv_ln(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor, cache: dict) -> torch.Tensor:
-    """ConvNeXt block head: depthwise 7x7 then LayerNorm over C.  Returns the NHWC *view* [N,H,W,C]."""
+def _dwconv_hip_ok(conv: nn.Conv2d, x: torch.Tensor) -> bool:
     c = conv.in_channels
     q = c // 4
-    if enabled_for(x) and conv.kernel_size == (7, 7) and conv.groups == c and c % 4 == 0 and q <= 256 and 256 % q == 0:
+    return enabled_for(x) and conv.kernel_size == (7, 7) and conv.groups == c and c % 4 == 0 and q <= 256 and 256 % q == 0
+
+
+def dwconv_ln(conv: nn.Conv2d, ln: nn.LayerNorm, x: torch.Tensor, cache: dict, y_rows: bool = False) -> torch.Tensor:
+    """ConvNeXt block head: depthwise 7x7 then LayerNorm over C.  Returns the NHWC *view* [N,H,W,C].  ``y_rows``: as an "f16x2
+    rows" tensor for ``convnext_mlp(..., a_rows=True)`` (HIP path only; ``mlp_takes_rows`` says when)."""
+    c = conv.in_channels
+    if _dwconv_hip_ok(conv, x):
         tag = weight_tag(conv.weight)
         hit = cache.get("w49c")
         if hit is None or hit[0] != tag:
             hit = (tag, conv.weight.detach().reshape(c, 49).t().contiguous())  # tap-major [49, C]
             cache["w49c"] = hit
-        y = hip_lib.dwconv7x7_ln(_cl(x), hit[1], conv.bias, ln.weight, ln.bias, ln.eps)
+        y = hip_lib.dwconv7x7_ln(_cl(x), hit[1], conv.bias, ln.weight, ln.bias, ln.eps, y_rows=y_rows)
         return y.permute(0, 2, 3, 1)
+    if y_rows:
+        raise RuntimeError("dwconv_ln: an f16x2-rows result exists on the HIP path only")
     y = conv(x).permute(0, 2, 3, 1)
     return F.layer_norm(y, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
 
@@ -290,34 +298,67 @@ def _fused_mlp_weights(mlp, cache: dict, m: int, c: int):
     return (hit[1], s1, s2) if hit[2] else None
 
 
-def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: torch.Tensor, cache: dict) -> torch.Tensor:
+# "f16x2 rows" hand-over between the kernels of a ConvNeXt block (include/gdrnpp_hip.h: gdrnpp_linear_f32_split2_rows): the
+# depthwise conv + LayerNorm kernel writes fc1's operand already split, fc1's GELU epilogue writes fc2's.  Bit-identical results;
+# the k-loops lose their split arithmetic (32 of ~90 VALU operations per k-tile).  False: fp32 tensors between the kernels (A/B).
+_F16X2_ROWS = True
+
+
+def set_f16x2_rows(flag: bool) -> None:
+    global _F16X2_ROWS
+    _F16X2_ROWS = bool(flag)
+
+
+def _mlp_split_ok(x_nhwc: torch.Tensor, shortcut_nhwc: torch.Tensor, m: int, c: int) -> bool:
+    return (_MLP_GEMM == "split" and enabled_for(x_nhwc) and x_nhwc.is_contiguous() and shortcut_nhwc.is_contiguous() and c % 128 == 0
+            and hip_lib.split_gemm_tiles(m, c) >= _LIBRARY_BELOW_TILES)
+
+
+def mlp_takes_rows(mlp, conv_dw: nn.Conv2d, x_nchw: torch.Tensor, cache: dict) -> bool:
+    """Will ``convnext_mlp`` of this block read its input through the three-product fc1 kernel (so that ``dwconv_ln`` may hand it
+    an f16x2-rows tensor)?  Same tests, same state (demotions, forced products) as ``convnext_mlp`` itself applies a moment later."""
+    c = x_nchw.shape[1]
+    m = x_nchw.numel() // c
+    nhwc = x_nchw.permute(0, 2, 3, 1)
+    if not (_F16X2_ROWS and _dwconv_hip_ok(conv_dw, x_nchw) and c % 8 == 0 and _mlp_split_ok(nhwc, nhwc, m, c)):
+        return False
+    if _fused_mlp_weights(mlp, cache, m, c) is not None:
+        return False
+    return x3_for(cache, "fc1", mlp.fc1.weight, hip_lib.pack_weight_f16x2, m, 4 * c, c)[0] is not None
+
+
+def convnext_mlp(mlp, gamma: torch.Tensor, x_nhwc: torch.Tensor, shortcut_nhwc: torch.Tensor, cache: dict, a_rows: bool = False) -> torch.Tensor:
     """timm ConvNeXtBlock tail on NHWC tensors: shortcut + gamma * fc2(gelu(fc1(x))).  On the GPU both Linear layers
     run in the library's own GEMM with the exact-erf GELU and the layer-scale/residual fused into the epilogues
-    (two HBM passes over the hidden tensor saved); otherwise plain PyTorch."""
+    (two HBM passes over the hidden tensor saved); otherwise plain PyTorch.  ``a_rows``: x_nhwc is an f16x2-rows tensor
+    (``dwconv_ln(..., y_rows=True)`` after ``mlp_takes_rows`` said yes)."""
     c = x_nhwc.shape[-1]
     m = x_nhwc.numel() // c
-    ok = (_MLP_GEMM != "torch" and enabled_for(x_nhwc) and x_nhwc.is_contiguous() and shortcut_nhwc.is_contiguous()
-          and c % 128 == 0)
-    if ok and _MLP_GEMM == "split" and hip_lib.split_gemm_tiles(m, c) >= _LIBRARY_BELOW_TILES:
-        fused = _fused_mlp_weights(mlp, cache, m, c)
+    if _MLP_GEMM != "torch" and _mlp_split_ok(x_nhwc, shortcut_nhwc, m, c):
+        fused = None if a_rows else _fused_mlp_weights(mlp, cache, m, c)
         if fused is not None:     # stage 0 (C = 128): fc1 + GELU + fc2 + layer scale + residual in one launch, no hidden tensor in HBM
             y = hip_lib.convnext_mlp_f32_fused(x_nhwc.view(m, c), fused[0], mlp.fc1.bias, mlp.fc2.bias, gamma, shortcut_nhwc.view(m, c),
                                                fused[1], fused[2])
             return y.view(x_nhwc.shape)
-        # fewer than two output tiles per CU (small ROI counts at the deep stages): split K as well, or most of the chip idles
-        w3, slot = x3_for(cache, "fc1", mlp.fc1.weight, hip_lib.pack_weight_f16x2, m, 4 * c, c)
-        if w3 is not None:
-            h = hip_lib.linear_f32_split(x_nhwc.view(m, c), w3, mlp.fc1.bias, "gelu", x3_slot=slot)
+        w31, slot1 = x3_for(cache, "fc1", mlp.fc1.weight, hip_lib.pack_weight_f16x2, m, 4 * c, c)
+        w32, slot2 = x3_for(cache, "fc2", mlp.fc2.weight, hip_lib.pack_weight_f16x2, m, c, 4 * c)
+        if a_rows and w31 is None:
+            raise RuntimeError("convnext_mlp: f16x2-rows input, but fc1 is not on the three-product kernel (mlp_takes_rows decides)")
+        h_rows = _F16X2_ROWS and w31 is not None and w32 is not None     # fc1's GELU epilogue writes fc2's operand already split
+        if w31 is not None:
+            h = hip_lib.linear_f32_split(x_nhwc.view(m, c), w31, mlp.fc1.bias, "gelu", x3_slot=slot1, a_rows=a_rows, c_rows=h_rows)
         else:
+            # fewer than two output tiles per CU (small ROI counts at the deep stages): split K as well, or most of the chip idles
             f1 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, 4 * c) < _SPLITK_BELOW_TILES else hip_lib.linear_f32_split
             h = f1(x_nhwc.view(m, c), _packed(mlp.fc1, cache, "fc1_pk"), mlp.fc1.bias, "gelu")
-        w3, slot = x3_for(cache, "fc2", mlp.fc2.weight, hip_lib.pack_weight_f16x2, m, c, 4 * c)
-        if w3 is not None:
-            y = hip_lib.linear_f32_split(h, w3, mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c), x3_slot=slot)
+        if w32 is not None:
+            y = hip_lib.linear_f32_split(h, w32, mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c), x3_slot=slot2, a_rows=h_rows)
         else:
             f2 = hip_lib.linear_f32_splitk if hip_lib.split_gemm_tiles(m, c) < _SPLITK_BELOW_TILES else hip_lib.linear_f32_split
             y = f2(h, _packed(mlp.fc2, cache, "fc2_pk"), mlp.fc2.bias, "scale_res", gamma, shortcut_nhwc.view(m, c))
         return y.view(x_nhwc.shape)
+    if a_rows:
+        raise RuntimeError("convnext_mlp: f16x2-rows input outside the split-GEMM path")
     return torch.addcmul(shortcut_nhwc, mlp(x_nhwc), gamma)
 
 

@@ -95,6 +95,7 @@ SIGNATURES = {
     "gdrnpp_flow_forward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gdrnpp_pack_pose_records": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "gdrnpp_dwconv7x7_ln_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "gdrnpp_dwconv7x7_ln_nhwc_rows": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "gdrnpp_layernorm_nhwc": (c_int, [_P, _P, _P, _P, c_long, c_int, c_float, _P]),
     "gdrnpp_upsample_bilinear2x_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "gdrnpp_groupnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -110,6 +111,7 @@ SIGNATURES = {
     "gdrnpp_pack_weight_f16x2_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "gdrnpp_pack_weight_f16x2": (c_int, [_P, _P, c_int, c_int, _P]),
     "gdrnpp_linear_f32_split2": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "gdrnpp_linear_f32_split2_rows": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "gdrnpp_conv3x3_f32_split2": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "gdrnpp_conv2d_f32_split2": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "gdrnpp_split2_range_word": (c_int, [_P, c_int, _P]),
@@ -435,16 +437,28 @@ def _nhwc(t: torch.Tensor, name: str) -> int:
     return t.data_ptr()
 
 
-def dwconv7x7_ln(x, w49c, bias, ln_w=None, ln_b=None, eps: float = 1e-6):
-    """x (N,C,H,W) channels_last -> depthwise 7x7 (+ LayerNorm over C), same shape/format."""
+def dwconv7x7_ln(x, w49c, bias, ln_w=None, ln_b=None, eps: float = 1e-6, y_rows: bool = False):
+    """x (N,C,H,W) channels_last -> depthwise 7x7 (+ LayerNorm over C), same shape/format.  ``y_rows``: the result is written as an
+    "f16x2 rows" tensor (include/gdrnpp_hip.h: every 8 consecutive channels of a pixel replaced by their fp16 h and l halves) for
+    ``linear_f32_split(..., a_rows=True)`` — same shape and dtype, NOT readable as floats."""
     n, c, h, w = x.shape
     y = torch.empty_like(x, memory_format=torch.channels_last)
     args = (_nhwc(x, "x"), _dev(w49c, torch.float32, "w49c"), _dev(bias, torch.float32, "bias"),
             _dev(ln_w, torch.float32, "ln_w") if ln_w is not None else None,
-            _dev(ln_b, torch.float32, "ln_b") if ln_b is not None else None, y.data_ptr(), n, h, w, c, float(eps), _stream())
-    _check(_timed("hbm:dwconv7_ln", 0.0, lambda: load().gdrnpp_dwconv7x7_ln_nhwc(*args), 8.0 * x.numel()),
+            _dev(ln_b, torch.float32, "ln_b") if ln_b is not None else None, y.data_ptr(), n, h, w, c, float(eps), int(bool(y_rows)), _stream())
+    _check(_timed("hbm:dwconv7_ln", 0.0, lambda: load().gdrnpp_dwconv7x7_ln_nhwc_rows(*args), 8.0 * x.numel()),
            "gdrnpp_dwconv7x7_ln_nhwc")
     return y
+
+
+A_F16X2_ROWS, C_F16X2_ROWS = 1, 2      # include/gdrnpp_hip.h
+
+
+def f16x2_rows_decode(t: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """(h, l) as float16 tensors of ``t``'s shape from an "f16x2 rows" tensor (tests / debugging): x ~ h + l."""
+    k = t.shape[-1]
+    v = t.contiguous().view(torch.float16).view(*t.shape[:-1], k // 8, 2, 8)
+    return v[..., 0, :].reshape(t.shape), v[..., 1, :].reshape(t.shape)
 
 
 def layernorm_nhwc(x, weight, bias, eps: float = 1e-6):
@@ -799,9 +813,12 @@ def _count_x3():
 X3 = "_x3"   # LaunchTimer kind suffix of the three-product (fp16x2) kernels: 3 instead of 6 MFMA flops per fp32-equivalent flop
 
 
-def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None, _kind: str = "linear", x3_slot: int = 0):
+def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=None, resid=None, _kind: str = "linear", x3_slot: int = 0,
+                     a_rows: bool = False, c_rows: bool = False):
     """out = epilogue(x2d @ W^T + bias) with the weight given as pack_weight_bf16x3(weight); runs on the bf16 matrix cores
-    with six partial products per fp32 product (fp32-accurate, see csrc/gemm_split.hip)."""
+    with six partial products per fp32 product (fp32-accurate, see csrc/gemm_split.hip).  With a pack_weight_f16x2 weight: the
+    three-product kernel; there ``a_rows`` = x2d is an "f16x2 rows" tensor (epilogues gelu / scale_res), ``c_rows`` = write the
+    result as one (epilogues none / gelu) — gdrnpp_linear_f32_split2_rows, bit-identical to the fp32 hand-over."""
     m, k = x2d.shape
     fp16x2 = weight_packed.dtype == torch.float16     # pack_weight_f16x2: the three-product kernel
     if weight_packed.dtype not in (torch.bfloat16, torch.float16) or weight_packed.dim() != 6 or not weight_packed.is_contiguous() \
@@ -813,11 +830,14 @@ def linear_f32_split(x2d, weight_packed, bias, epilogue: str = "none", gamma=Non
             _dev(bias, torch.float32, "bias") if bias is not None else None,
             _dev(gamma, torch.float32, "gamma") if gamma is not None else None,
             _dev(resid, torch.float32, "resid") if resid is not None else None, out.data_ptr(), m, n, k,
-            {"none": 0, "gelu": 1, "scale_res": 2}[epilogue]) + ((_x3_flag_ptr(x3_slot),) if fp16x2 else ()) + (_stream(),)
+            {"none": 0, "gelu": 1, "scale_res": 2}[epilogue]) + \
+        (((A_F16X2_ROWS if a_rows else 0) | (C_F16X2_ROWS if c_rows else 0), _x3_flag_ptr(x3_slot)) if fp16x2 else ()) + (_stream(),)
+    if (a_rows or c_rows) and not fp16x2:
+        raise ValueError("f16x2-rows tensors exist for the three-product kernel (pack_weight_f16x2) only")
     nbytes = 4.0 * m * k + (4.0 if fp16x2 else 6.0) * n * k + 4.0 * m * n * (2 if epilogue == "scale_res" else 1)
     if fp16x2:
         _count_x3()
-        _check(_timed(_kind + X3, 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split2(*args), nbytes), "gdrnpp_linear_f32_split2")
+        _check(_timed(_kind + X3, 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split2_rows(*args), nbytes), "gdrnpp_linear_f32_split2")
     else:
         _check(_timed(_kind, 2.0 * m * n * k, lambda: load().gdrnpp_linear_f32_split(*args), nbytes), "gdrnpp_linear_f32_split")
     return out

@@ -323,6 +323,11 @@ int gdrnpp_layernorm_nhwc(const float* x, const float* weight, const float* bias
 int gdrnpp_dwconv7x7_ln_nhwc(const float* x, const float* w49c, const float* bias,
                              const float* ln_w, const float* ln_b, float* y, int N,
                              int H, int W, int C, float eps, void* stream);
+/* ... with y written as an "f16x2 rows" tensor when y_rows != 0 (C % 8 == 0; see gdrnpp_linear_f32_split2_rows): the block's
+ * LayerNorm output then reaches fc1 already split. */
+int gdrnpp_dwconv7x7_ln_nhwc_rows(const float* x, const float* w49c, const float* bias,
+                                  const float* ln_w, const float* ln_b, float* y, int N,
+                                  int H, int W, int C, float eps, int y_rows, void* stream);
 int gdrnpp_upsample_bilinear2x_nhwc(const float* x, float* y, int N, int H, int W,
                                     int C, void* stream);
 size_t gdrnpp_groupnorm_workspace_bytes(int N, int HW, int G);
@@ -475,6 +480,18 @@ size_t gdrnpp_pack_weight_f16x2_bytes(int N, int K);
 int gdrnpp_pack_weight_f16x2(const float* W, void* packed, int N, int K, void* stream);
 int gdrnpp_linear_f32_split2(const float* A, const void* W_packed, const float* bias, const float* gamma, const float* resid,
                              float* C, int M, int N, int K, int epilogue, int* range_flag, void* stream);
+/* "f16x2 rows": an activation tensor f32[M,K] in which every aligned group of 8 consecutive elements of a row has been replaced,
+ * in the same 32 bytes, by its 8 fp16 h halves followed by its 8 fp16 l halves (h = rn_f16(x), l = rn_f16(x - h): the operand
+ * split of the three-product kernels).  Same shape, strides and size as the fp32 tensor; only a consumer with the flag can read it.
+ * A consumer takes its MFMA operands straight from it instead of splitting every k-tile again for every 128-column tile of the
+ * output (K = 512, N = 2048: 16 times per element); a producer pays ~3 VALU operations per element once.  Results are bit-identical
+ * to the fp32 hand-over (same conversions), range words unchanged (the consumer still sums the squares of the h halves per row).
+ * rows: GDRNPP_A_F16X2_ROWS = A is one (epilogue 1 / 2: the two ConvNeXt MLP layers), GDRNPP_C_F16X2_ROWS = write C as one
+ * (epilogue 0 / 1; N % 8 == 0 holds by N % 128 == 0).  Producers: this function, gdrnpp_dwconv7x7_ln_nhwc_rows. */
+#define GDRNPP_A_F16X2_ROWS 1
+#define GDRNPP_C_F16X2_ROWS 2
+int gdrnpp_linear_f32_split2_rows(const float* A, const void* W_packed, const float* bias, const float* gamma, const float* resid,
+                                  float* C, int M, int N, int K, int epilogue, int rows, int* range_flag, void* stream);
 int gdrnpp_conv3x3_f32_split2(const float* x_nhwc, const void* W_packed, const float* bias, float* y_nhwc, double* gn_partials,
                               int n_img, int H, int W, int Cin, int Cout, int groups, int epilogue, int* range_flag,
                               void* stream);
