@@ -14,6 +14,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write --
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline-pass --no-other-mode-line > /dev/null 2> $O/pmc_mfma.err
 python tools/pmc_parse_bench_gemm.py $O/pmc_fetch $O/pmc_write > $O/pmc_gemm_traffic.json
 python tools/pmc_mfma_busy.py $O/pmc_mfma > $O/pmc_gemm_mfma_busy.json
+( for k in gemm_split2_pipe mlp_fused_x3 dwconv7_ln gn_apply depth_refine; do python tools/pmc_clock.py $O/pmc_mfma $k; done ) > $O/effective_clock.txt 2>&1
 python tools/step_breakdown.py $O/trace "steady-state step, YCB-V convnext_a6 + refine, 128 ROIs" > $O/step_breakdown.md
 find $O/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 # keep the merged output small: raw traces stay on the box
