@@ -105,6 +105,7 @@ def parse(argv=None):
                         "(fp16x2 operand split where the batch is large enough, overflow detected per step and repeated with 6), "
                         "6 = bf16x3 everywhere (exact to 2^-26)")
     p.add_argument("--no-fused-mlp", action="store_true", help="A/B: stage-0 ConvNeXt MLPs as two three-product launches instead of the fused kernel")
+    p.add_argument("--fused-mlp-max-c", type=int, default=256, help="A/B: widest ConvNeXt block on the fused MLP kernel (128 = stage 0 only, 256 = stages 0 and 1)")
     p.add_argument("--no-f16x2-rows", action="store_true", help="A/B: fp32 tensors between dwconv+LN / fc1 / fc2 of a ConvNeXt block instead of the pre-split f16x2-rows hand-over")
     p.add_argument("--no-other-mode-line", action="store_true",
                    help="skip the extra measurement of the other --gemm-products setting after the timed region")
@@ -284,7 +285,7 @@ def worker(args):
                 "parallelism": f"roi-shard x{world}", "collective": "all_gather f32[n,16] pose records" if world > 1 else None,
                 "class_sliced_out_layer": not args.exact_reference_order, "rois_class_sorted_within_rank": True,
                 "parameters": "default-init" if args.random_init else "seeded O(1)", "hip_network_layers": not args.no_hip_layers,
-                "mlp_gemm": args.mlp_gemm, "gemm_products": args.gemm_products, "fused_stage0_mlp": not args.no_fused_mlp, "f16x2_rows": not args.no_f16x2_rows,
+                "mlp_gemm": args.mlp_gemm, "gemm_products": args.gemm_products, "fused_mlp": (not args.no_fused_mlp) and args.fused_mlp_max_c, "f16x2_rows": not args.no_f16x2_rows,
                 "gemm_numerics": ("fp32 operands, fp32 accumulation, fp32 results; operands enter the fp16 matrix cores as two fp16 values "
                                   "(22 significant bits), three partial products; measured error against fp64 = that of the six-product "
                                   "bf16x3 form and below hipBLASLt's fp32 GEMM on the same operands, network outputs at the same distance "
@@ -327,7 +328,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
     hip_layers.set_conv_gn_fused(not args.no_conv_gn_fusion)
     hip_layers.set_mlp_gemm(args.mlp_gemm)
     hip_layers.set_gemm_products(args.gemm_products)
-    hip_layers.set_fused_mlp_x3(not args.no_fused_mlp)
+    hip_layers.set_fused_mlp_x3(not args.no_fused_mlp, args.fused_mlp_max_c)
     hip_layers.set_f16x2_rows(not args.no_f16x2_rows)
     opts = ["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"] if refine else []
 

@@ -65,7 +65,7 @@ __device__ __forceinline__ f16x8 frag(const unsigned (&s)[4]) { return __builtin
 // ~320 VALU operations per tile run in the shadow of MFMAs instead of between them.  The weight images then live in two rings of
 // two slots (W1 of tiles t + 1 / t + 2, W2 of tiles t / t + 1): the same 64 KB.
 template <int FC, int FH, int WAVES, bool PIPE>
-__global__ __launch_bounds__(64 * WAVES, 2) void mlp_fused_x3_kernel(const float* __restrict__ X, const uint4* __restrict__ Wp,
+__global__ __launch_bounds__(64 * WAVES, FC <= 128 ? 2 : 1) void mlp_fused_x3_kernel(const float* __restrict__ X, const uint4* __restrict__ Wp,
                                                              const float* __restrict__ b1, const float* __restrict__ b2,
                                                              const float* __restrict__ gamma, const float* __restrict__ resid,
                                                              float* __restrict__ Y, int M, int* flag1, int* flag2) {
@@ -95,22 +95,24 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_fused_x3_kernel(const float
   // (measured: prologue + epilogue of that form alone took 437 of the kernel's 675 us at 128 ROIs).  Row r of the wave sits in 1 KB
   // piece r >> 1, half r & 1, and its 16-byte chunk c at position c ^ (r & 15): the 16 lanes of a ds_read_b128 group then read 16
   // different bank groups (same chunk of 16 rows), and the DMA side only permutes the chunks inside a row.
-  static_assert(FC == 128 && WAVES == 4, "row staging: 32 chunks per row, 16 KB per wave over the 64 KB weight ring");
+  static_assert((FC == 128 || FC == 256) && WAVES == 4, "row staging: 32 / 64 chunks per row, the waves' 32 rows cover the weight ring");
+  constexpr int CPR = FC / 4;                           // 16-byte chunks per row
+  constexpr int RPP = 64 / CPR;                         // rows per 1 KB piece (= per DMA instruction)
   const long pix0 = (long)blockIdx.x * (32 * WAVES) + wave * 32;
   const int rl = lane & 31;                             // the lane's pixel in the operand / accumulator layouts
-  const int cl = lane & 31;                             // the lane's chunk in the row-major (coalesced) layout
-  uint4* rows = smem + wave * 1024;                     // the wave's 16 KB
+  const int cl = lane % CPR, rsub = lane / CPR;         // the lane's chunk / row of the piece in the row-major (coalesced) layout
+  uint4* rows = smem + wave * (32 * CPR);               // the wave's 16 / 32 KB: row r at r * CPR, chunk c at position c ^ (r & 15)
   unsigned xh[NK1][4], xl[NK1][4];
   float ssx = 0.f;
   {
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      const int row = 2 * p + g;
+    for (int p = 0; p < 32 / RPP; ++p) {
+      const int row = RPP * p + rsub;
       const long rp = pix0 + row < M ? pix0 + row : (long)M - 1;
-      dma_v(reinterpret_cast<const uint4*>(X + rp * FC) + (cl ^ (row & 15)), lds0 + (unsigned)(wave * 1024 + p * 64) * 16u);
+      dma_v(reinterpret_cast<const uint4*>(X + rp * FC) + (cl ^ (row & 15)), lds0 + (unsigned)(wave * (32 * CPR) + p * 64) * 16u);
     }
     wait_vmcnt<0>();
-    const uint4* xr = rows + (rl >> 1) * 64 + (rl & 1) * 32;
+    const uint4* xr = rows + rl * CPR;
 #pragma unroll
     for (int ks = 0; ks < NK1; ++ks) {
       const float4 a = __builtin_bit_cast(float4, xr[(4 * ks + 2 * g) ^ (rl & 15)]), b = __builtin_bit_cast(float4, xr[(4 * ks + 2 * g + 1) ^ (rl & 15)]);
@@ -307,14 +309,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_fused_x3_kernel(const float
           if constexpr (pr == 0) {
             acc2[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[o], frag(hh[1]), acc2[o], 0, 0, 0);
             w2h[o] = __builtin_bit_cast(f16x8, w2c[((1 * NOT + o) * 2 + 0) * 64]);                          // h of k-step 1
-            if constexpr (!LAST) bvq[o] = b1s[8 * (t + 1) + 2 * o + g];   // NOT == 4 quads of the next tile
+            if constexpr (!LAST && o < 4) bvq[o] = b1s[8 * (t + 1) + 2 * o + g];   // the 4 bias quads of the next tile
           } else {
             acc2[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[o], pr == 1 ? frag(hl[1]) : frag(hh[1]), acc2[o], 0, 0, 0);
           }
         }
         // ---- the slot's share of the VALU work: phases A and B, alternately 2 and 1 (A) / 2, 2, 1 (B) micro-steps
-        constexpr int m0 = S < NSA ? (3 * S + 1) / 2 : (S < NSA + NSB ? 36 + (5 * (S - NSA) + 2) / 3 : NMICRO);
-        constexpr int m1 = S + 1 < NSA ? (3 * (S + 1) + 1) / 2 : (S + 1 < NSA + NSB ? 36 + (5 * (S + 1 - NSA) + 2) / 3 : NMICRO);
+        // (36 micro-steps over phase A, 20 over phase B; NSA = 24, NSB = 12: (3 S + 1) / 2 and 36 + (5 s + 2) / 3)
+        constexpr auto mstart = [](int sl) { return sl < NSA ? (36 * sl + NSA / 2) / NSA : (sl < NSA + NSB ? 36 + (20 * (sl - NSA) + 2 * NSB / 3) / NSB : NMICRO); };
+        constexpr int m0 = mstart(S), m1 = mstart(S + 1);
         if constexpr (!(GDRNPP_MLPF_ABL & 64)) static_for<(m0 < NMICRO ? m0 : NMICRO), (m1 < NMICRO ? m1 : NMICRO)>(micro);
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_fused_x3_kernel(const float
   // the lane's pixel: through the wave's 16 KB of LDS (same layout as the x rows; the loop's last barrier freed the ring) into the
   // row-major form, where lane = (row parity, chunk): resid loads and y stores are whole 512-byte rows, b2 / gamma one quad per lane.
   {
-    uint4* yr = rows + (rl >> 1) * 64 + (rl & 1) * 32;
+    uint4* yr = rows + rl * CPR;
 #pragma unroll
     for (int o = 0; o < NOT; ++o)
 #pragma unroll
@@ -348,16 +351,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_fused_x3_kernel(const float
   bool bad = false;
   {
     long pix0e = pix0;                                  // opaque copies: the row addresses are recomputed here instead of being kept
-    int cle = cl, ge = g;                               // (spilled) across the tile loop
-    asm volatile("" : "+s"(pix0e), "+v"(cle), "+v"(ge));
+    int cle = cl, rse = rsub;                           // (spilled) across the tile loop
+    asm volatile("" : "+s"(pix0e), "+v"(cle), "+v"(rse));
     const float4 bv = *reinterpret_cast<const float4*>(b2 + 4 * cle), gv = *reinterpret_cast<const float4*>(gamma + 4 * cle);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      const int row = 2 * p + ge;
+    for (int p = 0; p < 32 / RPP; ++p) {
+      const int row = RPP * p + rse;
       const long rp = pix0e + row;
       const long rpc = rp < M ? rp : (long)M - 1;
       const float4 rs = *reinterpret_cast<const float4*>(resid + rpc * FC + 4 * cle);
-      const float4 a = __builtin_bit_cast(float4, rows[p * 64 + ge * 32 + (cle ^ (row & 15))]);
+      const float4 a = __builtin_bit_cast(float4, rows[p * 64 + rse * CPR + (cle ^ (row & 15))]);
       float4 v = make_float4(a.x * wsc2 + bv.x, a.y * wsc2 + bv.y, a.z * wsc2 + bv.z, a.w * wsc2 + bv.w);
       v.x = rs.x + gv.x * v.x; v.y = rs.y + gv.y * v.y; v.z = rs.z + gv.z * v.z; v.w = rs.w + gv.w * v.w;
       constexpr unsigned kInfNan = 0x203u;
@@ -429,30 +432,55 @@ __global__ void pack_mlp_fused_kernel(const float* __restrict__ W1, const float*
   packed[i] = plane == 0 ? make_uint4(h[0], h[1], h[2], h[3]) : make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-constexpr int kFC = 128, kFH = 512;
-using Geom = FusedGeom<kFC, kFH>;
+// the two shapes the fused form exists for: ConvNeXt-B stage 0 (two workgroups per CU) and stage 1 (512 registers per lane, one)
+template <int FC, int FH>
+size_t fused_bytes() { return (size_t)FusedGeom<FC, FH>::NT * FusedGeom<FC, FH>::TILE_SLOTS * 16 + 32; }
+
+template <int FC, int FH>
+int pack_fused(const float* W1, const float* W2, void* packed, hipStream_t st) {
+  using Geom = FusedGeom<FC, FH>;
+  unsigned* trailer = reinterpret_cast<unsigned*>(reinterpret_cast<uint4*>(packed) + (size_t)Geom::NT * Geom::TILE_SLOTS);
+  GDRNPP_HIP_TRY(hipMemsetAsync(trailer, 0, 32, st));
+  const long n = (long)FC * FH;
+  hipLaunchKernelGGL(amax_kernel, dim3(64), dim3(256), 0, st, W1, n, trailer);
+  hipLaunchKernelGGL(amax_kernel, dim3(64), dim3(256), 0, st, W2, n, trailer + 4);
+  const long slots = (long)Geom::NT * Geom::TILE_SLOTS;
+  hipLaunchKernelGGL((pack_mlp_fused_kernel<FC, FH>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, W1, W2, (uint4*)packed);
+  hipLaunchKernelGGL(weight_rows_range_kernel, dim3((unsigned)FH), dim3(256), 0, st, W1, trailer, trailer + 3, FC);
+  hipLaunchKernelGGL(weight_rows_range_kernel, dim3((unsigned)FC), dim3(256), 0, st, W2, trailer + 4, trailer + 7, FH);
+  return gdrnpp::check_launch("gdrnpp_pack_mlp_fused_f16x2");
+}
+
+template <int FC, int FH>
+int launch_fused(const float* x, const void* W_packed, const float* b1, const float* b2, const float* gamma, const float* resid, float* y,
+                 int M, int* range_flag_fc1, int* range_flag_fc2, hipStream_t st) {
+  using Geom = FusedGeom<FC, FH>;
+  constexpr int lds_bytes = 2 * Geom::TILE_SLOTS * 16 + FH * 4;   // weight ring + b1
+  const int pipe = gdrnpp::option_mlp_fused_pipe();
+  auto go = [&](auto kernel, int w) -> int {
+    if (int rc = gdrnpp::ensure_dynamic_lds((const void*)kernel, lds_bytes)) return rc;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((M + 32 * w - 1) / (32 * w))), dim3(64 * w), lds_bytes, st, x,
+                       (const uint4*)W_packed, b1, b2, gamma, resid, y, M, range_flag_fc1, range_flag_fc2);
+    return 0;
+  };
+  if (int rc = pipe ? go(mlp_fused_x3_kernel<FC, FH, 4, true>, 4) : go(mlp_fused_x3_kernel<FC, FH, 4, false>, 4)) return rc;
+  return gdrnpp::check_launch("gdrnpp_convnext_mlp_f32_fused");
+}
 
 }  // namespace
 
 extern "C" size_t gdrnpp_pack_mlp_fused_f16x2_bytes(int C, int hidden) {
-  return (C == kFC && hidden == kFH) ? (size_t)Geom::NT * Geom::TILE_SLOTS * 16 + 32 : 0;
+  if (C == 128 && hidden == 512) return fused_bytes<128, 512>();
+  if (C == 256 && hidden == 1024) return fused_bytes<256, 1024>();
+  return 0;
 }
 
 extern "C" int gdrnpp_pack_mlp_fused_f16x2(const float* W1, const float* W2, void* packed, int C, int hidden, void* stream) {
   GDRNPP_REQUIRE(W1 && W2 && packed, GDRNPP_EINVAL, "gdrnpp_pack_mlp_fused_f16x2: null pointer");
-  GDRNPP_REQUIRE(C == kFC && hidden == kFH, GDRNPP_ELIMIT, "gdrnpp_pack_mlp_fused_f16x2: C=%d hidden=%d (the fused form exists for %d / %d)",
-                 C, hidden, kFC, kFH);
-  hipStream_t st = (hipStream_t)stream;
-  unsigned* trailer = reinterpret_cast<unsigned*>(reinterpret_cast<uint4*>(packed) + (size_t)Geom::NT * Geom::TILE_SLOTS);
-  GDRNPP_HIP_TRY(hipMemsetAsync(trailer, 0, 32, st));
-  const long n = (long)C * hidden;
-  hipLaunchKernelGGL(amax_kernel, dim3(64), dim3(256), 0, st, W1, n, trailer);
-  hipLaunchKernelGGL(amax_kernel, dim3(64), dim3(256), 0, st, W2, n, trailer + 4);
-  const long slots = (long)Geom::NT * Geom::TILE_SLOTS;
-  hipLaunchKernelGGL((pack_mlp_fused_kernel<kFC, kFH>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, W1, W2, (uint4*)packed);
-  hipLaunchKernelGGL(weight_rows_range_kernel, dim3((unsigned)hidden), dim3(256), 0, st, W1, trailer, trailer + 3, C);
-  hipLaunchKernelGGL(weight_rows_range_kernel, dim3((unsigned)C), dim3(256), 0, st, W2, trailer + 4, trailer + 7, hidden);
-  return gdrnpp::check_launch("gdrnpp_pack_mlp_fused_f16x2");
+  if (C == 128 && hidden == 512) return pack_fused<128, 512>(W1, W2, packed, (hipStream_t)stream);
+  if (C == 256 && hidden == 1024) return pack_fused<256, 1024>(W1, W2, packed, (hipStream_t)stream);
+  GDRNPP_REQUIRE(false, GDRNPP_ELIMIT, "gdrnpp_pack_mlp_fused_f16x2: C=%d hidden=%d (the fused form exists for 128 / 512 and 256 / 1024)", C, hidden);
+  return 0;
 }
 
 extern "C" int gdrnpp_convnext_mlp_f32_fused(const float* x, const void* W_packed, const float* b1, const float* b2, const float* gamma,
@@ -461,16 +489,10 @@ extern "C" int gdrnpp_convnext_mlp_f32_fused(const float* x, const void* W_packe
   GDRNPP_REQUIRE(x && W_packed && b1 && b2 && gamma && resid && y && range_flag_fc1 && range_flag_fc2, GDRNPP_EINVAL,
                  "gdrnpp_convnext_mlp_f32_fused: null pointer");
   GDRNPP_REQUIRE(M > 0, GDRNPP_EINVAL, "gdrnpp_convnext_mlp_f32_fused: M=%d", M);
-  GDRNPP_REQUIRE(C == kFC && hidden == kFH, GDRNPP_ELIMIT, "gdrnpp_convnext_mlp_f32_fused: C=%d hidden=%d (the fused form exists for %d / %d)",
-                 C, hidden, kFC, kFH);
-  constexpr int lds_bytes = 2 * Geom::TILE_SLOTS * 16 + kFH * 4;   // weight ring + b1
-  const int pipe = gdrnpp::option_mlp_fused_pipe();
-  auto go = [&](auto kernel, int w) -> int {
-    if (int rc = gdrnpp::ensure_dynamic_lds((const void*)kernel, lds_bytes)) return rc;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)((M + 32 * w - 1) / (32 * w))), dim3(64 * w), lds_bytes, (hipStream_t)stream, x,
-                       (const uint4*)W_packed, b1, b2, gamma, resid, y, M, range_flag_fc1, range_flag_fc2);
-    return 0;
-  };
-  if (int rc = pipe ? go(mlp_fused_x3_kernel<kFC, kFH, 4, true>, 4) : go(mlp_fused_x3_kernel<kFC, kFH, 4, false>, 4)) return rc;
-  return gdrnpp::check_launch("gdrnpp_convnext_mlp_f32_fused");
+  if (C == 128 && hidden == 512)
+    return launch_fused<128, 512>(x, W_packed, b1, b2, gamma, resid, y, M, range_flag_fc1, range_flag_fc2, (hipStream_t)stream);
+  if (C == 256 && hidden == 1024)
+    return launch_fused<256, 1024>(x, W_packed, b1, b2, gamma, resid, y, M, range_flag_fc1, range_flag_fc2, (hipStream_t)stream);
+  GDRNPP_REQUIRE(false, GDRNPP_ELIMIT, "gdrnpp_convnext_mlp_f32_fused: C=%d hidden=%d (the fused form exists for 128 / 512 and 256 / 1024)", C, hidden);
+  return 0;
 }

@@ -26,7 +26,9 @@
 //   * the small side is checked on every launch as well, per A row: the k-loop accumulates the sum of squares of the row's h
 //     halves (v_dot2c_f32_f16, 8 per k-tile and wave), and a row that is not all zero with rms below 2^-4 raises bit 1 — below
 //     that scale the 2^-25 absolute operand error of the subnormal l would exceed 2^-21 of the row's own output scale (zero-padded
-//     taps of a convolution count as zeros).  A non-finite A element makes the sum non-finite and raises bit 0.
+//     taps of a convolution count as zeros; so does a row whose every element is below half the fp16 subnormal spacing, 3e-8:
+//     its h and l are all zero, what it would have contributed — less than 3e-8 * sum|w| — is dropped, which is the 2^-25 absolute
+//     operand error again).  A non-finite A element makes the sum non-finite and raises bit 0.
 //   On either bit the host side re-runs the step in the six-product form and keeps the flagged layer there
 //   (engine.run_with_range_check) — never silently wrong, on either side of the range, on every launch;
 //   * weights: gdrnpp_pack_weight_f16x2 applies the same per-row test to the scaled weight rows (trailer word 3); such a layer

@@ -272,19 +272,22 @@ def _packed(linear: nn.Linear, cache: dict, key: str) -> torch.Tensor:
 
 
 _FUSED_MLP = True
+_FUSED_MLP_MAX_C = 256              # widest block that takes the fused kernel (it exists for C = 128 and C = 256)
 _FUSED_MLP_MIN_ROWS = 256 * 256     # one workgroup (256 pixels) per CU at least
 
 
-def set_fused_mlp_x3(flag: bool) -> None:
-    """A/B switch: False runs the stage-0 ConvNeXt MLPs as two three-product launches again."""
-    global _FUSED_MLP
+def set_fused_mlp_x3(flag: bool, max_c: int = 256) -> None:
+    """A/B switch: False runs the stage-0 / stage-1 ConvNeXt MLPs as two three-product launches again; ``max_c`` = 128 keeps the
+    fused form to stage 0."""
+    global _FUSED_MLP, _FUSED_MLP_MAX_C
     _FUSED_MLP = bool(flag)
+    _FUSED_MLP_MAX_C = int(max_c)
 
 
 def _fused_mlp_weights(mlp, cache: dict, m: int, c: int):
     """-> (packed image, fc1 slot, fc2 slot) when this block can run ``hip_lib.convnext_mlp_f32_fused``: the shape the kernel exists
     for, enough rows to fill the chip, both layers eligible for the three-product form (not demoted, weight rows in range)."""
-    if not (_FUSED_MLP and gemm_products() == 3 and m >= _FUSED_MLP_MIN_ROWS and hip_lib.mlp_fused_supported(c, 4 * c)
+    if not (_FUSED_MLP and c <= _FUSED_MLP_MAX_C and gemm_products() == 3 and m >= _FUSED_MLP_MIN_ROWS and hip_lib.mlp_fused_supported(c, 4 * c)
             and m * c * 4 < (1 << 32)):
         return None
     s1, s2 = x3_slot(cache, "fc1"), x3_slot(cache, "fc2")

@@ -191,7 +191,7 @@ def test_default_path_matches_reference_forward_at_128_rois(hip, ds):
     words = hip.split2_range_words()
     kinds = [r[0] for r in timer.records]
     n_lin, n_fused = sum(k == "linear" + hip.X3 for k in kinds), sum(k == "mlp_fused" + hip.X3 for k in kinds)
-    assert n_fused == 2 * 3 and n_lin + 2 * n_fused == 2 * 72, "the ConvNeXt MLPs did not run on the three-product kernels"
+    assert n_fused == 2 * 6 and n_lin + 2 * n_fused == 2 * 72, "the ConvNeXt MLPs did not run on the three-product kernels (stages 0 and 1 fused)"
     assert words == {}, f"three-product launches left their range: {words}"
     o = {k: v.float().cpu().numpy() for k, v in out.items()}
     for k in ("mask", "full_mask", "coor_x", "coor_y", "coor_z"):

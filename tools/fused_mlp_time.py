@@ -7,7 +7,8 @@ from gdrnpp_bop2022_amd import hip_lib as hip
 B = int(os.environ.get("B", "128"))
 for o in os.environ.get("OPTS", "").split():
     hip.set_option(o.split("=")[0], int(o.split("=")[1]))
-m, c = B * 64 * 64, 128
+c = int(os.environ.get("C", "128"))
+m = B * 64 * 64 * 128 // c * 128 // c        # stage 0: 64 x 64 pixels per ROI at C = 128, stage 1: 32 x 32 at C = 256
 torch.manual_seed(0)
 x = torch.randn(m, c, device="cuda"); res = torch.randn(m, c, device="cuda")
 w1 = torch.randn(4 * c, c, device="cuda") * c ** -0.5; w2 = torch.randn(c, 4 * c, device="cuda") * (4 * c) ** -0.5
@@ -30,4 +31,4 @@ def t(fn, n=10):
 fused = t(lambda: hip.convnext_mlp_f32_fused(x, pkf, b1, b2, g, res))
 two = t(lambda: hip.linear_f32_split(hip.linear_f32_split(x, pk1, b1, "gelu"), pk2, b2, "scale_res", g, res))
 fl = 4.0 * m * c * 4 * c
-print(f"B={B} M={m}: fused {fused:.0f} us ({fl / fused / 1e6:.0f} TFLOP/s fp32-equivalent, {12.0 * m * c / fused / 1e3:.0f} GB/s algorithmic)   two launches {two:.0f} us   lib={os.environ.get('GDRNPP_HIP_LIB', 'default')} opts={os.environ.get('OPTS', '')}")
+print(f"B={B} M={m} C={c}: fused {fused:.0f} us ({fl / fused / 1e6:.0f} TFLOP/s fp32-equivalent, {12.0 * m * c / fused / 1e3:.0f} GB/s algorithmic)   two launches {two:.0f} us   lib={os.environ.get('GDRNPP_HIP_LIB', 'default')} opts={os.environ.get('OPTS', '')}")
