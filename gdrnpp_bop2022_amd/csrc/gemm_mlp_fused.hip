@@ -1,4 +1,4 @@
-// Fused ConvNeXt MLP in the three-product (fp16x2) form for the shallow stage (C = 128, hidden 512) — SURVEY.md §8 row a3:
+// Fused ConvNeXt MLP in the three-product (fp16x2) form for the two shallow stages (C = 128 / 256, hidden 4 C) — SURVEY.md §8 row a3:
 //     y = resid + gamma * (fc2(gelu(fc1(x))))          timm ConvNeXtBlock tail, one launch, the hidden tensor never leaves the CU.
 //
 // Why: at 128 ROIs the two stage-0 launches move 2.95 GB through HBM per block (1.07 GB of hidden tensor written and read back)
@@ -8,16 +8,18 @@
 //     H^T[hidden, pixel] = W1[hidden, c] . X^T[c, pixel]            MFMA A operand = weight tile, B operand = 32 pixels of x
 //     Y^T[out, pixel]    = W2[out, hidden] . gelu(H^T + b1)[hidden, pixel]
 // * a wave owns 32 pixels for the whole kernel.  Its x rows (NHWC: 8 consecutive channels of a pixel = 32 contiguous bytes = the B
-//   operand of one lane) are loaded ONCE, split ONCE into fp16 h + l (64 VGPRs for C = 128) and stay in registers;
+//   operand of one lane) are loaded ONCE, split ONCE into fp16 h + l (64 VGPRs for C = 128, 128 for C = 256) and stay in registers;
 // * the 32 x 32 accumulator tile of H^T holds, per lane, 16 hidden values OF THE LANE'S OWN PIXEL: after bias + GELU + split they
 //   ARE the B operand of the second GEMM (two k-steps of 8 values per lane) — no transpose, no LDS round trip.  The k order inside
 //   a 32-wide hidden tile is whatever the accumulator layout dictates (hidden = 32 t + (q & 3) + 8 (2 s + (q >> 2)) + 4 kb for k-step
 //   s, k-block kb, slot q); W2 is PACKED in that order (gdrnpp_pack_mlp_fused_f16x2), so both operands agree;
-// * Y^T accumulates in 4 x 16 registers over the 16 hidden tiles; the epilogue applies bias, layer scale and the residual and
-//   stores float4s (a lane holds 4 consecutive output channels of its pixel per register quad);
+// * Y^T accumulates in C / 32 x 16 registers over the hidden tiles; the epilogue applies bias, layer scale and the residual and
+//   stores whole rows (through LDS: a lane holds 4 consecutive output channels of ITS pixel per register quad);
 // * weights stream through LDS: per hidden tile one 32 KB image (W1 rows of the tile for all 8 k-steps + the W2 columns of the
 //   tile for the 4 output tiles, h and l planes, lane-linear 1 KB fragment blocks) by LDS-DMA into two stages — ONE barrier per
-//   hidden tile (16 per workgroup) instead of one per 16-wide k-tile.  The 4 (or 8) waves of a workgroup share every fragment.
+//   hidden tile instead of one per 16-wide k-tile.  The 4 waves of a workgroup share every fragment.  C = 256: 64 KB per tile,
+//   128 KB of ring, 464 registers per lane: one workgroup per CU, one wave per SIMD — the hand-placed pipeline below is what
+//   overlaps its VALU work with its MFMAs.
 // Per lane and hidden tile: 48 MFMAs, 32 ds_read_b128, ~270 VALU (the GELU is 13 of them per hidden value).
 //
 // Numerics: the three products of gemm_split2_pipe.hip (l_w.h_x, h_w.l_x, h_w.h_x per k-step, small terms first, fp32

@@ -500,10 +500,11 @@ int gdrnpp_conv2d_f32_split2(const float* x_nhwc, const void* W_packed, const fl
                              int Cin, int Cout, int KH, int KW, int stride, int pad, int epilogue, int* range_flag,
                              void* stream);
 /* ConvNeXt block tail  y = resid + gamma * fc2(gelu(fc1(x)))  (timm ConvNeXtBlock.forward behind conv_dw + norm; the reference's
- * backbone module, core/utils/timm_utils.py:34) for the shallow stage (C = 128, hidden = 512) in ONE launch, three-product form:
+ * backbone module, core/utils/timm_utils.py:34) for the two shallow stages (C = 128, hidden = 512 and C = 256, hidden = 1024) in ONE
+ * launch, three-product form:
  * the hidden tensor never reaches HBM (csrc/gemm_mlp_fused.hip: everything computed transposed, x rows split once and held in
  * registers, the GELU'd accumulator tile IS the second GEMM's operand, weights streamed through LDS once per 256 pixels).
- * W_packed: gdrnpp_pack_mlp_fused_f16x2(fc1.weight f32[512,128], fc2.weight f32[128,512]) — gdrnpp_pack_mlp_fused_f16x2_bytes(C,
+ * W_packed: gdrnpp_pack_mlp_fused_f16x2(fc1.weight f32[hidden,C], fc2.weight f32[C,hidden]) — gdrnpp_pack_mlp_fused_f16x2_bytes(C,
  * hidden) bytes (0 = shape not supported); 32-byte trailer behind the tiles {amax1, 2^-e1, 2^e1, rows1, amax2, 2^-e2, 2^e2, rows2}
  * (rows* = 1: a non-zero weight row of that layer is below the range, the layer belongs on the six-product form).
  * x, resid, y f32[M,C] row-major (NHWC pixels); b1 f32[hidden], b2 / gamma f32[C].  range_flag_fc1 / _fc2: the range words of the
