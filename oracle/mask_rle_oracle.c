@@ -2,7 +2,9 @@
  * gdrn_evaluator.py:914-945: detectron2 `paste_masks_in_image(mask_probs, boxes, (H, W), threshold)` followed by the
  * uncompressed COCO run-length encoding of lib/utils/mask_utils.py:96-109 (column-major, first run counts zeros).
  *
- * parity unpinned: detectron2 / pycocotools are not installed.  The paste is detectron2's `_do_paste_mask`
+ * parity: the ENCODER is pinned — run lengths equal the reference's own `binary_mask_to_rle(compressed=False)` executed from source
+ * (tests/golden/make_golden_pyref.py `rle_case`, tests/test_postproc_oracle.py); the PASTE is unpinned: detectron2 / pycocotools are not
+ * installed.  The paste is detectron2's `_do_paste_mask`
  * (layers/mask_ops.py): grid x = ((x + 0.5 - x0) / (x1 - x0)) * 2 - 1, bilinear `grid_sample(align_corners=False,
  * padding_mode="zeros")` as ATen computes it (ix = ((g + 1) * W_in - 1) / 2; corners nw, ne, sw, se accumulated in that
  * order, out-of-range corners contribute 0), then `>= threshold`.  tests/ pin the sampling against torch's own

@@ -17,6 +17,9 @@ seeded inputs are recorded in pyref_golden.npz:
                                              (neither exists here) are served by the oracle's rasteriser and its restated
                                              INTER_LINEAR x4, everything else (q-map, threshold, median, centroid ray,
                                              inv(K_crop), translation update) is the reference's own code
+  binary_mask_to_rle(compressed=False)       lib/utils/mask_utils.py:96-109 — the uncompressed COCO run lengths (column-major, first
+                                             run counts zeros) of the SAVE_RESULTS_ONLY writer; masks = the oracle's pasted
+                                             instance masks of tests/test_postproc_oracle.py plus empty / full / one-pixel ones
 The one third-party call inside that chain, transforms3d.axangles.axangle2mat (not installed), is served by
 scipy.spatial.transform.Rotation (same rotation, an independent implementation) — noted in DESIGN.md.
 """
@@ -184,6 +187,34 @@ def ransac_layer_case(ns):
     return dict(rv_mask=mask, rv_vertex=vertex, rv_win=win.numpy(), rv_idxs=np.stack([d.numpy() for d in draws]), rv_kpts=kpts.astype(np.float32))
 
 
+def rle_case():
+    """The reference's own run-length encoder (pure Python: itertools.groupby over the column-major mask) on pasted masks."""
+    from itertools import groupby
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import postproc as P
+    ns = dict(np=np, groupby=groupby)
+    exec(compile(cut("lib/utils/mask_utils.py", "binary_mask_to_rle"), os.path.join(REF, "lib/utils/mask_utils.py"), "exec"), ns)
+    rng = np.random.default_rng(0)                      # the inputs of test_paste_mask_oracle_matches_torch_grid_sample
+    yy, xx = np.mgrid[0:64, 0:64]
+    H, W = 120, 160
+    masks, boxes = [], [(30.3, 20.7, 110.9, 90.2), (-20.5, 40.0, 60.0, 130.5), (100.0, 5.0, 170.0, 60.0), (70.2, 50.1, 75.9, 58.7)]
+    soft = []
+    for k, box in enumerate(boxes):
+        m = (np.clip(1.4 - np.hypot(yy - 31.5 + 3 * k, xx - 31.5) / (12.0 + 3 * k), 0, 1) * 0.9 + 0.1 * rng.random((64, 64))).astype(np.float32)
+        soft.append(m)
+        masks.append(P.paste_mask_rle(m, box, H, W, 0.5, True)[1])
+    extra = [np.zeros((H, W), np.uint8), np.ones((H, W), np.uint8), np.zeros((H, W), np.uint8), np.zeros((H, W), np.uint8),
+             (np.random.default_rng(5).random((H, W)) < 0.5).astype(np.uint8)]
+    extra[2][0, 0] = 1                                  # starts with a one: the leading zero-length run
+    extra[3][H - 1, W - 1] = 1                          # ends with a one
+    masks += extra
+    counts = [ns["binary_mask_to_rle"](m, compressed=False) for m in masks]
+    assert all(c["size"] == [H, W] and sum(c["counts"]) == H * W for c in counts) and counts[6]["counts"][0] == 0
+    flat = np.concatenate([np.asarray(c["counts"], np.int64) for c in counts])
+    return dict(rle_soft=np.stack(soft), rle_boxes=np.asarray(boxes, np.float64), rle_masks=np.stack(masks).astype(np.uint8),
+                rle_counts=flat, rle_counts_len=np.asarray([len(c["counts"]) for c in counts], np.int64))
+
+
 def main():
     ns = dict(np=np, torch=torch, F=F, math=math, random=random, axangle2mat=axangle2mat)
     for path, name in [("core/gdrn_modeling/engine/engine_utils.py", "get_out_mask"),
@@ -244,6 +275,7 @@ def main():
     out.update(pred_centroids=cent, pred_z=zval, roi_whs=whs, resize_ratio=ratio[:, 0], R_ego=R_ego.numpy(), trans=trans.numpy())
     out.update(refine_case(ns, cfg))
     out.update(ransac_layer_case(ns))
+    out.update(rle_case())
     np.savez_compressed(os.path.join(HERE, "pyref_golden.npz"), **out)
     print("pyref_golden.npz", os.path.getsize(os.path.join(HERE, "pyref_golden.npz")), "correspondences per ROI:", counts)
 

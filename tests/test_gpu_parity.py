@@ -501,6 +501,16 @@ def test_paste_masks_rle_bit_exact(hip):
         want = P.paste_mask_rle(masks[i], boxes[i], H, W, 0.5)
         assert got[i] == want, i
     assert got[4] == [H * W] and len(got[5]) > 100
+    # ... and against the reference's own encoder (binary_mask_to_rle(compressed=False) run from source: pyref_golden.npz rle_*)
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "pyref_golden.npz"))
+    gm, lens = fx["rle_masks"], fx["rle_counts_len"]
+    want_ref = np.split(fx["rle_counts"], np.cumsum(lens)[:-1])
+    gh, gw = gm.shape[1:]
+    got_ref = hip.paste_masks_rle(torch.from_numpy(fx["rle_soft"]).to(DEV), torch.from_numpy(fx["rle_boxes"].astype(np.float32)).to(DEV), gh, gw, 0.5)
+    assert all(got_ref[k] == want_ref[k].tolist() for k in range(4))
+    ident = torch.tensor([[0.0, 0.0, float(gw), float(gh)]] * len(gm), device=DEV)
+    got_ref = hip.paste_masks_rle(torch.from_numpy(gm.astype(np.float32)).to(DEV), ident, gh, gw, 0.5, max_runs=256)   # 9 628 runs: re-run with a larger buffer
+    assert all(got_ref[k] == want_ref[k].tolist() for k in range(len(gm)))
     cfg = get_cfg("ycbv_convnext_a6", [])
     raw = torch.from_numpy(masks[:4, None] * 3.0 - 1.0).to(DEV)          # un-normalised L1 maps
     centre = torch.from_numpy((boxes[:4, :2] + boxes[:4, 2:]) / 2).to(DEV)

@@ -1,5 +1,7 @@
 """Host-side / oracle logic that needs no GPU: synthetic generator, decode + correspondence
 restatement properties, depth-refine restatement recovering a known depth error."""
+import os
+
 import numpy as np
 
 from gdrnpp_bop2022_amd import synthetic as S
@@ -242,6 +244,29 @@ def test_paste_mask_oracle_matches_torch_grid_sample():
         assert sum(counts) == H * W and binary.sum() > 0
         rle = M.rle_from_counts(counts, H, W)
         assert np.array_equal(M.rle_to_binary_mask(rle), binary)
+
+
+def test_rle_counts_equal_the_references_own_encoder():
+    """The run lengths against the reference's `binary_mask_to_rle(mask, compressed=False)` (/root/reference/lib/utils/
+    mask_utils.py:96-109, executed from source by tests/golden/make_golden_pyref.py: `rle_*` keys of pyref_golden.npz): the four pasted
+    instance masks of the test above, an empty, a full, a first-pixel, a last-pixel and a random mask.  Pins the ENCODER half of the
+    SAVE_RESULTS_ONLY writer to the reference; the paste half (detectron2) stays restated."""
+    import numpy as np
+    from oracle import postproc as P
+    from gdrnpp_bop2022_amd.lib.utils import mask_utils as M
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "pyref_golden.npz"))
+    masks, lens = fx["rle_masks"], fx["rle_counts_len"]
+    want = np.split(fx["rle_counts"], np.cumsum(lens)[:-1])
+    H, W = masks.shape[1:]
+    for k in range(4):                                   # paste + encode: same binary mask, the reference's run lengths
+        counts, binary = P.paste_mask_rle(fx["rle_soft"][k], fx["rle_boxes"][k], H, W, 0.5, True)
+        assert np.array_equal(binary, masks[k]) and counts == want[k].tolist(), k
+    for k in range(len(masks)):                          # encode alone: the mask pasted onto itself (box = the image: identity sampling)
+        counts = P.paste_mask_rle(masks[k].astype(np.float32), (0.0, 0.0, float(W), float(H)), H, W, 0.5)
+        assert counts == want[k].tolist(), k
+        assert np.array_equal(M.rle_to_binary_mask(M.rle_from_counts(counts, H, W)), masks[k])
+        assert np.array_equal(M.rle_to_binary_mask(M.rle_from_counts(counts, H, W, compressed=False)), masks[k])
+    assert want[4].tolist() == [H * W] and want[5].tolist() == [0, H * W] and want[6][0] == 0
 
 
 def test_coco_rle_string_codec():
