@@ -39,7 +39,7 @@
 // pre-packed fp16 weight tiles (8 KB: [split][k-block][128][8]) by LDS-DMA into two stages, the split of k-tile t+1 (cvt_pk,
 // v_fma_mix_f32 residual, cvt_pk: 32 VALU operations) spread over the MFMA slots of k-tile t, both weight fragment sets read
 // just in time (l behind the barrier of the previous k-tile, h in slots 1 and 3), one barrier per k-tile behind slot 19.
-// 64 KB of dynamic LDS, two workgroups per CU.  Linear form, the 3x3 / stride 1 / pad 1 convolution and the general K x K /
+// 80 KB of dynamic LDS (three A stages, four weight slots: one barrier per two k-tiles), two workgroups per CU.  Linear form, the 3x3 / stride 1 / pad 1 convolution and the general K x K /
 // stride / pad convolution (implicit im2col, k-tile order of gemm_split.hpp), optional GroupNorm statistics in the epilogue (as
 // gemm_split_glds_kernel<.., GNS>).  -DGDRNPP2_TIMING_NO_{BREAD,SPLIT,SYNC,DMA}: timing-only builds (results invalid) behind
 // profiles/r03y_split2_kloop_dissection.txt.
@@ -154,7 +154,7 @@ struct GnStats2 { double* part; int G; int tiles_per_img; };   // as GnStats of 
 // CONV: 0 = linear (A row-major [M,K]), 1 = 3x3 / stride 1 / pad 1 convolution over an NHWC image (geometry folded at compile
 //       time), 2 = any KH x KW / stride / zero padding with at most 32 taps (ConvNeXt's 2x2/2 downsamples, Patch-PnP's 3x3/2)
 // GNS: GroupNorm (sum, sum of squares) partials of the stored result per wave (64 rows x 8-channel groups), CONV only
-// NJ: 32-column MFMA tiles per wave.  4: block tile 256 x 128, 24 slots per k-tile, 64 KB LDS, two workgroups per CU.
+// NJ: 32-column MFMA tiles per wave.  4: block tile 256 x 128, 24 slots per k-tile, 80 KB LDS, two workgroups per CU.
 //     8: block tile 256 x 256 (two packed weight tiles side by side), 48 slots per k-tile, 256 accumulator registers — one wave
 //     per SIMD, 80 KB LDS, one workgroup per CU: per MFMA half the A traffic (LDS-DMA, raw fragment reads, split arithmetic) of NJ = 4.
 // APRE: A is an "f16x2 rows" tensor (linear form only).  c_rows (run time): C is written as one (bias / GELU epilogues).
@@ -169,6 +169,14 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
   constexpr int BNB = NJ * 32;                     // block columns
   constexpr int NWT = NJ / 4;                      // packed 128-column weight tiles per block
   constexpr int B_STAGE_B = NWT * W2_TILE_B;       // 8 / 16 KB
+#ifndef GDRNPP2_SINGLE_BARRIER   // -DGDRNPP2_SINGLE_BARRIER: the two-slot form with a barrier per k-tile (A/B; bitwise equal, 0.75 % slower per step)
+  // PAIR: FOUR weight slots (k-tile kt in slot kt & 3), the weight DMA runs two k-tiles ahead and the workgroup meets at ONE barrier per
+  // TWO k-tiles (behind the odd one): the slots a pair of k-tiles reads were complete at the previous barrier, the slots its DMA
+  // fills were last read before it.  Waves of a workgroup may then drift by a whole k-tile instead of waiting for each other 2 x.
+  constexpr bool PAIR = NJ == 4;
+#else
+  constexpr bool PAIR = false;
+#endif
   constexpr int NS = 6 * NJ;                       // MFMA slots per k-tile
   constexpr int NBP = 2 * NWT;                     // weight DMA pieces per wave and k-tile
   constexpr int SB = NS - NJ / 2 - 3;              // slot of the barrier: behind it NJ/2 slots of fragment reads + one raw A read
@@ -310,10 +318,10 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
   auto ktile = [&](int kt, HalfSplit2 (&cur)[2], HalfSplit2 (&nxt)[2], f16x8 (&fbL)[NJ], f16x8 (&fbH)[NJ], auto bs_, int sa1, int sa2,
                    int sa_wr) {
     constexpr int BS = decltype(bs_)::value;
-    const uint4* const b = sBf + BS * (B_STAGE_B / 16);
-    const uint4* const bn = sBf + (BS ^ 1) * (B_STAGE_B / 16);
-    const int kt_b = min(kt + 1, nk - 1), kt_a = min(kt + NA, nk - 1);
-    const unsigned sb_wr = (unsigned)((BS ^ 1) * B_STAGE_B), sa_wr_b = (unsigned)(sa_wr * A_STAGE_B);
+    const uint4* const b = sBf + (PAIR ? (kt & 3) : BS) * (B_STAGE_B / 16);
+    const uint4* const bn = sBf + (PAIR ? ((kt + 1) & 3) : (BS ^ 1)) * (B_STAGE_B / 16);
+    const int kt_b = min(kt + (PAIR ? 2 : 1), nk - 1), kt_a = min(kt + NA, nk - 1);
+    const unsigned sb_wr = (unsigned)((PAIR ? ((kt + 2) & 3) : (BS ^ 1)) * B_STAGE_B), sa_wr_b = (unsigned)(sa_wr * A_STAGE_B);
     static_for<0, NS>([&](auto s_) {
       constexpr int S = decltype(s_)::value;
       constexpr int G = S / (2 * NJ), I = (S % (2 * NJ)) / NJ, J = S % NJ;
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
 #ifndef GDRNPP2_TIMING_NO_SYNC
         wait_vmcnt<4>();
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): every LDS read of the stages about to be refilled has returned
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!PAIR || BS == 1) __builtin_amdgcn_s_barrier();
 #endif
       }
       // behind the barrier: weight split l of k-tile kt+1 (fbL is dead since slot 7) and the raw first half of k-tile kt+2
@@ -395,6 +403,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
   if constexpr (!ADIR) {
     static_for<0, 4>([&](auto c) { dma_a(0, 0u, c); });
     static_for<0, NBP>([&](auto c) { dma_b(0, 0u, c); });
+    if constexpr (PAIR) static_for<0, NBP>([&](auto c) { dma_b(min(1, nk - 1), (unsigned)B_STAGE_B, c); });
     static_for<0, 4>([&](auto c) { dma_a(min(1, nk - 1), (unsigned)A_STAGE_B, c); });
     static_for<0, 4>([&](auto c) { dma_a(min(2, nk - 1), 2u * A_STAGE_B, c); });
     wait_vmcnt<4>();
@@ -509,7 +518,11 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 1) void gemm_split2_pipe_kernel(
 template <int EPI, int CONV, bool GNS, int NJ, bool APRE = false>
 int launch_nj(const float* A, const uint4* Wp, const float* bias, const float* gamma, const float* resid, float* C, int M, int N,
               int K, ConvGeom cg, int panel, GnStats2 gn, int* range_flag, hipStream_t st, const char* what, int c_rows = 0) {
+#ifndef GDRNPP2_SINGLE_BARRIER
+  constexpr int lds_bytes = NA * A_STAGE_B + (NJ == 4 ? 4 : 2) * (NJ / 4) * W2_TILE_B;   // NJ = 4: 80 KB, two workgroups fill the CU's 160 KB
+#else
   constexpr int lds_bytes = NA * A_STAGE_B + 2 * (NJ / 4) * W2_TILE_B;
+#endif
   const int rc = gdrnpp::ensure_dynamic_lds((const void*)gemm_split2_pipe_kernel<EPI, CONV, GNS, NJ, APRE>, lds_bytes);
   if (rc) return rc;
   const long tiles = (long)((M + 255) / 256) * (N / (NJ * 32));
