@@ -106,6 +106,7 @@ def parse(argv=None):
                         "6 = bf16x3 everywhere (exact to 2^-26)")
     p.add_argument("--no-fused-mlp", action="store_true", help="A/B: stage-0 ConvNeXt MLPs as two three-product launches instead of the fused kernel")
     p.add_argument("--fused-mlp-max-c", type=int, default=256, help="A/B: widest ConvNeXt block on the fused MLP kernel (128 = stage 0 only, 256 = stages 0 and 1)")
+    p.add_argument("--fused-mlp-min-rows", type=int, default=None, help="A/B: fewest pixels of a block for the fused MLP kernel (default 32768)")
     p.add_argument("--no-f16x2-rows", action="store_true", help="A/B: fp32 tensors between dwconv+LN / fc1 / fc2 of a ConvNeXt block instead of the pre-split f16x2-rows hand-over")
     p.add_argument("--no-other-mode-line", action="store_true",
                    help="skip the extra measurement of the other --gemm-products setting after the timed region")
@@ -328,7 +329,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
     hip_layers.set_conv_gn_fused(not args.no_conv_gn_fusion)
     hip_layers.set_mlp_gemm(args.mlp_gemm)
     hip_layers.set_gemm_products(args.gemm_products)
-    hip_layers.set_fused_mlp_x3(not args.no_fused_mlp, args.fused_mlp_max_c)
+    hip_layers.set_fused_mlp_x3(not args.no_fused_mlp, args.fused_mlp_max_c, args.fused_mlp_min_rows)
     hip_layers.set_f16x2_rows(not args.no_f16x2_rows)
     opts = ["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"] if refine else []
 

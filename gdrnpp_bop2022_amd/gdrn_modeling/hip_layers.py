@@ -273,15 +273,17 @@ def _packed(linear: nn.Linear, cache: dict, key: str) -> torch.Tensor:
 
 _FUSED_MLP = True
 _FUSED_MLP_MAX_C = 256              # widest block that takes the fused kernel (it exists for C = 128 and C = 256)
-_FUSED_MLP_MIN_ROWS = 256 * 256     # one workgroup (256 pixels) per CU at least
+_FUSED_MLP_MIN_ROWS = 128 * 256     # one 128-pixel workgroup per CU at least (8 ROIs at stage 0, 32 at stage 1; measured: profiles/r04e)
 
 
-def set_fused_mlp_x3(flag: bool, max_c: int = 256) -> None:
+def set_fused_mlp_x3(flag: bool, max_c: int = 256, min_rows: int | None = None) -> None:
     """A/B switch: False runs the stage-0 / stage-1 ConvNeXt MLPs as two three-product launches again; ``max_c`` = 128 keeps the
-    fused form to stage 0."""
-    global _FUSED_MLP, _FUSED_MLP_MAX_C
+    fused form to stage 0; ``min_rows``: fewest pixels a block must have to take it."""
+    global _FUSED_MLP, _FUSED_MLP_MAX_C, _FUSED_MLP_MIN_ROWS
     _FUSED_MLP = bool(flag)
     _FUSED_MLP_MAX_C = int(max_c)
+    if min_rows is not None:
+        _FUSED_MLP_MIN_ROWS = int(min_rows)
 
 
 def _fused_mlp_weights(mlp, cache: dict, m: int, c: int):

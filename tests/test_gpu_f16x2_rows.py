@@ -92,48 +92,52 @@ def test_convnext_stage_with_and_without_rows_is_bitwise_equal(hip):
     from gdrnpp_bop2022_amd.gdrn_modeling.backbones import ConvNeXtBlock
 
     assert hip_layers.gemm_products() == 3
-    for c, hw, n in ((512, 16, 128), (256, 32, 32), (1024, 8, 128)):      # (256 channels from 65 536 pixels on: the fused kernel)
-        torch.manual_seed(c)
-        blk = ConvNeXtBlock(c).to(DEV).eval()
-        with torch.no_grad():
-            blk.gamma.normal_(0.0, 0.5)
-        x = torch.randn(n, c, hw, hw, device=DEV).contiguous(memory_format=torch.channels_last)
-
-        def run():
-            timer = hip.LaunchTimer()
-            hip.set_launch_timer(timer)
-            try:
-                with torch.no_grad():
-                    y = engine.run_with_range_check(lambda: blk(x))
-            finally:
-                hip.set_launch_timer(None)
-            return y, [r[0] for r in timer.records]
-
-        def takes_rows():
+    hip_layers.set_fused_mlp_x3(True, 128)            # C = 256 blocks on the two-launch path here (from 32 768 pixels on they take the fused kernel)
+    try:
+        for c, hw, n in ((512, 16, 128), (256, 32, 32), (1024, 8, 128)):
+            torch.manual_seed(c)
+            blk = ConvNeXtBlock(c).to(DEV).eval()
             with torch.no_grad():
-                return hip_layers.mlp_takes_rows(blk.mlp, blk.conv_dw, x, blk._cache)
+                blk.gamma.normal_(0.0, 0.5)
+            x = torch.randn(n, c, hw, hw, device=DEV).contiguous(memory_format=torch.channels_last)
 
-        try:
-            assert takes_rows()
-            y_rows, kinds = run()
-            assert kinds == ["hbm:dwconv7_ln", "linear" + hip.X3, "linear" + hip.X3]
-            hip_layers.set_f16x2_rows(False)
-            assert not takes_rows()
-            y_f32, kinds = run()
-            assert kinds == ["hbm:dwconv7_ln", "linear" + hip.X3, "linear" + hip.X3]
-            assert torch.equal(y_rows, y_f32)
-            hip_layers.set_f16x2_rows(True)
-            # a demoted fc2 takes fc1's result as fp32, a demoted fc1 takes the LayerNorm output as fp32
-            hip_layers.demote_x3({hip_layers.x3_slot(blk._cache, "fc2"): hip.X3_SMALL_ROWS})
-            y_d2, kinds = run()
-            assert kinds[1] == "linear" + hip.X3 and kinds[2] in ("linear", "linear_splitk")
-            hip_layers.reset_x3_demotions()
-            hip_layers.demote_x3({hip_layers.x3_slot(blk._cache, "fc1"): hip.X3_SMALL_ROWS})
-            assert not takes_rows()
-            y_d1, kinds = run()
-            assert kinds[1] in ("linear", "linear_splitk") and kinds[2] == "linear" + hip.X3
-            scale = y_f32.abs().max()
-            assert ((y_d2 - y_f32).abs().max() / scale).item() < 5e-6 and ((y_d1 - y_f32).abs().max() / scale).item() < 5e-6
-        finally:
-            hip_layers.set_f16x2_rows(True)
-            hip_layers.reset_x3_demotions()
+            def run():
+                timer = hip.LaunchTimer()
+                hip.set_launch_timer(timer)
+                try:
+                    with torch.no_grad():
+                        y = engine.run_with_range_check(lambda: blk(x))
+                finally:
+                    hip.set_launch_timer(None)
+                return y, [r[0] for r in timer.records]
+
+            def takes_rows():
+                with torch.no_grad():
+                    return hip_layers.mlp_takes_rows(blk.mlp, blk.conv_dw, x, blk._cache)
+
+            try:
+                assert takes_rows()
+                y_rows, kinds = run()
+                assert kinds == ["hbm:dwconv7_ln", "linear" + hip.X3, "linear" + hip.X3]
+                hip_layers.set_f16x2_rows(False)
+                assert not takes_rows()
+                y_f32, kinds = run()
+                assert kinds == ["hbm:dwconv7_ln", "linear" + hip.X3, "linear" + hip.X3]
+                assert torch.equal(y_rows, y_f32)
+                hip_layers.set_f16x2_rows(True)
+                # a demoted fc2 takes fc1's result as fp32, a demoted fc1 takes the LayerNorm output as fp32
+                hip_layers.demote_x3({hip_layers.x3_slot(blk._cache, "fc2"): hip.X3_SMALL_ROWS})
+                y_d2, kinds = run()
+                assert kinds[1] == "linear" + hip.X3 and kinds[2] in ("linear", "linear_splitk")
+                hip_layers.reset_x3_demotions()
+                hip_layers.demote_x3({hip_layers.x3_slot(blk._cache, "fc1"): hip.X3_SMALL_ROWS})
+                assert not takes_rows()
+                y_d1, kinds = run()
+                assert kinds[1] in ("linear", "linear_splitk") and kinds[2] == "linear" + hip.X3
+                scale = y_f32.abs().max()
+                assert ((y_d2 - y_f32).abs().max() / scale).item() < 5e-6 and ((y_d1 - y_f32).abs().max() / scale).item() < 5e-6
+            finally:
+                hip_layers.set_f16x2_rows(True)
+                hip_layers.reset_x3_demotions()
+    finally:
+        hip_layers.set_fused_mlp_x3(True, 256)

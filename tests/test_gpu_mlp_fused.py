@@ -101,7 +101,7 @@ def test_convnext_mlp_dispatches_the_fused_kernel_and_falls_back_when_demoted(hi
     with torch.no_grad():
         mlp.fc1.bias.uniform_(0.5, 1.5)                           # keeps the hidden rows in range when x is tiny (only fc1 is flagged below)
     gamma = torch.randn(c, device=DEV)
-    x = torch.randn(16, 64, 64, c, device=DEV)                    # 65 536 pixels: the fused form's threshold
+    x = torch.randn(16, 64, 64, c, device=DEV)                    # 65 536 pixels: above the fused form's threshold
     sc = torch.randn(16, 64, 64, c, device=DEV)
     cache = {}
 
@@ -122,7 +122,7 @@ def test_convnext_mlp_dispatches_the_fused_kernel_and_falls_back_when_demoted(hi
             want = sc.double() + gamma.double() * mlp.double()(x.double())
             mlp.float()
         assert ((y.double() - want).abs().max() / want.abs().max()).item() < 2e-6
-        _, kinds = run(x[:8])                                      # below the threshold: two launches (fc2 has too few tiles for x3)
+        _, kinds = run(x[:4])                                      # below the threshold (32 768 pixels): two launches (fc2 has too few tiles for x3)
         assert len(kinds) == 2 and kinds[0] == "linear" + hip.X3 and "mlp_fused" + hip.X3 not in kinds
         hip_layers.set_fused_mlp_x3(False)
         _, kinds = run(x)
