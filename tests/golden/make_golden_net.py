@@ -196,6 +196,63 @@ def record_b128(datasets=("ycbv", "tless"), b=128):
         print("wrote", f"net_golden_{ds}_b128.npz")
 
 
+def record_b128_f64(datasets=("ycbv", "tless"), b=128, chunk=16):
+    """The round-4 verdict's question "who is closer to the true value": the SAME reference module, parameters and 128-ROI batch
+    as record_b128, evaluated in fp64 (``model.double()``; the fp32 parameters and inputs convert exactly), in chunks of 16 ROIs
+    (eval mode: a ROI's outputs do not depend on the batch).  Stored: R, t, the Patch-PnP outputs in fp64, and — from an fp32 run
+    of the same chunks, which must reproduce record_b128's fixture — the distance of the reference's own fp32 chain from its fp64
+    value per ROI.  -> net_golden_<ds>_b128_f64.npz (a few KB)"""
+    torch.set_num_threads(os.cpu_count())
+    torch.set_grad_enabled(False)
+    hip_layers.set_enabled(False)
+    from core.gdrn_modeling.models import GDRN_double_mask as REFM
+    from core.gdrn_modeling.models import net_factory
+
+    net_factory.BACKBONES["timm/convnext_base"] = lambda model_name=None, **kw: create_backbone(type="timm/" + model_name, **kw)
+    for ds in datasets:
+        raw = _refimport.load_ref_config(CONFIGS[ds])
+        cfg = Config(raw)
+        cfg.MODEL.DEVICE = "cpu"
+        cfg.MODEL.POSE_NET.BACKBONE.INIT_CFG.pretrained = False
+        cfg.TEST.USE_DEPTH_REFINE = True
+        cfg.SOLVER.BASE_LR = cfg.SOLVER.OPTIMIZER_CFG["lr"]
+        model, opt = REFM.build_model_optimizer(cfg, is_test=True)
+        assert type(model).__module__ == "core.gdrn_modeling.models.GDRN_double_mask"
+        model.eval()
+        sd = model.state_dict()
+        model.load_state_dict(S.seeded_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], SEED, alias=norm_alias), strict=True)
+        model.double()
+        C = cfg.MODEL.POSE_NET.NUM_CLASSES
+        x, det = net_image(b), net_detections_b128(C, b)
+        coord2d = S.coord2d_roi(det["roi_center"], det["scale"])
+        grab = {}
+        model.pnp_net.register_forward_hook(lambda m, i, o: grab.update(pred_rot_=o[0].clone(), pred_t_=o[1].clone()))
+        acc = {k: [] for k in ("rot", "trans", "pred_rot_", "pred_t_")}
+        maps = {k: [] for k in ("mask", "full_mask", "coor_x", "coor_y", "coor_z")}
+        for s in range(0, b, chunk):
+            sl = slice(s, s + chunk)
+            D = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl])).double()   # noqa: E731
+            out = model(D(x), roi_classes=torch.from_numpy(det["roi_cls"][sl]), roi_cams=D(det["roi_cam"]), roi_whs=D(det["roi_wh"]),
+                        roi_centers=D(det["roi_center"]), resize_ratios=D(det["resize_ratio"]), roi_coord_2d=D(coord2d),
+                        roi_extents=D(det["roi_extent"]), do_loss=False)
+            assert out["rot"].dtype == torch.float64 and grab["pred_rot_"].dtype == torch.float64
+            acc["rot"].append(out["rot"].numpy()); acc["trans"].append(out["trans"].numpy())
+            acc["pred_rot_"].append(grab["pred_rot_"].numpy()); acc["pred_t_"].append(grab["pred_t_"].numpy())
+            for k in maps:
+                maps[k].append(out[k].numpy()[:, :, ::4, 1::4])
+            print(ds, "f64 chunk", s, flush=True)
+        rec = {k + "_f64": np.concatenate(v) for k, v in acc.items()}
+        for k, v in maps.items():
+            rec[k + "_sub_f64"] = np.concatenate(v)
+        f32 = np.load(os.path.join(HERE, f"net_golden_{ds}_b128.npz"))
+        for k in ("rot", "trans", "pred_rot_", "pred_t_"):
+            d = np.abs(f32[k].astype(np.float64) - rec[k + "_f64"]).reshape(b, -1).max(1)
+            rec["ref_f32_err_" + k] = d
+            print(ds, k, "reference fp32 vs its fp64: max", d.max(), "argmax ROI", int(d.argmax()), "ROIs > 5e-5:", np.nonzero(d > 5e-5)[0].tolist())
+        np.savez_compressed(os.path.join(HERE, f"net_golden_{ds}_b128_f64.npz"), **rec)
+        print("wrote", f"net_golden_{ds}_b128_f64.npz")
+
+
 def record_resnet34():
     """BASELINE configs[0]: models/GDRN.py built from configs/_base_/gdrn_base.py (NUM_CLASSES=1 for the single LM-O object;
     the base file's 13 gives the same graph — nothing in it is class-aware), 32 ROIs = the batch of configs[0].
@@ -255,6 +312,8 @@ def record_resnet34():
 if __name__ == "__main__":
     if "--b128-only" in sys.argv:
         record_b128()
+    elif "--b128-f64" in sys.argv:
+        record_b128_f64()
     elif "--resnet34-only" in sys.argv:
         torch.set_num_threads(os.cpu_count())
         torch.set_grad_enabled(False)

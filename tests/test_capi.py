@@ -35,6 +35,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/gdrnpp_hip.h but not exported"
 
 
+def test_library_exports_nothing_but_the_header():
+    """csrc/exports.map: the dynamic symbol table holds exactly the prototypes of include/gdrnpp_hip.h — no mangled
+    gdrnpp:: helpers, no __hip_cuid_* markers."""
+    import subprocess
+
+    from gdrnpp_bop2022_amd import hip_lib
+
+    out = subprocess.run(["nm", "-D", "--defined-only", hip_lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == _declared_symbols()
+
+
 def test_python_binding_covers_header():
     from gdrnpp_bop2022_amd import hip_lib
 
