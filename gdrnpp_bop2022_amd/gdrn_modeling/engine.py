@@ -202,34 +202,66 @@ def class_sorted_order(roi_cls):
     return np.argsort(np.asarray(roi_cls).reshape(-1), kind="stable")
 
 
-_GLOBAL_DETECTION_KEYS = ("extents",)     # per-class / per-dataset arrays of a detections dict: never permuted
+# The detections dict of ``batch_data_test_gpu`` — which entries are per ROI and which are not is a CONTRACT, not a guess:
+PER_ROI_DETECTION_KEYS = ("bbox", "im_idx", "roi_cls", "score", "time", "roi_id", "det_id", "scene_im_id", "inst_id")
+GLOBAL_DETECTION_KEYS = ("extents", "obj_ids", "model_points", "sym_infos")   # per class / per dataset: never permuted
+_GLOBAL_DETECTION_KEYS = GLOBAL_DETECTION_KEYS      # the round-3 name
 
 
-def sort_detections_by_class(detections: dict, roi_id_base: int = 0):
-    """-> (detections with every per-ROI array permuted into class order, roi_id i32[n] = ``roi_id_base`` + the position the
-    ROI had before).  Per-ROI = every array-like entry whose leading dimension is the number of ROIs (bbox, im_idx, roi_cls,
-    score, time, a per-ROI cam [n,3,3], detection / scene / image ids a caller carries along, ...); the per-class entries
-    (``extents``), a shared ``cam`` [3,3] and scalars pass through.  Sorting the DETECTIONS costs nothing on the device: the crop
-    kernel simply reads its ROI parameters in the new order, no ROI tensor is ever permuted."""
+def sort_detections_by_class(detections: dict, roi_id_base: int = 0, extra_per_roi_keys=(), extra_global_keys=()):
+    """-> (detections with every per-ROI entry permuted into class order, roi_id i32[n] = ``roi_id_base`` + the position the
+    ROI had before).
+
+    Per-ROI entries: ``PER_ROI_DETECTION_KEYS`` + ``extra_per_roi_keys`` (arrays, tensors or lists whose leading dimension is
+    the number of ROIs — anything else under such a key raises) and ``cam`` when it is [n,3,3].  Passed through untouched:
+    ``GLOBAL_DETECTION_KEYS`` + ``extra_global_keys``, a shared ``cam`` [3,3], scalars, strings, None.  Any OTHER entry whose
+    leading dimension happens to equal the number of ROIs is ambiguous (a per-class table when n == number of classes?) and
+    raises ``KeyError`` naming the two arguments that resolve it — nothing is reordered on a guess.  Sorting the DETECTIONS
+    costs nothing on the device: the crop kernel reads its ROI parameters in the new order, no ROI tensor is ever permuted."""
     import numpy as np
 
     order = class_sorted_order(np.asarray(detections["roi_cls"]))
     out = dict(detections)
     n = len(order)
-    for k, v in detections.items():
-        if k in _GLOBAL_DETECTION_KEYS or isinstance(v, (str, bytes)) or v is None:
-            continue
+    per_roi = set(PER_ROI_DETECTION_KEYS) | set(extra_per_roi_keys)
+    glob = set(GLOBAL_DETECTION_KEYS) | set(extra_global_keys)
+
+    def lead(v):
         if isinstance(v, torch.Tensor):
-            if v.dim() >= 1 and v.shape[0] == n and not (k == "cam" and v.dim() == 2):
-                out[k] = v[torch.as_tensor(order, device=v.device)]
+            return v.shape[0] if v.dim() >= 1 else None
+        if isinstance(v, (str, bytes)) or v is None or np.isscalar(v):
+            return None
+        if isinstance(v, (list, tuple)):
+            return len(v)
+        a = np.asarray(v)
+        return a.shape[0] if a.ndim >= 1 else None
+
+    def permuted(v):
+        if isinstance(v, torch.Tensor):
+            return v[torch.as_tensor(order, device=v.device)]
+        if isinstance(v, (list, tuple)) and not isinstance(v, np.ndarray) and any(isinstance(e, (str, bytes)) for e in v):
+            return [v[i] for i in order]
+        return np.asarray(v)[order]
+
+    for k, v in detections.items():
+        if k in glob:
             continue
-        if isinstance(v, (list, tuple)) and len(v) == n and not (k == "cam" and np.asarray(v).ndim == 2):
-            if all(isinstance(e, (str, bytes)) for e in v):
-                out[k] = [v[i] for i in order]
+        if k == "cam":
+            nd = v.dim() if isinstance(v, torch.Tensor) else np.asarray(v).ndim
+            if nd == 3:
+                if lead(v) != n:
+                    raise ValueError(f"detections['cam'] is per ROI ([n,3,3]) but has {lead(v)} entries for {n} ROIs")
+                out[k] = permuted(v)
+            continue
+        if k in per_roi:
+            if v is None:
                 continue
-        arr = np.asarray(v)
-        if arr.ndim >= 1 and arr.shape[0] == n and not (k == "cam" and arr.ndim == 2):
-            out[k] = arr[order]
+            if lead(v) != n:
+                raise ValueError(f"detections[{k!r}] is a per-ROI entry but has leading dimension {lead(v)} for {n} ROIs")
+            out[k] = permuted(v)
+        elif lead(v) == n:
+            raise KeyError(f"detections[{k!r}] has as many entries as there are ROIs ({n}) but is neither a known per-ROI key nor a "
+                           "known global one: pass it in extra_per_roi_keys (to be permuted with the ROIs) or extra_global_keys")
     return out, (roi_id_base + order).astype(np.int32)
 
 
@@ -257,7 +289,7 @@ def _note_range_words(words: dict) -> None:
         such steps the process stays on six products (with a warning)."""
     global _X3_OVERFLOW_STEPS
     hip_layers.demote_x3({s_: w for s_, w in words.items() if w & hip_lib.X3_SMALL_ROWS})
-    over = sorted(s_ for s_, w in words.items() if w & hip_lib.X3_NONFINITE)
+    over = hip_layers.x3_launch_order(s_ for s_, w in words.items() if w & hip_lib.X3_NONFINITE)   # slot order is not launch order
     if over:
         _X3_OVERFLOW_STEPS += 1
         first = [s_ for s_ in over if s_ > 0][:1]
@@ -522,6 +554,26 @@ class GraphedInference:
         self._capture()
 
     @torch.no_grad()
+    def _eager_pass(self):
+        """One eager step on a side stream with the CURRENT demotions / products, range check included (it may demote further
+        layers): everything a capture must not do — packing a weight for the first time (a block that left the fused MLP kernel
+        has never packed its two unfused images), ``packed_rows_in_range``'s host read, hipFuncSetAttribute — happens here."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            inference_step(self.model, self.post, self.static, self.roi_ids)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+    def _recapture(self):
+        for _ in range(4):          # an eager pass may itself demote a layer: repeat until the set is stable
+            before = (hip_layers.x3_demoted(), hip_layers.gemm_products())
+            self._eager_pass()
+            if (hip_layers.x3_demoted(), hip_layers.gemm_products()) == before:
+                break
+        self._capture()
+
+    @torch.no_grad()
     def _capture(self):
         run = _step_closure(self.model, self.post, self.static, self.roi_ids)
         self.graph = torch.cuda.CUDAGraph()
@@ -539,13 +591,13 @@ class GraphedInference:
     def replay(self) -> torch.Tensor:
         """Replay on the static buffers, then the range check of the graph's three-product kernels."""
         if self.uses_x3 and (hip_layers.x3_demoted() != self._demoted_at_capture or hip_layers.gemm_products() != self._products_at_capture):
-            self._capture()        # another step demoted a layer this graph still runs on three products
+            self._recapture()      # another step demoted a layer this graph still runs on three products
         self.graph.replay()
         if self.uses_x3:
             words = hip_lib.range_words_of(self.x3_flag.cpu())
             if words:
                 rec = _six_product_rerun(_step_closure(self.model, self.post, self.static, self.roi_ids), words)
-                self._capture()
+                self._recapture()
                 self.records.copy_(rec)
         return self.records
 
@@ -632,7 +684,7 @@ def detections_from_bop_json(detections: dict, scene_im_ids, obj_ids, cam, exten
 
 
 def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, device=None, sort_by_class: bool = False,
-                        roi_id_base: int = 0) -> dict:
+                        roi_id_base: int = 0, extra_per_roi_keys=(), extra_global_keys=()) -> dict:
     """``read_data_test`` + ``batch_data_test`` (data_loader.py:647-818, engine_utils.py:213-241) with the crops made
     on the GPU.  images u8[n_im,H,W,3] (BGR, device), depths f32[n_im,H,W] or None, detections:
     {"bbox": [n,4] xyxy, "im_idx": [n], "roi_cls": [n], "score": [n], "cam": [n,3,3] or [3,3], "extents": [C,3]}.
@@ -645,7 +697,7 @@ def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, dev
     dev = device or images.device
     roi_id = None
     if sort_by_class:
-        detections, roi_id = sort_detections_by_class(detections, roi_id_base)
+        detections, roi_id = sort_detections_by_class(detections, roi_id_base, extra_per_roi_keys, extra_global_keys)
     if "roi_id" in detections:        # the caller's own ids (RoiStreamScheduler: global stream ids), permuted with the rest
         roi_id = np.asarray(detections["roi_id"], np.int32)
     net_cfg = cfg.MODEL.POSE_NET
@@ -758,12 +810,18 @@ class RoiPacker:
         return all(e[0] != key for e in self._queue)
 
     def deliver(self, records) -> None:
-        """Records f32[m,16] of one step (any order, padding rows with valid = 0 ignored) -> their images."""
+        """Records f32[m,16] of one step (any order) -> their images.  A record is delivered when its id is one this packer dealt
+        and is still waiting for — whatever its ``valid`` column says: the refine kernel marks a ROI whose object id lies outside
+        the mesh set invalid, and that ROI's image must still complete (the row keeps valid = 0 for the consumer).  The only rows
+        skipped are ``gather_records``' padding (all 16 columns zero) and ids that are not in flight."""
         import numpy as np
 
         rec = np.asarray(records, np.float32).reshape(-1, 16)
-        for r in rec[rec[:, 15] > 0.5]:
-            key, j = self._where.pop(int(r[14]))
+        for r in rec:
+            rid = int(r[14])
+            if rid not in self._where or (r[15] <= 0.5 and not r.any()):
+                continue
+            key, j = self._where.pop(rid)
             ent = self._open[key]
             ent[1][j] = r
             ent[2] -= 1
@@ -800,6 +858,7 @@ class RoiStreamScheduler:
         self._images = {}                       # key -> (image, depth, detections, arrival time)
         self._arrival = {}
         self._in_flight = collections.deque()   # (StepHandle, batch) — the batch stays alive for a six-product repeat
+        self._with_depth = None                 # fixed by the first image that has ROIs
         self.steps_launched = 0
 
     # -- one step ----------------------------------------------------------------------------------
@@ -817,7 +876,7 @@ class RoiStreamScheduler:
 
         keys = [k for k, _, _ in pack]
         images = torch.stack([self._images[k][0] for k in keys])
-        depths = torch.stack([self._images[k][1] for k in keys]) if self._images[keys[0]][1] is not None else None
+        depths = torch.stack([self._images[k][1] for k in keys]) if self._with_depth else None
         det = dict(
             bbox=np.concatenate([per_roi(k, loc, "bbox", np.float32) for k, loc, _ in pack]),
             roi_cls=np.concatenate([per_roi(k, loc, "roi_cls", np.int64) for k, loc, _ in pack]),
@@ -848,10 +907,16 @@ class RoiStreamScheduler:
     def _admit(self, key, image, depth, detections) -> None:
         import time
 
-        self._arrival[key] = time.perf_counter()
-        if len(detections["roi_cls"]):
+        n = len(detections["roi_cls"])
+        if n and self._with_depth is not None and (depth is not None) != self._with_depth:
+            raise ValueError("RoiStreamScheduler: a stream is either with depth or without, not mixed "
+                             f"(image {key!r} {'has' if depth is not None else 'lacks'} a depth map)")
+        self.packer.add_image(key, n)           # raises for a key still in flight BEFORE any state of that image is touched
+        if n:
+            if self._with_depth is None:
+                self._with_depth = depth is not None
             self._images[key] = (image, depth, detections)
-        self.packer.add_image(key, len(detections["roi_cls"]))
+        self._arrival[key] = time.perf_counter()
 
     # -- the stream --------------------------------------------------------------------------------
     def push(self, key, image: torch.Tensor, depth, detections: dict):

@@ -177,6 +177,23 @@ class forced_gemm_products:
 _X3_NEXT_SLOT = 1            # slot 0: launches that name no layer
 _X3_DEMOTED = {}             # slot -> range word that demoted it
 _X3_EPOCH = 0                # bumped by reset_x3_demotions: slots handed out before it are forgotten
+_X3_LAUNCH_SEQ = {}          # slot -> sequence number of its latest three-product launch (process-wide monotonic counter)
+_X3_LAUNCH_COUNTER = 0
+
+
+def _note_x3_launch(*slots: int) -> None:
+    """Slots are handed out lazily (first eligible launch, any model, any batch size), so slot order is NOT launch order in
+    general; the order a step launched its layers in is what decides which of several overflowing layers was the first."""
+    global _X3_LAUNCH_COUNTER
+    for s_ in slots:
+        _X3_LAUNCH_COUNTER += 1
+        _X3_LAUNCH_SEQ[s_] = _X3_LAUNCH_COUNTER
+
+
+def x3_launch_order(slots) -> list:
+    """``slots`` sorted by the position of their latest three-product launch (slots never launched sort last, by number)."""
+    big = _X3_LAUNCH_COUNTER + 1
+    return sorted(slots, key=lambda s_: (_X3_LAUNCH_SEQ.get(s_, big), s_))
 
 
 def x3_slot(cache: dict, key: str) -> int:
@@ -205,6 +222,7 @@ def reset_x3_demotions() -> None:
     _X3_EPOCH += 1
     _X3_NEXT_SLOT = 1
     _X3_DEMOTED.clear()
+    _X3_LAUNCH_SEQ.clear()
 
 
 reset_x3_calibration = reset_x3_demotions    # the name GDRN_DoubleMask.load_state_dict has always called
@@ -230,6 +248,8 @@ def x3_for(cache: dict, key: str, weight: torch.Tensor, pack3, m: int, n: int, k
     if hit is None or hit[0] != tag:
         packed = pack3(weight.detach())
         hit = cache[key + "_pk_x3"] = (tag, packed, hip_lib.packed_rows_in_range(packed))
+    if hit[2]:
+        _note_x3_launch(slot)
     return (hit[1] if hit[2] else None), slot
 
 
@@ -300,6 +320,8 @@ def _fused_mlp_weights(mlp, cache: dict, m: int, c: int):
     if hit is None or hit[0] != tag:
         packed = hip_lib.pack_mlp_fused_f16x2(mlp.fc1.weight.detach().contiguous(), mlp.fc2.weight.detach().contiguous())
         hit = cache["mlp_fused_pk"] = (tag, packed, all(hip_lib.mlp_fused_rows_in_range(packed)))
+    if hit[2]:
+        _note_x3_launch(s1, s2)
     return (hit[1], s1, s2) if hit[2] else None
 
 

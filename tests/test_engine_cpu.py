@@ -298,6 +298,27 @@ def test_sort_detections_by_class_is_stable_and_carries_the_original_index():
     assert torch.equal(engine.class_sorted_order(torch.from_numpy(det["roi_cls"])), torch.from_numpy(orig.astype(np.int64)))
 
 
+def test_sort_detections_by_class_reorders_nothing_on_a_guess():
+    """The per-ROI / global split is a contract (engine.PER_ROI_DETECTION_KEYS / GLOBAL_DETECTION_KEYS): a per-class table whose
+    length happens to equal the number of ROIs passes through when it is a known global key, an unknown key of that length
+    raises until the caller says what it is, a per-ROI key of the wrong length raises."""
+    n = 6
+    cls = np.array([3, 1, 5, 0, 1, 2])
+    table = np.arange(n * 3, dtype=np.float32).reshape(n, 3)                 # n == number of classes
+    det = dict(roi_cls=cls, bbox=np.zeros((n, 4), np.float32), extents=table, obj_ids=list(range(1, n + 1)), cam=np.eye(3))
+    out, rid = engine.sort_detections_by_class(det)
+    assert np.array_equal(out["extents"], table) and out["obj_ids"] == list(range(1, n + 1))
+    with pytest.raises(KeyError, match="extra_per_roi_keys"):
+        engine.sort_detections_by_class(dict(det, keypoints=table))
+    out, rid = engine.sort_detections_by_class(dict(det, keypoints=table), extra_global_keys=("keypoints",))
+    assert np.array_equal(out["keypoints"], table)
+    out, rid = engine.sort_detections_by_class(dict(det, keypoints=table, names=list("abcdef")), extra_per_roi_keys=("keypoints", "names"))
+    assert np.array_equal(out["keypoints"], table[rid]) and out["names"] == [list("abcdef")[i] for i in rid]
+    with pytest.raises(ValueError, match="per-ROI"):
+        engine.sort_detections_by_class(dict(det, score=np.ones(n - 1)))
+    assert engine.sort_detections_by_class(dict(det, note="x", thr=0.5, mask=None))[0]["note"] == "x"   # scalars / strings / None pass
+
+
 def _sorted_shard_worker(rank, world, port, n_total, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -466,6 +487,66 @@ def test_roi_packer_deals_exact_steps_and_returns_records_to_their_images():
     assert sorted(done) == list(range(len(counts)))
     for k, n in enumerate(counts):
         assert done[k].shape == (n, 16) and done[k][:, 0].tolist() == [1000 * k + j for j in range(n)]
+
+
+def test_roi_packer_delivers_invalid_records_and_scheduler_admission_is_atomic():
+    """(round-4 advice) A real ROI may come back with valid = 0 (depth refine: object id outside the mesh set): its image must
+    still complete and keep the row's valid bit; only all-zero padding rows and foreign ids are skipped.  A key pushed while it
+    is still in flight raises BEFORE the scheduler's state for that key is touched; a stream cannot mix depth / no depth."""
+    pk = engine.RoiPacker(4, roi_id_base=0)
+    pk.add_image("a", 3)
+    pk.add_image("b", 1)
+    (ka, la, ia), (kb, lb, ib) = pk.next_pack()
+    rec = np.zeros((6, 16), np.float32)                       # 4 records + 2 padding rows (id 0 = the id of a's first ROI!)
+    rec[:3, 14], rec[3, 14] = ia, ib[0]
+    rec[:4, 15] = [0.0, 1.0, 1.0, 1.0]                        # a's first ROI (id 0) is INVALID but real: R is not zero
+    rec[:4, 0] = 1.0
+    pk.deliver(rec[[4, 0, 5, 3, 2, 1]])
+    done = dict(pk.pop_completed())
+    assert sorted(done) == ["a", "b"] and done["a"][:, 15].tolist() == [0.0, 1.0, 1.0] and not pk._where and not pk._open
+    pk.deliver(rec)                                           # a late duplicate of the same step: nothing in flight, nothing happens
+    assert pk.pop_completed() == []
+
+    sch = engine.RoiStreamScheduler(None, None, None, rois_per_step=64)
+    d1 = dict(roi_cls=np.array([1, 2]), bbox=np.zeros((2, 4), np.float32))
+    sch._admit("k", "image-1", "depth-1", d1)
+    t_first = sch._arrival["k"]
+    with pytest.raises(KeyError):
+        sch._admit("k", "image-2", "depth-2", dict(roi_cls=np.array([3]), bbox=np.zeros((1, 4), np.float32)))
+    assert sch._images["k"][0] == "image-1" and sch._arrival["k"] == t_first and sch.packer.pending == 2
+    with pytest.raises(ValueError, match="mixed"):
+        sch._admit("m", "image-3", None, d1)
+    assert "m" not in sch._images and "m" not in sch._arrival and sch.packer.pending == 2
+    sch._admit("e", "image-4", None, dict(roi_cls=np.zeros((0,), np.int64), bbox=np.zeros((0, 4), np.float32)))   # no ROIs: no depth needed
+    assert [k for k, _ in sch.packer.pop_completed()] == ["e"]
+
+
+def test_first_overflowing_layer_is_the_first_in_launch_order_not_the_smallest_slot(monkeypatch):
+    """(round-4 advice) Slots are handed out at a layer's first ELIGIBLE launch — a later layer may hold a smaller slot (another
+    model, another batch size).  Of the layers reporting non-finite values the one launched first in the step is demoted."""
+    import torch
+
+    from gdrnpp_bop2022_amd import hip_lib
+    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers as hl
+
+    hl.reset_x3_demotions()
+    monkeypatch.setattr(hip_lib, "packed_rows_in_range", lambda packed: True)
+    monkeypatch.setattr(engine, "_X3_OVERFLOW_STEPS", 0)
+    w = torch.zeros(512, 128)
+    big, small = (128 * 4096, 512, 128), (4 * 4096, 128, 512)
+    late, early = {}, {}
+    try:
+        # a small batch first: only the LATE layer is eligible (say, another model's) and takes slot 1
+        assert hl.x3_for(early, "fc", w, lambda t: "p", *small) == (None, 0)
+        assert hl.x3_for(late, "fc", w, lambda t: "p", *big)[1] == 1
+        # the step under test launches early (slot 2) and then late (slot 1)
+        assert hl.x3_for(early, "fc", w, lambda t: "p", *big)[1] == 2
+        assert hl.x3_for(late, "fc", w, lambda t: "p", *big)[1] == 1
+        assert hl.x3_launch_order([1, 2, 7]) == [2, 1, 7]
+        engine._note_range_words({1: hip_lib.X3_NONFINITE, 2: hip_lib.X3_NONFINITE})
+        assert hl.x3_demoted() == {2: hip_lib.X3_NONFINITE}
+    finally:
+        hl.reset_x3_demotions()
 
 
 def test_packed_loader_pools_images_until_the_step_is_full():
