@@ -112,6 +112,12 @@ def parse(argv=None):
                    help="skip the extra measurement of the other --gemm-products setting after the timed region")
     p.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                    help="library tuning switch (gdrnpp_set_option), e.g. --opt split_gemm_glds=0 for A/B measurements")
+    p.add_argument("--host-fed", action="store_true",
+                   help="stream workload: images / depth maps start in PINNED HOST memory (the reference's loader hands over host arrays, "
+                        "data_loader.py:754-797); hipMemcpyAsync on a copy stream, one step ahead of the device, inside the timed loop")
+    p.add_argument("--gather-to-rank0", action="store_true",
+                   help="gather the records to rank 0 only (dist.gather; the reference lets only the main process write, "
+                        "gdrn_evaluator.py:581-582) instead of the all-gather")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --stub-step: CPU test of the launch path")
     p.add_argument("--stub-step", action="store_true",
                    help="(tests) replace the GPU step by a host stub that emits this rank's records: exercises spawn, "
@@ -208,6 +214,7 @@ def worker(args):
         step = state["step"]
 
     launch = state["launch"] if state is not None else (lambda i: (lambda: step(i)))
+    dst = 0 if args.gather_to_rank0 else None
 
     def run_steps(n):
         """n steps, each resolved (range check + gather) after the next one has been launched."""
@@ -215,12 +222,14 @@ def worker(args):
         for i in range(n):
             cur = launch(i)
             if prev is not None:
-                rec = gather_records(prev(), b)
+                rec = gather_records(prev(), b, dst=dst)
             prev = cur
-        return gather_records(prev(), b)
+        return gather_records(prev(), b, dst=dst)
 
     run_steps(max(args.warmup, 1) * len(cfg_names) * 2)   # MIOpen find, weight packing, first range verdicts, both batches of every model
     sync()
+    if state is not None and state.get("after_warmup"):
+        state["after_warmup"]()
     if world > 1:
         dist.barrier()
     sync()
@@ -236,24 +245,33 @@ def worker(args):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # the gathered block holds every ROI id of the iteration exactly once, on every rank
-    ids = rec[:, 14][rec[:, 15] > 0.5].to(torch.int64).cpu().numpy()
-    if wname == "stream":     # stream ids keep counting: the last step holds n_global distinct consecutive ids per rank block
-        assert len(ids) == n_global and len(set(ids.tolist())) == n_global, "gathered records: ROI ids not distinct"
+    # the gathered block holds every ROI id of the iteration exactly once, on every rank (on rank 0 with --gather-to-rank0)
+    if dst is not None and rank != dst:
+        assert rec is None
     else:
-        assert len(ids) == n_global and np.array_equal(np.sort(ids), np.arange(n_global)), "gathered records: ROI ids not a permutation"
+        ids = rec[:, 14][rec[:, 15] > 0.5].to(torch.int64).cpu().numpy()
+        if wname == "stream":     # stream ids keep counting: the last step holds n_global distinct consecutive ids per rank block
+            assert len(ids) == n_global and len(set(ids.tolist())) == n_global, "gathered records: ROI ids not distinct"
+        else:
+            assert len(ids) == n_global and np.array_equal(np.sort(ids), np.arange(n_global)), "gathered records: ROI ids not a permutation"
 
-    gather_ms = None
+    gather_ms, collective = None, None
     if world > 1:                                           # the collective alone, after the timed region
-        local = rec[lo:hi].contiguous()
+        local = torch.zeros((b, 16), dtype=torch.float32, device=dev)
+        local[:, 14] = roi_ids.float()
         for _ in range(3):
-            gather_records(local, b)
+            gather_records(local, b, dst=dst)
         sync()
         g0 = time.perf_counter()
         for _ in range(20):
-            gather_records(local, b)
+            gather_records(local, b, dst=dst)
         sync()
         gather_ms = (time.perf_counter() - g0) / 20 * 1e3
+        # what the process group itself reports: a SCALE run proves from this that RCCL really saw N ranks
+        collective = {"op": "gather(dst=0)" if dst is not None else "all_gather_into_tensor", "backend": dist.get_backend(),
+                      "world_size_seen": dist.get_world_size(), "rank0_device": str(dev), "payload": "f32[rois_per_gpu,16]",
+                      "bytes_per_rank": b * 16 * 4, "bytes_received_per_rank": (world - 1) * b * 16 * 4,
+                      "calls_per_step": 1, "ms_alone": gather_ms}
 
     extras = {}
     if state is not None:
@@ -283,7 +301,8 @@ def worker(args):
                 "workload": f"{label}, batch={b} ROIs/GPU" + (f", {n_global} ROIs per iteration over {world} ranks" if world > 1 else ""),
                 "baseline_config_index": cfg_no, "workload_key": wname, "global_batch": n_global, "rois_per_gpu": b,
                 "roi_prep_on_gpu": bool(args.with_crop) or wname == "stream", "hipgraph": bool(args.graph), "input_res": 256, "output_res": 64,
-                "parallelism": f"roi-shard x{world}", "collective": "all_gather f32[n,16] pose records" if world > 1 else None,
+                "parallelism": f"roi-shard x{world}",
+                "collective": (("gather(dst=0)" if dst is not None else "all_gather") + " f32[n,16] pose records") if world > 1 else None,
                 "class_sliced_out_layer": not args.exact_reference_order, "rois_class_sorted_within_rank": True,
                 "parameters": "default-init" if args.random_init else "seeded O(1)", "hip_network_layers": not args.no_hip_layers,
                 "mlp_gemm": args.mlp_gemm, "gemm_products": args.gemm_products, "fused_mlp": (not args.no_fused_mlp) and args.fused_mlp_max_c, "f16x2_rows": not args.no_f16x2_rows,
@@ -299,7 +318,7 @@ def worker(args):
                 "timed_entry_point": ("engine.RoiStreamScheduler.launch_next (GPU crop + inference_step_async) + engine.gather_records"
                                       if wname == "stream" else "engine.inference_step_async / StepHandle.result + engine.gather_records"),
                 "stub_step": bool(args.stub_step)},
-            "gather_ms": gather_ms,
+            "gather_ms": gather_ms, "collective": collective,
         }
         line.update(extras)
         if "stream" in line:
@@ -414,10 +433,20 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                          torch.rand((S.IM_H, S.IM_W), device=dev, generator=g) + 0.3,
                          dict(bbox=np.concatenate([x1y1, x1y1 + det["roi_wh"]], 1).astype(np.float32), roi_cls=det["roi_cls"],
                               score=det["score"], cam=S.YCBV_K.astype(np.float32), extents=ext)))
+        # --host-fed: the very same images, but every push starts from PINNED HOST memory (the reference's loader hands over host
+        # arrays); the scheduler copies them on its copy stream, one step ahead of the device
+        host_pool = [(im.cpu().pin_memory(), dp.cpu().pin_memory(), dt_) for im, dp, dt_ in pool] if args.host_fed else None
         counter = itertools.count()
-        feeder = ((next(counter), im, dp, dt_) for im, dp, dt_ in itertools.cycle(pool))
-        sched = E.RoiStreamScheduler(m0["cfg"], m0["model"], m0["post"], rois_per_step=b, roi_id_base=lo)
-        stream = dict(sched=sched, feeder=feeder, counter=counter, rois_per_image=float(np.mean([len(p[2]["roi_cls"]) for p in pool])))
+
+        def make_feeder(src):
+            return ((next(counter), im, dp, dt_) for im, dp, dt_ in itertools.cycle(src))
+
+        def make_sched():
+            return E.RoiStreamScheduler(m0["cfg"], m0["model"], m0["post"], rois_per_step=b, roi_id_base=lo, device=dev,
+                                        time_h2d=args.host_fed)
+        stream = dict(sched=make_sched(), feeder=make_feeder(host_pool if args.host_fed else pool), counter=counter,
+                      rois_per_image=float(np.mean([len(p[2]["roi_cls"]) for p in pool])), pool=pool, make_sched=make_sched,
+                      make_feeder=make_feeder, h2d_ms_warmup=0.0, h2d_bytes_warmup=0)
 
     upnp = None
     if wname == "lmo_upnp":   # PVNet-style pose of config 1: 8 FPS keypoints + centre, noisy projections, cov^-1/2 weights
@@ -504,6 +533,34 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         finally:
             hip_layers.set_gemm_products(args.gemm_products)
 
+    def after_warmup():
+        if stream is not None and args.host_fed:       # copies of the warm-up steps are not the timed region's
+            stream["h2d_ms_warmup"] = stream["sched"].h2d_ms(reset=True)
+            stream["h2d_bytes_warmup"] = stream["sched"].h2d_bytes
+
+    @torch.no_grad()
+    def parity_in_run():
+        """Parity INSIDE the driver run (round-4 verdict item 2): the records of the two timed batches under the headline
+        arithmetic (three products, fused MLPs, rows hand-over) against the exact six-product form on the very same tensors."""
+        m = models[0]
+        dR, dt_, n = 0.0, 0.0, 0
+        reruns0 = E.range_reruns()
+        recs = []
+        for k in range(2):
+            bt = prepared(m, k)
+            r3 = inference_step(m["model"], m["post"], bt).clone()
+            with hip_layers.forced_gemm_products(6):
+                r6 = inference_step(m["model"], m["post"], bt).clone()
+            assert torch.equal(r3[:, 12:], r6[:, 12:])                      # score | obj | roi_id | valid: not arithmetic
+            ok = (r3[:, 15] > 0.5)
+            dR = max(dR, float((r3[ok, :9] - r6[ok, :9]).abs().max()))
+            dt_ = max(dt_, float((r3[ok, 9:12] - r6[ok, 9:12]).abs().max()))
+            n += int(ok.sum())
+            recs.append(r3)
+        return recs, {"compared": "records of the timed batches: headline arithmetic (--gemm-products %d) vs the exact six-product bf16x3 form, same tensors" % args.gemm_products,
+                      "max_abs_dR": dR, "max_abs_dt_m": dt_, "n_rois": n, "range_reruns": E.range_reruns() - reruns0,
+                      "tolerance": "north_star: R / t within 1e-4"}
+
     def measure_after(do_cpu):
         out = {"range_check": {"steps_repeated_with_six_products": E.range_reruns(),
                                "layers_kept_on_six_products": len(hip_layers.x3_demoted()),
@@ -535,6 +592,45 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         o = fwd()
         with torch.no_grad():
             out["stages_ms"] = {"forward": timed(fwd), "post_processing": timed(lambda: m["post"].process(bt, o, bt["roi_id"]))}
+        if args.mlp_gemm == "split" and not args.no_hip_layers and upnp is None:
+            try:
+                _, out["parity_in_run"] = parity_in_run()
+            except Exception as e:   # the headline line must not depend on the extra measurement
+                out["parity_in_run"] = {"error": repr(e)}
+        if stream is not None and args.host_fed:
+            # (a) the copies of the timed steps, device-side; (b) the same steps once more from the HBM-resident pool, same box, same process
+            sch = stream["sched"]
+            h2d_ms = sch.h2d_ms(reset=True)
+            h2d_bytes = sch.h2d_bytes - stream["h2d_bytes_warmup"]
+            sch.flush()
+            sch2 = stream["make_sched"]()
+            sch2._time_h2d = False
+            feeder2 = stream["make_feeder"](stream["pool"])
+            prev = None
+
+            def run2(n):
+                nonlocal prev
+                for _ in range(n):
+                    cur = sch2.launch_next(feeder2)
+                    if prev is not None:
+                        prev()
+                    prev = cur
+            run2(max(args.warmup, 3))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run2(args.steps)
+            prev()
+            prev = None
+            torch.cuda.synchronize()
+            ms_res = (time.perf_counter() - t0) / args.steps * 1e3
+            sch2.flush()
+            out["host_fed"] = {"h2d_ms_per_step": h2d_ms / args.steps, "h2d_bytes_per_step": h2d_bytes / args.steps,
+                               "h2d_gbs": (h2d_bytes / 1e9) / (h2d_ms * 1e-3) if h2d_ms > 0 else None,
+                               "resident_pool_ms_per_step": ms_res, "resident_pool_rois_per_s": b * 1000.0 / ms_res,
+                               "note": "h2d_* = device-side duration of the hipMemcpyAsync copies of the TIMED steps (copy-stream events; "
+                                       "full 480x640 u8 image + f32 depth per pushed image, pinned host memory); resident_pool_* = the same "
+                                       "number of steps run again right after from the HBM-resident pool; the line's ms_per_step vs "
+                                       "resident_pool_ms_per_step is what the host feed costs end to end"}
 
         if not args.no_roofline_pass and not args.graph:
             # per-launch HIP events on the launch stream over the same steps, outside the timed region
@@ -637,19 +733,38 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                          n_verts=np.array([len(v) for v in m["verts"]]), n_faces=np.array([len(f) for f in m["faces"]]),
                          coord2d=bt["roi_coord_2d"].cpu().numpy(), extent=det["roi_extent"],
                          **{k_: o[k_].detach().cpu().numpy() for k_ in ("mask", "coor_x", "coor_y", "coor_z", "rot", "trans")})
-                r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--inputs", path, "--seconds", str(args.cpu_seconds)],
+                with torch.no_grad():
+                    rec_gpu = m["post"].process(bt, o, bt["roi_id"]).cpu().numpy()      # the GPU records of the very tensors the child gets
+                r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--inputs", path, "--seconds", str(args.cpu_seconds),
+                                    "--parity-sample", "16", "--forward-cfg", cfg_names[0], "--forward-seconds", str(max(3.0, args.cpu_seconds / 4))],
                                    cwd=ROOT, capture_output=True, text=True)
             if r.returncode == 0:
                 out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+                ps = out["cpu_baseline"].pop("refine_parity_sample", None)
+                if ps is not None and isinstance(out.get("parity_in_run"), dict):
+                    idx = np.asarray(ps["idx"], int)
+                    d = np.abs(rec_gpu[idx, 9:12].astype(np.float64) - np.asarray(ps["t"], np.float64))
+                    out["parity_in_run"]["refine_vs_oracle"] = {
+                        "n_rois": int(len(idx)), "max_abs_dt_m": float(d.max()), "roi_index": idx.tolist(), "oracle": ps["oracle"],
+                        "tolerance_m": 1e-5, "compared": "t of gdrnpp_refine_to_records vs the CPU oracle on the same maps / depth / pose, "
+                                                         "computed in this run's cpu_baseline child"}
                 out["cpu_baseline"]["note"] = (
                     "value = the depth-refine stage ONLY (row a8, oracle port, 1 thread): the stage the reference runs on the host. "
-                    "The network forward - 99.8 % of the GPU step - runs on the GPU in the reference too and has no CPU leg; "
-                    "value is therefore not comparable with the line's ROIs/s, see stages for the other CPU-side ops")
+                    "The network forward - 99.8 % of the GPU step - runs on the GPU in the reference too; stages.forward_cpu_torch is the "
+                    "same network with PyTorch's CPU operators on all host cores (the like-for-like CPU figure of that stage); "
+                    "value is not comparable with the line's ROIs/s, see stages for the other CPU-side ops")
             else:
                 out["cpu_baseline"] = dict(value=None, error=r.stderr[-400:])
+        elif do_cpu and upnp is not None and not args.no_cpu_baseline:
+            # BASELINE configs[0] ("CPU uncertainty-PnP only"): ResNet-34 forward with PyTorch's CPU operators + uncertainty-PnP (pn = 9)
+            # on the host cores, SURVEY.md §8(d)(iii)
+            torch.cuda.synchronize()
+            r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--inputs", os.devnull, "--upnp-only", "--forward-cfg", cfg_names[0],
+                                "--seconds", str(args.cpu_seconds)], cwd=ROOT, capture_output=True, text=True)
+            out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else dict(value=None, error=r.stderr[-400:])
         return out
 
-    return dict(step=step, launch=launch, measure_after=measure_after, other_mode_line=other_mode_line)
+    return dict(step=step, launch=launch, measure_after=measure_after, other_mode_line=other_mode_line, after_warmup=after_warmup)
 
 
 if __name__ == "__main__":

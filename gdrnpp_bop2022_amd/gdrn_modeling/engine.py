@@ -385,11 +385,14 @@ def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor 
     return inference_step_async(model, post, batch, roi_ids).result()
 
 
-def gather_records(rec: torch.Tensor, n_local_max: int, group=None) -> torch.Tensor:
+def gather_records(rec: torch.Tensor, n_local_max: int, group=None, dst: int | None = None):
     """The one collective of the inference path (gdrn_evaluator.py:575-585 / my_comm.py:70-171): instead of
     pickling Python dicts into byte tensors (size all-gather + padded byte all-gather), every rank contributes a
     fixed-shape f32[n_local_max,16] block (``valid`` = 0 on padding rows) to ONE all_gather — 64 B per ROI,
-    latency-bound on xGMI.  Returns f32[world*n_local_max,16] on every rank."""
+    latency-bound on xGMI.  Returns f32[world*n_local_max,16] on every rank.
+
+    ``dst``: gather to that rank only (``my_comm.gather``, my_comm.py:119-171; the reference's ``evaluate`` lets only the main
+    process go on to write the results, gdrn_evaluator.py:581-582): rank ``dst`` gets the block, every other rank ``None``."""
     if rec.shape[0] < n_local_max:
         pad = torch.zeros((n_local_max - rec.shape[0], 16), dtype=rec.dtype, device=rec.device)
         rec = torch.cat([rec, pad], 0)
@@ -397,6 +400,11 @@ def gather_records(rec: torch.Tensor, n_local_max: int, group=None) -> torch.Ten
         return rec
     world = dist.get_world_size(group)
     rec = rec.contiguous()
+    if dst is not None:
+        mine = dist.get_rank(group) == dst
+        parts = [torch.empty_like(rec) for _ in range(world)] if mine else None
+        dist.gather(rec, parts, dst=dst, group=group)      # RCCL: world - 1 point-to-point receives on rank dst
+        return torch.cat(parts, 0) if mine else None
     if dist.get_backend(group) == "gloo":  # CPU tests: list form
         parts = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(parts, rec, group=group)
@@ -847,10 +855,25 @@ class RoiStreamScheduler:
         flush()  launches the tail (a short step) and returns everything still open.
 
     ``detections`` = the dict of ``batch_data_test_gpu`` for ONE image (bbox [n,4] xyxy, roi_cls [n], score [n], cam [3,3],
-    extents [C,3]).  All images of a stream share H x W (a BOP dataset's resolution)."""
+    extents [C,3]).  All images of a stream share H x W (a BOP dataset's resolution).
 
-    def __init__(self, cfg, model, post: GdrnHipPost, rois_per_step: int = 128, max_in_flight: int = 2, roi_id_base: int = 0):
+    Host-fed streams (the reference's loader hands over HOST arrays, data_loader.py:754-797, and ``batch_data_test`` moves the
+    ROI crops to the device, engine_utils.py:213-241): ``image`` / ``depth`` may be CPU tensors — pinned, or the copy is not
+    asynchronous.  They are copied to the device on the scheduler's own copy stream the moment they are admitted (the FULL
+    image once, 0.9 + 1.2 MB, not a 1 MB crop per ROI), an event per image orders the step's crop kernel behind its copies, and
+    since admission runs one step ahead of the device the copies overlap the previous step's kernels.  ``time_h2d=True``
+    brackets every image's copies with timing events (``h2d_ms()``)."""
+
+    def __init__(self, cfg, model, post: GdrnHipPost, rois_per_step: int = 128, max_in_flight: int = 2, roi_id_base: int = 0,
+                 device=None, time_h2d: bool = False):
         import collections
+
+        self.device = device
+        self._copy_stream = None
+        self._h2d_ready = {}                    # key -> event: the image's pixels are on the device
+        self._time_h2d = bool(time_h2d)
+        self._h2d_timing = []                   # (start, end) events per image, copy stream
+        self.h2d_bytes = 0
 
         self.cfg, self.model, self.post = cfg, model, post
         self.packer = RoiPacker(rois_per_step, roi_id_base)
@@ -875,6 +898,10 @@ class RoiStreamScheduler:
             return np.broadcast_to(c, (len(loc), 3, 3)) if c.ndim == 2 else c[loc]
 
         keys = [k for k, _, _ in pack]
+        for k in keys:                          # host-fed images: the crop kernel waits for their copies (device-side wait)
+            ev = self._h2d_ready.get(k)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
         images = torch.stack([self._images[k][0] for k in keys])
         depths = torch.stack([self._images[k][1] for k in keys]) if self._with_depth else None
         det = dict(
@@ -891,6 +918,7 @@ class RoiStreamScheduler:
         for k in keys:                          # pixels are only read by the crop kernel just enqueued
             if self.packer.last_roi_dealt(k):
                 del self._images[k]
+                self._h2d_ready.pop(k, None)
 
     def _resolve_oldest(self):
         handle, _batch = self._in_flight.popleft()
@@ -915,8 +943,41 @@ class RoiStreamScheduler:
         if n:
             if self._with_depth is None:
                 self._with_depth = depth is not None
+            if isinstance(image, torch.Tensor) and image.device.type == "cpu":
+                image, depth = self._to_device(key, image, depth)
             self._images[key] = (image, depth, detections)
         self._arrival[key] = time.perf_counter()
+
+    def _to_device(self, key, image, depth):
+        """Host image (+ depth) -> device on the copy stream; the event is what ``_launch`` waits for."""
+        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        compute = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(self._copy_stream):
+            if self._time_h2d:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record()
+            image_d = image.to(dev, non_blocking=True)
+            depth_d = depth.to(dev, non_blocking=True) if depth is not None else None
+            ev = torch.cuda.Event(enable_timing=self._time_h2d)
+            ev.record()
+        for t in (image_d, depth_d):            # allocated on the copy stream, read by kernels of the compute stream
+            if t is not None:
+                t.record_stream(compute)
+        self._h2d_ready[key] = ev
+        self.h2d_bytes += image.numel() * image.element_size() + (depth.numel() * depth.element_size() if depth is not None else 0)
+        if self._time_h2d:
+            self._h2d_timing.append((t0, ev))
+        return image_d, depth_d
+
+    def h2d_ms(self, reset: bool = True) -> float:
+        """Summed device-side duration of the host-to-device copies admitted so far (``time_h2d=True``), in ms."""
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._h2d_timing)
+        if reset:
+            self._h2d_timing = []
+        return ms
 
     # -- the stream --------------------------------------------------------------------------------
     def push(self, key, image: torch.Tensor, depth, detections: dict):

@@ -12,6 +12,11 @@ very batch the GPU ran:
   fps / nnd / flow   the reference's OWN compiled sources (oracle/_ref/*.so: farthest_point_sampling.cpp, nnd_cpu.cpp,
                 flow_cpu.cpp), 1 thread — kind "reference"; skipped with a note when oracle/_ref was not built
   warpAffine / solvePnP[Ransac]   OpenCV is not installed: "cv2 unavailable" is recorded instead of a substitute number
+  forward_cpu_torch   (``--forward-cfg NAME``) the network forward of the workload's config with PyTorch's CPU operators, all
+                host cores, on a bounded number of ROIs — the reference runs this stage on the GPU too; this is the like-for-like
+                CPU figure of the stage that is 99.8 % of the step (ResNet-34 / 32 ROIs for configs[0])
+  refine_parity_sample   (``--parity-sample N``) the refined translation of N evenly spaced ROIs of the batch from
+                ``depth_refine_roi``: bench.py compares the GPU records of the same ROIs with it inside the driver run
 
 Prints one JSON object on stdout.
 """
@@ -96,7 +101,13 @@ def main():
     ap.add_argument("--inputs", required=True, help="npz written by bench.py: maps, poses, depth crops, meshes of the batch")
     ap.add_argument("--seconds", type=float, default=20.0, help="total CPU wall budget over all stages")
     ap.add_argument("--cores", type=int, default=0, help="workers of the all-core legs (0 = os.cpu_count())")
+    ap.add_argument("--parity-sample", type=int, default=0, help="also return depth_refine_roi's t for this many ROIs of the batch")
+    ap.add_argument("--forward-cfg", default="", help="named config whose network forward is timed with PyTorch CPU operators")
+    ap.add_argument("--forward-seconds", type=float, default=6.0)
+    ap.add_argument("--upnp-only", action="store_true", help="configs[0] leg: uncertainty-PnP pn = 9 (+ the forward), no refine inputs")
     args = ap.parse_args()
+    if args.upnp_only:
+        return main_upnp(args)
     cores = args.cores or os.cpu_count() or 1
     z = np.load(args.inputs, allow_pickle=False)
     n = int(z["mask"].shape[0])
@@ -183,9 +194,79 @@ def main():
     for name in ("cv2.warpAffine (ROI crops, data_loader.py:773-797)", "cv2.solvePnPRansac / solvePnP (lib/pysixd/misc.py:153-208)"):
         stages[name] = dict(value=None, note="cv2 unavailable")
 
+    if args.forward_cfg:
+        stages["forward_cpu_torch"] = forward_cpu_torch(args.forward_cfg, args.forward_seconds)
     top = dict(stages["refine_1thread"])
     top.update(stages=stages, host_cores_available=os.cpu_count(),
                allcores=dict(value=stages["refine_allcores"]["value"], cores=cores))
+    if args.parity_sample > 0:
+        idx = np.unique(np.linspace(0, n - 1, min(args.parity_sample, n)).astype(int))
+        g = _G
+        ts = [np.asarray(P.depth_refine_roi(g["xyz"][i], g["mask"][i, 0], g["roi_depth"][i, 0], g["K_crop"][i], g["rot"][i], g["trans"][i],
+                                            g["verts"][int(g["roi_cls"][i])], g["faces"][int(g["roi_cls"][i])], iters=g["iters"],
+                                            threshold=g["thr"]), np.float64).tolist() for i in idx]
+        top["refine_parity_sample"] = dict(idx=idx.tolist(), t=ts, oracle="oracle.postproc.depth_refine_roi (gdrn_evaluator.py:485-561 restated, "
+                                           "pinned by the reference's process_depth_refine run from source)")
+    print(json.dumps(top))
+
+
+def forward_cpu_torch(cfg_name, seconds, rois=4):
+    """The network forward with PyTorch's CPU operators (this repo's module graph with its HIP layers switched off — the graph
+    tests/test_net_golden.py pins against the reference's own modules), all host cores, ``rois`` ROIs per call."""
+    import torch
+
+    from gdrnpp_bop2022_amd import synthetic as S
+    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+
+    hip_layers.set_enabled(False)
+    torch.set_grad_enabled(False)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = get_cfg(cfg_name, ["MODEL.DEVICE=cpu"])
+    if "resnet" in cfg_name:
+        from gdrnpp_bop2022_amd.gdrn_modeling import GDRN as G
+    else:
+        from gdrnpp_bop2022_amd.gdrn_modeling import GDRN_double_mask as G
+    model, _ = G.build_model_optimizer(cfg, is_test=True)
+    model = model.to("cpu").eval()
+    C = cfg.MODEL.POSE_NET.NUM_CLASSES
+    rng = np.random.default_rng(0)
+    ext = rng.uniform(0.05, 0.25, (C, 3)).astype(np.float32)
+    det = S.make_detections(rois, C, ext, rng)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    x = torch.rand(rois, 3, 256, 256)
+    cls, c2d, extent = T(det["roi_cls"]), T(S.coord2d_roi(det["roi_center"], det["scale"])), T(det["roi_extent"])
+    # forward_maps = backbone + geometry head + Patch-PnP (everything but the closing 6-D -> R / centroid -> t conversion, which
+    # the product does in a HIP kernel and which is a few hundred flops per ROI)
+    model.forward_maps(x, cls, c2d, None, extent)            # oneDNN primitive creation outside the clock
+    done, dt = _loop(lambda _: model.forward_maps(x, cls, c2d, None, extent), 1, seconds, 1)
+    return dict(value=done * rois / dt, unit="ROIs/s", cores=cores, kind="port",
+                sample=f"{done} forwards of {rois} ROIs ({cfg_name}, fp32, PyTorch CPU operators, {cores} threads), {dt:.2f} s",
+                note="the reference runs this stage on the GPU as well; CPU figure for scale only")
+
+
+def main_upnp(args):
+    """BASELINE configs[0] (LM-O ape, 32 ROIs, ResNet-34 forward + uncertainty-PnP, pn = 9): both stages on the host cores."""
+    cores = args.cores or os.cpu_count() or 1
+    rng = np.random.default_rng(20220925 + 1)
+    stages = {}
+    _G["upnp"] = make_upnp_problems(64, 9, rng)
+    done, dt = _loop(_upnp_one, 64, args.seconds / 3, 8)
+    stages["upnp_pn9_1thread"] = dict(value=done / dt, unit="ROIs/s", cores=1, kind="port",
+                                      sample=f"{done} LM solves (pn = 9) over 64 distinct problems, {dt:.2f} s")
+    done, dt = _pool_loop(_upnp_one, 64, args.seconds / 3, cores)
+    stages["upnp_pn9_allcores"] = dict(value=done / dt, unit="ROIs/s", cores=cores, kind="port",
+                                       sample=f"{done} LM solves, fork pool of {cores} workers, {dt:.2f} s")
+    if args.forward_cfg:
+        stages["forward_cpu_torch"] = forward_cpu_torch(args.forward_cfg, args.seconds / 3, rois=32)
+        f, u = stages["forward_cpu_torch"]["value"], stages["upnp_pn9_allcores"]["value"]
+        top = dict(value=1.0 / (1.0 / f + 1.0 / u), unit="ROIs/s", cores=cores, kind="port",
+                   sample=f"configs[0] end to end on the host: {stages['forward_cpu_torch']['sample']} + {stages['upnp_pn9_allcores']['sample']}",
+                   note="value = 1 / (1 / forward + 1 / uncertainty-PnP), both stages on all host cores one after the other")
+    else:
+        top = dict(stages["upnp_pn9_1thread"])
+    top.update(stages=stages, host_cores_available=os.cpu_count())
     print(json.dumps(top))
 
 

@@ -66,6 +66,40 @@ def test_gpus_flag_spawns_ranks_and_gathers_every_roi_once():
     assert abs(d["value"] - 10 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
 
 
+def test_eight_ranks_1024_tless_roi_ids_and_the_collective_block():
+    """BASELINE configs[3] launch path without hardware: `bench.py --gpus 8` (auto workload = tless, 128 ROIs per rank = 1024 per
+    iteration) through gloo with the GPU step stubbed — 8 spawned ranks, contiguous shards, ONE all-gather per step, the
+    1024-id permutation check on every rank, and the `collective` block filled from the process group itself
+    (dist.get_backend / dist.get_world_size), which is what a hardware SCALE run will prove RCCL's world size with."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--stub-step",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["config"]["workload_key"] == "tless" and d["config"]["baseline_config_index"] == 3
+    assert d["config"]["global_batch"] == 1024 and d["config"]["rois_per_gpu"] == 128 and d["scaling"] == "weak"
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["world_size_seen"] == 8 and c["op"] == "all_gather_into_tensor"
+    assert c["bytes_per_rank"] == 128 * 64 and c["bytes_received_per_rank"] == 7 * 128 * 64 and c["calls_per_step"] == 1
+    assert abs(d["value"] - 1024 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
+def test_gather_to_rank0_mirrors_the_main_process_only_write():
+    """--gather-to-rank0: dist.gather instead of the all-gather (the reference's evaluate() returns on every rank but the main
+    one, gdrn_evaluator.py:581-582): rank 0 holds every ROI id once, the other ranks hold nothing."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-step", "--gather-to-rank0",
+                        "--steps", "2", "--warmup", "1", "--batch", "7"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["collective"]["op"] == "gather(dst=0)" and d["collective"]["world_size_seen"] == 2 and d["config"]["global_batch"] == 14
+    assert d["config"]["collective"].startswith("gather(dst=0)")
+
+
 def test_world_size_must_match_gpus_flag():
     import subprocess
     import sys
