@@ -717,6 +717,14 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                                        bytes_per_launch=bytes_launch, bytes_per_roi=per_roi, rois_per_launch=b)
             out["roofline"] = roofline or refine_roofline
             out["roofline_other_kernels"] = ([refine_roofline] if (refine_roofline and roofline) else []) + hbm_rooflines
+            if upnp is not None:      # configs[0]: the uncertainty-PnP launch of the step against the HBM roofline (it is latency / fp64-VALU bound)
+                u = upnp[0]
+                ms_u = timed(lambda: hip_lib.uncertainty_pnp_batched(u["p2"], u["p3"], u["w"], u["K"], u["init"]), n=20)
+                by = b * (9 * (16 + 24 + 24) + 72 + 48 + 48)
+                out["roofline_other_kernels"].append(dict(
+                    kernel="upnp_kernel (gdrnpp_uncertainty_pnp_batched, pn = 9)", bound="latency / fp64 valu", achieved=by / (ms_u * 1e-3) / 1e9,
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=by / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, launch_ms=ms_u, bytes_per_launch=by,
+                    problems_per_launch=b, note="one wave per problem, ~10 dependent fp64 LM iterations; host-timed launch incl. the wrapper"))
 
         if do_cpu and refine and not args.no_cpu_baseline:
             torch.cuda.synchronize()

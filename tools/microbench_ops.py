@@ -172,5 +172,67 @@ rois = T(np.concatenate([rng.integers(0, 16, (b, 1)), det["roi_center"] - det["s
 t = gpu_time(lambda: hip_lib.roi_align(x, rois, 256))
 res["roi_align_b128_3x256x256"] = dict(gpu_s=t, bytes=b * 3 * 256 * 256 * 4, gpu_GBs=b * 3 * 256 * 256 * 4 / t / 1e9, gpu_rois_per_s=b / t)
 
-res["_peaks"] = dict(hbm_GBs=8000, note="CPU numbers: oracle port, 1 thread, bounded sample, host of the GPU box; GPU numbers: 30 calls replayed from one HIP graph where the wrapper can be captured")
+# ---- the reference's OWN compiled CPU sources beside the GPU numbers where they exist (oracle/_ref, kind "reference")
+import ctypes
+from oracle import ref_lib
+f32p, i32p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
+_fps = ref_lib("fps")
+if _fps is not None:
+    p0 = np.ascontiguousarray(pts[0]); idx = np.zeros(64, np.int32)
+    tc = cpu_time(lambda: _fps.farthest_point_sampling_init_center(p0.ctypes.data_as(f32p), idx.ctypes.data_as(i32p), len(p0), 64), 20)
+    res["fps_21x2562_sn64"].update(cpu_reference_s_per_cloud=tc, cpu_reference="core/csrc/fps/src/farthest_point_sampling.cpp compiled (oracle/_ref), 1 thread")
+_nnd = ref_lib("nnd")
+if _nnd is not None:
+    bb, nn, mm = 2, 1000, 1500
+    x1 = rng.uniform(0, 1, (bb, nn, 3)).astype(np.float32); x2 = rng.uniform(0, 1, (bb, mm, 3)).astype(np.float32)
+    d1, d2 = np.zeros((bb, nn), np.float32), np.zeros((bb, mm), np.float32)
+    i1, i2 = np.zeros((bb, nn), np.int32), np.zeros((bb, mm), np.int32)
+    tc = cpu_time(lambda: _nnd.ref_nnd_forward(x1.ctypes.data_as(f32p), x2.ctypes.data_as(f32p), d1.ctypes.data_as(f32p), d2.ctypes.data_as(f32p),
+                                               i1.ctypes.data_as(i32p), i2.ctypes.data_as(i32p), bb, nn, mm), 3)
+    for k_ in ("nnd_b10_n1000_m1500", "nnd_b32_n4096_m4096"):
+        res[k_].update(cpu_reference_Gpairs_s=2 * bb * nn * mm / tc / 1e9, cpu_reference="core/csrc/torch_nndistance/src/nnd_cpu.cpp compiled (oracle/_ref), 1 thread")
+
+# ---- what bounds each op, and how far it is from that bound (MI355X_MICROARCH.md: HBM 8 TB/s, fp32 vector 157.3 TFLOP/s)
+HBM, VALU32 = 8000.0, 157.3
+
+
+def roof(bound, achieved, peak, unit, why):
+    return dict(bound=bound, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak, why=why)
+
+
+def hbm(key, why, t_key="gpu_s", b_key="bytes"):
+    e = res[key]
+    e["roofline"] = roof("hbm", e[b_key] / e[t_key] / 1e9, HBM, "GB/s", why)
+
+
+e = res["fps_21x2562_sn64"]
+e["roofline"] = roof("latency", e["bytes"] / e["gpu_s"] / 1e9, HBM, "GB/s",
+                     "64 DEPENDENT rounds per cloud (distance update + argmax over 2562 points resident in LDS, wave DPP argmax + one barrier); one "
+                     "workgroup per cloud = 21 of 256 CUs; %.2f us per round; the cloud is read from HBM once (0.65 MB)" % (e["gpu_s"] / 64 * 1e6))
+e = res["fps_1x100000_sn256"]
+e["roofline"] = roof("latency", 100000 * 12 * 256 / e["gpu_s"] / 1e9, HBM, "GB/s",
+                     "cloud beyond the LDS form (> 12 288 points): every round re-reads it (L2-resident, 1.2 MB) on ONE workgroup; %.1f us per round" % (e["gpu_s"] / 256 * 1e6))
+for k_ in ("nnd_b10_n1000_m1500", "nnd_b32_n4096_m4096"):
+    e = res[k_]
+    e["roofline"] = roof("valu", e["pairs"] * 8 / e["gpu_s"] / 1e12, VALU32, "TFLOP/s",
+                         "all-pairs: 8 fp32 operations per pair (3 sub, 3 fma, compare + select with the index), operands from LDS tiles; HBM traffic is "
+                         "negligible (%.1f GB/s)" % (e["bytes"] / e["gpu_s"] / 1e9))
+e = res["ransac_voting_tn4096_vn9_hn128"]
+e["roofline"] = roof("valu", e["pairs"] * 10 / e["vote_count_s"] / 1e12, VALU32, "TFLOP/s",
+                     "vote_count: 10 fp32 operations per (hypothesis, point) pair incl. the normalisation + compare, ballot + popcount per wave; "
+                     "the flag form writes 1 B per pair instead (%.0f GB/s)" % (e["bytes_flags"] / e["voting_flags_s"] / 1e9))
+for k_, why in (("upnp_b128_pn9", "one wave per problem, fp64 Levenberg-Marquardt: ~10 dependent iterations of (residual + Jacobian over 9 points, 6x6 Cholesky), "
+                                   "launch + latency bound (128 waves on 256 CUs)"),
+                ("upnp_b128_pn4096", "one wave per problem, fp64 LM: per iteration 4096 residual / Jacobian rows per problem (64 per lane) + wave reductions of "
+                                     "the 27 normal-equation sums; fp64 vector work, inputs L2-resident after the first iteration")):
+    e = res[k_]
+    e["roofline"] = roof("latency / fp64 valu", e["bytes"] / e["gpu_s"] / 1e9, HBM, "GB/s", why)
+hbm("decode_correspondences_b128", "reads 6 map planes + writes the compacted points once; 6.9 us launch: too short to reach the streaming rate")
+e = res["render_depth_b128_64x64_5120F"]
+e["roofline"] = roof("latency (LDS atomics)", e["bytes"] / e["gpu_s"] / 1e9, HBM, "GB/s",
+                     "one workgroup per ROI: vertex transform into LDS, 5120 triangles rasterised with fp64 edge functions into a ds_min z-buffer; 128 of 256 CUs")
+hbm("crop_resize_roi_b128", "writes 1.08 MB per ROI (3x256x256 + 256x256 + 2x64x64 fp32), gathers the source pixels through L2")
+hbm("roi_align_b128_3x256x256", "writes 0.79 MB per ROI; 4 bilinear samples x sampling_ratio^2 gathers per output from the NCHW feature map")
+
+res["_peaks"] = dict(hbm_GBs=8000, fp32_vector_TFLOPs=157.3, note="CPU numbers: oracle port, 1 thread, bounded sample, host of the GPU box; GPU numbers: 30 calls replayed from one HIP graph where the wrapper can be captured")
 print(json.dumps(res, indent=1))
