@@ -93,6 +93,11 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="host wall time spent on the CPU baseline stages")
     p.add_argument("--no-roofline-pass", action="store_true", help="skip the per-launch event pass after the timed region")
+    p.add_argument("--no-pmc", action="store_true",
+                   help="do not measure roofline.traffic live (two rocprofv3 --pmc child runs of this command, ~1-2 min); the committed "
+                        "profiles/pmc_traffic.json figure is reported instead")
+    p.add_argument("--pmc-child", action="store_true", help="(internal) the run rocprofv3 wraps: steps only, nothing after the timed region")
+    p.add_argument("--pmc-timeout", type=float, default=240.0, help="seconds allowed per rocprofv3 counter pass")
     p.add_argument("--exact-reference-order", action="store_true",
                    help="run the reference's full 1470-channel output layer + gather instead of the class-sliced one")
     p.add_argument("--no-hip-layers", action="store_true", help="A/B: run the memory-bound network layers with PyTorch ops")
@@ -130,6 +135,64 @@ def algorithmic_bytes_refine(b, iters, n_verts, n_faces):
     (64^2 x 4 x 4 B) + K,R,t (84 B) + iters x (12 V + 12 F) mesh bytes + 12 B written."""
     per_roi = 65536 + 65536 + 84 + iters * (12 * n_verts + 12 * n_faces) + 12
     return b * per_roi, per_roi
+
+
+def pmc_traffic_live(args, wname, b):
+    """HBM-side bytes per launch of the split-GEMM family and of the refine kernel, measured NOW: two child runs of this very
+    command under ``rocprofv3 --pmc FETCH_SIZE --kernel-trace`` / ``--pmc WRITE_SIZE --kernel-trace`` (separate passes: the two
+    counters do not fit the TCC's four slots together, MI355X_MICROARCH.md "rocprofv3 PMC slots"), no other trace domain.  Units
+    KiB; gfx950 correction of that guide's HBM section: FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads -> x2;
+    WRITE_SIZE x1 (calibrated on fills, profiles/pmc_traffic.json).  Returns (dict | None, note)."""
+    import csv
+    import glob
+    import shutil
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--no-pmc", "--steps", "2", "--warmup", "1", "--workload", wname,
+             "--batch", str(b), "--gemm-products", str(args.gemm_products), "--mlp-gemm", args.mlp_gemm, "--subdiv", str(args.subdiv)]
+    for flag, on in (("--no-fused-mlp", args.no_fused_mlp), ("--no-f16x2-rows", args.no_f16x2_rows), ("--random-init", args.random_init),
+                     ("--with-crop", args.with_crop), ("--host-fed", args.host_fed), ("--no-hip-layers", args.no_hip_layers)):
+        if on:
+            child.append(flag)
+    for o in args.opt:
+        child += ["--opt", o]
+    raw = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="gdrnpp_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp",
+                               env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=args.pmc_timeout)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}: {r.stderr[-300:]}"
+            per = {"gemm": [], "refine": []}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    kn = row["Kernel_Name"]
+                    if ("gemm_split" in kn or "mlp_fused_x3" in kn) and "reduce" not in kn and "pack" not in kn:
+                        per["gemm"].append(float(row["Counter_Value"]))
+                    elif "depth_refine_kernel" in kn:
+                        per["refine"].append(float(row["Counter_Value"]))
+            if not per["gemm"]:
+                return None, f"rocprofv3 --pmc {counter}: no split-GEMM rows in the counter file"
+            raw[counter] = per
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} did not finish in {args.pmc_timeout:.0f} s"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    mean = lambda v: sum(v) / len(v) if v else None  # noqa: E731
+    out = {"seconds": time.perf_counter() - t0}
+    for k in ("gemm", "refine"):
+        f_, w_ = mean(raw["FETCH_SIZE"][k]), mean(raw["WRITE_SIZE"][k])
+        if f_ is not None and w_ is not None:
+            out[k] = {"traffic_bytes_per_launch": (2.0 * f_ + w_) * 1024.0, "fetch_kib_raw_mean": f_, "write_kib_raw_mean": w_,
+                      "launches_fetch_pass": len(raw["FETCH_SIZE"][k]), "launches_write_pass": len(raw["WRITE_SIZE"][k])}
+    return out, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around child runs of "
+                 "this command (--steps 2 --warmup 1, same workload and switches); KiB units, FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md), WRITE_SIZE x1")
 
 
 def resolve_workload(args):
@@ -274,8 +337,34 @@ def worker(args):
                       "calls_per_step": 1, "ms_alone": gather_ms}
 
     extras = {}
+    if args.pmc_child:          # the run rocprofv3 wraps: the steps above are all it is for
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        print(json.dumps({"pmc_child": True, "ms_per_step": dt / args.steps * 1e3}), flush=True)
+        return
     if state is not None:
         extras = state["measure_after"](rank == 0 and world == 1)
+    if state is not None and rank == 0 and world == 1 and not args.no_pmc and not args.graph and extras.get("roofline"):
+        live, note = pmc_traffic_live(args, wname, b)
+        rl = extras["roofline"]
+        if live is not None:
+            key = "gemm" if rl.get("bound") == "mfma" else "refine"
+            if key in live:
+                rl["traffic_committed_file"] = rl.get("traffic")
+                rl["traffic"] = live[key]["traffic_bytes_per_launch"]
+                rl["traffic_source"] = note
+                rl["traffic_detail"] = live[key]
+                if rl.get("algorithmic_bytes_per_launch"):
+                    rl["traffic_over_algorithmic"] = rl["traffic"] / rl["algorithmic_bytes_per_launch"]
+            for other in extras.get("roofline_other_kernels") or []:
+                if other and "depth_refine" in str(other.get("kernel")) and "refine" in live:
+                    other["traffic_committed_file"] = other.get("traffic")
+                    other["traffic"] = live["refine"]["traffic_bytes_per_launch"]
+                    other["traffic_source"] = note + "; maps / depth of the alternating batches partly L2 / Infinity-Cache resident (the committed figure evicted them)"
+            extras["pmc_live_seconds"] = live["seconds"]
+        else:
+            rl["traffic_live_error"] = note
     if state is not None and world == 1 and not args.no_other_mode_line and args.mlp_gemm == "split" and not args.graph \
             and not args.no_hip_layers:
         # the same K steps once more with the other split-GEMM setting (reported beside the headline, never as `value`)
