@@ -221,7 +221,9 @@ def forward_cpu_torch(cfg_name, seconds, rois=4):
 
     hip_layers.set_enabled(False)
     torch.set_grad_enabled(False)
-    cores = os.cpu_count() or 1
+    # PyTorch's CPU operators stop scaling (and collapse: 256 threads ran one 4-ROI forward in 53 s on the GPU box's host) long
+    # before a 256-core host is full: 32 threads is where oneDNN's convolutions / sgemm of these sizes still scale
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     cfg = get_cfg(cfg_name, ["MODEL.DEVICE=cpu"])
     if "resnet" in cfg_name:

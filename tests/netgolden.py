@@ -58,6 +58,13 @@ def load_fixture(ds):
     return fx
 
 
+def load_f64_fixture(ds):
+    """net_golden_<ds>_b128_f64.npz: the reference's module evaluated in fp64 on the 128-ROI batch (make_golden_net.py
+    record_b128_f64) + the per-ROI distance of its own fp32 forward (the b128 fixture) from that."""
+    z = np.load(os.path.join(GOLDEN, f"net_golden_{ds}_b128_f64.npz"))
+    return {k: z[k] for k in z.files}
+
+
 def seeded_reference_state_dict(model, fx):
     """The state_dict the reference model held when the fixture was recorded: geo head + Patch-PnP entries by the
     REFERENCE's key/shape manifest (incl. its duplicate ``norm.*`` keys), backbone entries by this model's own keys."""

@@ -200,14 +200,21 @@ def test_default_path_matches_reference_forward_at_128_rois(hip, ds):
     assert (o["region"].argmax(1) == fx["region_argmax"]).mean() > 0.999
     assert np.abs(rot_.cpu().numpy() - fx["pred_rot_"]).max() <= 1e-4 * max(1.0, np.abs(fx["pred_rot_"]).max())
     assert np.abs(t_.cpu().numpy() - fx["pred_t_"]).max() <= 1e-4 * max(1.0, np.abs(fx["pred_t_"]).max())
-    # R is derived from the network's 6-D output (Gram-Schmidt: rot6d_to_mat_batch, /root/reference/core/gdrn_modeling/models/
-    # pose_from_pred*.py) — the map amplifies an input error by ~1 / |a2 - (b1 . a2) b1|.  1e-4 holds wherever that is below 4x;
-    # a ROI whose two predicted axes are nearly parallel (T-LESS ROI 16: 25x; the six-product engine sits at 1.8e-4 there,
-    # profiles/r04f_b128_engine_errors.txt) gets the tolerance of its amplification.  The network output itself: 1e-4 above, measured 1.5e-5.
-    a1, a2 = fx["pred_rot_"].reshape(b, -1)[:, 0:3].astype(np.float64), fx["pred_rot_"].reshape(b, -1)[:, 3:6].astype(np.float64)
-    b1 = a1 / np.linalg.norm(a1, axis=1, keepdims=True)
-    u2 = np.linalg.norm(a2 - (b1 * a2).sum(1, keepdims=True) * b1, axis=1)
-    amp = 1.0 / np.minimum(u2, np.linalg.norm(a1, axis=1))
-    tol = 1e-4 * np.maximum(1.0, amp / 4.0)
-    assert (np.abs(o["rot"] - fx["rot"]).reshape(b, -1).max(1) <= tol).all() and (amp > 4.0).sum() <= 4
+    # R / t: the plain 1e-4 bar of BASELINE.json's north_star on EVERY ROI — no conditioning clause.  (R is the Gram-Schmidt of
+    # the 6-D output; T-LESS ROI 16 amplifies 25x and is still inside: 3.9e-5, profiles/r05a_b128_engine_errors_vs_fp64.txt.)
+    e_rot = np.abs(o["rot"] - fx["rot"]).reshape(b, -1).max(1)
+    assert (e_rot <= 1e-4).all(), f"ROIs beyond 1e-4: {np.nonzero(e_rot > 1e-4)[0].tolist()} {e_rot.max():.3e}"
+    # ... and anchored on the TRUE value of the reference's function: its own module evaluated in fp64 on the same parameters and
+    # batch (net_golden_<ds>_b128_f64.npz).  For every ROI this path is as close to the fp64 result as the reference's fp32
+    # forward is (+ 2e-5): on 74 of the 128 T-LESS ROIs it is closer.
+    f64 = NG.load_f64_fixture(ds)
+    got = {"rot": o["rot"], "trans": o["trans"], "pred_rot_": rot_.cpu().numpy(), "pred_t_": t_.cpu().numpy()}
+    for k in ("rot", "trans", "pred_rot_", "pred_t_"):
+        ours = np.abs(got[k].astype(np.float64) - f64[k + "_f64"]).reshape(b, -1).max(1)
+        ref = f64["ref_f32_err_" + k]
+        worse = np.nonzero(ours > ref + 2e-5)[0]
+        assert worse.size == 0, f"{k}: farther from the fp64 value than the reference's fp32 forward + 2e-5 at ROIs {worse.tolist()} ({ours[worse]}, reference {ref[worse]})"
+        assert ours.max() <= 1e-4 * max(1.0, np.abs(f64[k + "_f64"]).max())
+    for k in ("mask", "full_mask", "coor_x", "coor_y", "coor_z"):       # the maps against their fp64 values, same sub-sampling
+        assert _err(o[k][:, :, ::4, 1::4], f64[k + "_sub_f64"], float(fx[k + "_absmax"])) <= 1e-4, k
     assert np.abs(o["trans"] - fx["trans"]).max() <= 1e-4 * max(1.0, np.abs(fx["trans"]).max())

@@ -314,3 +314,34 @@ def test_b128_fixture_rois_match_the_cpu_graph(ds):
     _close(maps["region"].numpy()[:, :, 5::16, 9::16], fx["region_sub"][sel], 2e-5, scale=float(fx["region_absmax"]))
     _close(rot6.numpy(), fx["pred_rot_"][sel], 5e-5, scale=float(np.abs(fx["pred_rot_"]).max()))
     _close(t3.numpy(), fx["pred_t_"][sel], 5e-5, scale=float(np.abs(fx["pred_t_"]).max()))
+
+
+@pytest.mark.parametrize("ds", ["ycbv", "tless"])
+def test_b128_fp64_fixture_is_consistent_and_names_no_outlier_roi(ds):
+    """net_golden_<ds>_b128_f64.npz = the reference's own module evaluated in fp64 on the 128-ROI batch (make_golden_net.py
+    record_b128_f64).  Checked here without a GPU:
+      * the per-ROI distances it stores ARE |fp32 fixture - fp64 values|, and none reaches 5e-5 — the reference's fp32 forward is
+        nowhere an outlier against its own fp64 value, so the plain 1e-4 bar of the GPU test applies to EVERY ROI;
+      * R_f64 is orthonormal and equals the oracle's rot6d -> R -> allo-to-ego chain applied to the fp64 network outputs to fp32
+        rounding (the oracle's functions are float32 restatements): the fp64 run went through the same pose conversion;
+      * the Gram-Schmidt amplification of T-LESS ROI 16 (the one ROI the round-4 test relaxed) really is ~25x."""
+    from oracle import postproc as P
+
+    fx, f64 = NG.load_fixture(ds + "_b128"), NG.load_f64_fixture(ds)
+    b = 128
+    for k in ("rot", "trans", "pred_rot_", "pred_t_"):
+        d = np.abs(fx[k].astype(np.float64) - f64[k + "_f64"]).reshape(b, -1).max(1)
+        assert np.array_equal(d, f64["ref_f32_err_" + k])
+        assert d.max() < 5e-5, (k, int(d.argmax()), d.max())
+    R = f64["rot_f64"]
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-12 and np.abs(np.linalg.det(R) - 1).max() < 1e-12
+    allo = P.rot6d_to_mat_batch(f64["pred_rot__f64"].reshape(b, -1)[:, :6].astype(np.float32))
+    ego, trans = P.pose_from_predictions_test(allo, f64["pred_t__f64"][:, :2], f64["pred_t__f64"][:, 2:3], fx["roi_cam"], fx["roi_center"],
+                                              fx["resize_ratio"], fx["roi_wh"], is_allo=True, z_type="REL")
+    a1, a2 = f64["pred_rot__f64"].reshape(b, -1)[:, 0:3], f64["pred_rot__f64"].reshape(b, -1)[:, 3:6]
+    b1 = a1 / np.linalg.norm(a1, axis=1, keepdims=True)
+    amp = 1.0 / np.minimum(np.linalg.norm(a2 - (b1 * a2).sum(1, keepdims=True) * b1, axis=1), np.linalg.norm(a1, axis=1))
+    assert (np.abs(ego - R).reshape(b, -1).max(1) <= 4e-7 * np.maximum(1.0, amp) + 5e-6).all()   # float32 oracle chain (acos of the allo->ego axis-angle)
+    assert np.abs(trans - f64["trans_f64"]).max() < 2e-6
+    if ds == "tless":
+        assert int(amp.argmax()) == 16 and 20.0 < amp[16] < 30.0
