@@ -624,7 +624,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
 
     def after_warmup():
         if stream is not None and args.host_fed:       # copies of the warm-up steps are not the timed region's
-            stream["h2d_ms_warmup"] = stream["sched"].h2d_ms(reset=True)
+            stream["h2d_ms_warmup"] = stream["sched"].h2d_timeline(reset=True)["h2d_ms"]
             stream["h2d_bytes_warmup"] = stream["sched"].h2d_bytes
 
     @torch.no_grad()
@@ -689,7 +689,8 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         if stream is not None and args.host_fed:
             # (a) the copies of the timed steps, device-side; (b) the same steps once more from the HBM-resident pool, same box, same process
             sch = stream["sched"]
-            h2d_ms = sch.h2d_ms(reset=True)
+            tl = sch.h2d_timeline(reset=True)
+            h2d_ms = tl["h2d_ms"]
             h2d_bytes = sch.h2d_bytes - stream["h2d_bytes_warmup"]
             sch.flush()
             sch2 = stream["make_sched"]()
@@ -713,11 +714,14 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             torch.cuda.synchronize()
             ms_res = (time.perf_counter() - t0) / args.steps * 1e3
             sch2.flush()
-            out["host_fed"] = {"h2d_ms_per_step": h2d_ms / args.steps, "h2d_bytes_per_step": h2d_bytes / args.steps,
+            out["host_fed"] = {"h2d_ms_per_step": h2d_ms / args.steps, "h2d_overlapped_frac": tl["overlapped_frac"],
+                               "h2d_overlapped_ms_per_step": tl["overlapped_ms"] / args.steps, "h2d_bytes_per_step": h2d_bytes / args.steps,
                                "h2d_gbs": (h2d_bytes / 1e9) / (h2d_ms * 1e-3) if h2d_ms > 0 else None,
                                "resident_pool_ms_per_step": ms_res, "resident_pool_rois_per_s": b * 1000.0 / ms_res,
                                "note": "h2d_* = device-side duration of the hipMemcpyAsync copies of the TIMED steps (copy-stream events; "
-                                       "full 480x640 u8 image + f32 depth per pushed image, pinned host memory); resident_pool_* = the same "
+                                       "full 480x640 u8 image + f32 depth per pushed image, pinned host memory); h2d_overlapped_frac = the share "
+                                       "of that copy time during which a step's kernels were executing on the compute stream (events of both "
+                                       "streams on one clock); resident_pool_* = the same "
                                        "number of steps run again right after from the HBM-resident pool; the line's ms_per_step vs "
                                        "resident_pool_ms_per_step is what the host feed costs end to end"}
 

@@ -873,6 +873,7 @@ class RoiStreamScheduler:
         self._h2d_ready = {}                    # key -> event: the image's pixels are on the device
         self._time_h2d = bool(time_h2d)
         self._h2d_timing = []                   # (start, end) events per image, copy stream
+        self._step_timing = []                  # (start, end) events per step, compute stream (time_h2d only)
         self.h2d_bytes = 0
 
         self.cfg, self.model, self.post = cfg, model, post
@@ -912,8 +913,15 @@ class RoiStreamScheduler:
             roi_id=np.concatenate([ids for _, _, ids in pack]),
             cam=np.concatenate([cams(k, loc) for k, loc, _ in pack]),
             extents=self._images[keys[0]][2]["extents"])
+        if self._time_h2d:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record()
         batch = batch_data_test_gpu(self.cfg, images, depths, det, sort_by_class=True)
         self._in_flight.append((inference_step_async(self.model, self.post, batch), batch))
+        if self._time_h2d:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()
+            self._step_timing.append((t0, t1))
         self.steps_launched += 1
         for k in keys:                          # pixels are only read by the crop kernel just enqueued
             if self.packer.last_roi_dealt(k):
@@ -973,11 +981,31 @@ class RoiStreamScheduler:
 
     def h2d_ms(self, reset: bool = True) -> float:
         """Summed device-side duration of the host-to-device copies admitted so far (``time_h2d=True``), in ms."""
+        return self.h2d_timeline(reset)["h2d_ms"]
+
+    def h2d_timeline(self, reset: bool = True) -> dict:
+        """Device timeline of the copies against the steps (``time_h2d=True``): every image's copies are bracketed by events on
+        the copy stream, every step's kernels by events on the compute stream; one clock (elapsed time from the first event).
+        -> h2d_ms (summed copy durations), overlapped_ms (the part of them during which a step's kernels were executing) and
+        overlapped_frac = overlapped_ms / h2d_ms."""
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in self._h2d_timing)
+        copies, steps = self._h2d_timing, self._step_timing
+        out = {"h2d_ms": sum(a.elapsed_time(b) for a, b in copies), "overlapped_ms": 0.0, "overlapped_frac": None,
+               "images": len(copies), "steps": len(steps)}
+        if copies and steps:
+            origin = copies[0][0]
+            busy = sorted((origin.elapsed_time(a), origin.elapsed_time(b)) for a, b in steps)
+            for a, b in copies:
+                c0, c1 = origin.elapsed_time(a), origin.elapsed_time(b)
+                for s0, s1 in busy:
+                    lo, hi = max(c0, s0), min(c1, s1)
+                    if hi > lo:
+                        out["overlapped_ms"] += hi - lo
+            if out["h2d_ms"] > 0:
+                out["overlapped_frac"] = min(1.0, out["overlapped_ms"] / out["h2d_ms"])
         if reset:
-            self._h2d_timing = []
-        return ms
+            self._h2d_timing, self._step_timing = [], []
+        return out
 
     # -- the stream --------------------------------------------------------------------------------
     def push(self, key, image: torch.Tensor, depth, detections: dict):

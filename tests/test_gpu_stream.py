@@ -92,3 +92,33 @@ def test_launch_next_runs_exact_steps_and_resolves_one_launch_late(setup):
     ids.append(pending().cpu().numpy()[:, 14])
     assert sch.steps_launched == 5
     assert np.array_equal(np.sort(np.concatenate(ids)), np.arange(5 * P))
+
+
+def test_host_fed_stream_equals_the_device_resident_one_bit_for_bit(setup):
+    """The reference's loader hands over HOST arrays (data_loader.py:754-797): the same stream pushed from pinned host memory —
+    copied on the scheduler's copy stream, the crop kernel ordered behind the copies by events — returns bit-identical records,
+    the copies are timed, and part of their time lies under the previous step's kernels (device timeline)."""
+    cfg, model, post, stream = setup
+    P = 32
+
+    def run(feed, **kw):
+        sch = engine.RoiStreamScheduler(cfg, model, post, rois_per_step=P, **kw)
+        out = {}
+        for key, img, dep, det in feed:
+            for k, rec, _ in sch.push(key, img, dep, det):
+                out[k] = rec
+        for k, rec, _ in sch.flush():
+            out[k] = rec
+        return sch, out
+
+    _, want = run(stream)
+    host = [(k, img.cpu().pin_memory(), dep.cpu().pin_memory(), det) for k, img, dep, det in stream]
+    sch, got = run(host, time_h2d=True)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    n_img = sum(1 for _, _, _, d in stream if len(d["roi_cls"]))
+    assert sch.h2d_bytes == n_img * (S.IM_H * S.IM_W * 3 + S.IM_H * S.IM_W * 4)
+    tl = sch.h2d_timeline()
+    assert tl["images"] == n_img and tl["steps"] == sch.steps_launched and tl["h2d_ms"] > 0 and 0.0 <= tl["overlapped_frac"] <= 1.0
+    assert not sch._h2d_ready and not sch._images                      # nothing of the stream is kept alive
