@@ -17,6 +17,8 @@ Workloads (``--workload``; index into BASELINE.json ``configs``):
   bop7                     configs[4]  BOP-7 mixed stream (lmo/ycbv/tless/icbin/hb/itodd/tudl models cycled per step) + refine
   stream                   (configs[2] fed the reference's way) a stream of 480x640 images with 3-30 detections each, packed by
                            engine.RoiStreamScheduler into steps of exactly 128 ROIs, GPU crop inside the step: ROIs/s AND images/s
+  bop7_stream              configs[4]  the same image-stream feed for all seven BOP datasets (one stream + model each, cycled per step);
+                           with --host-fed every image starts in pinned host memory: detections -> pose -> refine end to end
 
 Multi-GPU: ``python bench.py --gpus N`` spawns N ranks by itself (one process per GPU, RCCL); under
 ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` it joins the launcher's ranks instead.
@@ -72,6 +74,9 @@ WORKLOADS = {  # name -> (index into BASELINE.json configs, cfg names, ROIs per 
     # not a BASELINE.json config of its own: configs[2]'s model fed by an image stream through the ROI packer
     "stream": (None, ["ycbv_convnext_a6"], 128, True,
                "YCB-V convnext_a6 + fast depth refine on a stream of 480x640 images (3-30 detections each) packed into 128-ROI steps, GPU crop in the step"),
+    "bop7_stream": (4, [f"{d}_convnext_a6" for d in ("lmo", "ycbv", "tless", "icbin", "hb", "itodd", "tudl")], 128, True,
+                    "BOP-7 mixed stream end to end: per dataset a stream of 480x640 images (3-30 detections each) -> ROI packer -> GPU crop -> "
+                    "convnext_a6 forward -> fast depth refine -> records; the seven datasets' models cycled per 128-ROI step"),
     "ycbv_so": (None, ["ycbv_convnext_so"], 128, True,
                 "YCB-V single-object convnext (configs/gdrn/ycbvSO/*, class-agnostic head) + fast depth refine"),
 }
@@ -313,7 +318,7 @@ def worker(args):
         assert rec is None
     else:
         ids = rec[:, 14][rec[:, 15] > 0.5].to(torch.int64).cpu().numpy()
-        if wname == "stream":     # stream ids keep counting: the last step holds n_global distinct consecutive ids per rank block
+        if wname.endswith("stream"):     # stream ids keep counting: the last step holds n_global distinct consecutive ids per rank block
             assert len(ids) == n_global and len(set(ids.tolist())) == n_global, "gathered records: ROI ids not distinct"
         else:
             assert len(ids) == n_global and np.array_equal(np.sort(ids), np.arange(n_global)), "gathered records: ROI ids not a permutation"
@@ -389,7 +394,7 @@ def worker(args):
             "config": {
                 "workload": f"{label}, batch={b} ROIs/GPU" + (f", {n_global} ROIs per iteration over {world} ranks" if world > 1 else ""),
                 "baseline_config_index": cfg_no, "workload_key": wname, "global_batch": n_global, "rois_per_gpu": b,
-                "roi_prep_on_gpu": bool(args.with_crop) or wname == "stream", "hipgraph": bool(args.graph), "input_res": 256, "output_res": 64,
+                "roi_prep_on_gpu": bool(args.with_crop) or wname.endswith("stream"), "host_fed": bool(args.host_fed), "hipgraph": bool(args.graph), "input_res": 256, "output_res": 64,
                 "parallelism": f"roi-shard x{world}",
                 "collective": (("gather(dst=0)" if dst is not None else "all_gather") + " f32[n,16] pose records") if world > 1 else None,
                 "class_sliced_out_layer": not args.exact_reference_order, "rois_class_sorted_within_rank": True,
@@ -405,7 +410,7 @@ def worker(args):
                                   "fp32 operands split exactly into three bf16 values, six partial products, fp32 accumulation (exact to 2^-26)"),
                 "library_options": args.opt,
                 "timed_entry_point": ("engine.RoiStreamScheduler.launch_next (GPU crop + inference_step_async) + engine.gather_records"
-                                      if wname == "stream" else "engine.inference_step_async / StepHandle.result + engine.gather_records"),
+                                      if wname.endswith("stream") else "engine.inference_step_async / StepHandle.result + engine.gather_records"),
                 "stub_step": bool(args.stub_step)},
             "gather_ms": gather_ms, "collective": collective,
         }
@@ -503,39 +508,40 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         post = GdrnHipPost(cfg, meshes if refine else None)
         pair = [make_batch(cfg, rng, ext, meshes, K=S.LMO_K if wname == "lmo_upnp" else S.YCBV_K) for _ in range(2)]
         models.append(dict(cfg=cfg, model=model, post=post, batches=[p[0] for p in pair], dets=[p[1] for p in pair],
-                           K_crops=[p[2] for p in pair], meshes=meshes, verts=verts, faces=faces, C=C, graphs={}))
+                           K_crops=[p[2] for p in pair], meshes=meshes, verts=verts, faces=faces, C=C, graphs={}, ext=ext))
 
     stream = None
-    if wname == "stream":
+    if wname in ("stream", "bop7_stream"):
         # the reference's feed: one image at a time (data_loader.py:901, batch_size = 1), 3-30 detections each.  64 distinct images
         # + detections resident in HBM, cycled; every pushed image gets a fresh key, ROI ids keep counting (per-rank id block).
         import itertools
-        m0 = models[0]
-        rng = np.random.default_rng(20220925 + 17 + rank)
-        g = torch.Generator(device=dev).manual_seed(20220925 + rank)
-        pool = []
-        for _ in range(64):
-            n = int(rng.integers(3, 31))
-            det = S.make_detections(n, m0["C"], ext, rng)
-            x1y1 = det["roi_center"] - det["roi_wh"] / 2
-            pool.append((torch.randint(0, 256, (S.IM_H, S.IM_W, 3), dtype=torch.uint8, device=dev, generator=g),
-                         torch.rand((S.IM_H, S.IM_W), device=dev, generator=g) + 0.3,
-                         dict(bbox=np.concatenate([x1y1, x1y1 + det["roi_wh"]], 1).astype(np.float32), roi_cls=det["roi_cls"],
-                              score=det["score"], cam=S.YCBV_K.astype(np.float32), extents=ext)))
-        # --host-fed: the very same images, but every push starts from PINNED HOST memory (the reference's loader hands over host
-        # arrays); the scheduler copies them on its copy stream, one step ahead of the device
-        host_pool = [(im.cpu().pin_memory(), dp.cpu().pin_memory(), dt_) for im, dp, dt_ in pool] if args.host_fed else None
         counter = itertools.count()
+        subs = []                 # one image stream + scheduler per model ("stream": YCB-V; "bop7_stream": the seven BOP datasets)
+        for di, m_ in enumerate(models):
+            rng = np.random.default_rng(20220925 + 17 + rank + 1000 * di)
+            g = torch.Generator(device=dev).manual_seed(20220925 + rank + 1000 * di)
+            pool = []
+            for _ in range(64 if len(models) == 1 else 24):
+                n = int(rng.integers(3, 31))
+                det = S.make_detections(n, m_["C"], m_["ext"], rng)
+                x1y1 = det["roi_center"] - det["roi_wh"] / 2
+                pool.append((torch.randint(0, 256, (S.IM_H, S.IM_W, 3), dtype=torch.uint8, device=dev, generator=g),
+                             torch.rand((S.IM_H, S.IM_W), device=dev, generator=g) + 0.3,
+                             dict(bbox=np.concatenate([x1y1, x1y1 + det["roi_wh"]], 1).astype(np.float32), roi_cls=det["roi_cls"],
+                                  score=det["score"], cam=S.YCBV_K.astype(np.float32), extents=m_["ext"])))
+            # --host-fed: the very same images, but every push starts from PINNED HOST memory (the reference's loader hands over host
+            # arrays); the scheduler copies them on its copy stream, one step ahead of the device
+            host_pool = [(im.cpu().pin_memory(), dp.cpu().pin_memory(), dt_) for im, dp, dt_ in pool] if args.host_fed else None
 
-        def make_feeder(src):
-            return ((next(counter), im, dp, dt_) for im, dp, dt_ in itertools.cycle(src))
+            def make_feeder(src):
+                return ((next(counter), im, dp, dt_) for im, dp, dt_ in itertools.cycle(src))
 
-        def make_sched():
-            return E.RoiStreamScheduler(m0["cfg"], m0["model"], m0["post"], rois_per_step=b, roi_id_base=lo, device=dev,
-                                        time_h2d=args.host_fed)
-        stream = dict(sched=make_sched(), feeder=make_feeder(host_pool if args.host_fed else pool), counter=counter,
-                      rois_per_image=float(np.mean([len(p[2]["roi_cls"]) for p in pool])), pool=pool, make_sched=make_sched,
-                      make_feeder=make_feeder, h2d_ms_warmup=0.0, h2d_bytes_warmup=0)
+            def make_sched(m_=m_, timed=args.host_fed):
+                return E.RoiStreamScheduler(m_["cfg"], m_["model"], m_["post"], rois_per_step=b, roi_id_base=lo, device=dev, time_h2d=timed)
+            subs.append(dict(sched=make_sched(), feeder=make_feeder(host_pool if args.host_fed else pool), pool=pool, make_sched=make_sched,
+                             make_feeder=make_feeder))
+        stream = dict(subs=subs, counter=counter, h2d_bytes_warmup=0,
+                      rois_per_image=float(np.mean([len(p[2]["roi_cls"]) for s_ in subs for p in s_["pool"]])))
 
     upnp = None
     if wname == "lmo_upnp":   # PVNet-style pose of config 1: 8 FPS keypoints + centre, noisy projections, cov^-1/2 weights
@@ -570,7 +576,8 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         m = models[i % len(models)]
         k = (i // len(models)) % 2
         if stream is not None:
-            return stream["sched"].launch_next(stream["feeder"])
+            s_ = stream["subs"][i % len(stream["subs"])]
+            return s_["sched"].launch_next(s_["feeder"])
         if args.graph and not args.with_crop and upnp is None:
             if k not in m["graphs"]:
                 m["graphs"][k] = GraphedInference(m["model"], m["post"], m["batches"][k], m["batches"][k]["roi_id"])
@@ -624,8 +631,9 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
 
     def after_warmup():
         if stream is not None and args.host_fed:       # copies of the warm-up steps are not the timed region's
-            stream["h2d_ms_warmup"] = stream["sched"].h2d_timeline(reset=True)["h2d_ms"]
-            stream["h2d_bytes_warmup"] = stream["sched"].h2d_bytes
+            for s_ in stream["subs"]:
+                s_["sched"].h2d_timeline(reset=True)
+            stream["h2d_bytes_warmup"] = sum(s_["sched"].h2d_bytes for s_ in stream["subs"])
 
     @torch.no_grad()
     def parity_in_run():
@@ -688,24 +696,25 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                 out["parity_in_run"] = {"error": repr(e)}
         if stream is not None and args.host_fed:
             # (a) the copies of the timed steps, device-side; (b) the same steps once more from the HBM-resident pool, same box, same process
-            sch = stream["sched"]
-            tl = sch.h2d_timeline(reset=True)
+            subs = stream["subs"]
+            tl = E.h2d_overlap([c for s_ in subs for c in s_["sched"]._h2d_timing], [t for s_ in subs for t in s_["sched"]._step_timing])
             h2d_ms = tl["h2d_ms"]
-            h2d_bytes = sch.h2d_bytes - stream["h2d_bytes_warmup"]
-            sch.flush()
-            sch2 = stream["make_sched"]()
-            sch2._time_h2d = False
-            feeder2 = stream["make_feeder"](stream["pool"])
-            prev = None
+            h2d_bytes = sum(s_["sched"].h2d_bytes for s_ in subs) - stream["h2d_bytes_warmup"]
+            for s_ in subs:
+                s_["sched"].flush()
+            subs2 = [dict(sched=s_["make_sched"](timed=False), feeder=s_["make_feeder"](s_["pool"])) for s_ in subs]
+            prev, k2 = None, 0
 
             def run2(n):
-                nonlocal prev
+                nonlocal prev, k2
                 for _ in range(n):
-                    cur = sch2.launch_next(feeder2)
+                    s2 = subs2[k2 % len(subs2)]
+                    k2 += 1
+                    cur = s2["sched"].launch_next(s2["feeder"])
                     if prev is not None:
                         prev()
                     prev = cur
-            run2(max(args.warmup, 3))
+            run2(max(args.warmup, 3) * len(subs2))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             run2(args.steps)
@@ -713,7 +722,8 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             prev = None
             torch.cuda.synchronize()
             ms_res = (time.perf_counter() - t0) / args.steps * 1e3
-            sch2.flush()
+            for s2 in subs2:
+                s2["sched"].flush()
             out["host_fed"] = {"h2d_ms_per_step": h2d_ms / args.steps, "h2d_overlapped_frac": tl["overlapped_frac"],
                                "h2d_overlapped_ms_per_step": tl["overlapped_ms"] / args.steps, "h2d_bytes_per_step": h2d_bytes / args.steps,
                                "h2d_gbs": (h2d_bytes / 1e9) / (h2d_ms * 1e-3) if h2d_ms > 0 else None,

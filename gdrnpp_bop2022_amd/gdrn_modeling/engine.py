@@ -843,6 +843,33 @@ class RoiPacker:
         return done
 
 
+def h2d_overlap(copies, steps) -> dict:
+    """Device timeline of host-to-device copies against compute: ``copies`` = (start, end) timing events on copy streams,
+    ``steps`` = (start, end) timing events around the steps' kernels on the compute stream (of one or several schedulers feeding
+    the same device); one clock (elapsed time from the first copy's start).  -> h2d_ms (summed copy durations), overlapped_ms
+    (the part of them during which some step's kernels were executing) and overlapped_frac = overlapped_ms / h2d_ms."""
+    torch.cuda.synchronize()
+    out = {"h2d_ms": sum(a.elapsed_time(b) for a, b in copies), "overlapped_ms": 0.0, "overlapped_frac": None,
+           "images": len(copies), "steps": len(steps)}
+    if copies and steps:
+        origin = copies[0][0]
+        busy, merged = sorted((origin.elapsed_time(a), origin.elapsed_time(b)) for a, b in steps), []
+        for s0, s1 in busy:                      # union of the step intervals
+            if merged and s0 <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], s1)
+            else:
+                merged.append([s0, s1])
+        for a, b in copies:
+            c0, c1 = origin.elapsed_time(a), origin.elapsed_time(b)
+            for s0, s1 in merged:
+                lo, hi = max(c0, s0), min(c1, s1)
+                if hi > lo:
+                    out["overlapped_ms"] += hi - lo
+        if out["h2d_ms"] > 0:
+            out["overlapped_frac"] = min(1.0, out["overlapped_ms"] / out["h2d_ms"])
+    return out
+
+
 class RoiStreamScheduler:
     """detections -> pose records for a STREAM of images, at the step size the kernels want.
 
@@ -984,25 +1011,8 @@ class RoiStreamScheduler:
         return self.h2d_timeline(reset)["h2d_ms"]
 
     def h2d_timeline(self, reset: bool = True) -> dict:
-        """Device timeline of the copies against the steps (``time_h2d=True``): every image's copies are bracketed by events on
-        the copy stream, every step's kernels by events on the compute stream; one clock (elapsed time from the first event).
-        -> h2d_ms (summed copy durations), overlapped_ms (the part of them during which a step's kernels were executing) and
-        overlapped_frac = overlapped_ms / h2d_ms."""
-        torch.cuda.synchronize()
-        copies, steps = self._h2d_timing, self._step_timing
-        out = {"h2d_ms": sum(a.elapsed_time(b) for a, b in copies), "overlapped_ms": 0.0, "overlapped_frac": None,
-               "images": len(copies), "steps": len(steps)}
-        if copies and steps:
-            origin = copies[0][0]
-            busy = sorted((origin.elapsed_time(a), origin.elapsed_time(b)) for a, b in steps)
-            for a, b in copies:
-                c0, c1 = origin.elapsed_time(a), origin.elapsed_time(b)
-                for s0, s1 in busy:
-                    lo, hi = max(c0, s0), min(c1, s1)
-                    if hi > lo:
-                        out["overlapped_ms"] += hi - lo
-            if out["h2d_ms"] > 0:
-                out["overlapped_frac"] = min(1.0, out["overlapped_ms"] / out["h2d_ms"])
+        """Device timeline of this scheduler's copies against its steps (``time_h2d=True``), see ``h2d_overlap``."""
+        out = h2d_overlap(self._h2d_timing, self._step_timing)
         if reset:
             self._h2d_timing, self._step_timing = [], []
         return out
