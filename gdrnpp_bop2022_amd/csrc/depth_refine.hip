@@ -174,10 +174,11 @@ struct RefineArgs {
   // SPLIT form (small batches): `split` workgroups per ROI share the rasterisation by face range
   int split, b, spread;   // spread: parts of a ROI on neighbouring workgroup ids (= different XCDs) instead of the same XCD
   unsigned* zmerge;   // u32[b][iters][hw] merged z-buffers as ~(float-Z bits) (0 = empty): zero before the launch, zeroed again by it
-  int* sync;          // i32[b][2] arrive / done counters (same contract); sync[-1] = status word (1: a barrier timed out)
+  int* sync;          // i32[b][2] arrive / done counters (same contract)
+  int* status;        // first word of the workspace: set to 1 when a barrier timed out (sticky)
 };
 
-constexpr int kSpinLimit = 1 << 22;   // polls of the inter-workgroup barrier before it gives up (~1 s): never hang the device
+constexpr int kSpinLimit = 1 << 20;   // polls of the inter-workgroup barrier before it gives up (~1 s): never hang the device
 
 // STAGED: the transformed vertices of the current iteration live in LDS; otherwise in this ROI's slice of a.hv_global
 // SPLIT: a.split (2 or 4) workgroups per ROI.  Every part runs the prologue, the vertex stage and the compare on its own (same
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
         const int want = a.split * (it + 1);
         int polls = 0;
         while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-          if (++polls > kSpinLimit) { atomicExch(a.sync - 1, 1); break; }
+          if (++polls > kSpinLimit) { atomicExch(a.status, 1); break; }
           __builtin_amdgcn_s_sleep(2);
         }
       }
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
       s_last = (n_it > 0 && atomicAdd(a.sync + 2 * bi + 1, 1) == a.split - 1) ? 1 : 0;
     }
     __syncthreads();
-    timed_out = __hip_atomic_load(a.sync - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    timed_out = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     if (s_last) {
       unsigned* zm = a.zmerge + (size_t)bi * iters * hw;
       for (int p = tid; p < iters * hw; p += kTS) zm[p] = 0u;
@@ -680,7 +681,7 @@ int launch_refine(const gdrnpp_meshes* meshes, RefineArgs a, int b, void* worksp
                   const char* who, int split = 1, void* split_ws = nullptr, size_t split_ws_bytes = 0) {
   a.verts = meshes->verts; a.faces = meshes->faces; a.vert_off = meshes->vert_off; a.face_off = meshes->face_off;
   a.n_obj = meshes->n_obj;
-  a.split = 1; a.b = b; a.zmerge = nullptr; a.sync = nullptr;
+  a.split = 1; a.b = b; a.spread = 0; a.zmerge = nullptr; a.sync = nullptr; a.status = nullptr;
   if (meshes->max_verts > 0 && meshes->max_verts <= kMaxStagedVerts) {
     static bool done[64];
     if (int rc = raise_dynamic_lds_once(depth_refine_kernel<true>, kStageBytes * kMaxStagedVerts, done)) return rc;
@@ -696,6 +697,7 @@ int launch_refine(const gdrnpp_meshes* meshes, RefineArgs a, int b, void* worksp
       if (int rc = raise_dynamic_lds_once(depth_refine_kernel<true, true>, kStageBytes * kMaxStagedVerts, done2)) return rc;
       a.split = split;
       a.spread = gdrnpp::option_refine_split_spread();
+      a.status = reinterpret_cast<int*>(split_ws);
       a.sync = reinterpret_cast<int*>(static_cast<char*>(split_ws) + 16);
       a.zmerge = reinterpret_cast<unsigned*>(static_cast<char*>(split_ws) + split_sync_bytes(b));
       hipLaunchKernelGGL((depth_refine_kernel<true, true>), dim3((b + 7) / 8 * 8 * split), dim3(kTS),
