@@ -379,8 +379,11 @@ def worker(args):
         metric = ("ROIs/sec (GDRNPP fwd + PnP + depth refine), 256x256 crops" if refine else
                   "ROIs/sec (GDRNPP fwd + uncertainty-PnP), 256x256 crops" if wname == "lmo_upnp" else
                   "ROIs/sec (GDRNPP fwd + Patch-PnP, RGB only), 256x256 crops")
+        product_path = args.mlp_gemm == "split" and not args.no_hip_layers and not args.stub_step
+        if not product_path:      # hip_layers keeps PyTorch's operators selectable for A/B measurements and CPU graph tests: never the headline
+            metric += " [A/B run: " + ("host stub" if args.stub_step else "PyTorch-operator layers") + ", NOT the product path]"
         line = {
-            "metric": metric, "value": n_global * args.steps / dt, "unit": "ROIs/s", "n_gpus": world, "steps": args.steps,
+            "metric": metric, "product_path": product_path, "value": n_global * args.steps / dt, "unit": "ROIs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",   # fp32 in, fp32 accumulate, fp32 out; how the operands enter the matrix cores:
             "arithmetic": (("fp16x2 operand split (22 bits) on the fp16 matrix cores, fp32 accumulate; range checked per launch on both sides, "
