@@ -74,7 +74,6 @@ int option_split_gemm_mi4();    // -1: by tile count, 0 / 1: force 128- / 256-ro
 int option_splitk_small_tiles();   // 1 (default): unsplit problems of gdrnpp_linear_f32_splitk pick their tile height by tile count (128 rows below 256 tiles of 256x128: 8 ROIs 4.65 -> 4.41 ms per step), 0: always 256-row tiles
 int option_split2_wide();        // 1: 256x256 block tiles of the three-product kernels when N % 256 == 0 (A/B; default off: measured slower)
 int option_mlp_fused_pipe();    // 1 (default): software-pipelined tile loop of the fused MLP; 0: plain loop (A/B)
-int option_refine_split_spread();   // 0 (default): the parts of a ROI of the split refine kernel share an XCD; 1: neighbouring workgroup ids = different XCDs (test aid: device-scope coherence)
 int option_dwconv_tile();       // -1 (default): by launch size; 0 / 1 / 2: force the 2x8 / 2x4 / 1x4 pixel tile of dwconv7x7+LN
 
 }  // namespace gdrnpp

@@ -171,24 +171,10 @@ struct RefineArgs {
   double* hv_global; int hv_stride;                    // vertex stage of meshes too large for LDS: [b] x (hv_stride x 40 bytes)
   int max_verts;                                       // of the mesh set (LDS stage layout)
   int res, iters; float threshold; int mask_type, use_coor_z; float z_near, z_far;
-  // SPLIT form (small batches): `split` workgroups per ROI share the rasterisation by face range
-  int split, b, spread;   // spread: parts of a ROI on neighbouring workgroup ids (= different XCDs) instead of the same XCD
-  unsigned* zmerge;   // u32[b][iters][hw] merged z-buffers as ~(float-Z bits) (0 = empty): zero before the launch, zeroed again by it
-  int* sync;          // i32[b][2] arrive / done counters (same contract)
-  int* status;        // first word of the workspace: set to 1 when a barrier timed out (sticky)
 };
 
-constexpr int kSpinLimit = 1 << 20;   // polls of the inter-workgroup barrier before it gives up (~1 s): never hang the device
-
 // STAGED: the transformed vertices of the current iteration live in LDS; otherwise in this ROI's slice of a.hv_global
-// SPLIT: a.split (2 or 4) workgroups per ROI.  Every part runs the prologue, the vertex stage and the compare on its own (same
-// inputs, same fixed-order reductions: bit-identical t in every part — no exchange of poses); the triangles are dealt by face
-// range, each part rasterises its range into its LDS z-buffer, the parts merge through atomicMax on ~Z bits in the workspace
-// (min of Z is order-independent: the merged buffer is bit for bit the one-workgroup z-buffer), meet at a counter barrier and read
-// the merged buffer back.  The last part to finish zeroes the ROI's workspace slice for the next launch.  Parts of one ROI sit on
-// the same XCD under the round-robin dispatch (block id = group of 8 ROIs x part x XCD); correctness does not depend on it
-// (device-scope atomics + fences).  The launcher keeps the grid within half the CUs so that all parts are resident at once.
-template <bool STAGED, bool SPLIT = false>
+template <bool STAGED>
 __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
   const float* __restrict__ coor_x = a.coor_x; const float* __restrict__ coor_y = a.coor_y; const float* __restrict__ coor_z = a.coor_z;
   const float* __restrict__ mask_raw = a.mask_raw; const float* __restrict__ roi_depth = a.roi_depth;
@@ -208,19 +194,7 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
   __shared__ double s_K[9], s_R[9], s_t[3];
   __shared__ float s_Rf[3];
 
-  const int tid = threadIdx.x;
-  int bi = blockIdx.x, part = 0;
-  if constexpr (SPLIT) {
-    if (a.spread) {
-      bi = blockIdx.x / a.split;
-      part = blockIdx.x - bi * a.split;
-    } else {
-      const int per = 8 * a.split, g = blockIdx.x / per, r = blockIdx.x - g * per;
-      bi = g * 8 + (r & 7);
-      part = r >> 3;
-    }
-    if (bi >= a.b) return;
-  }
+  const int bi = blockIdx.x, tid = threadIdx.x;
   const int hw = res * res;
   const int ob = a.obj[bi];
   // an object id outside the mesh set (a detector with another class map): the ROI keeps the network translation and
@@ -361,9 +335,7 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
       }
       return triangle_edges(h0, h1, h2, s);
     };
-    const int f_lo = SPLIT ? (int)((long)nfaces * part / a.split) : 0;
-    const int f_hi = SPLIT ? (int)((long)nfaces * (part + 1) / a.split) : nfaces;
-    for (int f = f_lo + tid; f < f_hi; f += kTS) {
+    for (int f = tid; f < nfaces; f += kTS) {
       TriSetup s;
       if (!staged_setup(f, s)) continue;
       if ((s.i_hi - s.i_lo + 1) * (s.j_hi - s.j_lo + 1) > kLargeArea) {
@@ -393,40 +365,6 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
       }
     }
     __syncthreads();
-    if constexpr (SPLIT) {
-      unsigned* zm = a.zmerge + ((size_t)bi * iters + it) * hw;
-#pragma unroll
-      for (int k = 0; k < kPPTS; ++k) {
-        const int p = k * kTS + tid;
-        if (p < hw) {
-          const unsigned zb = zbuf[p];
-          if (zb != kInfBits) atomicMax(&zm[p], ~zb);      // positive float bits: larger ~bits = nearer surface
-        }
-      }
-      __threadfence();                                       // release this part's atomics device-wide
-      __syncthreads();
-      if (tid == 0) {
-        int* arrive = a.sync + 2 * bi;
-        atomicAdd(arrive, 1);
-        const int want = a.split * (it + 1);
-        int polls = 0;
-        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-          if (++polls > kSpinLimit) { atomicExch(a.status, 1); break; }
-          __builtin_amdgcn_s_sleep(2);
-        }
-      }
-      __syncthreads();
-      __threadfence();                                       // acquire
-#pragma unroll
-      for (int k = 0; k < kPPTS; ++k) {
-        const int p = k * kTS + tid;
-        if (p < hw) {
-          const unsigned key = __hip_atomic_load(&zm[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          zbuf[p] = key ? ~key : kInfBits;
-        }
-      }
-      __syncthreads();
-    }
     PROF_STAMP(3 + 5 * it);
 
     // ---- query map -----------------------------------------------------------------------------------------------
@@ -440,7 +378,7 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
         ds[k] = s_ds[p];
         const unsigned zb = zbuf[p];
         ren[k] = (zb == kInfBits) ? 0.f : __uint_as_float(zb);
-        if (debug_depth && part == 0) debug_depth[((size_t)bi * iters + it) * hw + p] = ren[k];
+        if (debug_depth) debug_depth[((size_t)bi * iters + it) * hw + p] = ren[k];
         const float rm = ren[k] > 0.f ? 1.f : 0.f, dm = ds[k] > 0.f ? 1.f : 0.f;
         q[k] = (s_qbase[p] * rm) * dm;
         part += (double)q[k];
@@ -520,24 +458,6 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
     PROF_STAMP(6 + 5 * it);
   }
   __syncthreads();
-  bool timed_out = false;
-  if constexpr (SPLIT) {
-    // every merged buffer of this ROI has been read by this part; the LAST part to get here zeroes the ROI's slice of the
-    // workspace (merged buffers + counters) so that the next launch on this stream finds it as the first one did
-    __shared__ int s_last;
-    if (tid == 0) {
-      __threadfence();
-      s_last = (n_it > 0 && atomicAdd(a.sync + 2 * bi + 1, 1) == a.split - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    timed_out = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    if (s_last) {
-      unsigned* zm = a.zmerge + (size_t)bi * iters * hw;
-      for (int p = tid; p < iters * hw; p += kTS) zm[p] = 0u;
-      if (tid < 2) a.sync[2 * bi + tid] = 0;
-    }
-    if (part != 0) return;
-  }
   if (tid < 3 && a.t_out) a.t_out[3 * (size_t)bi + tid] = s_t[tid];
   if (a.rec && tid < 16) {  // pose_prediction_to_json's fields as one f32[16] record (gdrn_evaluator.py:636-665)
     float v;
@@ -546,7 +466,7 @@ __global__ __launch_bounds__(kTS) void depth_refine_kernel(const RefineArgs a) {
     else if (tid == 12) v = a.score ? a.score[bi] : 1.f;
     else if (tid == 13) v = (float)ob;
     else if (tid == 14) v = a.roi_id ? (float)a.roi_id[bi] : (float)bi;
-    else v = (known && !timed_out) ? 1.f : 0.f;
+    else v = known ? 1.f : 0.f;
     a.rec[16 * (size_t)bi + tid] = v;
   }
 }
@@ -657,53 +577,14 @@ int raise_dynamic_lds_once(F kernel, int bytes, bool* done /*[64]*/) {
   return 0;
 }
 
-// split workspace: [status i32 x 4][arrive / done i32 x 2 per ROI, padded to 16 B][merged z-buffers u32[b][iters][hw]]
-size_t split_sync_bytes(int b) { return 16 + (((size_t)b * 8 + 15) & ~(size_t)15); }
-
-int cu_count() {
-  static int n[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-  if (n[dev] == 0 && hipDeviceGetAttribute(&n[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n[dev] = 0;
-  return n[dev];
-}
-
-// the split the library picks for b ROIs: every part of every ROI resident at once on at most HALF the CUs (a kernel of another
-// stream may hold the rest), one workgroup per CU (the kernel's LDS)
-int pick_split(int b) {
-  const int cus = cu_count();
-  for (int s = 4; s >= 2; s >>= 1)
-    if ((b + 7) / 8 * 8 * s <= cus / 2) return s;
-  return 1;
-}
-
 int launch_refine(const gdrnpp_meshes* meshes, RefineArgs a, int b, void* workspace, size_t workspace_bytes, hipStream_t st,
-                  const char* who, int split = 1, void* split_ws = nullptr, size_t split_ws_bytes = 0) {
+                  const char* who) {
   a.verts = meshes->verts; a.faces = meshes->faces; a.vert_off = meshes->vert_off; a.face_off = meshes->face_off;
   a.n_obj = meshes->n_obj;
-  a.split = 1; a.b = b; a.spread = 0; a.zmerge = nullptr; a.sync = nullptr; a.status = nullptr;
   if (meshes->max_verts > 0 && meshes->max_verts <= kMaxStagedVerts) {
     static bool done[64];
     if (int rc = raise_dynamic_lds_once(depth_refine_kernel<true>, kStageBytes * kMaxStagedVerts, done)) return rc;
     a.hv_global = nullptr; a.hv_stride = 0; a.max_verts = meshes->max_verts;
-    if (split > 1 && a.iters > 0) {
-      const size_t need = split_sync_bytes(b) + (size_t)b * a.iters * a.res * a.res * sizeof(unsigned);
-      GDRNPP_REQUIRE(split == 2 || split == 4, GDRNPP_EINVAL, "%s: split=%d (1, 2 or 4)", who, split);
-      GDRNPP_REQUIRE(split_ws && split_ws_bytes >= need, GDRNPP_EINVAL,
-                     "%s: split=%d needs a zero-initialised workspace of %zu bytes (gdrnpp_refine_split_workspace_bytes)", who, split, need);
-      GDRNPP_REQUIRE((b + 7) / 8 * 8 * split <= cu_count(), GDRNPP_ELIMIT,
-                     "%s: %d ROIs x %d parts do not fit the device's %d CUs at once (gdrnpp_refine_split_factor)", who, b, split, cu_count());
-      static bool done2[64];
-      if (int rc = raise_dynamic_lds_once(depth_refine_kernel<true, true>, kStageBytes * kMaxStagedVerts, done2)) return rc;
-      a.split = split;
-      a.spread = gdrnpp::option_refine_split_spread();
-      a.status = reinterpret_cast<int*>(split_ws);
-      a.sync = reinterpret_cast<int*>(static_cast<char*>(split_ws) + 16);
-      a.zmerge = reinterpret_cast<unsigned*>(static_cast<char*>(split_ws) + split_sync_bytes(b));
-      hipLaunchKernelGGL((depth_refine_kernel<true, true>), dim3((b + 7) / 8 * 8 * split), dim3(kTS),
-                         kStageBytes * ((meshes->max_verts + 1) & ~1), st, a);
-      return gdrnpp::check_launch(who);
-    }
     hipLaunchKernelGGL(depth_refine_kernel<true>, dim3(b), dim3(kTS), kStageBytes * ((meshes->max_verts + 1) & ~1), st, a);
   } else {
     GDRNPP_REQUIRE(meshes->max_verts > 0, GDRNPP_EINVAL, "%s: gdrnpp_meshes.max_verts must be set", who);
@@ -788,44 +669,6 @@ int gdrnpp_refine_to_records(const gdrnpp_meshes* meshes, const int* obj, const 
   a.res = res; a.iters = iters; a.threshold = threshold; a.mask_type = mask_type; a.use_coor_z = use_coor_z;
   a.z_near = z_near; a.z_far = z_far;
   return launch_refine(meshes, a, b, workspace, workspace_bytes, (hipStream_t)stream, "gdrnpp_refine_to_records");
-}
-
-size_t gdrnpp_refine_split_workspace_bytes(int b, int res, int iters, int split) {
-  if (b <= 0 || res <= 0 || iters <= 0 || split <= 1) return 0;
-  return split_sync_bytes(b) + (size_t)b * iters * res * res * sizeof(unsigned);
-}
-
-int gdrnpp_refine_split_factor(const gdrnpp_meshes* meshes, int b) {
-  if (!meshes || b <= 0 || meshes->max_verts <= 0 || meshes->max_verts > kMaxStagedVerts) return 1;
-  return pick_split(b);
-}
-
-int gdrnpp_refine_to_records_split(const gdrnpp_meshes* meshes, const int* obj, const float* coor_x, const float* coor_y,
-                                   const float* coor_z, const float* mask_raw, const float* roi_depth, const float* cam,
-                                   const float* center, const float* scale, const float* R, const float* t_in,
-                                   const float* score, const int* roi_id, float* rec, int b, int res, int in_res, int iters,
-                                   float threshold, int mask_type, int use_coor_z, float z_near, float z_far, void* workspace,
-                                   size_t workspace_bytes, int split, void* split_workspace, size_t split_workspace_bytes,
-                                   void* stream) {
-  if (b == 0) return 0;
-  if (int rc = check_meshes(meshes, "gdrnpp_refine_to_records_split")) return rc;
-  GDRNPP_REQUIRE(obj && coor_x && coor_y && coor_z && mask_raw && roi_depth && cam && center && scale && R && t_in && rec,
-                 GDRNPP_EINVAL, "gdrnpp_refine_to_records_split: null pointer");
-  GDRNPP_REQUIRE(b > 0 && res > 0 && iters >= 0, GDRNPP_EINVAL, "gdrnpp_refine_to_records_split: b=%d res=%d iters=%d", b, res, iters);
-  GDRNPP_REQUIRE(res * res <= kMaxPix && in_res == 4 * res, GDRNPP_ELIMIT,
-                 "gdrnpp_refine_to_records_split: res=%d (<= 64) and in_res=%d (= 4 x res) required", res, in_res);
-  GDRNPP_REQUIRE(mask_type >= 0 && mask_type <= 2, GDRNPP_EINVAL, "gdrnpp_refine_to_records_split: mask_type=%d", mask_type);
-  GDRNPP_REQUIRE(split == 1 || split == 2 || split == 4, GDRNPP_EINVAL, "gdrnpp_refine_to_records_split: split=%d (1, 2 or 4)", split);
-  GDRNPP_REQUIRE(split == 1 || (meshes->max_verts > 0 && meshes->max_verts <= kMaxStagedVerts), GDRNPP_ELIMIT,
-                 "gdrnpp_refine_to_records_split: split > 1 needs meshes of at most %d vertices (the LDS-staged kernel)", kMaxStagedVerts);
-  RefineArgs a{};
-  a.obj = obj; a.coor_x = coor_x; a.coor_y = coor_y; a.coor_z = coor_z; a.mask_raw = mask_raw; a.roi_depth = roi_depth;
-  a.K_crop = nullptr; a.cam = cam; a.center = center; a.scale = scale; a.out_res = (float)res;
-  a.R = R; a.t_in = t_in; a.t_out = nullptr; a.debug_depth = nullptr; a.rec = rec; a.score = score; a.roi_id = roi_id;
-  a.res = res; a.iters = iters; a.threshold = threshold; a.mask_type = mask_type; a.use_coor_z = use_coor_z;
-  a.z_near = z_near; a.z_far = z_far;
-  return launch_refine(meshes, a, b, workspace, workspace_bytes, (hipStream_t)stream, "gdrnpp_refine_to_records_split", split,
-                       split_workspace, split_workspace_bytes);
 }
 
 /* debug: s_memtime stamps of workgroup 0 of the last staged refine launch (see g_refine_prof) */

@@ -70,11 +70,6 @@ SIGNATURES = {
     "gdrnpp_refine_to_records": (
         c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                 c_float, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
-    "gdrnpp_refine_split_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "gdrnpp_refine_split_factor": (c_int, [POINTER(gdrnpp_meshes), c_int]),
-    "gdrnpp_refine_to_records_split": (
-        c_int, [POINTER(gdrnpp_meshes), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
-                c_float, c_int, c_int, c_float, c_float, _P, c_size_t, c_int, _P, c_size_t, _P]),
     "gdrnpp_pose_from_pred": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "gdrnpp_debug_refine_profile": (c_int, [_P]),
     "gdrnpp_pack_weight_bf16x3": (c_int, [_P, _P, c_int, c_int, _P]),
@@ -374,66 +369,29 @@ def depth_refine(meshes: MeshSet, obj, coor_x, coor_y, coor_z, mask_raw, roi_dep
     return (t_out, dbg) if debug else t_out
 
 
-_REFINE_SPLIT = None          # None: the library's choice per launch (gdrnpp_refine_split_factor); 1 / 2 / 4: forced (A/B, tests)
-_REFINE_SPLIT_WS = {}         # (device index, stream handle) -> zero-initialised workspace the split kernel leaves zeroed
-
-
-def set_refine_split(split) -> None:
-    """None = automatic (small batches are split over 2 or 4 workgroups per ROI), 1 = always one workgroup per ROI, 2 / 4 = forced."""
-    global _REFINE_SPLIT
-    if split not in (None, 1, 2, 4):
-        raise ValueError(f"refine split must be None, 1, 2 or 4, got {split!r}")
-    _REFINE_SPLIT = split
-
-
-def _refine_split_workspace(device, b: int, res: int, iters: int, split: int):
-    """The split kernel's workspace of this (device, stream): zeroed once when it is allocated — every launch hands it back zeroed
-    (include/gdrnpp_hip.h) — and grown (a fresh zeroed tensor) when a launch needs more."""
-    need = load().gdrnpp_refine_split_workspace_bytes(b, res, iters, split)
-    key = (torch.device(device).index or 0, _stream() or 0)
-    ws = _REFINE_SPLIT_WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _REFINE_SPLIT_WS[key] = torch.zeros((need,), dtype=torch.uint8, device=device)
-    return ws, need
-
-
-def refine_split_status(device=None) -> int:
-    """1 if an inter-workgroup barrier of a split refine launch on the current stream ever timed out (its records carry valid = 0)."""
-    dev = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
-    ws = _REFINE_SPLIT_WS.get((dev.index or 0, _stream() or 0))
-    return 0 if ws is None else int(ws[:4].view(torch.int32).item())
-
-
 def refine_to_records(meshes: MeshSet, obj, coor_x, coor_y, coor_z, mask_raw, roi_depth, cam, center, scale, R, t, score=None,
                       roi_id=None, res: int = 64, iters: int = 2, threshold: float = 0.8, mask_type: int = 0,
-                      use_coor_z: bool = False, z_near: float = 0.1, z_far: float = 100.0, split=None):
-    """The refine configuration's post-processing tail in ONE launch (``gdrnpp_refine_to_records[_split]``): K_crop from cam /
-    center / scale, the depth refinement, and the f32[b,16] pose records.  Small batches (the reference's own: one image per
-    forward) run 2 or 4 workgroups per ROI — ``split`` / ``set_refine_split`` override the library's choice; records are
-    bit-identical for every split.  Under hipGraph capture the one-workgroup form is used (the split workspace is per stream)."""
+                      use_coor_z: bool = False, z_near: float = 0.1, z_far: float = 100.0):
+    """The refine configuration's post-processing tail in ONE launch (``gdrnpp_refine_to_records``): K_crop from cam /
+    center / scale, the depth refinement, and the f32[b,16] pose records."""
     lib = load()
     b = obj.shape[0]
     rec = torch.empty((b, 16), dtype=torch.float32, device=obj.device)
     if b == 0:
         return rec
     ws, nbytes = _refine_workspace(meshes, b, obj.device)
-    if split is None:
-        split = _REFINE_SPLIT
-    if split is None:
-        split = 1 if torch.cuda.is_current_stream_capturing() else lib.gdrnpp_refine_split_factor(meshes.c, b)
-    sws, sbytes = (None, 0) if split == 1 or iters == 0 else _refine_split_workspace(obj.device, b, res, iters, split)
     ev = None
     if _REFINE_EVENT_SINK is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    _check(lib.gdrnpp_refine_to_records_split(
+    _check(lib.gdrnpp_refine_to_records(
         meshes.c, _dev(obj, torch.int32, "obj"), _dev(coor_x, torch.float32, "coor_x"), _dev(coor_y, torch.float32, "coor_y"),
         _dev(coor_z, torch.float32, "coor_z"), _dev(mask_raw, torch.float32, "mask"), _dev(roi_depth, torch.float32, "roi_depth"),
         _dev(cam, torch.float32, "cam"), _dev(center, torch.float32, "center"), _dev(scale, torch.float32, "scale"),
         _dev(R, torch.float32, "R"), _dev(t, torch.float32, "t"), _dev(score, torch.float32, "score") if score is not None else None,
         _dev(roi_id, torch.int32, "roi_id") if roi_id is not None else None, rec.data_ptr(), b, res, int(roi_depth.shape[-1]),
         iters, float(threshold), mask_type, 1 if use_coor_z else 0, z_near, z_far, ws.data_ptr() if ws is not None else None,
-        nbytes, int(split), sws.data_ptr() if sws is not None else None, sbytes, _stream()), "gdrnpp_refine_to_records_split")
+        nbytes, _stream()), "gdrnpp_refine_to_records")
     if ev is not None:
         ev[1].record()
         _REFINE_EVENT_SINK.append(ev)

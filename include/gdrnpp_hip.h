@@ -294,25 +294,6 @@ int gdrnpp_refine_to_records(const gdrnpp_meshes* meshes, const int* obj, const 
                              float threshold, int mask_type, int use_coor_z, float z_near, float z_far, void* workspace,
                              size_t workspace_bytes, void* stream);
 
-/* The same tail for SMALL batches (the reference's own: one image = 3-30 ROIs per forward, gdrn_evaluator.py:702): one
- * workgroup per ROI leaves most of the chip idle, so `split` (2 or 4) workgroups share a ROI's rasterisation by face range and
- * merge their z-buffers through the workspace (atomic max on ~Z bits: the merged buffer is bit for bit the one-workgroup one, and
- * so are the records).  split = 1: exactly gdrnpp_refine_to_records.
- *   gdrnpp_refine_split_factor(meshes, b)  the split the library recommends: the largest of 4 / 2 whose workgroups are all resident
- *     at once on at most half of the device's CUs (1 otherwise, and for meshes beyond the LDS stage);
- *   split_workspace  gdrnpp_refine_split_workspace_bytes(b, res, iters, split) bytes, ZERO before the first launch; every launch
- *     leaves it zeroed again (reuse it across the launches of ONE stream; concurrent streams need one each).  Its first word is a
- *     status: 1 = an inter-workgroup barrier timed out (~1 s; the records of that launch carry valid = 0) — it stays set. */
-size_t gdrnpp_refine_split_workspace_bytes(int b, int res, int iters, int split);
-int gdrnpp_refine_split_factor(const gdrnpp_meshes* meshes, int b);
-int gdrnpp_refine_to_records_split(const gdrnpp_meshes* meshes, const int* obj, const float* coor_x, const float* coor_y,
-                                   const float* coor_z, const float* mask_raw, const float* roi_depth, const float* cam,
-                                   const float* center, const float* scale, const float* R, const float* t_in,
-                                   const float* score, const int* roi_id, float* rec, int b, int res, int in_res, int iters,
-                                   float threshold, int mask_type, int use_coor_z, float z_near, float z_far, void* workspace,
-                                   size_t workspace_bytes, int split, void* split_workspace, size_t split_workspace_bytes,
-                                   void* stream);
-
 /* device-to-device copy into a raw device pointer on `stream` — the transfer CppEGLRenderer::map_tensor performs with
  * cudaMemcpy2DFromArray in the reference (lib/egl_renderer/cpp/egl_renderer.cpp:262-298): attachment -> caller's tensor */
 int gdrnpp_copy_d2d(void* dst, const void* src, size_t bytes, void* stream);

@@ -563,54 +563,6 @@ def test_fused_tail_equals_the_three_launches(hip):
                          T(maps["t_init"]))
 
 
-@pytest.mark.parametrize("b", [3, 8, 17, 32, 64])
-def test_split_refine_records_are_bit_equal_to_the_one_workgroup_form(hip, b):
-    """Small batches: gdrnpp_refine_to_records_split runs 2 or 4 workgroups per ROI (rasterisation by face range, z-buffers merged
-    through atomic max on ~Z bits, a counter barrier per iteration, the last part zeroes the workspace).  Records bit-equal to the
-    one-workgroup form for every split the device allows, with the parts of a ROI on one XCD (default) AND on neighbouring
-    workgroup ids = different XCDs (device-scope coherence), on repeated launches over the same workspace (it comes back zeroed),
-    with unknown object ids in the batch (no iteration, no barrier), and the status word stays 0 (no barrier timed out)."""
-    rng = np.random.default_rng(100 + b)
-    verts, faces, ext = S.make_models(5, rng, 4)            # 2562 V / 5120 F: the benchmark's meshes
-    det = S.make_detections(b, 5, ext, rng)
-    meshes = hip.MeshSet(verts, faces)
-
-    def render_fn(obj, K, R, t, res):
-        d, x = hip.render_depth(meshes, T(obj), T(K), T(R), T(t), res, want_xyz=True)
-        return d.cpu().numpy(), x.cpu().numpy()
-
-    maps = S.make_map_inputs(det, verts, faces, render_fn, rng)
-    obj = T(det["roi_cls"].astype(np.int32))
-    ids = torch.arange(7, 7 + b, dtype=torch.int32, device=DEV)
-    args = (T(maps["coor_x"]), T(maps["coor_y"]), T(maps["coor_z"]), T(maps["mask"]), T(maps["roi_depth"]), T(det["roi_cam"]).reshape(b, 9),
-            T(det["roi_center"]), T(det["scale"]), T(det["R_gt"]).reshape(b, 9), T(maps["t_init"]), T(det["score"]), ids)
-    lib = hip.load()
-    auto = lib.gdrnpp_refine_split_factor(meshes.c, b)
-    assert auto == (4 if b <= 32 else 2)                    # half of 256 CUs: 32 ROIs x 4 parts, 64 x 2
-    want = hip.refine_to_records(meshes, obj, *args, split=1)
-    assert (want[:, 15] == 1).all() and (want[:, 9:12] != T(maps["t_init"])).any()     # the refinement moved the translations
-    bad = obj.clone()
-    bad[1] = 99
-    want_bad = hip.refine_to_records(meshes, bad, *args, split=1)
-    try:
-        for spread in (0, 1):
-            hip.set_option("refine_split_spread", spread)
-            for split in ([2, 4] if auto == 4 else [2]):
-                for rep in range(3):
-                    assert torch.equal(hip.refine_to_records(meshes, obj, *args, split=split), want), (split, spread, rep)
-                assert torch.equal(hip.refine_to_records(meshes, bad, *args, split=split), want_bad), (split, spread)
-                assert torch.equal(hip.refine_to_records(meshes, obj, *args, split=split), want), (split, spread, "after bad")
-    finally:
-        hip.set_option("refine_split_spread", 0)
-    assert torch.equal(hip.refine_to_records(meshes, obj, *args), want)                 # the automatic choice
-    assert hip.refine_split_status() == 0
-    ws = next(iter(hip._REFINE_SPLIT_WS.values()))
-    torch.cuda.synchronize()
-    assert int(ws.count_nonzero()) == 0                                                 # handed back zeroed
-    with pytest.raises(RuntimeError, match="1, 2 or 4"):
-        hip.refine_to_records(meshes, obj, *args, split=3)
-
-
 def test_pose_from_pred_variants(hip):
     """ROT_TYPE quaternion and TRANS_TYPE centroid_z_abs / trans (GDRN_double_mask.py:162-200) through the one kernel, against
     the reference's own formulas in torch: quat2mat_torch (pose_utils.py:349-400), pose_from_pred_centroid_z_abs.py:44-76,
