@@ -48,6 +48,30 @@ def test_committed_bench_lines_follow_the_contract():
         assert abs(d["value"] - d["n_gpus"] * d["config"]["rois_per_gpu"] * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
 
 
+def test_round5_lines_carry_in_run_parity_and_live_traffic():
+    """Round 5: the driver line proves more by itself — `parity_in_run` (three- vs six-product records of the timed batches and the
+    refine stage against the oracle, both inside the north_star tolerances), `roofline.traffic` measured by rocprofv3 in the run,
+    the CPU forward leg, and (host-fed stream lines) the copy / compute timeline."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05*_bench_refine_b128.json")))
+    assert files, "no committed round-5 bench line under profiles/"
+    for f in files:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        p = d["parity_in_run"]
+        assert p["n_rois"] == 2 * d["config"]["rois_per_gpu"] and p["max_abs_dR"] <= 1e-4 and p["max_abs_dt_m"] <= 1e-4 and p["range_reruns"] == 0
+        o = p["refine_vs_oracle"]
+        assert o["n_rois"] == 16 and o["max_abs_dt_m"] <= o["tolerance_m"] == 1e-5
+        r = d["roofline"]
+        assert r["traffic_source"].startswith("measured in this run") and r["traffic_detail"]["launches_fetch_pass"] > 0
+        assert 1.0 < r["traffic_over_algorithmic"] < 1.6
+        fwd = d["cpu_baseline"]["stages"]["forward_cpu_torch"]
+        assert fwd["unit"] == "ROIs/s" and fwd["value"] > 0 and fwd["cores"] >= 1
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05*_bench_*stream_hostfed.json"))):
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        h = d["host_fed"]
+        assert d["config"]["host_fed"] is True and h["h2d_ms_per_step"] > 0 and h["h2d_bytes_per_step"] > 1e6
+        assert d["value"] >= 0.95 * h["resident_pool_rois_per_s"]          # verdict r4 item 3: >= 0.95 of the resident-pool rate
+
+
 def test_gpus_flag_spawns_ranks_and_gathers_every_roi_once():
     """`python bench.py --gpus 2` without a launcher: spawn, rendezvous on 127.0.0.1, contiguous ROI shards, one all-gather
     of the records, ROI-id permutation check, MAX-over-ranks timing, one JSON line from rank 0 — on CPU through the gloo
