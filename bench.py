@@ -700,7 +700,10 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         if stream is not None and args.host_fed:
             # (a) the copies of the timed steps, device-side; (b) the same steps once more from the HBM-resident pool, same box, same process
             subs = stream["subs"]
-            tl = E.h2d_overlap([c for s_ in subs for c in s_["sched"]._h2d_timing], [t for s_ in subs for t in s_["sched"]._step_timing])
+            tl = E.h2d_overlap([c for s_ in subs for c in s_["sched"]._h2d_timing], [t for s_ in subs for t in s_["sched"]._step_timing],
+                               detail=bool(os.environ.get("GDRNPP_H2D_DEBUG")))
+            if "steps_ms" in tl:
+                sys.stderr.write("H2D_TIMELINE " + json.dumps({"steps_ms": tl.pop("steps_ms")[:8], "copies_ms": tl.pop("copies_ms")[:70]}) + "\n")
             h2d_ms = tl["h2d_ms"]
             h2d_bytes = sum(s_["sched"].h2d_bytes for s_ in subs) - stream["h2d_bytes_warmup"]
             for s_ in subs:

@@ -843,7 +843,7 @@ class RoiPacker:
         return done
 
 
-def h2d_overlap(copies, steps) -> dict:
+def h2d_overlap(copies, steps, detail: bool = False) -> dict:
     """Device timeline of host-to-device copies against compute: ``copies`` = (start, end) timing events on copy streams,
     ``steps`` = (start, end) timing events around the steps' kernels on the compute stream (of one or several schedulers feeding
     the same device); one clock (elapsed time from the first copy's start).  -> h2d_ms (summed copy durations), overlapped_ms
@@ -867,6 +867,9 @@ def h2d_overlap(copies, steps) -> dict:
                     out["overlapped_ms"] += hi - lo
         if out["h2d_ms"] > 0:
             out["overlapped_frac"] = min(1.0, out["overlapped_ms"] / out["h2d_ms"])
+        if detail:
+            out["steps_ms"] = busy
+            out["copies_ms"] = [(origin.elapsed_time(a), origin.elapsed_time(b)) for a, b in copies]
     return out
 
 
