@@ -318,6 +318,7 @@ class StepHandle:
 
     def __init__(self, run, out, host_words=None, event=None):
         self._run, self._out, self._host, self._event = run, out, host_words, event
+        self.reran = False                      # result() repeated the step with six products
 
     def result(self):
         if self._event is not None:
@@ -326,6 +327,7 @@ class StepHandle:
             self._event = self._host = None
             if words:
                 self._out = _six_product_rerun(self._run, words)
+                self.reran = True
         self._run = None
         return self._out
 
@@ -691,6 +693,33 @@ def detections_from_bop_json(detections: dict, scene_im_ids, obj_ids, cam, exten
                 time=np.asarray(times, np.float32))
 
 
+def upload_packed(arrays: dict, dev) -> dict:
+    """The small per-ROI host arrays of a step -> device tensors through ONE pinned staging buffer and ONE asynchronous copy on the
+    current stream.  A ``torch.from_numpy(a).to(dev)`` per array is a blocking pageable copy queued behind everything already on
+    the stream: the host would sit out the step that is still running there before it could prepare the next one."""
+    import numpy as np
+
+    dev = torch.device(dev)
+    arrs, offs, total = {}, {}, 0
+    for k, a in arrays.items():
+        a = np.ascontiguousarray(a)
+        arrs[k] = a
+        total = (total + 15) & ~15
+        offs[k] = total
+        total += a.nbytes
+    host = torch.empty((max(total, 16),), dtype=torch.uint8, pin_memory=dev.type == "cuda")
+    hv = host.numpy()
+    for k, a in arrs.items():
+        if a.nbytes:
+            hv[offs[k]:offs[k] + a.nbytes] = a.reshape(-1).view(np.uint8)
+    d = host.to(dev, non_blocking=True)
+    out = {}
+    for k, a in arrs.items():
+        dt = torch.from_numpy(np.empty((0,), a.dtype)).dtype
+        out[k] = d[offs[k]:offs[k] + a.nbytes].view(dt).reshape(a.shape)
+    return out
+
+
 def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, device=None, sort_by_class: bool = False,
                         roi_id_base: int = 0, extra_per_roi_keys=(), extra_global_keys=()) -> dict:
     """``read_data_test`` + ``batch_data_test`` (data_loader.py:647-818, engine_utils.py:213-241) with the crops made
@@ -716,25 +745,26 @@ def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, dev
     cam = np.asarray(detections["cam"], np.float32)
     cam = np.repeat(cam[None], n, 0) if cam.ndim == 2 else cam
 
-    def T(a, dt=None):
-        t = torch.from_numpy(np.ascontiguousarray(a))
-        return (t.to(dt) if dt is not None else t).to(dev)
-
-    centers64, scales64 = T(r["bbox_center"]), T(r["scale"])
+    host = dict(center64=r["bbox_center"], scale64=r["scale"], im_idx=np.asarray(detections["im_idx"], np.int32), roi_cls=cls, roi_cam=cam,
+                roi_center=np.asarray(r["bbox_center"], np.float32), roi_wh=r["roi_wh"], scale=np.asarray(r["scale"], np.float32),
+                resize_ratio=np.asarray(r["resize_ratio"], np.float32), roi_extent=np.asarray(detections["extents"], np.float32)[cls],
+                score=np.asarray(detections.get("score", np.ones(n)), np.float32))
+    if roi_id is not None:
+        host["roi_id"] = np.asarray(roi_id, np.int32)
+    up = upload_packed(host, dev)                 # one pinned buffer, one asynchronous copy: the host never waits for the stream
+    centers64, scales64 = up["center64"], up["scale64"]
     roi_img, roi_depth, roi_c2d = hip_lib.crop_resize_roi(
-        images, depths, T(np.asarray(detections["im_idx"], np.int32)), centers64, scales64,
+        images, depths, up["im_idx"], centers64, scales64,
         out_res=net_cfg.INPUT_RES, out_res_small=net_cfg.OUTPUT_RES, pixel_mean=cfg.MODEL.PIXEL_MEAN,
         pixel_std=cfg.MODEL.PIXEL_STD)
     batch = dict(
-        roi_img=roi_img, roi_coord_2d=roi_c2d, roi_cls=T(cls), roi_cam=T(cam), roi_center=T(r["bbox_center"], torch.float32),
-        roi_wh=T(r["roi_wh"]), scale=T(r["scale"], torch.float32), resize_ratio=T(r["resize_ratio"], torch.float32),
-        roi_extent=T(np.asarray(detections["extents"], np.float32)[cls]),
-        score=T(np.asarray(detections.get("score", np.ones(n)), np.float32)),
+        roi_img=roi_img, roi_coord_2d=roi_c2d, roi_cls=up["roi_cls"], roi_cam=up["roi_cam"], roi_center=up["roi_center"],
+        roi_wh=up["roi_wh"], scale=up["scale"], resize_ratio=up["resize_ratio"], roi_extent=up["roi_extent"], score=up["score"],
         im_H=torch.full((n,), float(H), device=dev), im_W=torch.full((n,), float(W), device=dev))
     if roi_depth is not None:
         batch["roi_depth"] = roi_depth
     if roi_id is not None:
-        batch["roi_id"] = T(roi_id)
+        batch["roi_id"] = up["roi_id"]
     if net_cfg.PNP_NET.COORD_2D_TYPE == "rel":
         # data_loader.py:799-804: (bbox_center - roi_coord_2d * (im_W, im_H)) / scale, float64 like NumPy, stored float32
         wh = torch.tensor([float(W), float(H)], dtype=torch.float64, device=dev).view(1, 2, 1, 1)
@@ -913,6 +943,7 @@ class RoiStreamScheduler:
         self._arrival = {}
         self._in_flight = collections.deque()   # (StepHandle, batch) — the batch stays alive for a six-product repeat
         self._with_depth = None                 # fixed by the first image that has ROIs
+        self._d2h_stream = None                 # side stream of the 8 KB record copies
         self.steps_launched = 0
 
     # -- one step ----------------------------------------------------------------------------------
@@ -947,7 +978,10 @@ class RoiStreamScheduler:
             t0 = torch.cuda.Event(enable_timing=True)
             t0.record()
         batch = batch_data_test_gpu(self.cfg, images, depths, det, sort_by_class=True)
-        self._in_flight.append((inference_step_async(self.model, self.post, batch), batch))
+        handle = inference_step_async(self.model, self.post, batch)
+        done = torch.cuda.Event()               # everything of this step, on the compute stream
+        done.record()
+        self._in_flight.append((handle, batch, done))
         if self._time_h2d:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record()
@@ -959,9 +993,25 @@ class RoiStreamScheduler:
                 self._h2d_ready.pop(k, None)
 
     def _resolve_oldest(self):
-        handle, _batch = self._in_flight.popleft()
-        rec = handle.result()
-        self.packer.deliver(rec.cpu().numpy())
+        """Records of the OLDEST step in flight -> their images.  The 8 KB device-to-host copy runs on a side stream behind that
+        step's own event: a ``rec.cpu()`` on the compute stream would queue behind the NEWER steps already launched there and
+        stall the host until they finish — no step would ever be prepared while another runs (measured: every image copy of a
+        host-fed stream landed in the idle gap between two steps, profiles/r05d_h2d_timeline_before_fix.txt)."""
+        handle, _batch, done = self._in_flight.popleft()
+        rec = handle.result()                   # waits for that step's range-word event only (and repeats a flagged step)
+        if rec.is_cuda:
+            if self._d2h_stream is None:
+                self._d2h_stream = torch.cuda.Stream(device=rec.device)
+            with torch.cuda.stream(self._d2h_stream):
+                if handle.reran:                # a six-product repeat ran on the compute stream just now: its records are the newest work there
+                    self._d2h_stream.wait_stream(torch.cuda.current_stream(rec.device))
+                else:
+                    self._d2h_stream.wait_event(done)
+                host = rec.to("cpu", non_blocking=False)
+            rec.record_stream(self._d2h_stream)
+        else:
+            host = rec
+        self.packer.deliver(host.numpy())
         return rec
 
     def _finished(self):

@@ -489,6 +489,20 @@ def test_roi_packer_deals_exact_steps_and_returns_records_to_their_images():
         assert done[k].shape == (n, 16) and done[k][:, 0].tolist() == [1000 * k + j for j in range(n)]
 
 
+def test_upload_packed_round_trips_every_dtype_and_shape():
+    """engine.upload_packed: the per-ROI host arrays of a step through one staging buffer (pinned + one asynchronous copy on a
+    device) come back as tensors of the same dtype / shape / values, 16-byte aligned, empty arrays included."""
+    rng = np.random.default_rng(3)
+    arrays = dict(center64=rng.uniform(0, 640, (7, 2)), scale64=rng.uniform(10, 300, 7), im_idx=rng.integers(0, 4, 7).astype(np.int32),
+                  roi_cls=rng.integers(0, 21, 7), cam=np.tile(np.eye(3, dtype=np.float32), (7, 1, 1)), score=rng.uniform(0, 1, 7).astype(np.float32),
+                  empty=np.zeros((0, 3), np.float32), ids=np.arange(7, dtype=np.int32)[::-1])
+    out = engine.upload_packed(arrays, "cpu")
+    assert list(out) == list(arrays)
+    for k, a in arrays.items():
+        assert out[k].shape == a.shape and np.array_equal(out[k].numpy(), a) and str(out[k].dtype).split(".")[1] == str(a.dtype), k
+        assert out[k].data_ptr() % 16 == 0 or a.size == 0
+
+
 def test_roi_packer_delivers_invalid_records_and_scheduler_admission_is_atomic():
     """(round-4 advice) A real ROI may come back with valid = 0 (depth refine: object id outside the mesh set): its image must
     still complete and keep the row's valid bit; only all-zero padding rows and foreign ids are skipped.  A key pushed while it
