@@ -315,31 +315,69 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DW_WPE))) v
 // bilinear x2 upsample, align_corners=True (nn.UpsamplingBilinear2d), NHWC.  Index/lambda arithmetic follows
 // ATen's area_pixel_compute_source_index (scale = (in-1)/(out-1) in fp32, src = scale*dst).
 // --------------------------------------------------------------------------------------------------
-__global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+// One thread = one channel quad of a 2 x 2 OUTPUT block (the four outputs above input pixel (i, j)): with scale (H-1)/(2H-1) the
+// source rows of output rows 2i / 2i+1 are (ya, ya+1) and (ya+1, ya+2) — the same for columns — except in the first block row /
+// column, so nine 16-byte loads serve four outputs instead of sixteen.  The kernel was bound by those loads (L2 -> L1 traffic 4x
+// the output bytes), not by HBM.  Each output is the expression of the one-output form below, bit for bit (generic path = that
+// form, taken where the row / column pattern differs).
+__device__ __forceinline__ float4 bilerp4(float ly0, float ly1, float lx0, float lx1, float4 v00, float4 v01, float4 v10, float4 v11) {
+  float4 o;
+  o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+  o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+  o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+  o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+  return o;
+}
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
   const int Q = C >> 2;
   const int OH = 2 * H, OW = 2 * W;
-  const long total = (long)N * OH * OW * Q;
+  const long total = (long)N * H * W * Q;
   const float sh = (OH > 1) ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float sw = (OW > 1) ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % Q);
-    long p = i / Q;
-    const int ox = (int)(p % OW); p /= OW;
-    const int oy = (int)(p % OH);
-    const int n = (int)(p / OH);
-    const float fy = sh * (float)oy, fx = sw * (float)ox;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int yp = (y0 < H - 1) ? 1 : 0, xp = (x0 < W - 1) ? 1 : 0;
-    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(t % Q);
+    long p = t / Q;
+    const int j = (int)(p % W); p /= W;
+    const int i = (int)(p % H);
+    const int n = (int)(p / H);
+    float fy[2], fx[2];
+    int y0[2], x0[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      fy[d] = sh * (float)(2 * i + d); y0[d] = (int)fy[d];
+      fx[d] = sw * (float)(2 * j + d); x0[d] = (int)fx[d];
+    }
     const float* b = x + ((size_t)n * H * W) * C + 4 * q;
-    const float4 v00 = ld4(b + ((size_t)y0 * W + x0) * C), v01 = ld4(b + ((size_t)y0 * W + x0 + xp) * C);
-    const float4 v10 = ld4(b + ((size_t)(y0 + yp) * W + x0) * C), v11 = ld4(b + ((size_t)(y0 + yp) * W + x0 + xp) * C);
-    float4 o;
-    o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
-    o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
-    o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
-    o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
-    st4s(y + (((size_t)n * OH + oy) * OW + ox) * C + 4 * q, o);
+    float* yo = y + (((size_t)n * OH + 2 * i) * OW + 2 * j) * C + 4 * q;
+    if (y0[1] == y0[0] + 1 && x0[1] == x0[0] + 1) {
+      const int ya = y0[0], xa = x0[0];
+      const int r2 = min(ya + 2, H - 1), c2 = min(xa + 2, W - 1);
+      const int rr[3] = {ya, ya + 1, r2}, cc[3] = {xa, xa + 1, c2};
+      float4 v[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[r][c] = ld4(b + ((size_t)rr[r] * W + cc[c]) * C);
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const float ly1 = fy[dy] - (float)y0[dy], ly0 = 1.f - ly1, lx1 = fx[dx] - (float)x0[dx], lx0 = 1.f - lx1;
+          st4s(yo + ((size_t)dy * OW + dx) * C, bilerp4(ly0, ly1, lx0, lx1, v[dy][dx], v[dy][dx + 1], v[dy + 1][dx], v[dy + 1][dx + 1]));
+        }
+    } else {
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int yy = y0[dy], xx = x0[dx];
+          const int yp = (yy < H - 1) ? 1 : 0, xp = (xx < W - 1) ? 1 : 0;
+          const float ly1 = fy[dy] - (float)yy, ly0 = 1.f - ly1, lx1 = fx[dx] - (float)xx, lx0 = 1.f - lx1;
+          const float4 v00 = ld4(b + ((size_t)yy * W + xx) * C), v01 = ld4(b + ((size_t)yy * W + xx + xp) * C);
+          const float4 v10 = ld4(b + ((size_t)(yy + yp) * W + xx) * C), v11 = ld4(b + ((size_t)(yy + yp) * W + xx + xp) * C);
+          st4s(yo + ((size_t)dy * OW + dx) * C, bilerp4(ly0, ly1, lx0, lx1, v00, v01, v10, v11));
+        }
+    }
   }
 }
 
@@ -511,7 +549,33 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   __shared__ float s_mean[64], s_rstd[64];
   const int Q = C >> 2, cpg = C / G;
   const int n = blockIdx.y;
-  if ((int)threadIdx.x < G) {
+  // Group statistics from the P x G fp64 partials.  Every workgroup needs them before it can stream: 8 lanes per group share the P
+  // partials (8 independent loads in flight per lane instead of a chain of 64 per group thread: the serial form held each of the
+  // 8192 workgroups of a 64x64 launch ~6 us before its first store — a quarter of its lifetime), then a 3-step shuffle tree.
+  if (G * 8 <= (int)blockDim.x) {
+    const int g8 = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    double a = 0.0, c2 = 0.0;
+    if (g8 < G) {
+      for (int p = sub; p < P; p += 8) {
+        const double* o = part + (((size_t)n * P + p) * G + g8) * 2;
+        a += o[0];
+        c2 += o[1];
+      }
+    }
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) {
+      a += __shfl_xor(a, off, 64);
+      c2 += __shfl_xor(c2, off, 64);
+    }
+    if (g8 < G && sub == 0) {
+      const double cnt = (double)HW * cpg;
+      const double m = a / cnt;
+      double var = c2 / cnt - m * m;
+      if (var < 0.0) var = 0.0;
+      s_mean[g8] = (float)m;
+      s_rstd[g8] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  } else if ((int)threadIdx.x < G) {
     double a = 0.0, c2 = 0.0;
     for (int p = 0; p < P; ++p) {
       const double* o = part + (((size_t)n * P + p) * G + threadIdx.x) * 2;
@@ -688,6 +752,8 @@ __global__ __launch_bounds__(256) void layernorm_nhwc_kernel(const float* __rest
 // a layout copy and a LayerNorm launch followed.  One wave = the 64 channel pairs of a pixel: the 2 x 48 weights of a lane
 // live in registers for the whole kernel, the 4 x 256 x 3 input floats of an output row are staged in LDS and read back as
 // broadcast float4s, LayerNorm over the 128 channels is a wave reduction (DPP).  fp32 fma chain in (ci, ky, kx) order.
+// (Round 5: the lane's two channels as one v_pk_fma_f32 accumulator — 48 instead of 96 instructions per pixel — ran 194 instead of
+// 164 us: one dependent chain per wave instead of two independent ones; not kept, gpurun_out/r05f.)
 // --------------------------------------------------------------------------------------------------
 constexpr int kStemC = 128, kStemK = 48;
 __global__ __launch_bounds__(256) void stem_conv_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -911,7 +977,7 @@ int gdrnpp_upsample_bilinear2x_nhwc(const float* x, float* y, int N, int H, int 
   GDRNPP_REQUIRE(x && y, GDRNPP_EINVAL, "gdrnpp_upsample_bilinear2x_nhwc: null pointer");
   GDRNPP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, GDRNPP_EINVAL,
                  "gdrnpp_upsample_bilinear2x_nhwc: N=%d H=%d W=%d C=%d (C %% 4 == 0 required)", N, H, W, C);
-  const long total = (long)N * 4 * H * W * (C / 4);
+  const long total = (long)N * H * W * (C / 4);          // one thread per channel quad of a 2 x 2 output block
   const long blocks = (total + 255) / 256;
   hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)(blocks < 65536 * 8 ? blocks : 65536 * 8)), dim3(256), 0,
                      (hipStream_t)stream, x, y, N, H, W, C);

@@ -39,7 +39,8 @@ def test_dwconv7x7_ln(hip, n, c, h, w, fuse_ln, tile):
     torch.testing.assert_close(y, ref, rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("n,c,h,w", [(4, 256, 16, 16), (2, 256, 32, 32), (1, 8, 3, 5)])
+@pytest.mark.parametrize("n,c,h,w", [(4, 256, 16, 16), (2, 256, 32, 32), (1, 8, 3, 5), (1, 4, 1, 1), (2, 12, 1, 7), (3, 16, 2, 2),
+                                     (1, 128, 64, 48)])
 def test_upsample_bilinear2x(hip, n, c, h, w):
     torch.manual_seed(0)
     x = _cl(torch.randn(n, c, h, w, device=DEV))
