@@ -5,7 +5,7 @@ out=${1:-gpurun_out/bench_configs.jsonl}
 mkdir -p "$(dirname "$out")"
 : > "$out"
 for w in lmo_upnp rgb refine tless bop7; do
-  extra="--no-cpu-baseline"
+  extra="--no-cpu-baseline --no-pmc"
   [ "$w" = refine ] && extra=""
   python bench.py --workload $w --steps 20 --warmup 3 $extra 2>>"$out.err" | grep '^{' >> "$out"
 done

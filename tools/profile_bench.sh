@@ -7,11 +7,11 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_${1:-r02}
 rm -rf $O; mkdir -p $O
 cd $R
-B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline-pass --no-other-mode-line"
+B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline-pass --no-other-mode-line --no-pmc --pmc-child"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O/bench_under_trace.json 2> $O/trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline-pass --no-other-mode-line > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline-pass --no-other-mode-line > /dev/null 2> $O/pmc_write.err
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline-pass --no-other-mode-line > /dev/null 2> $O/pmc_mfma.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline-pass --no-other-mode-line --no-pmc --pmc-child > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline-pass --no-other-mode-line --no-pmc --pmc-child > /dev/null 2> $O/pmc_write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline-pass --no-other-mode-line --no-pmc --pmc-child > /dev/null 2> $O/pmc_mfma.err
 python tools/pmc_parse_bench_gemm.py $O/pmc_fetch $O/pmc_write > $O/pmc_gemm_traffic.json
 python tools/pmc_mfma_busy.py $O/pmc_mfma > $O/pmc_gemm_mfma_busy.json
 ( for k in gemm_split2_pipe mlp_fused_x3 dwconv7_ln gn_apply depth_refine; do python tools/pmc_clock.py $O/pmc_mfma $k; done ) > $O/effective_clock.txt 2>&1

@@ -6,7 +6,7 @@ mkdir -p "$(dirname "$out")"
 : > "$out"
 for b in 8 16 32 64; do
   for g in "" "--graph"; do
-    python bench.py --batch $b --steps 40 --warmup 5 --no-cpu-baseline $g 2>>"$out.err" | grep '^{' >> "$out"
+    python bench.py --batch $b --steps 40 --warmup 5 --no-cpu-baseline --no-pmc $g 2>>"$out.err" | grep '^{' >> "$out"
   done
 done
 python - "$out" <<'PY'
