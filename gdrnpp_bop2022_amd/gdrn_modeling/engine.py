@@ -941,7 +941,7 @@ class RoiStreamScheduler:
         self.max_in_flight = max(1, int(max_in_flight))
         self._images = {}                       # key -> (image, depth, detections, arrival time)
         self._arrival = {}
-        self._in_flight = collections.deque()   # (StepHandle, batch) — the batch stays alive for a six-product repeat
+        self._in_flight = collections.deque()   # (StepHandle, batch, done event) — the batch stays alive for a six-product repeat
         self._with_depth = None                 # fixed by the first image that has ROIs
         self._d2h_stream = None                 # side stream of the 8 KB record copies
         self.steps_launched = 0
@@ -1002,9 +1002,10 @@ class RoiStreamScheduler:
         if rec.is_cuda:
             if self._d2h_stream is None:
                 self._d2h_stream = torch.cuda.Stream(device=rec.device)
+            compute = torch.cuda.current_stream(rec.device)      # looked up OUTSIDE the side stream's context
             with torch.cuda.stream(self._d2h_stream):
                 if handle.reran:                # a six-product repeat ran on the compute stream just now: its records are the newest work there
-                    self._d2h_stream.wait_stream(torch.cuda.current_stream(rec.device))
+                    self._d2h_stream.wait_stream(compute)
                 else:
                     self._d2h_stream.wait_event(done)
                 host = rec.to("cpu", non_blocking=False)
