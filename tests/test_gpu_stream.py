@@ -122,3 +122,53 @@ def test_host_fed_stream_equals_the_device_resident_one_bit_for_bit(setup):
     tl = sch.h2d_timeline()
     assert tl["images"] == n_img and tl["steps"] == sch.steps_launched and tl["h2d_ms"] > 0 and 0.0 <= tl["overlapped_frac"] <= 1.0
     assert not sch._h2d_ready and not sch._images                      # nothing of the stream is kept alive
+
+
+def test_a_flagged_step_inside_the_scheduler_is_repeated_with_six_products(setup):
+    """A three-product launch of a step leaves the fp16x2 range (one block's LayerNorm output shrunk to the 1e-3 scale): the
+    scheduler's resolve repeats that step with six products on the compute stream and reads the REPEATED records back (the
+    side-stream copy waits for the compute stream then, not for the step's first event) — every image gets exactly the records
+    of the six-product mode; steps launched after the verdict run with the layer demoted and need no repeat."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
+
+    cfg, model, post, stream = setup
+    P = 32
+
+    def run():
+        sch = engine.RoiStreamScheduler(cfg, model, post, rois_per_step=P)
+        out = {}
+        for key, img, dep, det in stream:
+            for k, rec, _ in sch.push(key, img, dep, det):
+                out[k] = rec
+        for k, rec, _ in sch.flush():
+            out[k] = rec
+        return out
+
+    blk = model.backbone.stages_0.blocks[1]
+    w_ok, b_ok = blk.norm.weight.detach().clone(), blk.norm.bias.detach().clone()
+    old = hip_layers.gemm_products()
+    try:
+        with torch.no_grad():
+            blk.norm.weight.mul_(1e-3)
+            blk.norm.bias.mul_(1e-3)
+        hip_layers.set_gemm_products(6)
+        want = run()
+        hip_layers.set_gemm_products(3)
+        hip_layers.reset_x3_demotions()
+        reruns = engine.range_reruns()
+        got = run()
+        # the steps launched before the first verdict was read (up to max_in_flight + 1 = 3) run the layer on three products too
+        assert 1 <= engine.range_reruns() - reruns <= 3 and len(hip_layers.x3_demoted()) >= 1
+        assert sorted(got) == sorted(want)
+        first = [k for k, _, _, d in stream if len(d["roi_cls"])][:2]                         # images of the flagged (first) step
+        for k in first:
+            assert np.array_equal(got[k], want[k]), k                                           # the repeat IS the six-product step
+        for k in want:
+            assert np.abs(got[k][:, :12] - want[k][:, :12]).max(initial=0.0) <= 1e-4, k
+    finally:
+        with torch.no_grad():
+            blk.norm.weight.copy_(w_ok)
+            blk.norm.bias.copy_(b_ok)
+        hip_layers.set_gemm_products(old)
+        hip_layers.reset_x3_demotions()
+        engine._X3_OVERFLOW_STEPS = 0
