@@ -128,6 +128,9 @@ def parse(argv=None):
     p.add_argument("--gather-to-rank0", action="store_true",
                    help="gather the records to rank 0 only (dist.gather; the reference lets only the main process write, "
                         "gdrn_evaluator.py:581-582) instead of the all-gather")
+    p.add_argument("--force-dist", action="store_true",
+                   help="initialise the process group even with one rank and send the records through the collective: the closest a "
+                        "1-GPU box gets to the N > 1 path (RCCL loads, rendezvous on 127.0.0.1, all_gather_into_tensor on the device)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --stub-step: CPU test of the launch path")
     p.add_argument("--stub-step", action="store_true",
                    help="(tests) replace the GPU step by a host stub that emits this rank's records: exercises spawn, "
@@ -250,8 +253,12 @@ def worker(args):
         assert torch.cuda.is_available(), "bench.py needs a HIP device"
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
         else:
@@ -298,17 +305,17 @@ def worker(args):
     sync()
     if state is not None and state.get("after_warmup"):
         state["after_warmup"]()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     rec = run_steps(args.steps)
     sync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -324,7 +331,7 @@ def worker(args):
             assert len(ids) == n_global and np.array_equal(np.sort(ids), np.arange(n_global)), "gathered records: ROI ids not a permutation"
 
     gather_ms, collective = None, None
-    if world > 1:                                           # the collective alone, after the timed region
+    if use_dist:                                            # the collective alone, after the timed region
         local = torch.zeros((b, 16), dtype=torch.float32, device=dev)
         local[:, 14] = roi_ids.float()
         for _ in range(3):
@@ -343,7 +350,7 @@ def worker(args):
 
     extras = {}
     if args.pmc_child:          # the run rocprofv3 wraps: the steps above are all it is for
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         print(json.dumps({"pmc_child": True, "ms_per_step": dt / args.steps * 1e3}), flush=True)
@@ -399,7 +406,7 @@ def worker(args):
                 "baseline_config_index": cfg_no, "workload_key": wname, "global_batch": n_global, "rois_per_gpu": b,
                 "roi_prep_on_gpu": bool(args.with_crop) or wname.endswith("stream"), "host_fed": bool(args.host_fed), "hipgraph": bool(args.graph), "input_res": 256, "output_res": 64,
                 "parallelism": f"roi-shard x{world}",
-                "collective": (("gather(dst=0)" if dst is not None else "all_gather") + " f32[n,16] pose records") if world > 1 else None,
+                "collective": (("gather(dst=0)" if dst is not None else "all_gather") + " f32[n,16] pose records") if use_dist else None,
                 "class_sliced_out_layer": not args.exact_reference_order, "rois_class_sorted_within_rank": True,
                 "parameters": "default-init" if args.random_init else "seeded O(1)", "hip_network_layers": not args.no_hip_layers,
                 "mlp_gemm": args.mlp_gemm, "gemm_products": args.gemm_products, "fused_mlp": (not args.no_fused_mlp) and args.fused_mlp_max_c, "f16x2_rows": not args.no_f16x2_rows,
@@ -423,7 +430,7 @@ def worker(args):
         line.setdefault("roofline", None)
         line.setdefault("cpu_baseline", None)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -398,9 +398,9 @@ def gather_records(rec: torch.Tensor, n_local_max: int, group=None, dst: int | N
     if rec.shape[0] < n_local_max:
         pad = torch.zeros((n_local_max - rec.shape[0], 16), dtype=rec.dtype, device=rec.device)
         rec = torch.cat([rec, pad], 0)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return rec
-    world = dist.get_world_size(group)
+    world = dist.get_world_size(group)          # a one-rank group still goes through the collective (bench.py --force-dist)
     rec = rec.contiguous()
     if dst is not None:
         mine = dist.get_rank(group) == dst
