@@ -126,6 +126,22 @@ def test_gather_to_rank0_mirrors_the_main_process_only_write():
     assert d["config"]["collective"].startswith("gather(dst=0)")
 
 
+def test_force_dist_runs_the_collective_with_one_rank():
+    """--force-dist: a one-rank process group (what a 1-GPU box can show of the N > 1 path: profiles/r05k_*): the records go through
+    the collective, the line carries the collective block."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--backend", "gloo", "--stub-step", "--steps", "2",
+                        "--warmup", "1", "--batch", "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["collective"]["world_size_seen"] == 1 and d["collective"]["backend"] == "gloo" and d["gather_ms"] > 0
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05k_bench_rccl_one_rank_*.json"))):
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        assert d["collective"]["backend"] == "nccl" and d["collective"]["rank0_device"] == "cuda:0" and d["product_path"] is True
+
+
 def test_world_size_must_match_gpus_flag():
     import subprocess
     import sys
