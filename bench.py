@@ -20,18 +20,29 @@ Workloads (``--workload``; index into BASELINE.json ``configs``):
   bop7_stream              configs[4]  the same image-stream feed for all seven BOP datasets (one stream + model each, cycled per step);
                            with --host-fed every image starts in pinned host memory: detections -> pose -> refine end to end
 
+  --host-fed (stream workloads): every image starts in pinned host memory (the reference's loader hands over host arrays) and is
+  copied once on the scheduler's copy stream, one step ahead of the device; the line reports h2d_ms_per_step, h2d_overlapped_frac
+  (device timeline of copy vs step events) and the resident-pool rate of the same process.
+
 Multi-GPU: ``python bench.py --gpus N`` spawns N ranks by itself (one process per GPU, RCCL); under
 ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` it joins the launcher's ranks instead.
 ROIs are sharded (every rank owns its contiguous block of the global ROI ids, weak scaling); the only collective is the
-all-gather of the pose records, and rank 0 checks that the gathered block holds every ROI id exactly once.
+all-gather of the pose records (``--gather-to-rank0``: a gather to the main process, as the reference's evaluate() only lets that
+one write), and rank 0 checks that the gathered block holds every ROI id exactly once.  ``--force-dist`` runs the same path with a
+one-rank process group (what a 1-GPU box can show of it); the line's ``collective`` block is read from the process group itself.
 
 Rank 0 prints ONE JSON line (driver contract) carrying two extra objects:
-  roofline      the dominant kernel, gemm_split_kernel (MFMA-bound): bf16 MFMA flops executed / summed launch durations,
+  roofline      the dominant kernel family, the split GEMMs (MFMA-bound): MFMA flops executed / summed launch durations,
                 every launch bracketed by HIP events on the launch stream in a SEPARATE pass of the same steps right after
-                the timed region (the timed region itself carries no per-launch events); ``roofline_other_kernels``: the
-                refine kernel and the other hand-written kernels against the HBM roofline.
+                the timed region (the timed region itself carries no per-launch events); ``traffic`` = HBM-side bytes per launch
+                measured IN this run: two child runs of this command under ``rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace``
+                (``--no-pmc``: the committed figure instead); ``roofline_other_kernels``: the refine kernel and the other
+                hand-written kernels against the HBM / vector roofline.
+  parity_in_run records of the timed batches under the headline arithmetic vs the exact six-product form (max |dR|, max |dt|), and the
+                refine stage's t of 16 ROIs vs the CPU oracle (computed in the cpu_baseline child)
   cpu_baseline  oracle/cpu_baseline.py in a child process on the host cores (N = 1 only): refine stage 1 thread and all
-                cores, uncertainty-PnP, decode, and the reference's own compiled FPS / NN-distance / flow sources.
+                cores, uncertainty-PnP, decode, the reference's own compiled FPS / NN-distance / flow sources, and the network
+                forward with PyTorch's CPU operators (configs[0]: ResNet-34 forward + uncertainty-PnP end to end).
 """
 from __future__ import annotations
 
