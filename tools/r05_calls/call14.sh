@@ -1,0 +1,12 @@
+#!/bin/bash
+# final commit check: what the driver runs — pytest -m gpu, smoke(), default bench.py
+O=gpurun_out/r05final; mkdir -p $O
+( timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -4 ) > $O/gpu_tests.txt
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 ) >> $O/gpu_tests.txt
+cat $O/gpu_tests.txt
+/usr/bin/time -v python bench.py > $O/bench_default.json 2> $O/bench_default.err; grep -E "Elapsed|Maximum resident" $O/bench_default.err
+python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/r05final/bench_default.json') if l.startswith('{')][-1])
+print(round(d['value'],1), round(d['ms_per_step'],3), d['steps'], d['warmup'], d['parity_in_run']['max_abs_dR'], d['roofline']['frac'], d['roofline']['traffic'], d.get('pmc_live_seconds'), d['cpu_baseline']['value'])
+PY
