@@ -1,10 +1,7 @@
 #!/bin/bash
 # final commit check: what the driver runs — pytest -m gpu, smoke(), default bench.py
 O=gpurun_out/r05final; mkdir -p $O
-( timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -4 ) > $O/gpu_tests.txt
-( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 ) >> $O/gpu_tests.txt
-cat $O/gpu_tests.txt
-/usr/bin/time -v python bench.py > $O/bench_default.json 2> $O/bench_default.err; grep -E "Elapsed|Maximum resident" $O/bench_default.err
+S=$(date +%s); python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench.py wall: $(( $(date +%s) - S )) s"
 python - <<'PY'
 import json
 d=json.loads([l for l in open('gpurun_out/r05final/bench_default.json') if l.startswith('{')][-1])
