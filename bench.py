@@ -308,9 +308,9 @@ def worker(args):
         for i in range(n):
             cur = launch(i)
             if prev is not None:
-                rec = gather_records(prev(), b, dst=dst)
+                rec = gather_records(prev(), b, dst=dst, single_rank_collective=args.force_dist)
             prev = cur
-        return gather_records(prev(), b, dst=dst)
+        return gather_records(prev(), b, dst=dst, single_rank_collective=args.force_dist)
 
     run_steps(max(args.warmup, 1) * len(cfg_names) * 2)   # MIOpen find, weight packing, first range verdicts, both batches of every model
     sync()
@@ -346,11 +346,11 @@ def worker(args):
         local = torch.zeros((b, 16), dtype=torch.float32, device=dev)
         local[:, 14] = roi_ids.float()
         for _ in range(3):
-            gather_records(local, b, dst=dst)
+            gather_records(local, b, dst=dst, single_rank_collective=args.force_dist)
         sync()
         g0 = time.perf_counter()
         for _ in range(20):
-            gather_records(local, b, dst=dst)
+            gather_records(local, b, dst=dst, single_rank_collective=args.force_dist)
         sync()
         gather_ms = (time.perf_counter() - g0) / 20 * 1e3
         # what the process group itself reports: a SCALE run proves from this that RCCL really saw N ranks

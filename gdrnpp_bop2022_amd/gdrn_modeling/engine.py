@@ -387,20 +387,23 @@ def inference_step(model, post: GdrnHipPost, batch: dict, roi_ids: torch.Tensor 
     return inference_step_async(model, post, batch, roi_ids).result()
 
 
-def gather_records(rec: torch.Tensor, n_local_max: int, group=None, dst: int | None = None):
+def gather_records(rec: torch.Tensor, n_local_max: int, group=None, dst: int | None = None, single_rank_collective: bool = False):
     """The one collective of the inference path (gdrn_evaluator.py:575-585 / my_comm.py:70-171): instead of
     pickling Python dicts into byte tensors (size all-gather + padded byte all-gather), every rank contributes a
     fixed-shape f32[n_local_max,16] block (``valid`` = 0 on padding rows) to ONE all_gather — 64 B per ROI,
     latency-bound on xGMI.  Returns f32[world*n_local_max,16] on every rank.
 
-    ``dst``: gather to that rank only (``my_comm.gather``, my_comm.py:119-171; the reference's ``evaluate`` lets only the main
+    ``single_rank_collective``: run the collective even in a one-rank group (``bench.py --force-dist``: what a 1-GPU box can show
+    of the path).  ``dst``: gather to that rank only (``my_comm.gather``, my_comm.py:119-171; the reference's ``evaluate`` lets only the main
     process go on to write the results, gdrn_evaluator.py:581-582): rank ``dst`` gets the block, every other rank ``None``."""
     if rec.shape[0] < n_local_max:
         pad = torch.zeros((n_local_max - rec.shape[0], 16), dtype=rec.dtype, device=rec.device)
         rec = torch.cat([rec, pad], 0)
     if not (dist.is_available() and dist.is_initialized()):
         return rec
-    world = dist.get_world_size(group)          # a one-rank group still goes through the collective (bench.py --force-dist)
+    world = dist.get_world_size(group)
+    if world == 1 and not single_rank_collective:     # bench.py --force-dist sends a one-rank group's records through the collective
+        return rec
     rec = rec.contiguous()
     if dst is not None:
         mine = dist.get_rank(group) == dst
