@@ -753,7 +753,8 @@ __global__ __launch_bounds__(256) void layernorm_nhwc_kernel(const float* __rest
 // live in registers for the whole kernel, the 4 x 256 x 3 input floats of an output row are staged in LDS and read back as
 // broadcast float4s, LayerNorm over the 128 channels is a wave reduction (DPP).  fp32 fma chain in (ci, ky, kx) order.
 // (Round 5: the lane's two channels as one v_pk_fma_f32 accumulator — 48 instead of 96 instructions per pixel — ran 194 instead of
-// 164 us: one dependent chain per wave instead of two independent ones; not kept, gpurun_out/r05f.)
+// 164 us in the step, and with two pixels per trip (two independent packed chains) 211 instead of 191 us isolated: the packed form
+// with a broadcast operand issues slower than two scalar chains (profiles/r04_dwconv_valu.txt, pk_bcast); not kept.)
 // --------------------------------------------------------------------------------------------------
 constexpr int kStemC = 128, kStemK = 48;
 __global__ __launch_bounds__(256) void stem_conv_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
