@@ -437,6 +437,21 @@ def records_to_bop(rec: torch.Tensor, scene_im_ids, obj_ids, times=None):
     return results
 
 
+def xyz_back_projection(depth: torch.Tensor, ego_rot: torch.Tensor, trans: torch.Tensor, K: torch.Tensor) -> torch.Tensor:
+    """``calc_xyz_bp_batch(..., fmt="BHWC")`` (lib/pysixd/misc.py:412-448): rendered depth f32[b,h,w] -> object-space points
+    f32[b,h,w,3] = R^T ((x - cx) z / fx, (y - cy) z / fy, z) - t), zero where the depth is zero; integer pixel coordinates like the
+    reference.  Plain tensor arithmetic on whatever device the depth lives on; pinned by tests/golden/xyz_bp_golden.npz (the
+    reference's function executed from its source)."""
+    bs, h, w = depth.shape
+    dev = depth.device
+    gy, gx = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32), torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+    X = gx.expand(bs, h, w) - K[:, 0, 2].view(bs, 1, 1)
+    Y = gy.expand(bs, h, w) - K[:, 1, 2].view(bs, 1, 1)
+    cam = torch.stack((X * depth / K[:, 0, 0].view(bs, 1, 1), Y * depth / K[:, 1, 1].view(bs, 1, 1), depth), dim=-1)
+    mask = (depth != 0).to(depth).unsqueeze(-1)
+    return torch.einsum("bij,bhwj->bhwi", ego_rot.transpose(1, 2), cam - trans.view(bs, 1, 1, 3)) * mask
+
+
 def render_roi_xyz_batch(meshes: hip_lib.MeshSet, roi_cls, ego_rot, trans, roi_zoom_K, out_res: int = 64, xyz_bp: bool = False,
                          z_near: float = 0.25, z_far: float = 6.0):
     """Online XYZ targets of the training-side ``batch_data`` (engine_utils.py:131-172) in ONE launch instead of a Python
@@ -450,17 +465,7 @@ def render_roi_xyz_batch(meshes: hip_lib.MeshSet, roi_cls, ego_rot, trans, roi_z
                                ego_rot.contiguous().float(), trans.contiguous().float(), out_res, z_near, z_far,
                                want_xyz=not xyz_bp)
     depth, xyz = (out, None) if xyz_bp else out
-    if xyz_bp:
-        K = roi_zoom_K.reshape(bs, 3, 3).float()
-        gy, gx = torch.meshgrid(torch.arange(out_res, device=dev, dtype=torch.float32),
-                                torch.arange(out_res, device=dev, dtype=torch.float32), indexing="ij")
-        X = gx.expand(bs, out_res, out_res) - K[:, 0, 2].view(bs, 1, 1)
-        Y = gy.expand(bs, out_res, out_res) - K[:, 1, 2].view(bs, 1, 1)
-        cam = torch.stack((X * depth / K[:, 0, 0].view(bs, 1, 1), Y * depth / K[:, 1, 1].view(bs, 1, 1), depth), dim=-1)
-        mask = (depth != 0).to(depth).unsqueeze(-1)
-        roi_xyz = torch.einsum("bij,bhwj->bhwi", ego_rot.transpose(1, 2).float(), cam - trans.view(bs, 1, 1, 3).float()) * mask
-    else:
-        roi_xyz = xyz
+    roi_xyz = xyz_back_projection(depth, ego_rot.float(), trans.float(), roi_zoom_K.reshape(bs, 3, 3).float()) if xyz_bp else xyz
     roi_mask_obj = ((roi_xyz[..., 0] != 0) & (roi_xyz[..., 1] != 0) & (roi_xyz[..., 2] != 0)).to(torch.float32)
     return roi_xyz, roi_mask_obj
 

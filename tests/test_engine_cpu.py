@@ -623,3 +623,16 @@ def test_packed_streams_shard_gather_and_restore_gloo_world2():
         assert ids == sorted(set(ids)) and all(rank * 100000 <= i < (rank + 1) * 100000 for i in ids)
     rec = engine.records_in_roi_order(torch.from_numpy(g0.reshape(-1, 16))).numpy()
     assert (np.diff(rec[:, 14]) > 0).all() and len(rec) == 2 * 5 * 8
+
+
+def test_xyz_back_projection_equals_the_reference_function():
+    """engine.xyz_back_projection (the XYZ_BP branch of the training-side batch_data, engine_utils.py:131-150) against
+    calc_xyz_bp_batch of the reference executed from its source (tests/golden/make_golden_xyz.py -> xyz_bp_golden.npz): same
+    depth / R / t / K in, the same points out to fp32 rounding, the same object mask."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xyz_bp_golden.npz"))
+    T = torch.from_numpy
+    xyz = engine.xyz_back_projection(T(z["depth"]), T(z["R"]), T(z["t"]), T(z["K_crop"])).numpy()
+    assert xyz.shape == z["xyz_bp"].shape == (6, 64, 64, 3)
+    assert np.abs(xyz - z["xyz_bp"]).max() <= 2e-7 * np.abs(z["xyz_bp"]).max() + 1e-8
+    mask = ((xyz[..., 0] != 0) & (xyz[..., 1] != 0) & (xyz[..., 2] != 0)).astype(np.float32)
+    assert np.array_equal(mask, z["mask_obj"]) and 0.1 < mask.mean() < 0.5

@@ -242,3 +242,25 @@ def test_online_xyz_targets_one_launch(hip):
     both = (m > 0) & (m_bp > 0)
     assert (m - m_bp).abs().mean().item() < 0.01
     assert ((xyz - xyz_bp).abs()[both].mean() / half.mean()).item() < 0.05
+
+
+def test_online_xyz_back_projection_against_the_reference_function(hip):
+    """The XYZ_BP form end to end — HIP render at the default z range of the EGL renderer + engine.xyz_back_projection — against
+    xyz_bp_golden.npz: the fixture's depth is the oracle rasteriser's (the HIP render equals it bit for bit here too), its points
+    are calc_xyz_bp_batch of the reference executed from source (tests/golden/make_golden_xyz.py)."""
+    import os
+
+    from gdrnpp_bop2022_amd import synthetic as S
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+    from gdrnpp_bop2022_amd.hip_lib import MeshSet, render_depth
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xyz_bp_golden.npz"))
+    verts, faces, ext = S.make_models(3, np.random.default_rng(20220925 + 31), 3)        # make_golden_xyz.case()
+    meshes = MeshSet(verts, faces)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    cls, R, t, K = T(z["roi_cls"].astype(np.int64)), T(z["R"]), T(z["t"]), T(z["K_crop"])
+    depth = render_depth(meshes, cls.to(torch.int32), K, R, t, 64)                         # the fixture's render: z range 0.1 .. 100
+    assert np.array_equal(depth.cpu().numpy().view(np.uint32), z["depth"].view(np.uint32))
+    xyz, m = engine.render_roi_xyz_batch(meshes, cls, R, t, K, 64, xyz_bp=True, z_near=0.1, z_far=100.0)
+    assert np.abs(xyz.cpu().numpy() - z["xyz_bp"]).max() <= 2e-7 * np.abs(z["xyz_bp"]).max() + 1e-8
+    assert np.array_equal(m.cpu().numpy(), z["mask_obj"])
