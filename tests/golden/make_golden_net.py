@@ -201,7 +201,7 @@ def record_b128_f64(datasets=("ycbv", "tless"), b=128, chunk=16):
     as record_b128, evaluated in fp64 (``model.double()``; the fp32 parameters and inputs convert exactly), in chunks of 16 ROIs
     (eval mode: a ROI's outputs do not depend on the batch).  Stored: R, t, the Patch-PnP outputs in fp64, and — from an fp32 run
     of the same chunks, which must reproduce record_b128's fixture — the distance of the reference's own fp32 chain from its fp64
-    value per ROI.  -> net_golden_<ds>_b128_f64.npz (a few KB)"""
+    value per ROI.  -> net_golden_<ds>_b128_f64.npz (1.3 MB: the sub-sampled maps in fp64)"""
     torch.set_num_threads(os.cpu_count())
     torch.set_grad_enabled(False)
     hip_layers.set_enabled(False)
@@ -309,11 +309,55 @@ def record_resnet34():
     print("wrote net_golden_lmo_resnet34.npz")
 
 
+def record_resnet34_f64(b=32):
+    """BASELINE configs[0] anchored on the true value: the same reference module (models/GDRN.py, ResNet-34), parameters and 32-ROI
+    batch as record_resnet34, evaluated in fp64.  Stored: R, t, the Patch-PnP outputs in fp64 and the per-ROI distance of the
+    reference's own fp32 forward (the lmo_resnet34 fixture) from them.  -> net_golden_lmo_resnet34_f64.npz"""
+    torch.set_num_threads(os.cpu_count())
+    torch.set_grad_enabled(False)
+    hip_layers.set_enabled(False)
+    from core.gdrn_modeling.models import GDRN as REFG
+    from core.gdrn_modeling.models import net_factory
+
+    net_factory.BACKBONES["timm/resnet34"] = lambda model_name=None, **kw: create_backbone(type="timm/" + model_name, **kw)
+    raw = _refimport.load_ref_config("configs/_base_/gdrn_base.py")
+    cfg = Config(raw)
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.MODEL.POSE_NET.NUM_CLASSES = 1
+    cfg.MODEL.POSE_NET.BACKBONE.INIT_CFG.pretrained = False
+    cfg.TEST.USE_PNP = True
+    cfg.SOLVER.BASE_LR = cfg.SOLVER.OPTIMIZER_CFG["lr"]
+    model, _ = REFG.build_model_optimizer(cfg, is_test=True)
+    model.eval()
+    sd = model.state_dict()
+    model.load_state_dict(S.seeded_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], SEED, alias=norm_alias), strict=True)
+    model.double()
+    x, det = net_image(b), net_detections(1, b)
+    D = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()   # noqa: E731
+    grab = {}
+    model.pnp_net.register_forward_hook(lambda m, i, o: grab.update(pred_rot_=o[0].clone(), pred_t_=o[1].clone()))
+    out = model(D(x), roi_classes=torch.from_numpy(det["roi_cls"]), roi_cams=D(det["roi_cam"]), roi_whs=D(det["roi_wh"]),
+                roi_centers=D(det["roi_center"]), resize_ratios=D(det["resize_ratio"]),
+                roi_coord_2d=D(S.coord2d_roi(det["roi_center"], det["scale"])), roi_extents=D(det["roi_extent"]), do_loss=False)
+    assert out["rot"].dtype == torch.float64
+    rec = dict(rot_f64=out["rot"].numpy(), trans_f64=out["trans"].numpy(), pred_rot__f64=grab["pred_rot_"].numpy(),
+               pred_t__f64=grab["pred_t_"].numpy())
+    f32 = np.load(os.path.join(HERE, "net_golden_lmo_resnet34.npz"))
+    for k in ("rot", "trans", "pred_rot_", "pred_t_"):
+        d = np.abs(f32[k].astype(np.float64) - rec[k + "_f64"]).reshape(b, -1).max(1)
+        rec["ref_f32_err_" + k] = d
+        print("lmo_resnet34", k, "reference fp32 vs its fp64: max", d.max(), "ROI", int(d.argmax()))
+    np.savez_compressed(os.path.join(HERE, "net_golden_lmo_resnet34_f64.npz"), **rec)
+    print("wrote net_golden_lmo_resnet34_f64.npz")
+
+
 if __name__ == "__main__":
     if "--b128-only" in sys.argv:
         record_b128()
     elif "--b128-f64" in sys.argv:
         record_b128_f64()
+    elif "--resnet34-f64" in sys.argv:
+        record_resnet34_f64()
     elif "--resnet34-only" in sys.argv:
         torch.set_num_threads(os.cpu_count())
         torch.set_grad_enabled(False)

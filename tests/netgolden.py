@@ -61,7 +61,8 @@ def load_fixture(ds):
 def load_f64_fixture(ds):
     """net_golden_<ds>_b128_f64.npz: the reference's module evaluated in fp64 on the 128-ROI batch (make_golden_net.py
     record_b128_f64) + the per-ROI distance of its own fp32 forward (the b128 fixture) from that."""
-    z = np.load(os.path.join(GOLDEN, f"net_golden_{ds}_b128_f64.npz"))
+    name = f"net_golden_{ds}_f64.npz" if ds == "lmo_resnet34" else f"net_golden_{ds}_b128_f64.npz"
+    z = np.load(os.path.join(GOLDEN, name))
     return {k: z[k] for k in z.files}
 
 

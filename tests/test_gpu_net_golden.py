@@ -144,6 +144,14 @@ def test_resnet34_hip_path_matches_reference_forward_32_rois(resnet_model):
     check_resnet34_outputs(fx, o, rot6.cpu().numpy(), t3.cpu().numpy(), 1e-4, 1e-4)
     assert np.abs(o["rot"] - fx["rot"]).max() <= 1e-4
     assert np.abs(o["trans"] - fx["trans"]).max() <= 1e-4 * max(1.0, np.abs(fx["trans"]).max())
+    # anchored on the reference module's fp64 run of the same 32 ROIs (net_golden_lmo_resnet34_f64.npz): per ROI as close to the
+    # true value as the reference's own fp32 forward (+ 2e-5)
+    f64 = NG.load_f64_fixture("lmo_resnet34")
+    got = {"rot": o["rot"], "trans": o["trans"], "pred_rot_": rot6.cpu().numpy(), "pred_t_": t3.cpu().numpy()}
+    for k in ("rot", "trans", "pred_rot_", "pred_t_"):
+        ours = np.abs(got[k].astype(np.float64) - f64[k + "_f64"]).reshape(32, -1).max(1)
+        worse = np.nonzero(ours > f64["ref_f32_err_" + k] + 2e-5)[0]
+        assert worse.size == 0, f"{k}: ROIs {worse.tolist()} {ours[worse]} vs reference {f64['ref_f32_err_' + k][worse]}"
 
 
 def test_resnet34_hip_path_matches_reference_forward_4_rois(resnet_model):
