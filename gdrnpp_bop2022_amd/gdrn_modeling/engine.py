@@ -135,11 +135,11 @@ class GdrnHipPost:
         return R, t, status
 
     def process_net_and_ransac(self, batch: dict, out_dict: dict, rot_only: bool = False, draws=None):
-        """``PNP_TYPE="net_ransac_pnp"`` / ``"net_ransac_pnp_rot"`` (gdrn_evaluator.py:241-371 with pnp_type "ransac" /
-        "ransac_rot"): solvePnPRansac(EPNP, reprojErr 3, 20 iterations) on the correspondences (the extrinsic guess is
-        ignored by EPnP).  "ransac": translation falls back to the network's when it moved by more than 1 m (:347-351);
-        "ransac_rot": rotation from RANSAC, translation always the network's; fewer than 4 correspondences or no model: the
-        network pose (:355-358)."""
+        """``PNP_TYPE="net_ransac_pnp"`` (gdrn_evaluator.py:241-371 with pnp_type "ransac"): solvePnPRansac(EPNP, reprojErr 3, 20
+        iterations) on the correspondences (the extrinsic guess is ignored by EPnP); the translation falls back to the network's
+        when it moved by more than 1 m (:347-351); fewer than 4 correspondences or no model: the network pose (:355-358).
+        ``rot_only``: RANSAC rotation with the network's translation — what the NAME ``net_ransac_pnp_rot`` suggests; NOT what the
+        reference does under that name (``process_net_and_rot_pnp`` below is), kept for callers that want it."""
         b = out_dict["trans"].shape[0]
         count, _, img_pts, mdl_pts, _ = self.process_correspondences(batch, out_dict)
         R, t, _, status, _ = hip_lib.epnp_ransac(img_pts, mdl_pts, count, batch["roi_cam"].reshape(b, 9).contiguous(),
@@ -151,6 +151,14 @@ class GdrnHipPost:
         R = torch.where(use.view(b, 1, 1), R, R_net)
         return R, t
 
+    def process_net_and_rot_pnp(self, batch: dict, out_dict: dict):
+        """``PNP_TYPE="net_ransac_pnp_rot"`` exactly as the reference runs it: ``process`` passes pnp_type "ransac_rot"
+        (gdrn_evaluator.py:171-173), and ``process_net_and_pnp`` only takes its RANSAC branch for ``pnp_type == "ransac"`` (:319)
+        — "ransac_rot" falls through to the ITERATIVE solvePnP seeded with the network pose, after which the network's translation
+        is kept (:341-348).  So: rotation of the net-initialised LM, translation of the network (pinned by eval_pnp_golden.npz)."""
+        R, _ = self.process_net_and_pnp(batch, out_dict)
+        return R, out_dict["trans"].float()
+
     def process(self, batch: dict, out_dict: dict, roi_ids: torch.Tensor | None = None) -> torch.Tensor:
         """-> pose records f32[b,16] = R(9) | t(3, metres) | score | obj | roi_id | valid."""
         if out_dict["trans"].shape[0] == 0:       # an image / a rank without detections: nothing to launch (the reference
@@ -161,8 +169,10 @@ class GdrnHipPost:
                 R, t, _ = self.process_pnp_ransac(batch, out_dict)
             elif pnp_type == "net_iter_pnp":
                 R, t = self.process_net_and_pnp(batch, out_dict)
-            elif pnp_type in ("net_ransac_pnp", "net_ransac_pnp_rot"):
-                R, t = self.process_net_and_ransac(batch, out_dict, rot_only=pnp_type.endswith("_rot"))
+            elif pnp_type == "net_ransac_pnp":
+                R, t = self.process_net_and_ransac(batch, out_dict)
+            elif pnp_type == "net_ransac_pnp_rot":
+                R, t = self.process_net_and_rot_pnp(batch, out_dict)
             else:
                 raise NotImplementedError(f"TEST.PNP_TYPE={self.cfg.TEST.PNP_TYPE}")
             b = t.shape[0]

@@ -38,3 +38,22 @@ def out_dict(e, device):
     m = e["maps"]
     return dict(coor_x=T(m["coor_x"]), coor_y=T(m["coor_y"]), coor_z=T(m["coor_z"]), mask=T(m["mask"]), rot=T(e["R"]),
                 trans=T(m["t_init"]))
+
+
+def load_pnp():
+    """eval_pnp_golden.npz: the reference's GDRN_Evaluator.process with TEST.USE_PNP for the four PNP_TYPEs on the same two images
+    (tests/golden/make_golden_eval_pnp.py); the mask of ROI 3 holds a single pixel (fewer than 4 correspondences)."""
+    e = load()
+    z = np.load(os.path.join(GOLDEN, "eval_pnp_golden.npz"))
+    for k in z.files:
+        e["pnp_" + k] = json.loads(str(z[k])) if k.endswith(("_predictions", "_calls")) else z[k]
+    return e
+
+
+def image_inputs_pnp(e, device="cpu"):
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    out = image_inputs(e, device)
+    for k, (lo, hi) in enumerate(e["split"]):
+        out[k].update(roi_coord_2d=T(e["pnp_roi_coord_2d"][lo:hi]), roi_extent=T(e["pnp_roi_extent"][lo:hi]), im_H=T(e["pnp_im_H"][lo:hi]),
+                      im_W=T(e["pnp_im_W"][lo:hi]))
+    return out

@@ -214,3 +214,20 @@ def test_roi_pool_oracle_against_an_independent_formulation_and_closed_forms():
     assert np.array_equal(px[0], x[0, :, 6:10, 4:9])
     whole = P.roi_pool(x[:, :, :16, :20], np.array([[1, 0, 0, 19, 15]], np.float32), (4, 5))
     assert np.array_equal(whole[0], F.max_pool2d(torch.from_numpy(x[1:2, :, :16, :20]), 4)[0].numpy())
+
+
+def test_nms_oracle_equals_the_reference_postprocess_executed_from_source(golden_dir):
+    """yolox_golden.npz = the reference's ``postprocess`` (det/yolox/utils/boxes.py:34-74) run from its source text with only the
+    torchvision NMS primitive served by a stand-in (tests/golden/make_golden_yolox.py): the oracle reproduces counts, rows and keep
+    order bit for bit — corner conversion, class argmax, the obj * class >= thr mask, the 7-column layout and the None of an empty
+    image are therefore the reference's own; what stays a restatement is the NMS primitive."""
+    z = np.load(os.path.join(golden_dir, "yolox_golden.npz"))
+    total = 0
+    for name in "abcd":
+        c, conf, thr, agn = z[name + "_args"]
+        outs = P.yolox_postprocess(z[name + "_det"], int(c), float(conf), float(thr), bool(agn))
+        assert [0 if o is None else len(o) for o in outs] == z[name + "_count"].tolist(), name
+        cat = np.concatenate([np.zeros((0, 7), np.float32)] + [o for o in outs if o is not None])
+        assert np.array_equal(cat, z[name + "_out"]), name
+        total += len(cat)
+    assert total > 400 and z["d_count"].sum() == 0

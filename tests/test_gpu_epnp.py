@@ -97,8 +97,11 @@ def _maps_case(b, rng):
 
 @pytest.mark.parametrize("pnp_type", ["ransac_pnp", "net_ransac_pnp", "net_ransac_pnp_rot"])
 def test_pnp_types_through_the_post_processing(hip, pnp_type):
-    """TEST.USE_PNP with the RANSAC variants through GdrnHipPost.process (gdrn_evaluator.py:165-176): maps -> decode ->
-    compaction -> RANSAC/EPnP, against the oracle chain on the same maps (ROI 1 has an empty mask: sentinel / net pose)."""
+    """TEST.USE_PNP with the RANSAC-named variants through GdrnHipPost.process (gdrn_evaluator.py:165-176): maps -> decode ->
+    compaction -> RANSAC/EPnP, against the oracle chain on the same maps (ROI 1 has an empty mask: sentinel / net pose).
+    ``net_ransac_pnp_rot`` as the reference really runs it: pnp_type "ransac_rot" misses the ``== "ransac"`` test of
+    process_net_and_pnp (:319) and goes through the ITERATIVE solvePnP seeded with the network pose; the network's translation is
+    kept (:341-348) — tests/golden/eval_pnp_golden.npz records exactly that from the reference's own class."""
     rng = np.random.default_rng(21)
     b = 6
     det, maps = _maps_case(b, rng)
@@ -127,12 +130,14 @@ def test_pnp_types_through_the_post_processing(hip, pnp_type):
             else:
                 assert np.array_equal(Rr, R_net[i]) and np.array_equal(tr, t_net[i])
             continue
-        ok, Ro, to, _ = E.solve_pnp_ransac_epnp(mp, ip, det["roi_cam"][i].astype(np.float64), 3.0, iters)
-        assert ok
         if pnp_type == "net_ransac_pnp_rot":
+            Ro, _ = P.net_iter_pnp(ip, mp, det["roi_cam"][i], R_net[i], t_net[i])
             to = t_net[i]
-        elif pnp_type == "net_ransac_pnp" and np.linalg.norm(to - t_net[i]) > 1:
-            to = t_net[i]
+        else:
+            ok, Ro, to, _ = E.solve_pnp_ransac_epnp(mp, ip, det["roi_cam"][i].astype(np.float64), 3.0, iters)
+            assert ok
+            if pnp_type == "net_ransac_pnp" and np.linalg.norm(to - t_net[i]) > 1:
+                to = t_net[i]
         assert np.abs(Rr - Ro).max() < 1e-4 and np.abs(tr - to).max() < 1e-4, i
         assert np.abs(tr - det["t_gt"][i]).max() < 0.03                      # and it is a sensible pose
 

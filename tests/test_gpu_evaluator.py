@@ -49,6 +49,35 @@ def test_process_emits_the_reference_records(hip, tmp_path, branch, images_per_c
     assert rows[0] == "scene_id,im_id,obj_id,score,R,t,time" and len(rows) == 6
 
 
+@pytest.mark.parametrize("pnp_type", ["ransac_pnp", "net_iter_pnp", "net_ransac_pnp", "net_ransac_pnp_rot"])
+def test_process_emits_the_reference_records_of_the_pnp_branches(hip, tmp_path, pnp_type):
+    """TEST.USE_PNP: the records of ``GDRN_Evaluator.process`` against eval_pnp_golden.npz — the reference's own
+    process_pnp_ransac / process_net_and_pnp executed on the same two images (correspondence selection, the -100 sentinel / network
+    pose below 4 points, the 1 m translation guard, "ransac_rot" running the ITERATIVE solver and keeping the network translation,
+    pnp_v2's plumbing are the reference's code; OpenCV's solvers inside are the oracle's restatements).  R within 1e-4, t within
+    1e-4 m; the ROI with a one-pixel mask takes the fall-back of its branch exactly."""
+    e = EG.load_pnp()
+    cfg = get_cfg("ycbv_convnext_a6", opts=["TEST.USE_PNP=True", f"TEST.PNP_TYPE={pnp_type}"])
+    cfg.EXP_ID = e["exp_id"]
+    ev = GDRN_Evaluator(cfg, "ycbv_test", False, str(tmp_path), obj_names=e["names"], obj2id=e["obj2id"])
+    ev.reset()
+    od = EG.out_dict(e, DEV)
+    od["mask"] = torch.from_numpy(e["pnp_mask"]).to(DEV)
+    ev.process(EG.image_inputs_pnp(e, DEV), [dict(time=float(t)) for t in e["fwd_time"]], od)
+    ref = e[f"pnp_{pnp_type}_predictions"]
+    assert len(ev._predictions) == len(ref) == 5
+    for i, (p, r) in enumerate(zip(ev._predictions, ref)):
+        assert (p["scene_id"], p["im_id"], p["obj_id"], p["score"]) == (r["scene_id"], r["im_id"], r["obj_id"], r["score"])
+        dR, dt = np.abs(np.array(p["R"]) - np.array(r["R"])).max(), np.abs(np.array(p["t"]) - np.array(r["t"])).max()
+        if i == 3:                                     # fewer than 4 correspondences: sentinel / network pose, exactly
+            assert dR == 0 and dt == 0, (i, dR, dt)
+            assert (np.array(p["t"]) == -100000.0).all() if pnp_type == "ransac_pnp" else p["R"] == np.asarray(e["R"][3], np.float32).reshape(-1).tolist()
+        else:
+            assert dR <= 1e-4 and dt <= 1e-4 * 1000.0, (i, dR, dt)
+    if pnp_type.startswith("net_ransac_pnp_rot"):      # the network translation is what comes out
+        assert all(np.allclose(np.array(p["t"]) / 1000.0, e["maps"]["t_init"][i], atol=1e-6) for i, p in enumerate(ev._predictions))
+
+
 def test_train_objs_subset_skips_untrained_classes(hip, tmp_path):
     e = EG.load()
     cfg = get_cfg("ycbv_convnext_a6")

@@ -481,6 +481,23 @@ def test_yolox_postprocess_bit_exact(hip, conf, agnostic):
         assert n_tot > 50
 
 
+def test_yolox_postprocess_equals_the_reference_function(hip):
+    """The device ``postprocess`` against yolox_golden.npz: the reference's own ``postprocess`` (det/yolox/utils/boxes.py:34-74)
+    executed from its source text, with only torchvision's NMS primitive served by a stand-in (tests/golden/make_golden_yolox.py):
+    class-aware and class-agnostic, one class, an image where nothing survives, two-decimal scores (exact ties)."""
+    import os
+
+    from gdrnpp_bop2022_amd.det.yolox.utils.boxes import postprocess
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yolox_golden.npz"))
+    for name in "abcd":
+        c, conf, thr, agn = z[name + "_args"]
+        got = postprocess(torch.from_numpy(z[name + "_det"].copy()).to(DEV), int(c), float(conf), float(thr), bool(agn))
+        counts = [0 if g is None else g.shape[0] for g in got]
+        assert counts == z[name + "_count"].tolist(), name
+        cat = np.concatenate([np.zeros((0, 7), np.float32)] + [g.cpu().numpy() for g in got if g is not None])
+        assert np.array_equal(cat, z[name + "_out"]), name
+
+
 def test_paste_masks_rle_bit_exact(hip):
     """gdrnpp_paste_masks_rle vs the oracle: identical COCO run lengths per instance (boxes inside, partly outside and
     tiny; an empty and a full mask; a buffer that is too small and gets re-run), and the evaluator-side helper."""
