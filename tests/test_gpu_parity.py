@@ -612,6 +612,27 @@ def test_pose_from_pred_variants(hip):
     assert torch.equal(ta, want)
 
 
+def test_every_trans_type_matches_the_reference_functions(hip, golden_dir):
+    """gdrnpp_pose_from_pred for TRANS_TYPE centroid_z (Z_TYPE REL / ABS), centroid_z_abs and trans, allocentric and egocentric, against
+    the reference's own pose_from_pred_centroid_z / pose_from_pred_centroid_z_abs / pose_from_pred run from their files with
+    is_train=False (tests/golden/make_golden_pose.py -> pose_golden.npz), incl. translations on / next to the optical axis (the
+    allo -> ego rotation's degenerate branch): t 1e-6 of scale, R 2e-6."""
+    g = np.load(f"{golden_dir}/pose_golden.npz")
+    b = g["R"].shape[0]
+    R9 = T(g["R"]).reshape(b, 9).contiguous()
+    cams, centers, whs, rr = T(g["cams"]).reshape(b, 9).contiguous(), T(g["centers"]), T(g["whs"]), T(g["resize_ratios"])
+    tin = {"centroid_z_rel": g["t_rel"], "centroid_z_abs_z": g["t_absz"], "centroid_z_abs": g["t_cabs"], "trans": g["t_trans"]}
+    for mode, t_ in tin.items():
+        for allo in (True, False):
+            tag = "allo" if allo else "ego"
+            R, t = hip.pose_from_pred(R9, T(t_), cams, centers, whs, rr, rot_mode="mat", t_mode=mode, is_allo=allo)
+            eR = np.abs(R.cpu().numpy() - g[f"{mode}_{tag}_R"]).max()
+            et = np.abs(t.cpu().numpy() - g[f"{mode}_{tag}_t"]).max()
+            assert eR < 2e-6 and et <= 1e-6 * np.abs(g[f"{mode}_{tag}_t"]).max(), (mode, tag, eR, et)
+            if not allo:
+                assert torch.equal(R, T(g["R"]))
+
+
 def test_rot_types_match_reference_get_rot_mat(hip, golden_dir):
     """Every ROT_TYPE family of get_rot_mat (model_utils.py:347-359) — quaternion, log-quaternion (quaternion_lf.qexp),
     Lie vector (lie_algebra.lie_vec_to_rot, incl. its first-order small-angle branch) and rot6d — against the reference's own
