@@ -245,6 +245,31 @@ def test_detections_from_bop_json_selection_rules():
     assert d2["roi_cls"].tolist() == [1, 1] and np.allclose(d2["score"], [0.9, 0.6])
 
 
+def test_detections_from_bop_json_equals_the_reference_loader():
+    """engine.detections_from_bop_json against ``load_detections_into_dataset`` of the reference executed from its source text
+    (tests/golden/make_golden_dets.py -> dets_golden.npz) on a seeded detection file with equal scores, foreign objects, scores
+    under the threshold, an image without an entry and one whose entries are all filtered: the same ROIs in the same order with
+    the same class index, box (xywh -> xyxy), score and time, for four (top_k, score_thr, train_objs) settings."""
+    import json
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dets_golden.npz"))
+    keys, dets, names = json.loads(str(z["keys"])), json.loads(str(z["detections"])), json.loads(str(z["names"]))
+    obj_ids = z["obj_ids"].tolist()
+    total = 0
+    for case in json.loads(str(z["cases"])):
+        a = case["args"]
+        train = None if a["train_objs"] is None else [obj_ids[names.index(n)] for n in a["train_objs"]]
+        d = engine.detections_from_bop_json(dets, keys, obj_ids, cam=None, extents=None, top_k_per_obj=a["top_k_per_obj"],
+                                            score_thr=a["score_thr"], train_obj_ids=train)
+        want = [(keys.index(im["scene_im_id"]), ann) for im in case["images"] for ann in im["annotations"]]
+        assert d["im_idx"].tolist() == [w[0] for w in want] and d["roi_cls"].tolist() == [w[1][0] for w in want], a
+        assert np.allclose(d["score"], [w[1][2] for w in want]) and np.allclose(d["time"], [w[1][3] for w in want]), a
+        boxes = np.array([[w[1][1][0], w[1][1][1], w[1][1][0] + w[1][1][2], w[1][1][1] + w[1][1][3]] for w in want], np.float32).reshape(-1, 4)
+        assert np.allclose(d["bbox"], boxes), a
+        total += len(want)
+    assert total == 57
+
+
 def test_folded_conv_bn_equals_batchnorm_of_conv():
     """hip_layers.folded_conv_bn (inference BatchNorm folded into the convolution in front of it, ResNet path of config 1):
     conv(x, w', b') == bn(conv(x)) in eval mode, for a biased and an unbiased convolution, and the cache follows in-place
