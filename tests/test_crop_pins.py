@@ -231,3 +231,42 @@ def test_nms_oracle_equals_the_reference_postprocess_executed_from_source(golden
         assert np.array_equal(cat, z[name + "_out"]), name
         total += len(cat)
     assert total > 400 and z["d_count"].sum() == 0
+
+
+def _readdata_case(golden_dir):
+    import sys
+    sys.path.insert(0, golden_dir)
+    z = np.load(os.path.join(golden_dir, "readdata_golden.npz"))
+    rng = np.random.default_rng(20220925 + 71)                 # tests/golden/make_golden_readdata.case()
+    image = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    depth = (rng.integers(300, 2000, (480, 640)).astype(np.uint16) / 1000.0).astype(np.float32)
+    return z, image, depth
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_roi_plumbing_equals_the_reference_read_data_test(golden_dir):
+    """readdata_golden.npz = the reference's own ``read_data_test`` (data_loader.py:647-818) executed from source on one seeded image
+    with six detections (tests/golden/make_golden_readdata.py).  engine.rois_from_detections reproduces its per-ROI scalars exactly —
+    XYWH -> XYXY, centre, scale = min(max(w, h) * 1.5, 640), roi_wh clamped to >= 1, resize_ratio — and the oracle's crop chain
+    (fed those scalars) reproduces every crop BYTE FOR BYTE (SHA-256), i.e. which array is warped with which interpolation to which
+    size, the fp64 normalisation and the float32 casts are the reference's."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+
+    z, image, depth = _readdata_case(golden_dir)
+    b = z["boxes_xywh"]
+    xyxy = np.stack([b[:, 0], b[:, 1], b[:, 0] + b[:, 2], b[:, 1] + b[:, 3]], 1)
+    r = engine.rois_from_detections(xyxy, 480, 640, 1.5, 64)
+    assert np.array_equal(r["bbox_center"].astype(np.float32), z["abs_bbox_center"]) and np.array_equal(r["scale"], z["abs_scale"])
+    assert np.array_equal(r["roi_wh"], z["abs_roi_wh"]) and np.array_equal(r["resize_ratio"], z["abs_resize_ratio"])
+    assert z["abs_scale"].tolist()[2] == 640.0 and z["abs_roi_wh"][3, 0] == 1.0            # the clamps are exercised
+    assert str(z["abs_scale_dtype"]) == "float64" and str(z["abs_bbox_center_dtype"]) == "float32" and str(z["abs_roi_cls_dtype"]) == "int64"
+    for i in range(len(b)):
+        img, dep, c2d = P.crop_resize_roi(image, depth, r["bbox_center"][i], float(r["scale"][i]))
+        assert _sha(img) == str(z["abs_roi_img_sha256"][i]) and _sha(dep) == str(z["abs_roi_depth_sha256"][i]), i
+        assert _sha(c2d) == str(z["abs_roi_coord_2d_sha256"][i]), i
+        rel = ((r["bbox_center"][i].reshape(2, 1, 1) - c2d * np.array([640, 480]).reshape(2, 1, 1)) / r["scale"][i]).astype(np.float32)
+        assert _sha(rel) == str(z["rel_roi_coord_2d_rel_sha256"][i]), i
