@@ -345,3 +345,96 @@ def test_b128_fp64_fixture_is_consistent_and_names_no_outlier_roi(ds):
     assert np.abs(trans - f64["trans_f64"]).max() < 2e-6
     if ds == "tless":
         assert int(amp.argmax()) == 16 and 20.0 < amp[16] < 30.0
+
+
+def test_convnext_backbone_equals_the_huggingface_implementation():
+    """Third-party witness for the re-declared backbone (timm is not installable here): Hugging Face's ``ConvNextModel`` — an
+    independent implementation of the same published architecture (4x4/4 stem + LayerNorm, [depthwise 7x7 -> LayerNorm(eps 1e-6) ->
+    Linear 4x -> exact GELU -> Linear -> layer scale -> residual] x (3, 3, 27, 3), LayerNorm + 2x2/2 between stages, widths
+    128..1024 = ConvNeXt-B) — gets THIS model's parameters through a name map, and its last stage output (before the pooling-side
+    norm, which timm's features_only(out_indices=(3,)) drops too) must equal this backbone's plain-PyTorch forward.  What this
+    does NOT show: that the key NAMES are timm 0.6.7's (tools/check_timm_keys.py is for that)."""
+    pytest.importorskip("transformers")
+    from transformers import ConvNextConfig, ConvNextModel
+
+    from gdrnpp_bop2022_amd import synthetic as S
+    from gdrnpp_bop2022_amd.gdrn_modeling.backbones import create_backbone
+
+    hip_layers.set_enabled(False)
+    try:
+        torch.manual_seed(0)
+        ours = create_backbone(type="timm/convnext_base", in_chans=3, features_only=True, out_indices=(3,)).eval()
+        sd = S.seeded_state_dict([(k, tuple(v.shape)) for k, v in ours.state_dict().items()], 11)
+        ours.load_state_dict(sd, strict=True)
+        hf = ConvNextModel(ConvNextConfig(num_channels=3, depths=[3, 3, 27, 3], hidden_sizes=[128, 256, 512, 1024],
+                                          hidden_act="gelu", layer_norm_eps=1e-12, drop_path_rate=0.0)).eval()
+        m = {"embeddings.patch_embeddings.weight": "stem_0.weight", "embeddings.patch_embeddings.bias": "stem_0.bias",
+             "embeddings.layernorm.weight": "stem_1.weight", "embeddings.layernorm.bias": "stem_1.bias"}
+        for s_, depth in enumerate((3, 3, 27, 3)):
+            if s_ > 0:
+                for a, b in (("0", "0"), ("1", "1")):          # downsampling_layer = [LayerNorm(channels_first), Conv2d 2x2/2]
+                    for p in ("weight", "bias"):
+                        m[f"encoder.stages.{s_}.downsampling_layer.{a}.{p}"] = f"stages_{s_}.downsample.{b}.{p}"
+            for j in range(depth):
+                h, o = f"encoder.stages.{s_}.layers.{j}.", f"stages_{s_}.blocks.{j}."
+                m[h + "layer_scale_parameter"] = o + "gamma"
+                for a, b in (("dwconv", "conv_dw"), ("layernorm", "norm"), ("pwconv1", "mlp.fc1"), ("pwconv2", "mlp.fc2")):
+                    for p in ("weight", "bias"):
+                        m[h + a + "." + p] = o + b + "." + p
+        hsd = hf.state_dict()
+        new = {k: (sd[m[k]].clone() if k in m else v) for k, v in hsd.items()}
+        assert set(m.values()) == set(sd) and all(new[k].shape == hsd[k].shape for k in hsd)      # every parameter of ours is used
+        hf.load_state_dict(new, strict=True)
+        # the eps of the in-block / stem / downsample LayerNorms is 1e-6 in both (HF hard-codes it; layer_norm_eps is the pooler's)
+        x = torch.from_numpy(NG.net_image(2))
+        with torch.no_grad():
+            want = hf(x, output_hidden_states=True).hidden_states[-1]
+            got = ours(x)[0]
+        assert got.shape == want.shape == (2, 1024, 8, 8)
+        assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    finally:
+        hip_layers.set_enabled(True)
+
+
+def test_resnet34_backbone_equals_the_huggingface_implementation():
+    """The same third-party witness for configs[0]'s backbone: Hugging Face's ``ResNetModel`` (basic blocks, depths 3-4-6-3, widths
+    64..512 = ResNet-34: 7x7/2 conv + BatchNorm + ReLU + 3x3/2 max-pool, two 3x3 conv + BatchNorm per block, 1x1/2 conv + BatchNorm
+    shortcuts) with THIS model's parameters and BatchNorm buffers against the plain-PyTorch forward of the re-declared timm
+    ``resnet34`` features (out_indices=(4,)), eval mode."""
+    pytest.importorskip("transformers")
+    from transformers import ResNetConfig, ResNetModel
+
+    from gdrnpp_bop2022_amd import synthetic as S
+    from gdrnpp_bop2022_amd.gdrn_modeling.backbones import create_backbone
+
+    hip_layers.set_enabled(False)
+    try:
+        torch.manual_seed(0)
+        ours = create_backbone(type="timm/resnet34", in_chans=3, features_only=True, out_indices=(4,)).eval()
+        sd = S.seeded_state_dict([(k, tuple(v.shape)) for k, v in ours.state_dict().items()], 12)
+        ours.load_state_dict(sd, strict=True)
+        hf = ResNetModel(ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[64, 128, 256, 512], depths=[3, 4, 6, 3],
+                                      layer_type="basic", hidden_act="relu", downsample_in_first_stage=False)).eval()
+        bn = ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")
+        m = {"embedder.embedder.convolution.weight": "conv1.weight"}
+        m.update({f"embedder.embedder.normalization.{p}": f"bn1.{p}" for p in bn})
+        for s_, depth in enumerate((3, 4, 6, 3)):
+            for j in range(depth):
+                h, o = f"encoder.stages.{s_}.layers.{j}.", f"layer{s_ + 1}.{j}."
+                for c in (0, 1):
+                    m[h + f"layer.{c}.convolution.weight"] = o + f"conv{c + 1}.weight"
+                    m.update({h + f"layer.{c}.normalization.{p}": o + f"bn{c + 1}.{p}" for p in bn})
+                if s_ > 0 and j == 0:
+                    m[h + "shortcut.convolution.weight"] = o + "downsample.0.weight"
+                    m.update({h + f"shortcut.normalization.{p}": o + f"downsample.1.{p}" for p in bn})
+        hsd = hf.state_dict()
+        assert set(m) == set(hsd) and set(m.values()) == set(sd)
+        hf.load_state_dict({k: sd[m[k]].clone() for k in hsd}, strict=True)
+        x = torch.from_numpy(NG.net_image(2))
+        with torch.no_grad():
+            want = hf(x).last_hidden_state
+            got = ours(x)[0]
+        assert got.shape == want.shape == (2, 512, 8, 8)
+        assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    finally:
+        hip_layers.set_enabled(True)
