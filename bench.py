@@ -129,6 +129,9 @@ def parse(argv=None):
     p.add_argument("--fused-mlp-max-c", type=int, default=256, help="A/B: widest ConvNeXt block on the fused MLP kernel (128 = stage 0 only, 256 = stages 0 and 1)")
     p.add_argument("--fused-mlp-min-rows", type=int, default=None, help="A/B: fewest pixels of a block for the fused MLP kernel (default 32768)")
     p.add_argument("--no-f16x2-rows", action="store_true", help="A/B: fp32 tensors between dwconv+LN / fc1 / fc2 of a ConvNeXt block instead of the pre-split f16x2-rows hand-over")
+    p.add_argument("--compute-streams", type=int, default=2,
+                   help="HIP streams consecutive steps are dealt to (engine.StepStreams): 2 = two independent steps in flight on the device, "
+                        "1 = the single-stream schedule (reported beside the headline as single_stream_mode)")
     p.add_argument("--no-other-mode-line", action="store_true",
                    help="skip the extra measurement of the other --gemm-products setting after the timed region")
     p.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
@@ -301,16 +304,19 @@ def worker(args):
 
     launch = state["launch"] if state is not None else (lambda i: (lambda: step(i)))
     dst = 0 if args.gather_to_rank0 else None
+    depth = state["compute_streams"] if state is not None else 1     # launches ahead of the oldest unresolved step (stream workloads: the scheduler's own queue)
 
     def run_steps(n):
-        """n steps, each resolved (range check + gather) after the next one has been launched."""
-        rec, prev = None, None
+        """n steps, each resolved (range check + gather) after the next `depth` ones have been launched: with two compute streams
+        two steps stay in flight on the device while the host reads the oldest one's verdict."""
+        rec, pend = None, []
         for i in range(n):
-            cur = launch(i)
-            if prev is not None:
-                rec = gather_records(prev(), b, dst=dst, single_rank_collective=args.force_dist)
-            prev = cur
-        return gather_records(prev(), b, dst=dst, single_rank_collective=args.force_dist)
+            pend.append(launch(i))
+            if len(pend) > depth:
+                rec = gather_records(pend.pop(0)(), b, dst=dst, single_rank_collective=args.force_dist)
+        while pend:
+            rec = gather_records(pend.pop(0)(), b, dst=dst, single_rank_collective=args.force_dist)
+        return rec
 
     run_steps(max(args.warmup, 1) * len(cfg_names) * 2)   # MIOpen find, weight packing, first range verdicts, both batches of every model
     sync()
@@ -393,6 +399,9 @@ def worker(args):
         # the same K steps once more with the other split-GEMM setting (reported beside the headline, never as `value`)
         other = 6 if args.gemm_products == 3 else 3
         extras["six_product_mode" if other == 6 else "three_product_mode"] = state["other_mode_line"](other, args.steps, n_global, sync)
+    n_cs = state["compute_streams"] if state is not None else 1
+    if state is not None and world == 1 and not args.no_other_mode_line and n_cs > 1:
+        extras["single_stream_mode"] = state["single_stream_line"](args.steps, n_global, sync)
     if rank == 0:
         metric = ("ROIs/sec (GDRNPP fwd + PnP + depth refine), 256x256 crops" if refine else
                   "ROIs/sec (GDRNPP fwd + uncertainty-PnP), 256x256 crops" if wname == "lmo_upnp" else
@@ -417,6 +426,8 @@ def worker(args):
                 "baseline_config_index": cfg_no, "workload_key": wname, "global_batch": n_global, "rois_per_gpu": b,
                 "roi_prep_on_gpu": bool(args.with_crop) or wname.endswith("stream"), "host_fed": bool(args.host_fed), "hipgraph": bool(args.graph), "input_res": 256, "output_res": 64,
                 "parallelism": f"roi-shard x{world}",
+                "compute_streams": n_cs, "steps_in_flight": ("consecutive steps dealt round-robin to %d HIP streams (engine.StepStreams): independent batches, "
+                                                             "records bit-equal to the single-stream schedule (tests/test_gpu_streams2.py)" % n_cs) if n_cs > 1 else "one stream",
                 "collective": (("gather(dst=0)" if dst is not None else "all_gather") + " f32[n,16] pose records") if use_dist else None,
                 "class_sliced_out_layer": not args.exact_reference_order, "rois_class_sorted_within_rank": True,
                 "parameters": "default-init" if args.random_init else "seeded O(1)", "hip_network_layers": not args.no_hip_layers,
@@ -582,6 +593,12 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             init = np.concatenate([rv, det["t_gt"].astype(np.float64)], 1) + rng.uniform(0, 0.05, (b, 6))
             upnp.append(dict(p2=T(p2), p3=T(np.repeat(kpts[None], b, 0)), w=T(w), K=T(np.repeat(K.reshape(1, 9), b, 0)), init=T(init)))
 
+    dealer = {"streams": E.StepStreams(1 if (args.graph or stream is not None) else max(1, args.compute_streams), dev)}
+
+    def set_compute_streams(n):
+        torch.cuda.synchronize(dev)
+        dealer["streams"] = E.StepStreams(n, dev)
+
     @torch.no_grad()
     def prepared(m, k):
         """The batch of step (model m, parity k), through the GPU ROI crop when --with-crop."""
@@ -604,7 +621,8 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                 m["graphs"][k] = GraphedInference(m["model"], m["post"], m["batches"][k], m["batches"][k]["roi_id"])
             rec = m["graphs"][k].replay()   # inputs already live in the graph's static buffers (resident in HBM)
             return lambda: rec
-        h = inference_step_async(m["model"], m["post"], prepared(m, k))     # records carry batch["roi_id"]
+        with dealer["streams"].next():       # consecutive steps on alternating compute streams (engine.StepStreams); the crop too
+            h = inference_step_async(m["model"], m["post"], prepared(m, k))     # records carry batch["roi_id"]
         if upnp is None:
             return h.result
 
@@ -620,13 +638,15 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         return launch(i)()
 
     def run_pipelined(n):
-        prev = None
+        pend, out = [], None
+        depth = len(dealer["streams"].streams)
         for i in range(n):
-            cur = launch(i)
-            if prev is not None:
-                prev()
-            prev = cur
-        return prev()
+            pend.append(launch(i))
+            if len(pend) > depth:
+                out = pend.pop(0)()
+        while pend:
+            out = pend.pop(0)()
+        return out
 
     def other_mode_line(products, steps, n_rois, sync):
         try:
@@ -649,6 +669,23 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             return {"gemm_products": products, "error": repr(e)}
         finally:
             hip_layers.set_gemm_products(args.gemm_products)
+
+    def single_stream_line(steps, n_rois, sync):
+        """The same K steps on ONE compute stream (the schedule of rounds 1-4), reported beside the headline."""
+        try:
+            set_compute_streams(1)
+            run_pipelined(4 * len(models))
+            sync()
+            t0 = time.perf_counter()
+            run_pipelined(steps)
+            sync()
+            dt = time.perf_counter() - t0
+            return {"compute_streams": 1, "value": n_rois * steps / dt, "unit": "ROIs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                    "note": "every step queued behind the previous one on one HIP stream"}
+        except Exception as e:  # the headline line must not depend on the extra measurement
+            return {"compute_streams": 1, "error": repr(e)}
+        finally:
+            set_compute_streams(max(1, args.compute_streams))
 
     def after_warmup():
         if stream is not None and args.host_fed:       # copies of the warm-up steps are not the timed region's
@@ -899,7 +936,8 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else dict(value=None, error=r.stderr[-400:])
         return out
 
-    return dict(step=step, launch=launch, measure_after=measure_after, other_mode_line=other_mode_line, after_warmup=after_warmup)
+    return dict(step=step, launch=launch, measure_after=measure_after, other_mode_line=other_mode_line, after_warmup=after_warmup,
+                single_stream_line=single_stream_line, set_compute_streams=set_compute_streams, compute_streams=len(dealer["streams"].streams))
 
 
 if __name__ == "__main__":

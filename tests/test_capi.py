@@ -47,6 +47,55 @@ def test_library_exports_nothing_but_the_header():
     assert exported == _declared_symbols()
 
 
+def _isa_checker():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("check_isa_hazards", os.path.join(ROOT, "tools", "check_isa_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_shipped_device_code_holds_no_swizzled_packed_fp32():
+    """MI355X returns wrong values in lanes 48..63 for v_pk_{add,mul}_f32 with op_sel:[0,1] while another wave of the SIMD issues
+    f16 MFMAs (two streams sharing the chip: profiles/r05p_pk_hazard_probe.txt, tests/test_gpu_streams2.py).  The library is built
+    with -fno-slp-vectorize (the SLP vectorizer is what emits that form); this disassembles every gfx950 code object that was
+    actually linked.  The link step of csrc/Makefile runs the same check."""
+    from gdrnpp_bop2022_amd import hip_lib
+
+    chk = _isa_checker()
+    if chk.tool("llvm-objdump") is None:
+        pytest.skip("no llvm-objdump")
+    n_obj, n_pk, bad = chk.scan(hip_lib.LIB_PATH)
+    assert n_obj == len([f for f in os.listdir(os.path.join(ROOT, "gdrnpp_bop2022_amd", "csrc")) if f.endswith(".hip")])
+    assert n_pk > 1000, "the depthwise / GroupNorm kernels are packed-fp32 code: the scan must see it"
+    assert bad == []
+
+
+def test_the_isa_check_catches_the_swizzled_form(tmp_path):
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    chk = _isa_checker()
+    src = tmp_path / "k.hip"
+    src.write_text("""#include <hip/hip_runtime.h>
+using f2 = __attribute__((ext_vector_type(2))) float;
+extern "C" __global__ void k(f2* p) {
+  f2 a = p[threadIdx.x], b = p[threadIdx.x + 64], r;
+  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  p[threadIdx.x] = r;
+}
+""")
+    lib = tmp_path / "libk.so"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", str(src), "-o", str(lib)], check=True, capture_output=True)
+    n_obj, n_pk, bad = chk.scan(str(lib))
+    assert n_obj == 1 and n_pk == 1 and len(bad) == 1 and "op_sel:[0,1]" in bad[0]
+    assert chk.main(["check", str(lib)]) == 1
+
+
 def test_python_binding_covers_header():
     from gdrnpp_bop2022_amd import hip_lib
 

@@ -1,0 +1,138 @@
+"""-m gpu: two independent steps in flight on two HIP streams (engine.StepStreams) give the records of the single-stream schedule,
+bit for bit — and the kernel that first did not (round 5): the 2x2-block upsample, SLP-packed by hipcc into v_pk_add_f32 ...
+op_sel:[0,1], returned wrong values in lanes 48..63 whenever its waves shared a SIMD with the split GEMM's f16 MFMAs
+(tools/pk_hazard_probe.py, profiles/r05p_pk_hazard_probe.txt).  The library is built with -fno-slp-vectorize and checked at link
+time (tools/check_isa_hazards.py, tests/test_capi.py); these tests are the behaviour."""
+import numpy as np
+import pytest
+import torch
+
+from gdrnpp_bop2022_amd import hip_lib, synthetic as S
+from gdrnpp_bop2022_amd.gdrn_modeling import engine, hip_layers
+from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_upsample_beside_the_conv_gemm_of_another_stream_is_bitwise_the_serial_result(hip):
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(256, 256, 3, padding=1, bias=False).to(DEV)
+    xg = torch.randn(64, 256, 32, 32, device=DEV).contiguous(memory_format=torch.channels_last)      # 256 tiles of 256 x 128: the three-product kernel
+    xu = torch.randn(64, 256, 32, 32, device=DEV).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        n0 = hip_lib.x3_launch_count()
+        yg_ref = hip_layers.conv2d(conv, xg).clone()
+        assert hip_lib.x3_launch_count() > n0, "the companion must be the three-product (f16 MFMA) GEMM"
+        yu_ref = hip_lib.upsample_bilinear2x(xu).clone()
+        assert torch.equal(yu_ref, torch.nn.functional.interpolate(xu, scale_factor=2, mode="bilinear", align_corners=True)) or \
+            float((yu_ref - torch.nn.functional.interpolate(xu, scale_factor=2, mode="bilinear", align_corners=True)).abs().max()) < 2e-6
+        torch.cuda.synchronize()
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        for rep in range(6):
+            with torch.cuda.stream(sb):
+                ygs = [hip_layers.conv2d(conv, xg) for _ in range(4)]
+            with torch.cuda.stream(sa):
+                yus = [hip_lib.upsample_bilinear2x(xu) for _ in range(6)]
+            torch.cuda.synchronize()
+            assert all(torch.equal(y, yu_ref) for y in yus), f"rep {rep}: upsample differs beside the GEMM"
+            assert all(torch.equal(y, yg_ref) for y in ygs), f"rep {rep}: GEMM differs beside the upsample"
+
+
+@pytest.fixture(scope="module")
+def setup(hip):
+    cfg = get_cfg("ycbv_convnext_a6", opts=["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True"])
+    torch.manual_seed(0)
+    model, _ = build_model_optimizer(cfg)
+    model.load_state_dict(S.seeded_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], 5), strict=True)
+    with torch.no_grad():
+        model.pnp_net.fc_t.bias.copy_(torch.tensor([0.0, 0.0, 1.5 * float(S.YCBV_K[0, 0]) * 0.19 / 64.0]))
+    model = model.to(DEV).eval()
+    rng = np.random.default_rng(11)
+    verts, faces, ext = S.make_models(21, rng, 2)
+    post = engine.GdrnHipPost(cfg, hip_lib.MeshSet(verts, faces, DEV))
+    g = torch.Generator(device=DEV).manual_seed(2)
+    b = 64                                       # 64 ROIs: the three-product kernels (256-tile rule) carry the backbone and the head
+    batches = []
+    for k in range(3):
+        det = S.make_detections(b, 21, ext, rng)
+        x1y1 = det["roi_center"] - det["roi_wh"] / 2
+        d = dict(bbox=np.concatenate([x1y1, x1y1 + det["roi_wh"]], 1).astype(np.float32), roi_cls=det["roi_cls"], score=det["score"],
+                 cam=S.YCBV_K.astype(np.float32), extents=ext, im_idx=np.zeros(b, np.int64))
+        img = torch.randint(0, 256, (1, S.IM_H, S.IM_W, 3), dtype=torch.uint8, device=DEV, generator=g)
+        dep = torch.rand((1, S.IM_H, S.IM_W), device=DEV, generator=g) + 0.5
+        batches.append(engine.batch_data_test_gpu(cfg, img, dep, d, sort_by_class=True))
+    return cfg, model, post, batches
+
+
+def _run(model, post, batches, n_steps, streams):
+    dealer = engine.StepStreams(streams)
+    out, prev = [], None
+    for i in range(n_steps):
+        with dealer.next():
+            cur = engine.inference_step_async(model, post, batches[i % len(batches)])
+        if prev is not None:
+            out.append(prev.result().clone())
+        prev = cur
+    out.append(prev.result().clone())
+    torch.cuda.synchronize()
+    return out, dealer
+
+
+def test_two_steps_in_flight_give_the_single_stream_records_bit_for_bit(setup):
+    cfg, model, post, batches = setup
+    n0 = hip_lib.x3_launch_count()
+    one, _ = _run(model, post, batches, 9, 1)
+    assert hip_lib.x3_launch_count() > n0, "the steps must run the three-product kernels (the MFMAs the hazard needs)"
+    for rep in range(3):
+        two, dealer = _run(model, post, batches, 9, 2)
+        assert len(dealer.streams) == 2 and dealer.streams[0] != dealer.streams[1]
+        for i, (a, c) in enumerate(zip(one, two)):
+            assert torch.equal(a, c), f"rep {rep} step {i}: max |diff| {float((a - c).abs().max()):.3e}"
+    ok = one[0][:, 15] > 0.5
+    assert ok.all() and torch.isfinite(one[0]).all()
+    assert torch.equal(one[0], one[3]) and not torch.equal(one[0], one[1])       # the same batch again / another batch
+
+
+def test_handles_belong_to_their_stream_and_a_flagged_step_is_repeated_there(setup):
+    """The range words are per stream: a step on stream A whose three-product launches report a row below the fp16x2 range (here:
+    the word is set on A behind the step's kernels, where a launch would have set it) is repeated with six products ON A, while
+    the step in flight on stream B is not (its words are clean) and keeps its records."""
+    cfg, model, post, batches = setup
+    one, _ = _run(model, post, batches, 2, 1)
+    with hip_layers.forced_gemm_products(6):
+        want = engine.inference_step(model, post, batches[0]).clone()
+    dealer = engine.StepStreams(2)
+    reruns0 = engine.range_reruns()
+    step = torch.no_grad()(engine._step_closure(model, post, batches[0], batches[0]["roi_id"]))
+    calls = []
+
+    def flagged_step():
+        out = step()
+        calls.append(torch.cuda.current_stream())
+        if len(calls) == 1:
+            hip_lib._x3_flags()[0:1].fill_(hip_lib.X3_SMALL_ROWS)       # slot 0 (names no layer: nothing gets demoted); the current stream's words, stream-ordered behind the kernels
+        return out
+
+    try:
+        with dealer.next():
+            h_bad = engine.launch_with_range_check(flagged_step)
+        with dealer.next():
+            h_ok = engine.inference_step_async(model, post, batches[1])
+        assert h_bad.stream == dealer.streams[0] and h_ok.stream == dealer.streams[1]
+        r_ok = h_ok.result().clone()
+        r_bad = h_bad.result().clone()          # resolved from the default stream: the repeat still goes to stream A
+        torch.cuda.synchronize()
+        assert h_bad.reran and not h_ok.reran and engine.range_reruns() == reruns0 + 1
+        assert calls == [dealer.streams[0], dealer.streams[0]]
+        assert torch.equal(r_ok, one[1])
+        assert torch.equal(r_bad, want)                                   # the repeat IS the six-product step
+        assert float((r_bad[:, :12] - one[0][:, :12]).abs().max()) <= 1e-4
+        # stream A's words were cleared behind the flagged step: the next step there is clean
+        with torch.cuda.stream(dealer.streams[0]):
+            h = engine.inference_step_async(model, post, batches[1])
+        assert torch.equal(h.result(), one[1]) and not h.reran
+    finally:
+        hip_layers.reset_x3_demotions()
+        engine._X3_OVERFLOW_STEPS = 0
