@@ -400,7 +400,7 @@ def worker(args):
         other = 6 if args.gemm_products == 3 else 3
         extras["six_product_mode" if other == 6 else "three_product_mode"] = state["other_mode_line"](other, args.steps, n_global, sync)
     n_cs = state["compute_streams"] if state is not None else 1
-    if state is not None and world == 1 and not args.no_other_mode_line and n_cs > 1:
+    if state is not None and world == 1 and not args.no_other_mode_line and n_cs > 1 and state["single_stream_line"] is not None:
         extras["single_stream_mode"] = state["single_stream_line"](args.steps, n_global, sync)
     if rank == 0:
         metric = ("ROIs/sec (GDRNPP fwd + PnP + depth refine), 256x256 crops" if refine else
@@ -549,6 +549,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         import itertools
         counter = itertools.count()
         subs = []                 # one image stream + scheduler per model ("stream": YCB-V; "bop7_stream": the seven BOP datasets)
+        sched_streams = E.StepStreams(max(1, args.compute_streams), dev)      # one dealer for all of them: consecutive steps alternate
         for di, m_ in enumerate(models):
             rng = np.random.default_rng(20220925 + 17 + rank + 1000 * di)
             g = torch.Generator(device=dev).manual_seed(20220925 + rank + 1000 * di)
@@ -569,7 +570,8 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                 return ((next(counter), im, dp, dt_) for im, dp, dt_ in itertools.cycle(src))
 
             def make_sched(m_=m_, timed=args.host_fed):
-                return E.RoiStreamScheduler(m_["cfg"], m_["model"], m_["post"], rois_per_step=b, roi_id_base=lo, device=dev, time_h2d=timed)
+                return E.RoiStreamScheduler(m_["cfg"], m_["model"], m_["post"], rois_per_step=b, roi_id_base=lo, device=dev, time_h2d=timed,
+                                            compute_streams=sched_streams)
             subs.append(dict(sched=make_sched(), feeder=make_feeder(host_pool if args.host_fed else pool), pool=pool, make_sched=make_sched,
                              make_feeder=make_feeder))
         stream = dict(subs=subs, counter=counter, h2d_bytes_warmup=0,
@@ -764,23 +766,22 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             for s_ in subs:
                 s_["sched"].flush()
             subs2 = [dict(sched=s_["make_sched"](timed=False), feeder=s_["make_feeder"](s_["pool"])) for s_ in subs]
-            prev, k2 = None, 0
+            pend2, k2, depth2 = [], 0, max(1, args.compute_streams)
 
             def run2(n):
-                nonlocal prev, k2
+                nonlocal k2
                 for _ in range(n):
                     s2 = subs2[k2 % len(subs2)]
                     k2 += 1
-                    cur = s2["sched"].launch_next(s2["feeder"])
-                    if prev is not None:
-                        prev()
-                    prev = cur
+                    pend2.append(s2["sched"].launch_next(s2["feeder"]))
+                    if len(pend2) > depth2:
+                        pend2.pop(0)()
             run2(max(args.warmup, 3) * len(subs2))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             run2(args.steps)
-            prev()
-            prev = None
+            while pend2:
+                pend2.pop(0)()
             torch.cuda.synchronize()
             ms_res = (time.perf_counter() - t0) / args.steps * 1e3
             for s2 in subs2:
@@ -937,7 +938,8 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         return out
 
     return dict(step=step, launch=launch, measure_after=measure_after, other_mode_line=other_mode_line, after_warmup=after_warmup,
-                single_stream_line=single_stream_line, set_compute_streams=set_compute_streams, compute_streams=len(dealer["streams"].streams))
+                single_stream_line=single_stream_line if stream is None else None, set_compute_streams=set_compute_streams,
+                compute_streams=len(dealer["streams"].streams) if stream is None else max(1, args.compute_streams))
 
 
 if __name__ == "__main__":

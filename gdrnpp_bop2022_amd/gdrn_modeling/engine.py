@@ -993,13 +993,23 @@ class RoiStreamScheduler:
     asynchronous.  They are copied to the device on the scheduler's own copy stream the moment they are admitted (the FULL
     image once, 0.9 + 1.2 MB, not a 1 MB crop per ROI), an event per image orders the step's crop kernel behind its copies, and
     since admission runs one step ahead of the device the copies overlap the previous step's kernels.  ``time_h2d=True``
-    brackets every image's copies with timing events (``h2d_ms()``)."""
+    brackets every image's copies with timing events (``h2d_ms()``).
+
+    ``compute_streams`` (default 2): consecutive steps are launched on alternating HIP streams (``StepStreams``), so that with
+    ``max_in_flight`` >= 2 two steps really are in flight on the device — one step's narrow tail under the next one's GEMMs —
+    instead of queued behind each other; 1 = everything on the caller's current stream (rounds 1-4); a ``StepStreams`` object =
+    that dealer, shared by several schedulers of one device (bench.py's seven-dataset stream)."""
 
     def __init__(self, cfg, model, post: GdrnHipPost, rois_per_step: int = 128, max_in_flight: int = 2, roi_id_base: int = 0,
-                 device=None, time_h2d: bool = False):
+                 device=None, time_h2d: bool = False, compute_streams: int = 2):
         import collections
 
         self.device = device
+        if isinstance(compute_streams, StepStreams):     # shared with other schedulers feeding the same device
+            self._n_compute, self._dealer = len(compute_streams.streams), compute_streams
+        else:
+            self._n_compute = max(1, int(compute_streams))
+            self._dealer = None                 # StepStreams, made at the first launch (the device is known then)
         self._copy_stream = None
         self._h2d_ready = {}                    # key -> event: the image's pixels are on the device
         self._time_h2d = bool(time_h2d)
@@ -1031,10 +1041,31 @@ class RoiStreamScheduler:
             return np.broadcast_to(c, (len(loc), 3, 3)) if c.ndim == 2 else c[loc]
 
         keys = [k for k, _, _ in pack]
+        if self._dealer is None:
+            dev = self.device if self.device is not None else self._images[keys[0]][0].device
+            self._dealer = StepStreams(self._n_compute, dev)
+        caller = torch.cuda.current_stream(self._dealer.device)
+        with self._dealer.next():               # this step's crop, forward and post-processing: the next compute stream
+            self._launch_on_current_stream(pack, keys, per_roi, cams, caller)
+        for k in keys:                          # pixels are only read by the crop kernel just enqueued
+            if self.packer.last_roi_dealt(k):
+                del self._images[k]
+                self._h2d_ready.pop(k, None)
+
+    def _launch_on_current_stream(self, pack, keys, per_roi, cams, caller) -> None:
+        import numpy as np
+
+        cur = torch.cuda.current_stream(self._dealer.device)
+        if cur != caller:
+            cur.wait_stream(caller)             # device images handed over by the caller were produced on ITS stream
         for k in keys:                          # host-fed images: the crop kernel waits for their copies (device-side wait)
             ev = self._h2d_ready.get(k)
             if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
+                cur.wait_event(ev)
+        for k in keys:                          # allocated on the caller's / the copy stream, read by this stream's crop kernel:
+            for t in self._images[k][:2]:       # their memory must not be handed out again before that kernel has run
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(cur)
         images = torch.stack([self._images[k][0] for k in keys])
         depths = torch.stack([self._images[k][1] for k in keys]) if self._with_depth else None
         det = dict(
@@ -1058,10 +1089,6 @@ class RoiStreamScheduler:
             t1.record()
             self._step_timing.append((t0, t1))
         self.steps_launched += 1
-        for k in keys:                          # pixels are only read by the crop kernel just enqueued
-            if self.packer.last_roi_dealt(k):
-                del self._images[k]
-                self._h2d_ready.pop(k, None)
 
     def _resolve_oldest(self):
         """Records of the OLDEST step in flight -> their images.  The 8 KB device-to-host copy runs on a side stream behind that
@@ -1073,9 +1100,9 @@ class RoiStreamScheduler:
         if rec.is_cuda:
             if self._d2h_stream is None:
                 self._d2h_stream = torch.cuda.Stream(device=rec.device)
-            compute = torch.cuda.current_stream(rec.device)      # looked up OUTSIDE the side stream's context
+            compute = handle.stream if handle.stream is not None else torch.cuda.current_stream(rec.device)   # the step's own stream (looked up OUTSIDE the side stream's context)
             with torch.cuda.stream(self._d2h_stream):
-                if handle.reran:                # a six-product repeat ran on the compute stream just now: its records are the newest work there
+                if handle.reran:                # a six-product repeat ran on the step's stream just now: its records are the newest work there
                     self._d2h_stream.wait_stream(compute)
                 else:
                     self._d2h_stream.wait_event(done)
@@ -1116,7 +1143,6 @@ class RoiStreamScheduler:
             # (HIP multiplexes its streams over a few hardware queues) and its copies would then wait for the step in front of them —
             # measured: 3.5 % of the copy time under compute with a default stream (profiles/r05b_bench_stream_hostfed.json)
             self._copy_stream = torch.cuda.Stream(device=dev, priority=-1)
-        compute = torch.cuda.current_stream(dev)
         with torch.cuda.stream(self._copy_stream):
             if self._time_h2d:
                 t0 = torch.cuda.Event(enable_timing=True)
@@ -1125,10 +1151,7 @@ class RoiStreamScheduler:
             depth_d = depth.to(dev, non_blocking=True) if depth is not None else None
             ev = torch.cuda.Event(enable_timing=self._time_h2d)
             ev.record()
-        for t in (image_d, depth_d):            # allocated on the copy stream, read by kernels of the compute stream
-            if t is not None:
-                t.record_stream(compute)
-        self._h2d_ready[key] = ev
+        self._h2d_ready[key] = ev               # (_launch marks the tensors as used by the compute stream that crops them)
         self.h2d_bytes += image.numel() * image.element_size() + (depth.numel() * depth.element_size() if depth is not None else 0)
         if self._time_h2d:
             self._h2d_timing.append((t0, ev))

@@ -136,3 +136,45 @@ def test_handles_belong_to_their_stream_and_a_flagged_step_is_repeated_there(set
     finally:
         hip_layers.reset_x3_demotions()
         engine._X3_OVERFLOW_STEPS = 0
+
+
+@pytest.mark.parametrize("host_fed", [False, True])
+def test_scheduler_on_two_compute_streams_returns_the_single_stream_records(setup, host_fed):
+    """RoiStreamScheduler(compute_streams=2): steps of a packed image stream alternate between two HIP streams (crop, forward,
+    refine, records); every image gets bit for bit the records of the one-stream schedule — from device images of the caller's
+    stream and from pinned host images copied on the scheduler's copy stream."""
+    cfg, model, post, _ = setup
+    rng = np.random.default_rng(5)
+    g = torch.Generator(device=DEV).manual_seed(7)
+    ext = np.asarray(S.make_models(21, np.random.default_rng(11), 2)[2])        # the fixture's extents (same seed)
+    images = []
+    for i, n in enumerate([20, 7, 30, 0, 25, 13, 30, 4, 18, 29, 11, 30, 2, 16]):
+        det = S.make_detections(max(n, 1), 21, ext, rng)
+        x1y1 = det["roi_center"] - det["roi_wh"] / 2
+        d = dict(bbox=np.concatenate([x1y1, x1y1 + det["roi_wh"]], 1).astype(np.float32)[:n], roi_cls=det["roi_cls"][:n], score=det["score"][:n],
+                 cam=S.YCBV_K.astype(np.float32), extents=ext)
+        img = torch.randint(0, 256, (S.IM_H, S.IM_W, 3), dtype=torch.uint8, device=DEV, generator=g)
+        dep = torch.rand((S.IM_H, S.IM_W), device=DEV, generator=g) + 0.5
+        if host_fed:
+            img, dep = img.cpu().pin_memory(), dep.cpu().pin_memory()
+        images.append((f"s/{i}", img, dep, d))
+
+    def run(n_streams):
+        sch = engine.RoiStreamScheduler(cfg, model, post, rois_per_step=64, max_in_flight=2, compute_streams=n_streams, device=torch.device(DEV, 0))
+        out = {}
+        for key, img, dep, det in images:
+            for k, rec, _ in sch.push(key, img, dep, det):
+                out[k] = rec
+        for k, rec, _ in sch.flush():
+            out[k] = rec
+        torch.cuda.synchronize()
+        return out, sch
+
+    one, _ = run(1)
+    for rep in range(2):
+        two, sch = run(2)
+        assert len(sch._dealer.streams) == 2 and sch.steps_launched == -(-sum(len(d["roi_cls"]) for _, _, _, d in images) // 64)
+        assert sorted(two) == sorted(one) == sorted(k for k, _, _, _ in images)
+        for k in one:
+            assert np.array_equal(one[k], two[k]), (rep, k)
+    assert all(np.isfinite(v).all() for v in one.values())
