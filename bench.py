@@ -5,8 +5,11 @@ One "step" = one call of the product entry point ``engine.inference_step`` on on
 resident in HBM (+ the one collective of the path when N > 1):
     GDRN_Net forward (ConvNeXt-B + geometry head + Patch-PnP, fp32)  ->  K_crop  ->  fast depth refine
     (render + compare, 2 iterations, HIP)  ->  pose records  ->  (N>1) one RCCL all-gather of the f32[n,16] records.
-Two distinct batches per model alternate step by step; a step's records are resolved (range check of the three-product GEMM
-kernels, engine.StepHandle) after the NEXT step has been launched, all of them inside the timed region.  Timing = the reference's protocol (gdrn_evaluator.py:697-706,
+Two distinct batches per model alternate step by step.  Consecutive steps are independent and are dealt to ``--compute-streams``
+HIP streams (default 2, engine.StepStreams): two steps are in flight on the device, one's narrow tail under the other's GEMMs;
+records are bit-equal to the one-stream schedule (tests/test_gpu_streams2.py) and ``single_stream_mode`` reports that schedule
+from the same process.  A step's records are resolved (range check of the three-product GEMM kernels, engine.StepHandle) after
+the next ``compute_streams`` steps have been launched, all of them inside the timed region (K steps launched, K resolved).  Timing = the reference's protocol (gdrn_evaluator.py:697-706,
 748-750): host perf_counter, device synchronised (and ranks barriered) on both sides, warm-up steps discarded, MAX over ranks.
 
 Workloads (``--workload``; index into BASELINE.json ``configs``):
@@ -399,6 +402,13 @@ def worker(args):
         # the same K steps once more with the other split-GEMM setting (reported beside the headline, never as `value`)
         other = 6 if args.gemm_products == 3 else 3
         extras["six_product_mode" if other == 6 else "three_product_mode"] = state["other_mode_line"](other, args.steps, n_global, sync)
+    rl = extras.get("roofline") if extras else None
+    if rl and rl.get("bound") == "mfma" and rl.get("flops_per_launch"):
+        # the matrix-core rate of the WHOLE step as timed (every kernel of it, two steps in flight): MFMA flops per step / step time
+        tf = rl["flops_per_launch"] * rl["launches_per_step"] / (dt / args.steps) / 1e12
+        rl["whole_step"] = {"mfma_tflops": tf, "frac_of_peak": tf / rl["peak"], "gemm_share_of_step_alone": rl["ms_per_step"] / (dt / args.steps * 1e3),
+                            "note": "MFMA flops of one step / ms_per_step of the timed region; gemm_share_of_step_alone = summed GEMM launch time "
+                                    "measured alone / the timed step time (can exceed what a single stream could hold: the rest of the step runs beside them)"}
     n_cs = state["compute_streams"] if state is not None else 1
     if state is not None and world == 1 and not args.no_other_mode_line and n_cs > 1 and state["single_stream_line"] is not None:
         extras["single_stream_mode"] = state["single_stream_line"](args.steps, n_global, sync)
@@ -861,7 +871,8 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                                 launch_ms=ms_all / n_l, launches_per_step=n_l / args.steps, ms_per_step=ms_all / args.steps,
                                 flops_per_launch=mfma_fl / n_l, fp32_equiv_tflops=fl / (ms_all * 1e-3) / 1e12,
                                 fp32_mfma_peak_tflops=F32_MFMA_PEAK_TFLOPS, by_kind=by_kind, by_shape=by_shape,
-                                measured_in="separate event pass of the same steps after the timed region",
+                                measured_in="separate event pass of the same steps after the timed region, ONE step at a time (each launch has the chip to itself; "
+                                            "in the timed region two steps share it and a launch takes longer while the step takes less: whole_step below)",
                                 note="bf16 MFMA flops executed = 6 x fp32-equivalent flops (exact 3-way operand split, six "
                                      "partial products, fp32 accumulate)" if args.gemm_products == 6 else
                                      "MFMA flops executed = 3 x fp32-equivalent flops in the *_x3 kinds (two-way fp16 operand split, "

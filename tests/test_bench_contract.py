@@ -65,6 +65,13 @@ def test_round5_lines_carry_in_run_parity_and_live_traffic():
         assert 1.0 < r["traffic_over_algorithmic"] < 1.6
         fwd = d["cpu_baseline"]["stages"]["forward_cpu_torch"]
         assert fwd["unit"] == "ROIs/s" and fwd["value"] > 0 and fwd["cores"] >= 1
+        if "compute_streams" in d["config"]:       # from r05t on: two steps in flight (engine.StepStreams), the one-stream schedule beside it
+            one = d["single_stream_mode"]
+            assert d["config"]["compute_streams"] == 2 and one["compute_streams"] == 1 and one["steps"] == d["steps"]
+            assert 1.0 < d["value"] / one["value"] < 1.15
+            ws = r["whole_step"]
+            assert abs(ws["mfma_tflops"] - r["flops_per_launch"] * r["launches_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12) < 1e-6 * ws["mfma_tflops"]
+            assert ws["frac_of_peak"] < r["frac"] < 1
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05*_bench_*stream_hostfed.json"))):
         d = json.loads(open(f).read().strip().splitlines()[-1])
         h = d["host_fed"]

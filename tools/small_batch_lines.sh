@@ -11,11 +11,12 @@ for b in 8 16 32 64; do
 done
 python - "$out" <<'PY'
 import json, sys
-print("| ROIs | hipGraph | ROIs/s | ms/step | six-product mode ROIs/s |")
-print("|---|---|---|---|---|")
+print("| ROIs | hipGraph | compute streams | ROIs/s | ms/step | one stream, same run | six-product mode ROIs/s |")
+print("|---|---|---|---|---|---|---|")
 for l in open(sys.argv[1]):
     d = json.loads(l)
     six = d.get("six_product_mode") or {}
-    print(f"| {d['config']['rois_per_gpu']} | {d['config']['hipgraph']} | {d['value']:.0f} | {d['ms_per_step']:.3f} | "
-          f"{six.get('value', float('nan')):.0f} |")
+    one = d.get("single_stream_mode") or {}
+    print(f"| {d['config']['rois_per_gpu']} | {d['config']['hipgraph']} | {d['config'].get('compute_streams', 1)} | {d['value']:.0f} | {d['ms_per_step']:.3f} | "
+          f"{one.get('value', float('nan')):.0f} | {six.get('value', float('nan')):.0f} |")
 PY
