@@ -144,7 +144,7 @@ def test_force_dist_runs_the_collective_with_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["collective"]["world_size_seen"] == 1 and d["collective"]["backend"] == "gloo" and d["gather_ms"] > 0
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05k_bench_rccl_one_rank_*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05[ku]_bench_rccl_one_rank_*.json"))):
         d = json.loads(open(f).read().strip().splitlines()[-1])
         assert d["collective"]["backend"] == "nccl" and d["collective"]["rank0_device"] == "cuda:0" and d["product_path"] is True
 
