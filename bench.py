@@ -411,7 +411,7 @@ def worker(args):
                                     "measured alone / the timed step time (can exceed what a single stream could hold: the rest of the step runs beside them)"}
     n_cs = state["compute_streams"] if state is not None else 1
     if state is not None and world == 1 and not args.no_other_mode_line and n_cs > 1 and state["single_stream_line"] is not None:
-        extras["single_stream_mode"] = state["single_stream_line"](args.steps, n_global, sync)
+        extras["single_stream_mode"] = state["single_stream_line"](args.steps, n_global, sync, rec)
     if rank == 0:
         metric = ("ROIs/sec (GDRNPP fwd + PnP + depth refine), 256x256 crops" if refine else
                   "ROIs/sec (GDRNPP fwd + uncertainty-PnP), 256x256 crops" if wname == "lmo_upnp" else
@@ -682,18 +682,22 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         finally:
             hip_layers.set_gemm_products(args.gemm_products)
 
-    def single_stream_line(steps, n_rois, sync):
-        """The same K steps on ONE compute stream (the schedule of rounds 1-4), reported beside the headline."""
+    def single_stream_line(steps, n_rois, sync, headline_rec=None):
+        """The same K steps on ONE compute stream (the schedule of rounds 1-4), reported beside the headline; the records of its
+        last step against those of the timed region's last step (the same batch): two steps in flight must not change a bit."""
         try:
             set_compute_streams(1)
             run_pipelined(4 * len(models))
             sync()
             t0 = time.perf_counter()
-            run_pipelined(steps)
+            rec1 = run_pipelined(steps)
             sync()
             dt = time.perf_counter() - t0
-            return {"compute_streams": 1, "value": n_rois * steps / dt, "unit": "ROIs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-                    "note": "every step queued behind the previous one on one HIP stream"}
+            out = {"compute_streams": 1, "value": n_rois * steps / dt, "unit": "ROIs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                   "note": "every step queued behind the previous one on one HIP stream"}
+            if headline_rec is not None and torch.is_tensor(rec1) and rec1.shape == headline_rec.shape:
+                out["last_step_records_bit_equal_to_timed_region"] = bool(torch.equal(rec1, headline_rec.to(rec1.device)))
+            return out
         except Exception as e:  # the headline line must not depend on the extra measurement
             return {"compute_streams": 1, "error": repr(e)}
         finally:

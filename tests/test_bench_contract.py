@@ -69,6 +69,7 @@ def test_round5_lines_carry_in_run_parity_and_live_traffic():
             one = d["single_stream_mode"]
             assert d["config"]["compute_streams"] == 2 and one["compute_streams"] == 1 and one["steps"] == d["steps"]
             assert 1.0 < d["value"] / one["value"] < 1.15
+            assert one.get("last_step_records_bit_equal_to_timed_region", True) is True     # (r05v on: compared in the run)
             ws = r["whole_step"]
             assert abs(ws["mfma_tflops"] - r["flops_per_launch"] * r["launches_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12) < 1e-6 * ws["mfma_tflops"]
             assert ws["frac_of_peak"] < r["frac"] < 1
