@@ -135,6 +135,7 @@ def parse(argv=None):
     p.add_argument("--compute-streams", type=int, default=2,
                    help="HIP streams consecutive steps are dealt to (engine.StepStreams): 2 = two independent steps in flight on the device, "
                         "1 = the single-stream schedule (reported beside the headline as single_stream_mode)")
+    p.add_argument("--stream-priorities", default="", help="A/B: HIP priorities of the compute streams, e.g. -1,0 (default: all 0)")
     p.add_argument("--no-other-mode-line", action="store_true",
                    help="skip the extra measurement of the other --gemm-products setting after the timed region")
     p.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
@@ -605,11 +606,12 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             init = np.concatenate([rv, det["t_gt"].astype(np.float64)], 1) + rng.uniform(0, 0.05, (b, 6))
             upnp.append(dict(p2=T(p2), p3=T(np.repeat(kpts[None], b, 0)), w=T(w), K=T(np.repeat(K.reshape(1, 9), b, 0)), init=T(init)))
 
-    dealer = {"streams": E.StepStreams(1 if (args.graph or stream is not None) else max(1, args.compute_streams), dev)}
+    prios = [int(v) for v in args.stream_priorities.split(",")] if args.stream_priorities else None
+    dealer = {"streams": E.StepStreams(1 if (args.graph or stream is not None) else max(1, args.compute_streams), dev, prios)}
 
     def set_compute_streams(n):
         torch.cuda.synchronize(dev)
-        dealer["streams"] = E.StepStreams(n, dev)
+        dealer["streams"] = E.StepStreams(n, dev, prios)
 
     @torch.no_grad()
     def prepared(m, k):

@@ -428,11 +428,12 @@ class StepStreams:
     steps share nothing but the read-only weights.  What must NOT share the chip with the split GEMMs is packed fp32 code with
     op_sel swizzles (a hardware hazard, csrc/Makefile): the library is built without it and checked at link time."""
 
-    def __init__(self, n: int = 2, device=None):
+    def __init__(self, n: int = 2, device=None, priorities=None):
         if n < 1:
             raise ValueError("StepStreams needs at least one stream")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(n)] if n > 1 else [None]
+        pr = list(priorities) if priorities is not None else [0] * n     # (A/B only: equal priorities are what was measured best)
+        self.streams = [torch.cuda.Stream(self.device, priority=int(pr[i % len(pr)])) for i in range(n)] if n > 1 else [None]
         self._i = 0
         self.sync_with_current()
 
