@@ -132,9 +132,11 @@ def parse(argv=None):
     p.add_argument("--fused-mlp-max-c", type=int, default=256, help="A/B: widest ConvNeXt block on the fused MLP kernel (128 = stage 0 only, 256 = stages 0 and 1)")
     p.add_argument("--fused-mlp-min-rows", type=int, default=None, help="A/B: fewest pixels of a block for the fused MLP kernel (default 32768)")
     p.add_argument("--no-f16x2-rows", action="store_true", help="A/B: fp32 tensors between dwconv+LN / fc1 / fc2 of a ConvNeXt block instead of the pre-split f16x2-rows hand-over")
-    p.add_argument("--compute-streams", type=int, default=2,
+    p.add_argument("--compute-streams", type=int, default=0,
                    help="HIP streams consecutive steps are dealt to (engine.StepStreams): 2 = two independent steps in flight on the device, "
-                        "1 = the single-stream schedule (reported beside the headline as single_stream_mode)")
+                        "1 = the single-stream schedule (reported beside the headline as single_stream_mode); 0 (default) = "
+                        "engine.default_compute_streams: 2 for the ConvNeXt configurations (every kernel of a step is this library's), "
+                        "1 for the ResNet-34 one (MIOpen kernels in the step)")
     p.add_argument("--stream-priorities", default="", help="A/B: HIP priorities of the compute streams, e.g. -1,0 (default: all 0)")
     p.add_argument("--no-other-mode-line", action="store_true",
                    help="skip the extra measurement of the other --gemm-products setting after the timed region")
@@ -552,6 +554,9 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         pair = [make_batch(cfg, rng, ext, meshes, K=S.LMO_K if wname == "lmo_upnp" else S.YCBV_K) for _ in range(2)]
         models.append(dict(cfg=cfg, model=model, post=post, batches=[p[0] for p in pair], dets=[p[1] for p in pair],
                            K_crops=[p[2] for p in pair], meshes=meshes, verts=verts, faces=faces, C=C, graphs={}, ext=ext))
+
+    if args.compute_streams <= 0:        # default: two steps in flight only where every kernel of a step is this library's
+        args.compute_streams = min(E.default_compute_streams(m_["model"]) for m_ in models)
 
     stream = None
     if wname in ("stream", "bop7_stream"):

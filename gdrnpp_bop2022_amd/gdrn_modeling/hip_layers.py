@@ -263,6 +263,10 @@ def _packed_weight(cache: dict, key: str, weight: torch.Tensor, pack6) -> torch.
     return hit[1]
 
 
+def mlp_gemm() -> str:
+    return _MLP_GEMM
+
+
 def set_mlp_gemm(mode: str) -> None:
     global _MLP_GEMM
     if mode not in ("split", "torch"):

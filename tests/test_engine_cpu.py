@@ -661,3 +661,29 @@ def test_xyz_back_projection_equals_the_reference_function():
     assert np.abs(xyz - z["xyz_bp"]).max() <= 2e-7 * np.abs(z["xyz_bp"]).max() + 1e-8
     mask = ((xyz[..., 0] != 0) & (xyz[..., 1] != 0) & (xyz[..., 2] != 0)).astype(np.float32)
     assert np.array_equal(mask, z["mask_obj"]) and 0.1 < mask.mean() < 0.5
+
+
+def test_two_steps_in_flight_only_where_every_kernel_of_a_step_is_ours():
+    """engine.default_compute_streams: 2 for a ConvNeXt configuration with the HIP network layers and split GEMMs on (a step then
+    launches this library's kernels only — built and link-checked against the packed-fp32 / MFMA hazard of MI355X), 1 for the
+    ResNet-34 configuration (MIOpen convolutions in the step) and whenever PyTorch's operators are switched in."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine, hip_layers
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+    from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+    from gdrnpp_bop2022_amd.gdrn_modeling import GDRN
+
+    cx, _ = build_model_optimizer(get_cfg("ycbv_convnext_a6"))
+    cfg_r = get_cfg("lmo_resnet34_ape")
+    builder = GDRN.build_model_optimizer if cfg_r.MODEL.POSE_NET.NAME == "GDRN" else build_model_optimizer
+    rn, _ = builder(cfg_r)
+    assert hip_layers.is_enabled() and hip_layers.mlp_gemm() == "split"
+    assert engine.default_compute_streams(cx) == 2 and engine.default_compute_streams(rn) == 1
+    try:
+        hip_layers.set_enabled(False)
+        assert engine.default_compute_streams(cx) == 1
+        hip_layers.set_enabled(True)
+        hip_layers.set_mlp_gemm("torch")
+        assert engine.default_compute_streams(cx) == 1
+    finally:
+        hip_layers.set_enabled(True)
+        hip_layers.set_mlp_gemm("split")

@@ -178,3 +178,19 @@ def test_scheduler_on_two_compute_streams_returns_the_single_stream_records(setu
         for k in one:
             assert np.array_equal(one[k], two[k]), (rep, k)
     assert all(np.isfinite(v).all() for v in one.values())
+
+
+def test_steps_without_range_words_are_ordered_before_the_callers_stream_reads_them(setup):
+    """Six-product steps (small batches, set_gemm_products(6)) carry no range words, so ``StepHandle.result()`` has nothing to wait
+    for on the host: the caller's stream must then wait for the step ON THE DEVICE before it reads the records (here: ``.clone()``
+    on the default stream right after ``result()``, with the next step already queued on the other compute stream)."""
+    cfg, model, post, batches = setup
+    with hip_layers.forced_gemm_products(6):
+        n0 = hip_lib.x3_launch_count()
+        one, _ = _run(model, post, batches, 7, 1)
+        for rep in range(3):
+            two, _ = _run(model, post, batches, 7, 2)
+            for i, (a, c) in enumerate(zip(one, two)):
+                assert torch.equal(a, c), f"rep {rep} step {i}"
+        assert hip_lib.x3_launch_count() == n0, "six products were forced: no three-product launch, hence no range words"
+    assert torch.isfinite(one[0]).all() and (one[0][:, 15] > 0.5).all()
