@@ -701,9 +701,20 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             sync()
             dt = time.perf_counter() - t0
             out = {"compute_streams": 1, "value": n_rois * steps / dt, "unit": "ROIs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-                   "note": "every step queued behind the previous one on one HIP stream"}
+                   "note": "every step queued behind the previous one on one HIP stream, every launch sized to fill the chip by itself"}
             if headline_rec is not None and torch.is_tensor(rec1) and rec1.shape == headline_rec.shape:
-                out["last_step_records_bit_equal_to_timed_region"] = bool(torch.equal(rec1, headline_rec.to(rec1.device)))
+                # scheduling alone must not change a bit: the last step of the timed region once more on ONE stream, with the kernel
+                # choice of the shared chip (StepStreams.shared_min_tiles) — the same kernels, one stream instead of two
+                period = 2 * len(models)
+                old_rule = hip_lib.SPLIT2_SHARED_MIN_TILES
+                try:
+                    hip_lib.SPLIT2_SHARED_MIN_TILES = E.StepStreams(max(1, args.compute_streams), dev).shared_min_tiles() or old_rule
+                    rec_same = run_pipelined(((steps - 1) % period) + 1)
+                    sync()
+                finally:
+                    hip_lib.SPLIT2_SHARED_MIN_TILES = old_rule
+                out["last_step_records_bit_equal_to_timed_region"] = bool(torch.equal(rec_same, headline_rec.to(rec_same.device)))
+                out["max_abs_diff_of_its_own_kernel_choice"] = float((rec1 - headline_rec.to(rec1.device)).abs().max())
             return out
         except Exception as e:  # the headline line must not depend on the extra measurement
             return {"compute_streams": 1, "error": repr(e)}

@@ -463,11 +463,32 @@ class StepStreams:
             if s_ is not None:
                 s_.wait_stream(cur)
 
+    def shared_min_tiles(self) -> int:
+        """Tile count from which a launch takes the three-product 256-row form while this dealer's streams share the chip: a
+        launch need not give every CU a workgroup when a second step runs beside it (hip_lib.split2_tiles_ok; 0 = rule off)."""
+        n = len(self.streams)
+        return hip_lib.SPLIT2_MIN_TILES // n if n > 1 else 0
+
     def next(self):
-        """Context manager: the body's launches go to the next compute stream (with n = 1: the caller's current stream)."""
+        """Context manager: the body's launches go to the next compute stream (with n = 1: the caller's current stream) and, with
+        n > 1, choose their GEMM kernels for a shared chip (``shared_min_tiles``: 4 248 -> 4 525 ROIs/s at 32 ROIs, neutral at 8 and
+        128, profiles/r05y_shared_chip_tile_rule.txt)."""
+        import contextlib
+
         s_ = self.streams[self._i % len(self.streams)]
         self._i += 1
-        return torch.cuda.stream(s_)          # torch.cuda.stream(None) is a no-op context
+
+        @contextlib.contextmanager
+        def ctx():
+            old = hip_lib.SPLIT2_SHARED_MIN_TILES
+            if old == 0:                       # an explicit setting (tests, A/B runs) wins
+                hip_lib.SPLIT2_SHARED_MIN_TILES = self.shared_min_tiles()
+            try:
+                with torch.cuda.stream(s_):    # torch.cuda.stream(None) is a no-op context
+                    yield s_
+            finally:
+                hip_lib.SPLIT2_SHARED_MIN_TILES = old
+        return ctx()
 
 
 def gather_records(rec: torch.Tensor, n_local_max: int, group=None, dst: int | None = None, single_rank_collective: bool = False):

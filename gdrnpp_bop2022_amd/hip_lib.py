@@ -717,9 +717,18 @@ def pack_conv_weight_f16x2(weight):
 SPLIT2_MIN_TILES = int(os.environ.get("GDRNPP_SPLIT2_MIN_TILES", "256"))   # tests lower it to run the three-product kernels on the 4-ROI reference fixtures; the env var is for A/B runs
 
 
+# With a second step in flight on another stream (engine.StepStreams) a launch need not fill the chip by itself: from
+# SPLIT2_SHARED_MIN_TILES tiles on, if it has at least SPLIT2_SHARED_MIN_ROWS rows (fewer: the 128 x 128-tile six-product kernels stay ahead).
+SPLIT2_SHARED_MIN_TILES = int(os.environ.get("GDRNPP_SPLIT2_SHARED_MIN_TILES", "0"))      # 0 = off
+SPLIT2_SHARED_MIN_ROWS = int(os.environ.get("GDRNPP_SPLIT2_SHARED_MIN_ROWS", "4096"))
+
+
 def split2_tiles_ok(m: int, n: int) -> bool:
     """The three-product kernels exist as 256-row tiles only: used from 256 tiles of 256 x 128 on (every CU gets a workgroup)."""
-    return n % 128 == 0 and ((m + 255) // 256) * (n // 128) >= SPLIT2_MIN_TILES
+    if n % 128:
+        return False
+    tiles = ((m + 255) // 256) * (n // 128)
+    return tiles >= SPLIT2_MIN_TILES or (0 < SPLIT2_SHARED_MIN_TILES <= tiles and m >= SPLIT2_SHARED_MIN_ROWS)
 
 
 # Range words of the three-product launches (include/gdrnpp_hip.h: GDRNPP_SPLIT2_NONFINITE | GDRNPP_SPLIT2_SMALL_ROWS).  Every

@@ -687,3 +687,21 @@ def test_two_steps_in_flight_only_where_every_kernel_of_a_step_is_ours():
     finally:
         hip_layers.set_enabled(True)
         hip_layers.set_mlp_gemm("split")
+
+
+def test_three_product_tile_rule_alone_and_on_a_shared_chip():
+    """hip_lib.split2_tiles_ok: 256 tiles of 256 x 128 when a launch has the chip to itself; inside a StepStreams(2) context (a
+    second step beside it) from 128 tiles on, for launches of at least 4096 rows — and never for N not a multiple of 128."""
+    from gdrnpp_bop2022_amd import hip_lib
+
+    old = (hip_lib.SPLIT2_MIN_TILES, hip_lib.SPLIT2_SHARED_MIN_TILES, hip_lib.SPLIT2_SHARED_MIN_ROWS)
+    try:
+        hip_lib.SPLIT2_MIN_TILES, hip_lib.SPLIT2_SHARED_MIN_TILES, hip_lib.SPLIT2_SHARED_MIN_ROWS = 256, 0, 4096
+        assert hip_lib.split2_tiles_ok(128 * 256, 256) and not hip_lib.split2_tiles_ok(127 * 256, 256)      # 256 / 254 tiles
+        assert not hip_lib.split2_tiles_ok(32768, 128) and not hip_lib.split2_tiles_ok(1 << 20, 192)
+        hip_lib.SPLIT2_SHARED_MIN_TILES = 128
+        assert hip_lib.split2_tiles_ok(32768, 128)                  # 128 tiles, 32768 rows (Patch-PnP's second convolution at 128 ROIs)
+        assert not hip_lib.split2_tiles_ok(2048, 2048)              # 128 tiles but 8 row tiles only (stage-2 fc1 at 8 ROIs): stays six-product
+        assert not hip_lib.split2_tiles_ok(32768 - 256, 128) and not hip_lib.split2_tiles_ok(1 << 20, 192)
+    finally:
+        hip_lib.SPLIT2_MIN_TILES, hip_lib.SPLIT2_SHARED_MIN_TILES, hip_lib.SPLIT2_SHARED_MIN_ROWS = old

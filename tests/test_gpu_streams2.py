@@ -16,6 +16,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def same_kernels_on_one_and_two_streams():
+    """StepStreams(2) lets a launch of 128..255 tiles take the three-product form (a second step shares the chip); these tests
+    compare SCHEDULES bit for bit, so the one-stream runs choose their kernels by the same rule."""
+    old = hip_lib.SPLIT2_SHARED_MIN_TILES
+    hip_lib.SPLIT2_SHARED_MIN_TILES = hip_lib.SPLIT2_MIN_TILES // 2
+    yield
+    hip_lib.SPLIT2_SHARED_MIN_TILES = old
+
+
 def test_upsample_beside_the_conv_gemm_of_another_stream_is_bitwise_the_serial_result(hip):
     torch.manual_seed(3)
     conv = torch.nn.Conv2d(256, 256, 3, padding=1, bias=False).to(DEV)
