@@ -714,7 +714,6 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                 finally:
                     hip_lib.SPLIT2_SHARED_MIN_TILES = old_rule
                 out["last_step_records_bit_equal_to_timed_region"] = bool(torch.equal(rec_same, headline_rec.to(rec_same.device)))
-                out["max_abs_diff_of_its_own_kernel_choice"] = float((rec1 - headline_rec.to(rec1.device)).abs().max())
             return out
         except Exception as e:  # the headline line must not depend on the extra measurement
             return {"compute_streams": 1, "error": repr(e)}
