@@ -58,7 +58,7 @@ def _isa_checker():
 
 def test_shipped_device_code_holds_no_swizzled_packed_fp32():
     """MI355X returns wrong values in lanes 48..63 for v_pk_{add,mul}_f32 with op_sel:[0,1] while another wave of the SIMD issues
-    f16 MFMAs (two streams sharing the chip: profiles/r05p_pk_hazard_probe.txt, tests/test_gpu_streams2.py).  The library is built
+    double-rate f16 / bf16 MFMAs (two streams sharing the chip: profiles/r05p_pk_hazard_probe.txt, tests/test_gpu_streams2.py).  The library is built
     with -fno-slp-vectorize (the SLP vectorizer is what emits that form); this disassembles every gfx950 code object that was
     actually linked.  The link step of csrc/Makefile runs the same check."""
     from gdrnpp_bop2022_amd import hip_lib

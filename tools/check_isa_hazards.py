@@ -5,8 +5,8 @@
 
 Measured on MI355X (tools/pk_hazard_probe.py, profiles/r05p_pk_hazard_probe.txt): v_pk_add_f32 / v_pk_mul_f32 with op_sel:[0,1] (the
 low result takes the HIGH half of src1) return wrong values in lanes 48..63 while another wave of the same SIMD issues
-v_mfma_f32_16x16x32_f16 (every run) or v_mfma_f32_32x32x16_f16 (under the split GEMMs' density) — kernels of two streams sharing
-the chip.  Plain packed forms and op_sel_hi-only forms passed every run.  hipcc emits the swizzled forms from the SLP vectorizer
+gfx950's double-rate 16-bit MFMAs (this library's GEMMs, f16 and bf16 32x32x16 alike; a bare v_mfma_f32_16x16x32_f16 loop in every
+run) — kernels of two streams sharing the chip.  Plain packed forms and op_sel_hi-only forms passed every run.  hipcc emits the swizzled forms from the SLP vectorizer
 only, so the library is built with -fno-slp-vectorize; this check disassembles what was actually linked (every gfx950 code
 object of the .hip_fatbin section) and fails on ANY packed fp32 instruction with an explicit op_sel (conservative: op_sel:[1,0]
 and [1,1] passed the probe)."""
@@ -86,7 +86,7 @@ def main(argv):
         return 1
     if bad:
         print(f"check_isa_hazards: {len(bad)} packed-fp32 instruction(s) with op_sel in {argv[1]} (wrong in lanes 48..63 beside another "
-              "stream's f16 MFMAs on MI355X; build with -fno-slp-vectorize):", file=sys.stderr)
+              "stream's 16-bit MFMAs on MI355X; build with -fno-slp-vectorize):", file=sys.stderr)
         for b in bad[:20]:
             print("   " + b, file=sys.stderr)
         return 1
