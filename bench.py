@@ -310,7 +310,7 @@ def worker(args):
 
     launch = state["launch"] if state is not None else (lambda i: (lambda: step(i)))
     dst = 0 if args.gather_to_rank0 else None
-    depth = state["compute_streams"] if state is not None else 1     # launches ahead of the oldest unresolved step (stream workloads: the scheduler's own queue)
+    depth = state["compute_streams"] if state is not None else max(1, args.compute_streams)   # launches ahead of the oldest unresolved step
 
     def run_steps(n):
         """n steps, each resolved (range check + gather) after the next `depth` ones have been launched: with two compute streams

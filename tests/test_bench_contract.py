@@ -158,3 +158,17 @@ def test_world_size_must_match_gpus_flag():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-step"], capture_output=True,
                        text=True, timeout=120, env=env)
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_steps_resolved_two_launches_late_still_gather_every_step_once():
+    """The resolve queue of the two-stream schedule (a step's records are gathered after the next TWO have been launched) on the CPU
+    launch path: K steps launched, K gathered, the last gathered block holds every ROI id once on both ranks."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-step", "--compute-streams", "2",
+                        "--steps", "5", "--warmup", "1", "--batch", "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["config"]["global_batch"] == 12 and d["collective"]["calls_per_step"] == 1
+    assert abs(d["value"] - 12 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
