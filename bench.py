@@ -439,7 +439,9 @@ def worker(args):
                 "baseline_config_index": cfg_no, "workload_key": wname, "global_batch": n_global, "rois_per_gpu": b,
                 "roi_prep_on_gpu": bool(args.with_crop) or wname.endswith("stream"), "host_fed": bool(args.host_fed), "hipgraph": bool(args.graph), "input_res": 256, "output_res": 64,
                 "parallelism": f"roi-shard x{world}",
-                "compute_streams": n_cs, "steps_in_flight": ("consecutive steps dealt round-robin to %d HIP streams (engine.StepStreams): independent batches, "
+                "compute_streams": n_cs,
+                "compute_stream_overlap_probe": (state["overlap_probe"]() if state is not None and state.get("overlap_probe") else None),   # [(pool streams tried, overlap ratio of two spin kernels: ~2 = concurrent)]
+                "steps_in_flight": ("consecutive steps dealt round-robin to %d HIP streams (engine.StepStreams): independent batches, "
                                                              "records bit-equal to the single-stream schedule (tests/test_gpu_streams2.py)" % n_cs) if n_cs > 1 else "one stream",
                 "collective": (("gather(dst=0)" if dst is not None else "all_gather") + " f32[n,16] pose records") if use_dist else None,
                 "class_sliced_out_layer": not args.exact_reference_order, "rois_class_sorted_within_rank": True,
@@ -971,6 +973,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
 
     return dict(step=step, launch=launch, measure_after=measure_after, other_mode_line=other_mode_line, after_warmup=after_warmup,
                 single_stream_line=single_stream_line if stream is None else None, set_compute_streams=set_compute_streams,
+                overlap_probe=(lambda: (sched_streams if stream is not None else dealer["streams"]).overlap_probe),
                 compute_streams=len(dealer["streams"].streams) if stream is None else max(1, args.compute_streams))
 
 

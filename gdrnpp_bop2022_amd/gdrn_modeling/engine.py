@@ -432,6 +432,34 @@ def default_compute_streams(model) -> int:
     return 2 if ours else 1
 
 
+def streams_overlap_ratio(s0, s1, cycles: int = 400_000) -> float:
+    """(time of a spin kernel on s0 and then one on s1, each alone) / (time of both launched together): ~2 when the two streams
+    execute concurrently, ~1 when they share a hardware queue and run back to back.  ~1 ms of device time."""
+    dev = s0.device
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(s0):
+        torch.cuda._sleep(cycles)               # warm both paths (first launch on a fresh stream creates its queue)
+    with torch.cuda.stream(s1):
+        torch.cuda._sleep(cycles)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(s0):                  # alone
+        ev[0].record()
+        torch.cuda._sleep(cycles)
+        ev[1].record()
+    torch.cuda.synchronize(dev)
+    alone = ev[0].elapsed_time(ev[1])
+    with torch.cuda.stream(s0):                  # together: s1's kernel is launched while s0's spins
+        ev[2].record()
+        torch.cuda._sleep(cycles)
+    with torch.cuda.stream(s1):
+        torch.cuda._sleep(cycles)
+        ev[3].record()
+    torch.cuda.synchronize(dev)
+    together = ev[2].elapsed_time(ev[3])
+    return 2.0 * alone / max(together, 1e-6)
+
+
 class StepStreams:
     """Consecutive steps are independent (each batch its own ROIs, its own records), so they need not queue behind each other
     on ONE stream: dealt round-robin to ``n`` compute streams, the second step's GEMMs fill the chip while the first one is in
@@ -452,7 +480,26 @@ class StepStreams:
             raise ValueError("StepStreams needs at least one stream")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         pr = list(priorities) if priorities is not None else [0] * n     # (A/B only: equal priorities are what was measured best)
-        self.streams = [torch.cuda.Stream(self.device, priority=int(pr[i % len(pr)])) for i in range(n)] if n > 1 else [None]
+        self.streams = [None]
+        self.overlap_probe = None               # [(candidates tried, overlap ratio)] per stream after the first: what the choice was based on
+        if n > 1:
+            # HIP multiplexes its streams over a few hardware queues; two streams that land on the SAME queue run one after the
+            # other, and "two steps in flight" silently becomes the one-stream schedule (measured: a pair drawn later in a
+            # process gave 24.97 instead of 23.49 ms per step, profiles/r05last_two_stream_soak.txt).  So every further stream is
+            # drawn from torch's pool until a pair of spin kernels really overlaps with the first one.
+            self.streams = [torch.cuda.Stream(self.device, priority=int(pr[0]))]
+            self.overlap_probe = []
+            for i in range(1, n):
+                best = None
+                for attempt in range(8):
+                    cand = torch.cuda.Stream(self.device, priority=int(pr[i % len(pr)]))
+                    ratio = min(streams_overlap_ratio(s_, cand) for s_ in self.streams)
+                    if best is None or ratio > best[1]:
+                        best = (cand, ratio)
+                    if ratio > 1.6:
+                        break
+                self.streams.append(best[0])
+                self.overlap_probe.append((attempt + 1, round(best[1], 2)))
         self._i = 0
         self.sync_with_current()
 

@@ -204,3 +204,19 @@ def test_steps_without_range_words_are_ordered_before_the_callers_stream_reads_t
                 assert torch.equal(a, c), f"rep {rep} step {i}"
         assert hip_lib.x3_launch_count() == n0, "six products were forced: no three-product launch, hence no range words"
     assert torch.isfinite(one[0]).all() and (one[0][:, 15] > 0.5).all()
+
+
+def test_step_streams_are_chosen_so_that_they_really_overlap(hip):
+    """HIP multiplexes streams over a few hardware queues: two streams on one queue run back to back and 'two steps in flight'
+    silently becomes the one-stream schedule.  StepStreams probes a pair of spin kernels and draws from torch's stream pool until
+    they overlap; a stream against itself shows what 'no overlap' measures."""
+    dev = torch.device(DEV, 0)
+    s = torch.cuda.Stream(dev)
+    assert engine.streams_overlap_ratio(s, s) < 1.3
+    for _ in range(6):          # later pairs of a process are the ones that used to collide
+        d = engine.StepStreams(2, dev)
+        assert len(d.streams) == 2 and d.streams[0] != d.streams[1]
+        tried, ratio = d.overlap_probe[0]
+        assert ratio > 1.6 and 1 <= tried <= 8, d.overlap_probe
+        assert engine.streams_overlap_ratio(*d.streams) > 1.6
+    assert engine.StepStreams(1, dev).streams == [None] and engine.StepStreams(1, dev).overlap_probe is None
