@@ -1190,7 +1190,9 @@ class RoiStreamScheduler:
         rec = handle.result()                   # waits for that step's range-word event only (and repeats a flagged step)
         if rec.is_cuda:
             if self._d2h_stream is None:
-                self._d2h_stream = torch.cuda.Stream(device=rec.device)
+                # high priority = the other hardware-queue pool: a default-priority stream may share a queue with a compute stream, and
+                # a record copy queued there behind the NEWEST step's kernels would hold the host until that step is done
+                self._d2h_stream = torch.cuda.Stream(device=rec.device, priority=-1)
             compute = handle.stream if handle.stream is not None else torch.cuda.current_stream(rec.device)   # the step's own stream (looked up OUTSIDE the side stream's context)
             with torch.cuda.stream(self._d2h_stream):
                 if handle.reran:                # a six-product repeat ran on the step's stream just now: its records are the newest work there
