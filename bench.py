@@ -558,7 +558,9 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                            K_crops=[p[2] for p in pair], meshes=meshes, verts=verts, faces=faces, C=C, graphs={}, ext=ext))
 
     if args.compute_streams <= 0:        # default: two steps in flight only where every kernel of a step is this library's
-        args.compute_streams = min(E.default_compute_streams(m_["model"]) for m_ in models)
+        args.compute_streams = min(E.default_compute_streams(m_["model"], m_["cfg"]) for m_ in models)
+    else:                                # an explicit --compute-streams N is an A/B request: the dealer keeps sharing whatever a step launches
+        args.allow_foreign_streams = True
 
     stream = None
     if wname in ("stream", "bop7_stream"):
@@ -567,7 +569,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         import itertools
         counter = itertools.count()
         subs = []                 # one image stream + scheduler per model ("stream": YCB-V; "bop7_stream": the seven BOP datasets)
-        sched_streams = E.StepStreams(max(1, args.compute_streams), dev)      # one dealer for all of them: consecutive steps alternate
+        sched_streams = E.StepStreams(max(1, args.compute_streams), dev, allow_foreign=bool(getattr(args, "allow_foreign_streams", False)))      # one dealer for all of them: consecutive steps alternate
         for di, m_ in enumerate(models):
             rng = np.random.default_rng(20220925 + 17 + rank + 1000 * di)
             g = torch.Generator(device=dev).manual_seed(20220925 + rank + 1000 * di)
@@ -614,11 +616,12 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             upnp.append(dict(p2=T(p2), p3=T(np.repeat(kpts[None], b, 0)), w=T(w), K=T(np.repeat(K.reshape(1, 9), b, 0)), init=T(init)))
 
     prios = [int(v) for v in args.stream_priorities.split(",")] if args.stream_priorities else None
-    dealer = {"streams": E.StepStreams(1 if (args.graph or stream is not None) else max(1, args.compute_streams), dev, prios)}
+    allow_foreign = bool(getattr(args, "allow_foreign_streams", False))
+    dealer = {"streams": E.StepStreams(1 if (args.graph or stream is not None) else max(1, args.compute_streams), dev, prios, allow_foreign=allow_foreign)}
 
     def set_compute_streams(n):
         torch.cuda.synchronize(dev)
-        dealer["streams"] = E.StepStreams(n, dev, prios)
+        dealer["streams"] = E.StepStreams(n, dev, prios, allow_foreign=allow_foreign)
 
     @torch.no_grad()
     def prepared(m, k):
@@ -708,13 +711,10 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                 # scheduling alone must not change a bit: the last step of the timed region once more on ONE stream, with the kernel
                 # choice of the shared chip (StepStreams.shared_min_tiles) — the same kernels, one stream instead of two
                 period = 2 * len(models)
-                old_rule = hip_lib.SPLIT2_SHARED_MIN_TILES
-                try:
-                    hip_lib.SPLIT2_SHARED_MIN_TILES = E.StepStreams(max(1, args.compute_streams), dev).shared_min_tiles() or old_rule
+                rule = (hip_lib.SPLIT2_MIN_TILES // args.compute_streams if args.compute_streams > 1 else 0) or None   # = StepStreams(n).shared_min_tiles()
+                with hip_lib.shared_min_tiles_scope(rule):
                     rec_same = run_pipelined(((steps - 1) % period) + 1)
                     sync()
-                finally:
-                    hip_lib.SPLIT2_SHARED_MIN_TILES = old_rule
                 out["last_step_records_bit_equal_to_timed_region"] = bool(torch.equal(rec_same, headline_rec.to(rec_same.device)))
             return out
         except Exception as e:  # the headline line must not depend on the extra measurement
@@ -756,6 +756,11 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                                "layers_kept_on_six_products": len(hip_layers.x3_demoted()),
                                "note": "whole process (warm-up included): a layer whose A rows sat below 2^-4 rms or that overflowed "
                                        "the fp16 range is repeated once and then stays on the bf16x3 kernels"}}
+        d_ = sched_streams if stream is not None else dealer["streams"]
+        out["two_stream_guard"] = {"launches_outside_this_library": hip_layers.fallback_launches(), "last": hip_layers.last_fallback(),
+                                   "dealer_stopped_sharing": d_.stopped_sharing, "allow_foreign": d_.allow_foreign,
+                                   "note": "whole process: hip_layers counts every layer that fell back to a PyTorch operator while the HIP path was on; "
+                                           "a step that moves the counter inside a sharing dealer is repeated alone and the dealer drops to one stream"}
         if stream is not None:
             out["stream"] = {"images_per_s": None, "rois_per_image_mean": stream["rois_per_image"],
                              "images_pushed": next(stream["counter"]), "rois_per_step": b,

@@ -77,9 +77,23 @@ __global__ void stream_read_kernel(const float* __restrict__ p, size_t n, float*
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if ((threadIdx.x & 63) == 0) atomicAdd(out + blockIdx.x, acc);
 }
+// stream-overlap probe: one wave spins on the constant-rate wall clock (s_memrealtime) until `ticks` have passed
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
 }  // namespace
 
 extern "C" {
+int gdrnpp_debug_spin(int micros, void* stream) {
+  GDRNPP_REQUIRE(micros >= 1 && micros <= 1000000, GDRNPP_EINVAL, "gdrnpp_debug_spin: micros must be in [1, 1000000]");
+  int dev = 0, khz = 0;
+  GDRNPP_HIP_TRY(hipGetDevice(&dev));
+  GDRNPP_HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+  if (khz <= 0) khz = 100000;      // 100 MHz: the constant-rate counter of every CDNA part
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)micros * khz / 1000);
+  return gdrnpp::check_launch("gdrnpp_debug_spin");
+}
 int gdrnpp_debug_stream_read(const float* p, size_t n, int lane_bytes, float* out_blocks, int blocks, void* stream) {
   GDRNPP_REQUIRE(p && out_blocks && n > 0 && blocks > 0 && (lane_bytes == 4 || lane_bytes == 16), GDRNPP_EINVAL,
                  "gdrnpp_debug_stream_read: bad arguments");

@@ -83,7 +83,7 @@ class GDRN_DoubleMask(nn.Module):
         if self.slice_classes is not None and self.xyz_out_dim == 3:
             self.register_buffer("_cls_rows", geo_head_net.class_channel_index(self.slice_classes), persistent=False)
         self._sliced_w = None  # cache of (weight[C,70,256], bias[C,70]) for eval
-        self._sliced_pk = None  # cache of the packed, 128-row padded slices for the grouped split GEMM
+        self._sliced_pk = {}    # cache of the packed, 128-row padded slices for the grouped split GEMM (hip_layers.cached)
         self.fused_head_tail = True   # all-NHWC head tail on the HIP path (False: baddbmm + torch ops, for A/B)
 
     def load_state_dict(self, *args, **kwargs):
@@ -131,8 +131,8 @@ class GDRN_DoubleMask(nn.Module):
         tile), one kernel for [xyz * extent | coord2d | region softmax] + the map planes, Patch-PnP's first convolution with
         Cin padded 69 -> 96 on the implicit-GEMM kernel.  Same arithmetic as the module path (fp32-accurate GEMMs)."""
         ol = self.geo_head_net.out_layer
-        tag = hip_layers.weight_tag(ol.weight, ol.bias)
-        if self._sliced_pk is None or self._sliced_pk[0] != tag:
+
+        def build():
             w = ol.weight.detach().view(ol.out_channels, -1)[self._cls_rows]    # [C,70,256]
             b = ol.bias.detach()[self._cls_rows]                                  # [C,70]
             C, n70, k = w.shape
@@ -140,8 +140,10 @@ class GDRN_DoubleMask(nn.Module):
             w128[:, :n70] = w
             b128 = torch.zeros((C, 128), dtype=b.dtype, device=b.device)
             b128[:, :n70] = b
-            self._sliced_pk = (tag, hip_lib.pack_weight_bf16x3(w128.view(C * 128, k).contiguous()), b128.contiguous(), n70)
-        _, w_pk, b128, n70 = self._sliced_pk
+            return hip_lib.pack_weight_bf16x3(w128.view(C * 128, k).contiguous()), b128.contiguous(), n70
+
+        # (built with torch operators on the filling stream: hip_layers.cached drains it before another stream may hit the entry)
+        _, w_pk, b128, n70 = hip_layers.cached(self._sliced_pk, "pk", hip_layers.weight_tag(ol.weight, ol.bias), build, ol.weight)
         bs, ch, h, wd = feat.shape
         feat = feat.contiguous(memory_format=torch.channels_last)
         x2d = feat.permute(0, 2, 3, 1).reshape(bs * h * wd, ch)     # a view of the NHWC memory
@@ -184,12 +186,16 @@ class GDRN_DoubleMask(nn.Module):
             coord2d = roi_coord_2d_rel if pnp_net_cfg.WITH_2D_COORD and pnp_net_cfg.COORD_2D_TYPE == "rel" else roi_coord_2d
             if self._fused_tail_ok(x, feat, sel, coord2d, roi_extents):
                 return self._fused_tail(feat, sel, coord2d, roi_extents, pose)
+            if hip_layers.enabled_for(x):      # the module-path tail below is PyTorch operators (baddbmm, softmax, cat, gathers)
+                hip_layers.note_foreign_launch("GDRN_DoubleMask.forward_maps: head tail on the module path (configuration outside the fused NHWC tail)")
             if self.class_aware:
                 vis_mask, full_mask, coor_x, coor_y, coor_z, region = self._sliced_out_layer(feat, sel)
                 sliced = True
             else:
                 outs = self.geo_head_net.split(self.geo_head_net.out_layer(feat))
         else:
+            if hip_layers.enabled_for(x):
+                hip_layers.note_foreign_launch("GDRN_DoubleMask.forward_maps: full-width output layer + class gather on the module path")
             outs = self.geo_head_net(conv_feat)
         if not sliced:
             if self.double_mask:

@@ -159,6 +159,7 @@ class ResNetFeatures(nn.Module):
             x = self.act1(self.bn1(self.conv1(x)))
         if 0 in self.out_indices:
             feats.append(x)
+        hip_layers.foreign("ResNetFeatures: max-pooling as a PyTorch operator", x)
         x = self.maxpool(x)
         for i in range(1, 5):
             x = getattr(self, f"layer{i}")(x)

@@ -66,6 +66,8 @@ class ConvModule(nn.Module):
         x = hip_layers.conv2d(self.conv, x)
         if self.norm_name == "gn":
             return hip_layers.groupnorm_act(getattr(self, "gn"), self.activate, x)  # fused GN(+GELU) on the GPU
+        if self.norm_name is not None or self.activate is not None:
+            hip_layers.foreign("ConvModule: norm / activation as PyTorch operators", x)
         if self.norm_name is not None:
             x = getattr(self, self.norm_name)(x)
         if self.activate is not None:
@@ -93,6 +95,7 @@ def run_features(features, x):
                 if isinstance(nxt, nn.GELU):
                     x = hip_layers.groupnorm_act(layer, nxt, x)
                 else:
+                    hip_layers.foreign("run_features: " + type(nxt).__name__ + " behind GroupNorm as a PyTorch operator", x)
                     x = nxt(hip_layers.groupnorm_act(layer, None, x))
                 i += 2
                 continue
@@ -122,6 +125,8 @@ def run_features(features, x):
                     continue
             x = hip_layers.conv_transpose2d(layer, x)
         else:
+            if not isinstance(layer, nn.Identity):
+                hip_layers.foreign("run_features: " + type(layer).__name__ + " as a PyTorch operator", x)
             x = layer(x)
         i += 1
     return x
@@ -263,6 +268,7 @@ class ConvPnPNet(nn.Module):
 
     def forward(self, coor_feat, region=None, extents=None, mask_attention=None, pose=None):
         bs, in_c, fh, fw = coor_feat.shape
+        hip_layers.foreign("ConvPnPNet.forward: input de-normalisation / concatenation as PyTorch operators (module path)", coor_feat)
         if in_c in (3, 5) and self.denormalize_by_extent and extents is not None:
             coor_feat[:, :3] = (coor_feat[:, :3] - 0.5) * extents.view(bs, 3, 1, 1)  # in place, like :130-131
         x = torch.cat([coor_feat, region], dim=1) if region is not None else coor_feat
@@ -278,6 +284,7 @@ class ConvPnPNet(nn.Module):
         if isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none":
             x = hip_layers.linear(self.fc2, hip_layers.linear(self.fc1, x, gelu=True), gelu=True)   # GELU in the GEMM epilogues
         else:
+            hip_layers.foreign("ConvPnPNet: " + type(self.act).__name__ + " behind fc1 / fc2 as a PyTorch operator", x)
             x = self.act(hip_layers.linear(self.fc1, x))
             x = self.act(hip_layers.linear(self.fc2, x))
         return hip_layers.pnp_fc_heads(self.fc_r, self.fc_t, x, pose)

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 import torch
@@ -87,6 +88,7 @@ SIGNATURES = {
                                          c_size_t, _P]),
     "gdrnpp_roi_pool": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "gdrnpp_debug_stream_read": (c_int, [_P, c_size_t, c_int, _P, c_int, _P]),
+    "gdrnpp_debug_spin": (c_int, [c_int, _P]),
     "gdrnpp_crop_resize_roi": (
         c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "gdrnpp_yolox_postprocess_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -148,6 +150,12 @@ def copy_d2d(dst_ptr: int, src: torch.Tensor) -> None:
         raise RuntimeError("copy_d2d: src must be a contiguous CUDA(HIP) tensor")
     _check(load().gdrnpp_copy_d2d(c_void_p(int(dst_ptr)), src.data_ptr(), src.numel() * src.element_size(), _stream()),
            "gdrnpp_copy_d2d")
+
+
+def spin(micros: int) -> None:
+    """One wave busy-waiting ``micros`` microseconds of the device's wall clock on the current stream (``gdrnpp_debug_spin``): the
+    probe kernel of engine.streams_overlap_ratio — occupies a hardware queue, computes nothing."""
+    _check(load().gdrnpp_debug_spin(int(micros), _stream()), "gdrnpp_debug_spin")
 
 
 def set_option(name: str, value: int) -> None:
@@ -731,12 +739,41 @@ SPLIT2_SHARED_MIN_TILES = int(os.environ.get("GDRNPP_SPLIT2_SHARED_MIN_TILES", "
 SPLIT2_SHARED_MIN_ROWS = int(os.environ.get("GDRNPP_SPLIT2_SHARED_MIN_ROWS", "4096"))
 
 
+_SHARED_TLS = threading.local()     # .min_tiles: the shared-chip rule of the calling HOST THREAD (engine.StepStreams.next sets it for
+                                    # the launches of one step); unset = the process default above.  Two host threads driving
+                                    # their own dealers never see each other's setting.
+
+
+def shared_min_tiles() -> int:
+    """The shared-chip tile rule in force for the calling host thread (0 = off)."""
+    v = getattr(_SHARED_TLS, "min_tiles", None)
+    return SPLIT2_SHARED_MIN_TILES if v is None else v
+
+
+class shared_min_tiles_scope:
+    """``with shared_min_tiles_scope(n):`` — launches of the calling host thread inside choose their GEMM kernels for a chip shared
+    with another step (three-product 256-row form from ``n`` tiles on); ``None`` = leave whatever is in force."""
+
+    def __init__(self, n):
+        self.n = None if n is None else int(n)
+
+    def __enter__(self):
+        self.prev = getattr(_SHARED_TLS, "min_tiles", None)
+        if self.n is not None:
+            _SHARED_TLS.min_tiles = self.n
+        return self
+
+    def __exit__(self, *exc):
+        _SHARED_TLS.min_tiles = self.prev
+        return False
+
+
 def split2_tiles_ok(m: int, n: int) -> bool:
     """The three-product kernels exist as 256-row tiles only: used from 256 tiles of 256 x 128 on (every CU gets a workgroup)."""
     if n % 128:
         return False
     tiles = ((m + 255) // 256) * (n // 128)
-    return tiles >= SPLIT2_MIN_TILES or (0 < SPLIT2_SHARED_MIN_TILES <= tiles and m >= SPLIT2_SHARED_MIN_ROWS)
+    return tiles >= SPLIT2_MIN_TILES or (0 < shared_min_tiles() <= tiles and m >= SPLIT2_SHARED_MIN_ROWS)
 
 
 # Range words of the three-product launches (include/gdrnpp_hip.h: GDRNPP_SPLIT2_NONFINITE | GDRNPP_SPLIT2_SMALL_ROWS).  Every

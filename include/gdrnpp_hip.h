@@ -302,6 +302,11 @@ int gdrnpp_copy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 int gdrnpp_debug_stream_read(const float* p, size_t n, int lane_bytes, float* out_blocks,
                              int blocks, void* stream);
 
+/* debug aid: ONE wave busy-waits `micros` microseconds of the device's constant-rate wall clock on `stream` and computes nothing — the
+ * probe engine.streams_overlap_ratio launches on two streams to learn whether they sit on different hardware queues (replaces
+ * the private torch.cuda._sleep).  1 <= micros <= 1 000 000. */
+int gdrnpp_debug_spin(int micros, void* stream);
+
 /* debug aid: 16 s_memtime stamps written by workgroup 0 of the last gdrnpp_depth_refine launch (LDS-staged
  * kernel): [0] start, [1] prologue, then per iteration staged/rastered/reduced/median/updated. Host pointer. */
 int gdrnpp_debug_refine_profile(long long* h_out16);

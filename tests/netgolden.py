@@ -45,6 +45,17 @@ def net_detections_b128(num_classes, b=128, seed=SEED):
     return det
 
 
+def net_detections_large(num_classes, b, seed=SEED):
+    """The ROI batches of the iteration-size fixtures (net_golden_tless_b1024.npz, net_golden_ycbv_b512.npz): their own generator
+    stream, every class present (roi_cls = i mod C, unsorted)."""
+    rng = np.random.default_rng(seed + 5000 + b + num_classes)
+    ext = rng.uniform(0.05, 0.25, (num_classes, 3)).astype(np.float32)
+    det = S.make_detections(b, num_classes, ext, rng)
+    det["roi_cls"] = (np.arange(b) % num_classes).astype(np.int64)
+    det["roi_extent"] = ext[det["roi_cls"]]
+    return det
+
+
 def cfg_name(ds):
     """Fixture name -> named config: "ycbvso" is a single-object config (class-agnostic head, configs/gdrn/ycbvSO/...)."""
     return f"{ds[:-2]}_convnext_so" if ds.endswith("so") else f"{ds}_convnext_a6"

