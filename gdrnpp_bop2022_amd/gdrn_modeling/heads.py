@@ -125,7 +125,7 @@ def run_features(features, x):
                     continue
             x = hip_layers.conv_transpose2d(layer, x)
         else:
-            if not isinstance(layer, nn.Identity):
+            if type(layer).__module__.startswith("torch.nn") and not isinstance(layer, nn.Identity):   # (ConvModule dispatches by itself)
                 hip_layers.foreign("run_features: " + type(layer).__name__ + " as a PyTorch operator", x)
             x = layer(x)
         i += 1

@@ -76,7 +76,48 @@ def scan(lib_path):
     return len(objs), n_pk, bad
 
 
+def kernel_names(lib_path):
+    """Demangled names of every kernel the library can launch (the ``<name>.kd`` kernel descriptors of its gfx950 code objects):
+    the whitelist of tests/test_gpu_stream_guard.py — "a steady-state step launches nothing but these, copies and fills"."""
+    readelf, cxxfilt = tool("llvm-readelf") or shutil.which("readelf"), tool("llvm-cxxfilt") or shutil.which("c++filt")
+    if readelf is None or cxxfilt is None:
+        raise RuntimeError("no (llvm-)readelf / c++filt")
+    mangled = set()
+    for _, blob in code_objects(lib_path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob)
+            f.flush()
+            txt = subprocess.run([readelf, "--symbols", "--wide", f.name], check=True, capture_output=True, text=True).stdout
+        for line in txt.splitlines():
+            name = line.split()[-1] if line.split() else ""
+            if name.endswith(".kd"):
+                mangled.add(name[:-3])
+    out = subprocess.run([cxxfilt], input="\n".join(sorted(mangled)), check=True, capture_output=True, text=True).stdout
+    return sorted(set(out.split("\n")) - {""})
+
+
+def kernel_base_name(name):
+    """'void gdrnpp::(anonymous namespace)::foo_kernel<1, 2>(float*, int)' / a mangled name -> 'foo_kernel'."""
+    if name.startswith("_Z"):
+        cxxfilt = tool("llvm-cxxfilt") or shutil.which("c++filt")
+        if cxxfilt:
+            name = subprocess.run([cxxfilt, name], check=True, capture_output=True, text=True).stdout.strip()
+    name = name.replace("(anonymous namespace)::", "")
+    cut = len(name)
+    for i, ch in enumerate(name):           # drop the argument list and the template argument list
+        if ch in "<(":
+            cut = i
+            break
+    head = name[:cut].strip()
+    head = head.split(" ")[-1]               # drop a leading return type ("void ")
+    return head.split("::")[-1]
+
+
 def main(argv):
+    if len(argv) == 3 and argv[1] == "--kernels":
+        for n in kernel_names(argv[2]):
+            print(n)
+        return 0
     if len(argv) != 2:
         print(__doc__)
         return 2
