@@ -617,11 +617,13 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
 
     prios = [int(v) for v in args.stream_priorities.split(",")] if args.stream_priorities else None
     allow_foreign = bool(getattr(args, "allow_foreign_streams", False))
-    dealer = {"streams": E.StepStreams(1 if (args.graph or stream is not None) else max(1, args.compute_streams), dev, prios, allow_foreign=allow_foreign)}
+    dealer = {"streams": E.StepStreams(1 if stream is not None else max(1, args.compute_streams), dev, prios, allow_foreign=allow_foreign)}
 
     def set_compute_streams(n):
         torch.cuda.synchronize(dev)
         dealer["streams"] = E.StepStreams(n, dev, prios, allow_foreign=allow_foreign)
+        for m_ in models:                # hipGraphs were captured on the old dealer's streams
+            m_["graphs"].clear()
 
     @torch.no_grad()
     def prepared(m, k):
@@ -641,10 +643,13 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             s_ = stream["subs"][i % len(stream["subs"])]
             return s_["sched"].launch_next(s_["feeder"])
         if args.graph and not args.with_crop and upnp is None:
-            if k not in m["graphs"]:
-                m["graphs"][k] = GraphedInference(m["model"], m["post"], m["batches"][k], m["batches"][k]["roi_id"])
-            rec = m["graphs"][k].replay()   # inputs already live in the graph's static buffers (resident in HBM)
-            return lambda: rec
+            if "gs" not in m["graphs"]:      # one graph per slot (a resident batch), slots dealt to the dealer's streams: n hipGraphs in flight
+                n_st = len(dealer["streams"].streams)
+                n_slots = 2 * ((n_st + 1) // 2) if len(models) == 1 else 2          # slot j holds batch j % 2
+                m["graphs"]["gs"] = E.GraphedStepStreams(m["model"], m["post"], [m["batches"][j % 2] for j in range(n_slots)], compute_streams=dealer["streams"])
+                m["graphs"]["n_slots"] = n_slots
+            slot = i % m["graphs"]["n_slots"] if len(models) == 1 else k            # (one model: i % 2 == k, so slot % 2 == k)
+            return m["graphs"]["gs"].launch(slot).result   # inputs already live in the graphs' static buffers (resident in HBM)
         with dealer["streams"].next():       # consecutive steps on alternating compute streams (engine.StepStreams); the crop too
             h = inference_step_async(m["model"], m["post"], prepared(m, k))     # records carry batch["roi_id"]
         if upnp is None:

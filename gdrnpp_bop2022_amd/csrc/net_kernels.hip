@@ -876,7 +876,7 @@ int launch_dwconv(const float* x, const float* w49c, const float* bias, const fl
   const int buf_rows = ((Q >= 64) || (tiles_x % (64 / Q) == 0)) && (long)W * C * 4 < (1l << 31) ? 1 : 0;
   const size_t wbytes = (size_t)49 * C * sizeof(float);
   const bool fuse = ln_w && ln_b;
-  if (wbytes <= 112 * 1024) {
+  if (wbytes <= 112 * 1024 && gdrnpp::option_dwconv_lds_w()) {
     // weights in LDS, persistent workgroups: 512 threads when the weight set allows only one workgroup per CU
     const int threads = wbytes > 52 * 1024 ? 512 : 256;
     const long n_groups = (n_tiles + threads / Q - 1) / (threads / Q);
@@ -918,11 +918,16 @@ int launch_dwconv(const float* x, const float* w49c, const float* bias, const fl
     const int tiles_per_block = 256 / Q;
     const long blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;
     GDRNPP_REQUIRE(blocks < (1l << 31), GDRNPP_ELIMIT, "gdrnpp_dwconv7x7_ln_nhwc: grid too large");
+    const size_t pad = (size_t)gdrnpp::option_dwconv_lds_pad();      // experiment only (0 in the product): LDS the workgroup holds without using it
+    if (pad > 64 * 1024) {
+      const void* fn = fuse ? (const void*)dwconv7_ln_kernel<true, false, TH, TW> : (const void*)dwconv7_ln_kernel<false, false, TH, TW>;
+      if (int rc = gdrnpp::ensure_dynamic_lds(fn, 112 * 1024)) return rc;
+    }
     if (fuse) {
-      hipLaunchKernelGGL((dwconv7_ln_kernel<true, false, TH, TW>), dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias, ln_w,
+      hipLaunchKernelGGL((dwconv7_ln_kernel<true, false, TH, TW>), dim3((unsigned)blocks), dim3(256), pad, st, x, w49c, bias, ln_w,
                          ln_b, y, N, H, W, C, eps, buf_rows, y_rows);
     } else {
-      hipLaunchKernelGGL((dwconv7_ln_kernel<false, false, TH, TW>), dim3((unsigned)blocks), dim3(256), 0, st, x, w49c, bias,
+      hipLaunchKernelGGL((dwconv7_ln_kernel<false, false, TH, TW>), dim3((unsigned)blocks), dim3(256), pad, st, x, w49c, bias,
                          nullptr, nullptr, y, N, H, W, C, eps, buf_rows, y_rows);
     }
   }

@@ -766,33 +766,62 @@ def save_bop_csv(results, path: str) -> None:
             f.write(",".join(to_str(res[k]) for k in keys) + "\n")
 
 
+class GraphHandle:
+    """A replayed hipGraph whose range words have not been looked at yet (``GraphedInference.replay_async``).  ``result()``
+    waits for the replay (one event), and — when a three-product kernel of the graph left its range — repeats the step eagerly
+    with six products and has the graph captured again.  Must be resolved before the same graph is replayed again (the graph's
+    static buffers are reused; ``replay_async`` resolves a forgotten handle itself)."""
+
+    def __init__(self, owner, event, rec):
+        self._owner, self._event, self._rec = owner, event, rec
+
+    def result(self) -> torch.Tensor:
+        if self._owner is not None:
+            owner, self._owner = self._owner, None
+            self._rec = owner._resolve(self._event, self._rec)
+            self._event = None
+        return self._rec
+
+
 class GraphedInference:
     """The whole hot path (forward + HIP post-processing + record packing) captured once into a hipGraph and
     replayed per batch.  At the reference's own batch sizes (one image = a few to ~30 ROIs, gdrn_evaluator.py:702)
-    the ≈260 launches of a step are launch-bound; a graph replay removes the per-launch host cost.  Shapes are
-    fixed at capture time: batches are copied into static device buffers (pad the ROI dimension to the captured
-    size; padded rows are ordinary ROIs whose records the caller ignores).
+    the ~150 launches of a step are launch-bound (3.2 ms of host time per 8-ROI step through ctypes); a graph replay removes the
+    per-launch host cost.  Shapes are fixed at capture time: batches are copied into static device buffers (pad the ROI
+    dimension to the captured size; padded rows are ordinary ROIs whose records the caller ignores).
 
-    Three-product kernels inside the graph write their range words to a buffer the graph owns; ``replay`` reads it after every
-    replay (one 4 KB read-back).  When a layer left the range the step is repeated eagerly with six products, its records are
-    copied into the static output, the layer is demoted and the graph is captured again with it on the six-product kernels —
-    so a flagged layer is paid for once, not on every replay."""
+    ``stream``: the HIP stream the graph is captured and replayed on (default: the caller's current stream).  Two graphs on the
+    two streams of a ``StepStreams`` dealer are TWO STEPS IN FLIGHT without any per-launch host work (``GraphedStepStreams``).
+    ``shared_min_tiles``: the kernel rule of a shared chip (StepStreams.shared_min_tiles) the graph's launches are chosen by —
+    captured with the rule of the eager two-stream schedule a graph replays the same kernels and gives the same bits.
+    ``sharing``: the graph is going to run beside another stream's step: a captured step that launched anything outside this
+    library raises (hip_layers.fallback_launches; the packed-fp32 hazard of MI355X, profiles/r05p_two_stream_hazard.md).
+
+    Three-product kernels inside the graph write their range words to a buffer the graph owns; every replay copies it to pinned
+    host memory behind the graph (asynchronously — ``replay_async`` returns at once, ``GraphHandle.result()`` looks).  When a
+    layer left the range the step is repeated eagerly with six products, its records are copied into the static output, the
+    layer is demoted and the graph is captured again with it on the six-product kernels — so a flagged layer is paid for once,
+    not on every replay."""
 
     def __init__(self, model, post: GdrnHipPost, example_batch: dict, roi_ids: torch.Tensor | None = None,
-                 warmup: int = 3):
+                 warmup: int = 3, stream=None, shared_min_tiles=None, sharing: bool = False):
         self.model, self.post = model, post
+        self.stream = stream                                  # None = whatever stream is current when replay is called
+        self.shared_min_tiles, self.sharing = shared_min_tiles, bool(sharing)
         self.static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in example_batch.items()}
         self.roi_ids = roi_ids.clone() if roi_ids is not None else None
         self.captures = 0
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # MIOpen find, hipFuncSetAttribute, allocator warm-up, weight packing and the first
-            for _ in range(max(warmup, 1)):   # range verdicts (demotions) happen outside capture
-                inference_step(model, post, self.static, self.roi_ids)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.x3_flag = torch.zeros((hip_lib.X3_SLOTS,), dtype=torch.int32, device=self.static["roi_img"].device)   # the graph's own range words
+        self._pending = None                                  # the unresolved GraphHandle of the latest replay
+        dev = self.static["roi_img"].device
+        for _ in range(max(warmup, 1)):                       # MIOpen find, hipFuncSetAttribute, allocator warm-up, weight packing and the
+            self._eager_pass()                                # first range verdicts (demotions) happen outside capture
+        self.x3_flag = torch.zeros((hip_lib.X3_SLOTS,), dtype=torch.int32, device=dev)   # the graph's own range words
+        self._host_words = torch.zeros((hip_lib.X3_SLOTS,), dtype=torch.int32, pin_memory=True)
         self._capture()
+
+    def _on_stream(self):
+        """Context: the graph's stream is current (no-op when the graph follows the caller's stream)."""
+        return torch.cuda.stream(self.stream)
 
     @torch.no_grad()
     def _eager_pass(self):
@@ -801,7 +830,9 @@ class GraphedInference:
         has never packed its two unfused images), ``packed_rows_in_range``'s host read, hipFuncSetAttribute — happens here."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        if self.stream is not None:
+            side.wait_stream(self.stream)
+        with torch.cuda.stream(side), hip_lib.shared_min_tiles_scope(self.shared_min_tiles):
             inference_step(self.model, self.post, self.static, self.roi_ids)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -818,36 +849,125 @@ class GraphedInference:
     def _capture(self):
         run = _step_closure(self.model, self.post, self.static, self.roi_ids)
         self.graph = torch.cuda.CUDAGraph()
-        n_x3 = hip_lib.x3_launch_count()
+        n_x3, n_foreign = hip_lib.x3_launch_count(), hip_layers.fallback_launches()
         self.x3_flag.zero_()
         torch.cuda.synchronize()
-        with hip_lib.x3_flag_scope(self.x3_flag), torch.cuda.graph(self.graph):
+        with hip_lib.x3_flag_scope(self.x3_flag), hip_lib.shared_min_tiles_scope(self.shared_min_tiles), \
+                torch.cuda.graph(self.graph, stream=self.stream):
             self.records = run()
         self.uses_x3 = hip_lib.x3_launch_count() != n_x3     # the captured step holds three-product kernels
+        self.foreign_launches = hip_layers.fallback_launches() - n_foreign
+        if self.sharing and self.foreign_launches:
+            raise RuntimeError(f"GraphedInference(sharing=True): the captured step launched {self.foreign_launches} kernel(s) outside this "
+                               f"library (last: {hip_layers.last_fallback()}); such a graph must not run beside another stream's MFMAs on "
+                               "MI355X — replay it on ONE stream (sharing=False)")
         self._demoted_at_capture = hip_layers.x3_demoted()
         self._products_at_capture = hip_layers.gemm_products()
         self.captures += 1
 
     @torch.no_grad()
-    def replay(self) -> torch.Tensor:
-        """Replay on the static buffers, then the range check of the graph's three-product kernels."""
+    def replay_async(self) -> GraphHandle:
+        """Replay on the static buffers and return without waiting for the device; ``.result()`` -> the records f32[b,16] — a copy
+        of the graph's static output made on the graph's stream right behind the replay (64 B per ROI), so the next replay of this
+        graph cannot overwrite what the caller still reads on another stream."""
+        if self._pending is not None:
+            self._pending.result()
         if self.uses_x3 and (hip_layers.x3_demoted() != self._demoted_at_capture or hip_layers.gemm_products() != self._products_at_capture):
             self._recapture()      # another step demoted a layer this graph still runs on three products
-        self.graph.replay()
+        with self._on_stream():
+            self.graph.replay()
+            if self.uses_x3:
+                self._host_words.copy_(self.x3_flag, non_blocking=True)
+            rec = self.records.clone()
+            ev = torch.cuda.Event()
+            ev.record()
+        self._pending = GraphHandle(self, ev, rec)
+        return self._pending
+
+    def _resolve(self, event, rec) -> torch.Tensor:
+        self._pending = None
+        caller = torch.cuda.current_stream()
         if self.uses_x3:
-            words = hip_lib.range_words_of(self.x3_flag.cpu())
+            event.synchronize()
+            words = hip_lib.range_words_of(self._host_words)
             if words:
-                rec = _six_product_rerun(_step_closure(self.model, self.post, self.static, self.roi_ids), words)
-                self._recapture()
-                self.records.copy_(rec)
-        return self.records
+                with self._on_stream(), hip_lib.shared_min_tiles_scope(self.shared_min_tiles):
+                    rec = _six_product_rerun(_step_closure(self.model, self.post, self.static, self.roi_ids), words)
+                    self._recapture()
+                    self.records.copy_(rec)
+                    event = torch.cuda.Event()
+                    event.record()
+        if self.stream is not None and self.stream != caller:
+            caller.wait_event(event)            # the caller's stream reads the records behind the replay ...
+            rec.record_stream(caller)           # ... and their memory (the graph stream's pool) is not handed out under it
+        return rec
+
+    @torch.no_grad()
+    def replay(self) -> torch.Tensor:
+        """Replay on the static buffers, then the range check of the graph's three-product kernels (synchronous form)."""
+        return self.replay_async().result()
+
+    @torch.no_grad()
+    def load(self, batch: dict) -> None:
+        """Copy a batch into the graph's static buffers on the graph's stream (behind the previous replay, which is resolved
+        first: its inputs must not change under it)."""
+        if self._pending is not None:
+            self._pending.result()
+        caller = torch.cuda.current_stream()
+        with self._on_stream():
+            if self.stream is not None and self.stream != caller:
+                self.stream.wait_stream(caller)       # the batch was produced on the caller's stream
+            for k, v in batch.items():
+                if isinstance(v, torch.Tensor) and k in self.static:
+                    self.static[k].copy_(v, non_blocking=True)
+            if self.roi_ids is not None and isinstance(batch.get("roi_id"), torch.Tensor):
+                self.roi_ids.copy_(batch["roi_id"], non_blocking=True)      # the ids the records carry travel with the batch
 
     @torch.no_grad()
     def __call__(self, batch: dict) -> torch.Tensor:
-        for k, v in batch.items():
-            if isinstance(v, torch.Tensor) and k in self.static:
-                self.static[k].copy_(v, non_blocking=True)
+        self.load(batch)
         return self.replay()
+
+
+class GraphedStepStreams:
+    """Two hipGraphs in flight: the small-batch form of ``StepStreams``.  One ``GraphedInference`` per SLOT (a resident batch, or a
+    static buffer batches are copied into), slots dealt round-robin to the dealer's compute streams and captured there with the
+    dealer's shared-chip kernel rule — the kernels, and therefore every bit of the records, are those of the eager two-stream
+    schedule; what disappears is the host's ~150 launches per step, which is what bounds 8-32 ROIs (the reference's own regime:
+    one image per forward, gdrn_evaluator.py:697-750, demo/predictor_gdrn.py:133-143).
+
+        gs = GraphedStepStreams(model, post, [batch0, batch1])          # default_compute_streams(model) streams
+        h0 = gs.launch(0); h1 = gs.launch(1)                            # two steps in flight, ~0.1 ms of host time each
+        rec0 = h0.result(); h2 = gs.launch(0, new_batch) ...            # (launching a slot again resolves its previous handle first)
+
+    A model whose step launches kernels outside this library gets ONE stream (the static gate), and a capture that does so all
+    the same raises (``GraphedInference(sharing=True)``)."""
+
+    def __init__(self, model, post: GdrnHipPost, slot_batches, roi_ids=None, compute_streams=None, warmup: int = 2, device=None):
+        slot_batches = list(slot_batches)
+        if not slot_batches:
+            raise ValueError("GraphedStepStreams needs at least one slot batch")
+        dev = slot_batches[0]["roi_img"].device if device is None else torch.device(device)
+        if isinstance(compute_streams, StepStreams):
+            self.dealer = compute_streams
+        else:
+            n = default_compute_streams(model) if compute_streams is None else max(1, int(compute_streams))
+            self.dealer = StepStreams(n, dev)
+        streams = self.dealer.streams
+        multi = len(streams) > 1
+        rule = self.dealer.shared_min_tiles() if multi and hip_lib.shared_min_tiles() == 0 else None
+        ids = roi_ids if isinstance(roi_ids, (list, tuple)) else [roi_ids] * len(slot_batches)
+        self.graphs = []
+        for i, (bt, rid) in enumerate(zip(slot_batches, ids)):
+            st = streams[i % len(streams)]      # None (StepStreams(1)): captured on a side stream, replayed on the caller's current one
+            self.graphs.append(GraphedInference(model, post, bt, rid if rid is not None else bt.get("roi_id"), warmup=warmup, stream=st,
+                                                shared_min_tiles=rule, sharing=self.dealer.sharing()))
+
+    def launch(self, slot: int, batch: dict | None = None) -> GraphHandle:
+        g = self.graphs[slot % len(self.graphs)]
+        if batch is not None:
+            g.load(batch)
+        return g.replay_async()
 
 
 # --------------------------------------------------------------------------------------------------

@@ -94,3 +94,60 @@ def forward_kwargs(fx, device):
     return dict(roi_classes=T(fx["roi_cls"]), roi_cams=T(fx["roi_cam"]), roi_whs=T(fx["roi_wh"]),
                 roi_centers=T(fx["roi_center"]), resize_ratios=T(fx["resize_ratio"]), roi_coord_2d=T(coord2d),
                 roi_extents=T(fx["roi_extent"]))
+
+
+# ---- the reference's rot6d -> R_allo -> R_ego in float64, vectorised (rot_reps.py:34-55, core/utils/utils.py:31-62) --------------
+def ego_rot_from_rot6d_f64(d6, trans):
+    """R_ego f64[b,3,3] of allocentric 6-D rotations ``d6`` f64[b,6] and translations ``trans`` f64[b,3]: Gram-Schmidt with the
+    columns (x, y, z), then the rotation about ``z_cam x t`` by ``acos(t_z / |t|)`` applied from the left."""
+    d6, trans = np.asarray(d6, np.float64), np.asarray(trans, np.float64)
+    x = d6[:, 0:3] / np.linalg.norm(d6[:, 0:3], axis=1, keepdims=True)
+    z = np.cross(x, d6[:, 3:6])
+    z = z / np.linalg.norm(z, axis=1, keepdims=True)
+    y = np.cross(z, x)
+    R_allo = np.stack((x, y, z), axis=-1)
+    ray = trans / np.linalg.norm(trans, axis=1, keepdims=True)
+    angle = np.arccos(np.clip(ray[:, 2], -1.0, 1.0))
+    axis = np.cross(np.array([0.0, 0.0, 1.0])[None], ray)
+    n = np.linalg.norm(axis, axis=1, keepdims=True)
+    axis = axis / np.where(n > 0, n, 1.0)
+    c, s = np.cos(angle)[:, None, None], np.sin(angle)[:, None, None]
+    ax, ay, az = axis[:, 0], axis[:, 1], axis[:, 2]
+    zero = np.zeros_like(ax)
+    Kx = np.stack([np.stack([zero, -az, ay], -1), np.stack([az, zero, -ax], -1), np.stack([-ay, ax, zero], -1)], 1)
+    outer = axis[:, :, None] * axis[:, None, :]
+    Rd = c * np.eye(3)[None] + s * Kx + (1 - c) * outer
+    Rd = np.where((angle > 0)[:, None, None], Rd, np.eye(3)[None])
+    return Rd @ R_allo
+
+
+def pose_from_net_outputs_f64(pred_rot_, pred_t_, fx):
+    """The reference's pose function downstream of the network, in float64: ``pose_from_predictions_test`` for the convnext_a6
+    configs (allo_rot6d, centroid_z with Z_TYPE REL; pose_from_pred_centroid_z.py:56-154): centroid = (dx, dy) * (bw, bh) + centre,
+    z = z_rel * resize_ratio, t = (z (cx - px) / fx, z (cy - py) / fy, z), R_ego = allo->ego(R(6-D), t).  ``fx``: the fixture's
+    per-ROI arrays.  -> (R_ego f64[b,3,3], t f64[b,3])."""
+    pt = np.asarray(pred_t_, np.float64)
+    K, ctr, wh = fx["roi_cam"].astype(np.float64), fx["roi_center"].astype(np.float64), fx["roi_wh"].astype(np.float64)
+    rr = fx["resize_ratio"].astype(np.float64).reshape(-1)
+    cx, cy = pt[:, 0] * wh[:, 0] + ctr[:, 0], pt[:, 1] * wh[:, 1] + ctr[:, 1]
+    z = pt[:, 2] * rr
+    t = np.stack([z * (cx - K[:, 0, 2]) / K[:, 0, 0], z * (cy - K[:, 1, 2]) / K[:, 1, 1], z], 1)
+    return ego_rot_from_rot6d_f64(pred_rot_, t), t
+
+
+def ego_rot_sensitivity(pred_rot_, pred_t_, fx, h=1e-6):
+    """|dR_ego / dx_j| (max over the nine entries of R) for the nine NETWORK OUTPUTS x = (6-D rotation, centroid dx, dy, z_rel), by
+    central differences of ``pose_from_net_outputs_f64`` in float64: f64[b,9].  What the reference's own pose function does to an
+    error in the network's outputs — large where the 6-D vectors are short / nearly parallel (Gram-Schmidt) or the predicted
+    centroid lies near the principal point in front of or behind the camera (acos and the axis normalisation of
+    allocentric_to_egocentric)."""
+    x = np.concatenate([np.asarray(pred_rot_, np.float64), np.asarray(pred_t_, np.float64)], 1)
+    out = np.zeros((x.shape[0], 9))
+    scale = np.maximum(np.abs(x), 1e-3)
+    for j in range(9):
+        d = np.zeros_like(x)
+        d[:, j] = h * scale[:, j]
+        Rp, _ = pose_from_net_outputs_f64((x + d)[:, :6], (x + d)[:, 6:], fx)
+        Rm, _ = pose_from_net_outputs_f64((x - d)[:, :6], (x - d)[:, 6:], fx)
+        out[:, j] = np.abs((Rp - Rm) / (2 * d[:, j])[:, None, None]).reshape(x.shape[0], -1).max(1)
+    return out

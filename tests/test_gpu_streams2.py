@@ -220,3 +220,61 @@ def test_step_streams_are_chosen_so_that_they_really_overlap(hip):
         assert ratio > 1.6 and 1 <= tried <= 8, d.overlap_probe
         assert engine.streams_overlap_ratio(*d.streams) > 1.6
     assert engine.StepStreams(1, dev).streams == [None] and engine.StepStreams(1, dev).overlap_probe is None
+
+
+@pytest.mark.parametrize("b", [8, 64])
+def test_two_hipgraphs_in_flight_give_the_eager_two_stream_records(setup, b):
+    """engine.GraphedStepStreams: one captured hipGraph per slot, slots dealt to the dealer's two HIP streams — two steps in
+    flight without per-launch host work (the reference's own batch sizes are host-bound: 146 launches through ctypes per step).
+    The graphs are captured with the dealer's shared-chip kernel rule, so their records equal the EAGER two-stream schedule's
+    (and hence the one-stream one's) bit for bit: 64 ROIs (three-product kernels throughout the graphs, range words read back
+    asynchronously) and 8 ROIs (mostly six-product kernels); also after new batches were copied into the slots' static buffers."""
+    cfg, model, post, batches = setup
+    bs = [{k: (v[:b].contiguous() if isinstance(v, torch.Tensor) and v.shape[:1] == batches[0]["roi_img"].shape[:1] else v) for k, v in bt.items()}
+          for bt in batches]
+    order = [0, 1, 0, 1, 2, 1, 2, 0]                       # slot = i % 2; from step 4 on other batches are loaded into the slots
+    eager, _ = _run(model, post, [bs[k] for k in order], len(order), 2)
+    n0 = hip_lib.x3_launch_count()
+    gs = engine.GraphedStepStreams(model, post, bs[:2], compute_streams=2)
+    assert len(gs.dealer.streams) == 2 and gs.graphs[0].stream != gs.graphs[1].stream
+    assert all(g.captures == 1 and g.foreign_launches == 0 for g in gs.graphs)
+    assert b < 64 or (gs.graphs[0].uses_x3 and hip_lib.x3_launch_count() > n0)
+    for rep in range(3):
+        out, prev = [], None
+        for i, k in enumerate(order):
+            cur = gs.launch(i % 2, None if i < 2 and rep == 0 else bs[k])
+            if prev is not None:
+                out.append(prev.result())
+            prev = cur
+        out.append(prev.result())
+        torch.cuda.synchronize()
+        for i, (a, c) in enumerate(zip(eager, out)):
+            assert torch.equal(a, c), f"rep {rep} step {i}: max |diff| {float((a - c).abs().max()):.3e}"
+    assert all(g.captures == 1 for g in gs.graphs)
+    # the synchronous single-graph form (GraphedInference.__call__) on the caller's stream gives the same records
+    g1 = engine.GraphedInference(model, post, bs[0], bs[0]["roi_id"], warmup=1)
+    assert torch.equal(g1(bs[2]), eager[4]) and torch.equal(g1(bs[0]), eager[0])
+
+
+def test_a_graph_that_would_share_the_chip_refuses_foreign_kernels(hip):
+    """GraphedInference(sharing=True) — what GraphedStepStreams builds when its dealer shares the chip — raises at capture when
+    the step launched anything outside this library (here: Patch-PnP's ReLU / LeakyReLU activations as PyTorch operators)."""
+    cfg = get_cfg("ycbv_convnext_a6", opts=["TEST.USE_DEPTH_REFINE=True", "INPUT.WITH_DEPTH=True", "MODEL.POSE_NET.PNP_NET.INIT_CFG.act=relu"])
+    torch.manual_seed(0)
+    model, _ = build_model_optimizer(cfg)
+    model = model.to(DEV).eval()
+    rng = np.random.default_rng(11)
+    verts, faces, ext = S.make_models(21, rng, 2)
+    post = engine.GdrnHipPost(cfg, hip_lib.MeshSet(verts, faces, DEV))
+    det = S.make_detections(8, 21, ext, rng)
+    x1y1 = det["roi_center"] - det["roi_wh"] / 2
+    d = dict(bbox=np.concatenate([x1y1, x1y1 + det["roi_wh"]], 1).astype(np.float32), roi_cls=det["roi_cls"], score=det["score"],
+             cam=S.YCBV_K.astype(np.float32), extents=ext, im_idx=np.zeros(8, np.int64))
+    g = torch.Generator(device=DEV).manual_seed(2)
+    img = torch.randint(0, 256, (1, S.IM_H, S.IM_W, 3), dtype=torch.uint8, device=DEV, generator=g)
+    dep = torch.rand((1, S.IM_H, S.IM_W), device=DEV, generator=g) + 0.5
+    batch = engine.batch_data_test_gpu(cfg, img, dep, d, sort_by_class=True)
+    with pytest.raises(RuntimeError, match="outside this library"):
+        engine.GraphedInference(model, post, batch, warmup=1, stream=torch.cuda.Stream(), sharing=True)
+    g1 = engine.GraphedInference(model, post, batch, warmup=1)           # alone on a stream it is fine
+    assert g1.foreign_launches > 0 and torch.isfinite(g1.replay()).all()

@@ -438,3 +438,32 @@ def test_resnet34_backbone_equals_the_huggingface_implementation():
         assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
     finally:
         hip_layers.set_enabled(True)
+
+
+# ---- the iteration-size fixtures (net_golden_tless_b1024.npz / net_golden_ycbv_b512.npz): what they are and what they show -----------
+@pytest.mark.parametrize("ds,b", [("tless", 1024), ("ycbv", 512)])
+def test_iteration_size_fixture_pins_the_pose_function_and_shows_the_references_own_fp32_tail(ds, b):
+    """The fixtures record the reference's GDRN_DoubleMask in fp32 and in fp64 on b ROIs (make_golden_net.py record_large).
+      * tests/netgolden.py's float64 restatement of the reference's pose function (rot6d -> R, centroid / z -> t, allocentric ->
+        egocentric) reproduces the fixture's fp64 R and t from its fp64 network outputs to 1e-12: the conditioning the GPU test
+        uses is that of the reference's function;
+      * the reference's OWN fp32 forward passes the bars the GPU test applies to this library's path
+        (check_iteration_size_outputs) — and only thanks to the conditioning clause: its worst R is 1.2e-4 (T-LESS, ROI 30) /
+        5.9e-5 (YCB-V, ROI 123) from its fp64 value, at an ill-conditioned ROI both times, while its network outputs stay
+        within 1.4e-5 everywhere.  So no fp32 forward meets a plain 1e-4 R bar on every ROI of a 1 024-ROI iteration."""
+    from tests.test_gpu_net_golden import check_iteration_size_outputs
+
+    fx = NG.load_fixture(f"{ds}_b{b}")
+    R, t = NG.pose_from_net_outputs_f64(fx["pred_rot__f64"], fx["pred_t__f64"], fx)
+    assert np.abs(R - fx["rot_f64"]).max() < 1e-12 and np.abs(t - fx["trans_f64"]).max() < 1e-12
+    for k in ("rot", "trans", "pred_rot_", "pred_t_"):
+        d = np.abs(fx[k].astype(np.float64) - fx[k + "_f64"]).reshape(b, -1).max(1)
+        assert np.array_equal(d, fx["ref_f32_err_" + k])
+    report = check_iteration_size_outputs(fx, {k: fx[k] for k in ("rot", "trans", "pred_rot_", "pred_t_")}, b, "reference fp32")
+    ill = [r for r in report if "ill-conditioned ROI" in r]
+    assert 0 < len(ill) <= 0.04 * b
+    worst = int(fx["ref_f32_err_rot"].argmax())
+    assert any(f"ROI {worst}:" in r for r in ill), "the reference's own worst R error sits at an ill-conditioned ROI"
+    assert max(fx["ref_f32_err_pred_rot_"].max(), fx["ref_f32_err_pred_t_"].max()) < 1.5e-5
+    if ds == "tless":
+        assert worst == 30 and fx["ref_f32_err_rot"][30] > 1e-4          # the reference's fp32 forward itself is beyond the plain bar there
