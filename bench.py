@@ -23,6 +23,10 @@ Workloads (``--workload``; index into BASELINE.json ``configs``):
   bop7_stream              configs[4]  the same image-stream feed for all seven BOP datasets (one stream + model each, cycled per step);
                            with --host-fed every image starts in pinned host memory: detections -> pose -> refine end to end
 
+  --with-yolox-post (stream workloads): every image's detections are produced inside the timed loop by gdrnpp_yolox_postprocess from a
+  seeded YOLOX head output [8400, 5 + C] (decode + class-aware NMS on the device, eight images per launch) and handed to the
+  scheduler without the reference's JSON file; the line reports yolox_post.ms_per_image (device) and the host's share.
+
   --host-fed (stream workloads): every image starts in pinned host memory (the reference's loader hands over host arrays) and is
   copied once on the scheduler's copy stream, one step ahead of the device; the line reports h2d_ms_per_step, h2d_overlapped_frac
   (device timeline of copy vs step events) and the resident-pool rate of the same process.
@@ -145,6 +149,11 @@ def parse(argv=None):
     p.add_argument("--host-fed", action="store_true",
                    help="stream workload: images / depth maps start in PINNED HOST memory (the reference's loader hands over host arrays, "
                         "data_loader.py:754-797); hipMemcpyAsync on a copy stream, one step ahead of the device, inside the timed loop")
+    p.add_argument("--with-yolox-post", action="store_true",
+                   help="stream workloads: the detections of every image come out of gdrnpp_yolox_postprocess INSIDE the timed loop — a seeded "
+                        "YOLOX head output f32[8400, 5 + C] per image (resident in HBM, as the detector network leaves it) -> decode + "
+                        "class-aware NMS on the device -> engine.detections_from_yolox -> the scheduler (det/yolox/utils/boxes.py:34-74, "
+                        "demo/predictor_yolo.py:84-165): configs[4]'s detections -> pose -> refine leg from the detector's raw output on")
     p.add_argument("--gather-to-rank0", action="store_true",
                    help="gather the records to rank 0 only (dist.gather; the reference lets only the main process write, "
                         "gdrn_evaluator.py:581-582) instead of the all-gather")
@@ -181,7 +190,8 @@ def pmc_traffic_live(args, wname, b):
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--no-pmc", "--steps", "2", "--warmup", "1", "--workload", wname,
              "--batch", str(b), "--gemm-products", str(args.gemm_products), "--mlp-gemm", args.mlp_gemm, "--subdiv", str(args.subdiv)]
     for flag, on in (("--no-fused-mlp", args.no_fused_mlp), ("--no-f16x2-rows", args.no_f16x2_rows), ("--random-init", args.random_init),
-                     ("--with-crop", args.with_crop), ("--host-fed", args.host_fed), ("--no-hip-layers", args.no_hip_layers)):
+                     ("--with-crop", args.with_crop), ("--host-fed", args.host_fed), ("--no-hip-layers", args.no_hip_layers),
+                     ("--with-yolox-post", args.with_yolox_post)):
         if on:
             child.append(flag)
     for o in args.opt:
@@ -558,7 +568,9 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                            K_crops=[p[2] for p in pair], meshes=meshes, verts=verts, faces=faces, C=C, graphs={}, ext=ext))
 
     if args.compute_streams <= 0:        # default: two steps in flight only where every kernel of a step is this library's
-        args.compute_streams = min(E.default_compute_streams(m_["model"], m_["cfg"]) for m_ in models)
+        default_streams = E.default_graph_streams if (args.graph and not args.with_crop and wname != "lmo_upnp" and not wname.endswith("stream")) \
+            else E.default_compute_streams            # hipGraph replays leave the host free to keep four steps in flight
+        args.compute_streams = min(default_streams(m_["model"], m_["cfg"]) for m_ in models)
     else:                                # an explicit --compute-streams N is an A/B request: the dealer keeps sharing whatever a step launches
         args.allow_foreign_streams = True
 
@@ -568,6 +580,8 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
         # + detections resident in HBM, cycled; every pushed image gets a fresh key, ROI ids keep counting (per-rank id block).
         import itertools
         counter = itertools.count()
+        YOLOX_GROUP = 8
+        yolox = dict(stream=torch.cuda.Stream(dev, priority=-1), events=[], host_s=0.0, images=0, dets=0) if args.with_yolox_post else None
         subs = []                 # one image stream + scheduler per model ("stream": YCB-V; "bop7_stream": the seven BOP datasets)
         sched_streams = E.StepStreams(max(1, args.compute_streams), dev, allow_foreign=bool(getattr(args, "allow_foreign_streams", False)))      # one dealer for all of them: consecutive steps alternate
         for di, m_ in enumerate(models):
@@ -585,16 +599,59 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             # --host-fed: the very same images, but every push starts from PINNED HOST memory (the reference's loader hands over host
             # arrays); the scheduler copies them on its copy stream, one step ahead of the device
             host_pool = [(im.cpu().pin_memory(), dp.cpu().pin_memory(), dt_) for im, dp, dt_ in pool] if args.host_fed else None
+            heads = None
+            if args.with_yolox_post:
+                # what the detector network leaves in HBM for each image: f32[8400, 5 + C] = (cx, cy, w, h, obj, class scores); every
+                # synthetic detection is predicted by four jittered confident anchors (NMS keeps one), the other anchors are clutter
+                # below the confidence threshold.  Groups of YOLOX_GROUP images are post-processed by ONE launch.
+                A = 8400
+                hd = np.zeros((len(pool), A, 5 + m_["C"]), np.float32)
+                hd[..., 0] = rng.uniform(0, S.IM_W, (len(pool), A)); hd[..., 1] = rng.uniform(0, S.IM_H, (len(pool), A))
+                hd[..., 2:4] = rng.uniform(10, 60, (len(pool), A, 2)); hd[..., 4] = rng.uniform(0, 0.2, (len(pool), A))
+                hd[..., 5:] = rng.uniform(0, 0.5, (len(pool), A, m_["C"]))
+                for pi_, (_, _, dt_) in enumerate(pool):
+                    bb = dt_["bbox"]
+                    slots = rng.permutation(A // 4)[:len(bb)] * 4
+                    for (x1, y1, x2, y2), cl, sc, a0 in zip(bb, dt_["roi_cls"], dt_["score"], slots):
+                        for j in range(4):
+                            row = hd[pi_, a0 + j]
+                            row[:4] = (0.5 * (x1 + x2) + 0.3 * j, 0.5 * (y1 + y2) - 0.3 * j, (x2 - x1) + 0.5 * j, (y2 - y1) - 0.4 * j)
+                            row[4] = 0.97 - 0.01 * j
+                            row[5:] = 0.01
+                            row[5 + int(cl)] = min(0.99, max(0.6, float(sc)))
+                heads = torch.from_numpy(hd).to(dev)
 
-            def make_feeder(src):
-                return ((next(counter), im, dp, dt_) for im, dp, dt_ in itertools.cycle(src))
+            def make_feeder(src, heads=heads, C=m_["C"], ext=m_["ext"]):
+                if heads is None:
+                    return ((next(counter), im, dp, dt_) for im, dp, dt_ in itertools.cycle(src))
+
+                def gen():
+                    G = YOLOX_GROUP
+                    for g0 in itertools.cycle(range(0, len(src), G)):
+                        idx = list(range(g0, min(g0 + G, len(src))))
+                        t_host = time.perf_counter()
+                        with torch.cuda.stream(yolox["stream"]):      # its own (high-priority) stream: the host waits for THIS launch only,
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # not for the step in flight
+                            e0.record()
+                            dets, count = hip_lib.yolox_postprocess(heads[idx[0]:idx[-1] + 1], C, 0.5, 0.45, max_det=64)
+                            e1.record()
+                            d = E.detections_from_yolox(dets, count, S.YCBV_K.astype(np.float32), ext)     # one read-back per group
+                        yolox["events"].append((e0, e1, len(idx)))
+                        yolox["host_s"] += time.perf_counter() - t_host
+                        yolox["images"] += len(idx)
+                        yolox["dets"] += len(d["roi_cls"])
+                        for j, pi_ in enumerate(idx):
+                            sel = d["im_idx"] == j
+                            yield (next(counter), src[pi_][0], src[pi_][1],
+                                   dict(bbox=d["bbox"][sel], roi_cls=d["roi_cls"][sel], score=d["score"][sel], cam=d["cam"], extents=d["extents"]))
+                return gen()
 
             def make_sched(m_=m_, timed=args.host_fed):
                 return E.RoiStreamScheduler(m_["cfg"], m_["model"], m_["post"], rois_per_step=b, roi_id_base=lo, device=dev, time_h2d=timed,
                                             compute_streams=sched_streams)
             subs.append(dict(sched=make_sched(), feeder=make_feeder(host_pool if args.host_fed else pool), pool=pool, make_sched=make_sched,
                              make_feeder=make_feeder))
-        stream = dict(subs=subs, counter=counter, h2d_bytes_warmup=0,
+        stream = dict(subs=subs, counter=counter, h2d_bytes_warmup=0, yolox=yolox,
                       rois_per_image=float(np.mean([len(p[2]["roi_cls"]) for s_ in subs for p in s_["pool"]])))
 
     upnp = None
@@ -716,8 +773,8 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                 # scheduling alone must not change a bit: the last step of the timed region once more on ONE stream, with the kernel
                 # choice of the shared chip (StepStreams.shared_min_tiles) — the same kernels, one stream instead of two
                 period = 2 * len(models)
-                rule = (hip_lib.SPLIT2_MIN_TILES // args.compute_streams if args.compute_streams > 1 else 0) or None   # = StepStreams(n).shared_min_tiles()
-                with hip_lib.shared_min_tiles_scope(rule):
+                rule = (hip_lib.SPLIT2_MIN_TILES // args.compute_streams if args.compute_streams > 1 else 0) or None   # = StepStreams(n).shared_min_tiles() ...
+                with hip_lib.shared_min_tiles_scope(rule, 2048 if args.compute_streams > 2 else None):                   # ... and .shared_min_rows()
                     rec_same = run_pipelined(((steps - 1) % period) + 1)
                     sync()
                 out["last_step_records_bit_equal_to_timed_region"] = bool(torch.equal(rec_same, headline_rec.to(rec_same.device)))
@@ -728,6 +785,9 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             set_compute_streams(max(1, args.compute_streams))
 
     def after_warmup():
+        if stream is not None and stream.get("yolox") is not None:      # the warm-up's post-processing is not the timed region's
+            torch.cuda.synchronize()
+            stream["yolox"].update(events=[], host_s=0.0, images=0, dets=0)
         if stream is not None and args.host_fed:       # copies of the warm-up steps are not the timed region's
             for s_ in stream["subs"]:
                 s_["sched"].h2d_timeline(reset=True)
@@ -770,6 +830,18 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             out["stream"] = {"images_per_s": None, "rois_per_image_mean": stream["rois_per_image"],
                              "images_pushed": next(stream["counter"]), "rois_per_step": b,
                              "note": "value / rois_per_image_mean = images per second; ROI-granular packing, an image's ROIs may straddle two steps"}
+        if stream is not None and stream.get("yolox") is not None:
+            y_ = stream["yolox"]
+            torch.cuda.synchronize()
+            dev_ms = sum(a_.elapsed_time(b_) for a_, b_, _ in y_["events"])
+            out["yolox_post"] = {"images": y_["images"], "detections": y_["dets"], "images_per_launch": YOLOX_GROUP,
+                                 "ms_per_image": dev_ms / max(y_["images"], 1), "ms_per_step": dev_ms / args.steps,
+                                 "host_ms_per_image": 1e3 * y_["host_s"] / max(y_["images"], 1), "host_ms_per_step": 1e3 * y_["host_s"] / args.steps,
+                                 "anchors": 8400, "conf_thre": 0.5, "nms_thre": 0.45,
+                                 "note": "inside the timed loop: gdrnpp_yolox_postprocess (decode + sort + class-aware NMS) on a seeded YOLOX head "
+                                         "output f32[8, 8400, 5 + C] per launch, on its own high-priority stream; ms_per_image = device time of "
+                                         "the launch / 8; host_ms = launch + the one read-back of (dets, count) + engine.detections_from_yolox "
+                                         "(the hand-off that replaces the reference's detection JSON, dataset_utils.py:146-239)"}
         m = models[0]
         bt, det, K_crop, cfg = m["batches"][0], m["dets"][0], m["K_crops"][0], m["cfg"]
 

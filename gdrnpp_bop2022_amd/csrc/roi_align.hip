@@ -8,8 +8,7 @@
 // bilinear_interpolate with the (-1, size) validity window and clamping at the far border, mean over the grid.
 // fp32, accumulation order iy-major / ix-minor, val = w1*v1 + w2*v2 + w3*v3 + w4*v4 left to right, no FMA.
 //
-// pw fastest (coalesced stores), grid (plane tiles, channel, ROI); taps are gathers inside one [H,W] channel plane
-// (L2-resident for image-sized inputs).  Write-bound: 4 B per output element.
+// Write-bound: 4 B per output element; the source pixels under a ROI are read through L2.
 #include "common.hpp"
 #include <cfloat>
 
@@ -35,22 +34,173 @@ __device__ __forceinline__ AxisTap axis_tap(float v, int size) {
   return t;
 }
 
-// grid (tiles of row groups x PW, channel, ROI).  A thread owns kRows consecutive output rows of one column: the x taps of
-// a sample column are shared by its rows, and the 2 * kRows row loads of a sample are issued together (a workgroup lives
-// for a few dependent memory round trips, so the kernel's time is rounds x latency: more loads in flight per thread and
-// kRows times fewer workgroups is what it needs).  Per output the samples are still added iy-major, ix-minor, each as
-// w1*v1 + w2*v2 + w3*v3 + w4*v4 left to right.
-constexpr int kRows = 8;
+// Round 6 (profiles/r06_roi_align.md).  grid (row groups x column tiles, channel chunks, ROI); a workgroup = (256 / cols) row lanes x
+// cols output columns (cols = 64 / 128 / 256, so narrow outputs keep every lane busy and a wave never straddles two rows); a thread
+// = ONE OUTPUT COLUMN for ROWS consecutive output rows and up to 4 channel planes:
+//   * everything that depends on the column only — the x taps of the column's sample columns (kept in registers for up to 4
+//     per bin), their validity, which half of the 8-byte row load is the low / high tap — is computed ONCE per thread;
+//   * everything that depends on the row only — the y taps of a sample row — is uniform per wave: the scalar unit does it;
+//   * the four bilinear weights of a sample are formed once and applied to the channel planes;
+//   * a wave's stores are 256-byte row segments of each plane.
+// What bounds it (rocprofv3 counters, 128 ROIs -> 3 x 256 x 256): not HBM (50 MB fetched, 100 MB written in ~75 us) but the number
+// of vector instructions per output — 36 M VALU + 2.4 M gather loads per launch, each 8-byte gather load split into ~16 L1
+// accesses — with the waves parked on memory two thirds of the time.  Measured and NOT kept: 8 / 16 rows per thread (fewer
+// waves: slower, 85 / 100 us), all 2 x ROWS x channels loads of a sample column issued before the first use (100 - 150 us: the
+// registers cost the occupancy), the tile's source box staged in LDS and gathered from there (L1 accesses / 10, but 47 M VALU
+// instructions for box, copy and clamps: 126 us), non-temporal stores (+3 %).  This form: 4 rows per thread, plain stores, 75 us
+// = 0.17 of HBM against the round-5 kernel's 85 us (0.15).
+// Per output the samples are still added iy-major, ix-minor, each as w1*v1 + w2*v2 + w3*v3 + w4*v4 left to right, then divided by
+// the sample count (multiplied by its reciprocal when that is a power of two: the same bits): bit for bit roi_align_oracle.c.
 
-template <bool kAligned>
+
+struct RoiGeom {
+  float sw, sh, bin_h, bin_w, count, rcount;
+  int gh, gw;
+  bool pow2;
+};
+
+// rows ph0 .. ph0 + kRows of output column pw, channels c0 .. c0 + nch.  GW = sample columns per bin when <= 4 (their taps live
+// in registers for all rows), 0 = any number (recomputed per sample row).
+template <int GW, int ROWS, bool NT, int CH, bool FULL>
+__device__ __forceinline__ void roi_align_rows(const float* __restrict__ data, float* __restrict__ o, const RoiGeom& g, int nch,
+                                               size_t plane, int H, int W, int PH, int PW, int ph0, int pw) {
+  const float x0 = g.sw + pw * g.bin_w;
+  // The y taps are uniform per wave, but gfx950's scalar unit has no float arithmetic: computed per sample row they cost every
+  // wave ~35 vector instructions (an IEEE division among them) per (row, sample row) — 40 % of the kernel.  So the wave computes
+  // all its ROWS x gh taps ONCE, one per lane, and the loops below fetch them with v_readlane (same expression: same bits).
+  const int lane = (int)threadIdx.x & 63;
+  const bool lane_taps = ROWS * g.gh <= 64;                            // uniform
+  AxisTap tl = AxisTap{false, 0, 0, 0.f, 0.f};
+  if (lane_taps) {
+    const int k = lane / g.gh, iy = lane - k * g.gh;
+    tl = axis_tap(g.sh + (ph0 + k) * g.bin_h + (iy + .5f) * g.bin_h / (float)g.gh, H);
+  }
+  AxisTap txs[GW > 0 ? GW : 1];
+  int xbs[GW > 0 ? GW : 1];
+  if (GW > 0) {
+#pragma unroll
+    for (int ix = 0; ix < GW; ++ix) {
+      txs[ix] = axis_tap(x0 + (ix + .5f) * g.bin_w / (float)g.gw, W);
+      xbs[ix] = min(txs[ix].low, W - 2);
+    }
+  }
+#pragma unroll 2
+  for (int k = 0; k < ROWS; ++k) {
+    const int ph = ph0 + k;                                           // uniform
+    if (ph >= PH) break;
+    float acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+    for (int iy = 0; iy < g.gh; ++iy) {
+      AxisTap ty;
+      if (lane_taps) {
+        const int src_lane = k * g.gh + iy;                            // uniform
+        ty.valid = __builtin_amdgcn_readlane((int)tl.valid, src_lane) != 0;
+        ty.low = __builtin_amdgcn_readlane(tl.low, src_lane);
+        ty.high = __builtin_amdgcn_readlane(tl.high, src_lane);
+        ty.l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tl.l), src_lane));
+        ty.h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tl.h), src_lane));
+      } else {
+        ty = axis_tap(g.sh + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.gh, H);
+      }
+      const float* row_lo = data + (size_t)ty.low * W;
+      const float* row_hi = data + (size_t)ty.high * W;
+      auto sample = [&](const AxisTap& tx, int xb) {
+        // high is low + 1 or (clamped at the right border) low: both taps of a row come from one 8-byte load at
+        // min(low, W - 2) (4-byte alignment is enough for global_load_dwordx2); W == 1 has a single column
+        const bool lo_first = tx.low == xb, hi_first = tx.high == xb;
+        const float w1 = ty.h * tx.h, w2 = ty.h * tx.l, w3 = ty.l * tx.h, w4 = ty.l * tx.l;
+        const bool ok = ty.valid && tx.valid;
+        float2_u a[CH], b[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          if (FULL || c < nch) {
+            a[c] = *reinterpret_cast<const float2_u*>(row_lo + c * plane + xb);      // (W >= 2: the launcher sends W == 1 elsewhere)
+            b[c] = *reinterpret_cast<const float2_u*>(row_hi + c * plane + xb);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          if (FULL || c < nch) {
+            const float v1 = lo_first ? a[c].x : a[c].y, v2 = hi_first ? a[c].x : a[c].y;
+            const float v3 = lo_first ? b[c].x : b[c].y, v4 = hi_first ? b[c].x : b[c].y;
+            const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+            acc[c] += ok ? val : 0.f;
+          }
+        }
+      };
+      if (GW > 0) {
+#pragma unroll
+        for (int ix = 0; ix < GW; ++ix) sample(txs[ix], xbs[ix]);
+      } else {
+        for (int ix = 0; ix < g.gw; ++ix) {
+          const AxisTap tx = axis_tap(x0 + (ix + .5f) * g.bin_w / (float)g.gw, W);
+          sample(tx, min(tx.low, W - 2));
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (FULL || c < nch) {
+        const float v = g.pow2 ? acc[c] * g.rcount : acc[c] / g.count;
+        if (NT) __builtin_nontemporal_store(v, o + ((size_t)c * PH + ph) * PW);
+        else o[((size_t)c * PH + ph) * PW] = v;
+      }
+  }
+}
+
+template <bool kAligned, int ROWS, bool NT, int CH, bool FULL>
 __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict__ x, const float* __restrict__ rois,
                                                         float* __restrict__ out, int C, int H, int W, int PH, int PW,
-                                                        float spatial_scale, int sampling_ratio) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  const int groups = (PH + kRows - 1) / kRows;
-  if (p >= groups * PW) return;
-  const int g = p / PW, pw = p - g * PW, ph0 = g * kRows;
-  const int c = blockIdx.y, n = blockIdx.z;
+                                                        float spatial_scale, int sampling_ratio, int col_tiles, int cols) {
+  const int row_group = blockIdx.x / col_tiles, col_tile = blockIdx.x - row_group * col_tiles;
+  // row lane (uniform per wave: cols % 64 == 0 — readfirstlane tells the compiler, so the y taps stay on the scalar unit), column
+  const int ry = __builtin_amdgcn_readfirstlane((int)threadIdx.x / cols), cx = (int)threadIdx.x - ry * cols;
+  const int pw = col_tile * cols + cx;
+  const int ph0 = (row_group * (256 / cols) + ry) * ROWS;
+  const int c0 = blockIdx.y * CH, n = blockIdx.z;
+  const float* r = rois + 5 * (size_t)n;
+  const int bi = (int)r[0];
+  const float offset = kAligned ? 0.5f : 0.f;
+  RoiGeom g;
+  g.sw = r[1] * spatial_scale - offset;
+  g.sh = r[2] * spatial_scale - offset;
+  const float ew = r[3] * spatial_scale - offset, eh = r[4] * spatial_scale - offset;
+  float rw = ew - g.sw, rh = eh - g.sh;
+  if (!kAligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+  g.bin_h = rh / (float)PH;
+  g.bin_w = rw / (float)PW;
+  g.gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+  g.gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+  g.count = fmaxf((float)(g.gh * g.gw), 1.f);
+  const int icount = g.gh * g.gw;
+  g.pow2 = icount >= 1 && (icount & (icount - 1)) == 0;     // x / 2^k == x * 2^-k exactly, also into the subnormals
+  g.rcount = 1.f / g.count;
+  if (pw >= PW || ph0 >= PH) return;
+  const size_t plane = (size_t)H * W;
+  const float* data = x + ((size_t)bi * C + c0) * plane;
+  const int nch = FULL ? CH : min(CH, C - c0);              // uniform
+  float* o = out + (((size_t)n * C + c0) * PH) * PW + pw;
+  // the adaptive sampling grid (sampling_ratio = 0, the reference's setting) is per ROI, i.e. uniform in the workgroup
+  switch (g.gw) {
+    case 1: roi_align_rows<1, ROWS, NT, CH, FULL>(data, o, g, nch, plane, H, W, PH, PW, ph0, pw); break;
+    case 2: roi_align_rows<2, ROWS, NT, CH, FULL>(data, o, g, nch, plane, H, W, PH, PW, ph0, pw); break;
+    case 3: roi_align_rows<3, ROWS, NT, CH, FULL>(data, o, g, nch, plane, H, W, PH, PW, ph0, pw); break;
+    case 4: roi_align_rows<4, ROWS, NT, CH, FULL>(data, o, g, nch, plane, H, W, PH, PW, ph0, pw); break;
+    default: roi_align_rows<0, ROWS, NT, CH, FULL>(data, o, g, nch, plane, H, W, PH, PW, ph0, pw);
+  }
+}
+
+// W == 1 (a feature map one pixel wide: no 8-byte row load exists): one thread per output element, four taps loaded one by one.
+// Same sample order and arithmetic as above.
+template <bool kAligned>
+__global__ __launch_bounds__(256) void roi_align_generic_kernel(const float* __restrict__ x, const float* __restrict__ rois,
+                                                                float* __restrict__ out, int C, int H, int W, int PH, int PW,
+                                                                float spatial_scale, int sampling_ratio, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int pw = (int)(i % PW), ph = (int)((i / PW) % PH), c = (int)((i / ((long)PW * PH)) % C);
+  const int n = (int)(i / ((long)PW * PH * C));
   const float* r = rois + 5 * (size_t)n;
   const int bi = (int)r[0];
   const float offset = kAligned ? 0.5f : 0.f;
@@ -63,44 +213,19 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
   const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
   const float count = fmaxf((float)(gh * gw), 1.f);
   const float* data = x + ((size_t)bi * C + c) * H * W;
-  const float x0 = sw + pw * bin_w;
-  float acc[kRows];
-#pragma unroll
-  for (int k = 0; k < kRows; ++k) acc[k] = 0.f;
+  float acc = 0.f;
   for (int iy = 0; iy < gh; ++iy) {
-    const float dy = (iy + .5f) * bin_h / (float)gh;
-    AxisTap ty[kRows];
-#pragma unroll
-    for (int k = 0; k < kRows; ++k) ty[k] = axis_tap(sh + (ph0 + k) * bin_h + dy, H);
+    const AxisTap ty = axis_tap(sh + ph * bin_h + (iy + .5f) * bin_h / (float)gh, H);
     for (int ix = 0; ix < gw; ++ix) {
-      const AxisTap tx = axis_tap(x0 + (ix + .5f) * bin_w / (float)gw, W);
-      // high is low + 1 or (clamped at the right border) low: both taps of a row come from one 8-byte load at
-      // min(low, W - 2) (4-byte alignment is enough for global_load_dwordx2); W == 1 has a single column
-      const int xb = W >= 2 ? min(tx.low, W - 2) : 0;
-      float2_u r0[kRows], r1[kRows];
-#pragma unroll
-      for (int k = 0; k < kRows; ++k) {
-        if (W >= 2) {
-          r0[k] = *reinterpret_cast<const float2_u*>(data + ty[k].low * W + xb);
-          r1[k] = *reinterpret_cast<const float2_u*>(data + ty[k].high * W + xb);
-        } else {
-          r0[k].x = r0[k].y = data[ty[k].low * W];
-          r1[k].x = r1[k].y = data[ty[k].high * W];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < kRows; ++k) {
-        const float v1 = tx.low == xb ? r0[k].x : r0[k].y, v2 = tx.high == xb ? r0[k].x : r0[k].y;
-        const float v3 = tx.low == xb ? r1[k].x : r1[k].y, v4 = tx.high == xb ? r1[k].x : r1[k].y;
-        const float w1 = ty[k].h * tx.h, w2 = ty[k].h * tx.l, w3 = ty[k].l * tx.h, w4 = ty[k].l * tx.l;
-        const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-        acc[k] += (ty[k].valid && tx.valid) ? val : 0.f;
-      }
+      const AxisTap tx = axis_tap(sw + pw * bin_w + (ix + .5f) * bin_w / (float)gw, W);
+      const float v1 = data[(size_t)ty.low * W + tx.low], v2 = data[(size_t)ty.low * W + tx.high];
+      const float v3 = data[(size_t)ty.high * W + tx.low], v4 = data[(size_t)ty.high * W + tx.high];
+      const float w1 = ty.h * tx.h, w2 = ty.h * tx.l, w3 = ty.l * tx.h, w4 = ty.l * tx.l;
+      const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+      acc += (ty.valid && tx.valid) ? val : 0.f;
     }
   }
-#pragma unroll
-  for (int k = 0; k < kRows; ++k)
-    if (ph0 + k < PH) __builtin_nontemporal_store(acc[k] / count, out + (((size_t)n * C + c) * PH + ph0 + k) * PW + pw);
+  out[i] = acc / count;
 }
 
 // torchvision.ops.RoIPool forward (the "nearest" flavour of batch_crop_resize, core/utils/zoom_utils.py:92-93): ROI corners
@@ -158,12 +283,35 @@ extern "C" int gdrnpp_roi_align(const float* x, const float* rois, float* out, i
                  GDRNPP_EINVAL, "gdrnpp_roi_align: bad sizes");
   GDRNPP_REQUIRE(n_rois <= 65535 && C <= 65535 && (long)pooled_h * pooled_w < (1l << 30), GDRNPP_ELIMIT,
                  "gdrnpp_roi_align: n_rois=%d / C=%d above 65535 or output plane too large", n_rois, C);
-  const dim3 grid((unsigned)((((pooled_h + kRows - 1) / kRows) * pooled_w + 255) / 256), (unsigned)C, (unsigned)n_rois);
-  if (aligned)
-    hipLaunchKernelGGL(roi_align_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, rois, out, C, H, W, pooled_h,
-                       pooled_w, spatial_scale, sampling_ratio);
-  else
-    hipLaunchKernelGGL(roi_align_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, rois, out, C, H, W, pooled_h,
-                       pooled_w, spatial_scale, sampling_ratio);
+  if (W == 1) {
+    const long total = (long)n_rois * C * pooled_h * pooled_w;
+    GDRNPP_REQUIRE((total + 255) / 256 < (1l << 31), GDRNPP_ELIMIT, "gdrnpp_roi_align: output too large");
+    if (aligned)
+      hipLaunchKernelGGL(roi_align_generic_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rois, out, C, H, W,
+                         pooled_h, pooled_w, spatial_scale, sampling_ratio, total);
+    else
+      hipLaunchKernelGGL(roi_align_generic_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rois, out, C, H, W,
+                         pooled_h, pooled_w, spatial_scale, sampling_ratio, total);
+    return gdrnpp::check_launch("gdrnpp_roi_align");
+  }
+  const int cols = pooled_w > 128 ? 256 : (pooled_w > 64 ? 128 : 64);      // output columns per workgroup; 256 / cols row lanes
+  const int col_tiles = (pooled_w + cols - 1) / cols;
+  const int variant = gdrnpp::option_roi_align_variant();     // A/B switch: 0 (default) 4 rows per thread, non-temporal stores / 1: 8 rows / 2: 16 rows / 3: 4 rows, plain stores
+  const int rows = variant == 1 ? 8 : (variant == 2 ? 16 : 4);
+  const long rows_per_wg = (long)rows * (256 / cols);
+  const int ch = C >= 4 ? 4 : C;                              // channel planes per thread; full = no partial last chunk
+  const bool full = C % ch == 0;
+  GDRNPP_REQUIRE(((pooled_h + rows_per_wg - 1) / rows_per_wg) * col_tiles < (1l << 31), GDRNPP_ELIMIT, "gdrnpp_roi_align: output plane too large");
+  const dim3 grid((unsigned)(((pooled_h + rows_per_wg - 1) / rows_per_wg) * col_tiles), (unsigned)((C + ch - 1) / ch), (unsigned)n_rois);
+#define GDRNPP_RA(AL, R, NT, CHV, FU) hipLaunchKernelGGL((roi_align_kernel<AL, R, NT, CHV, FU>), grid, dim3(256), 0, (hipStream_t)stream, x, rois, out, C, H, W, \
+                                                        pooled_h, pooled_w, spatial_scale, sampling_ratio, col_tiles, cols)
+#define GDRNPP_RA_C(AL, R, NT) do { if (ch == 1) GDRNPP_RA(AL, R, NT, 1, true); else if (ch == 2) GDRNPP_RA(AL, R, NT, 2, true); \
+    else if (ch == 3) GDRNPP_RA(AL, R, NT, 3, true); else if (full) GDRNPP_RA(AL, R, NT, 4, true); else GDRNPP_RA(AL, R, NT, 4, false); } while (0)
+#define GDRNPP_RA_V(AL) switch (variant) { case 1: GDRNPP_RA_C(AL, 8, false); break; case 2: GDRNPP_RA_C(AL, 16, false); break; \
+    case 3: GDRNPP_RA_C(AL, 4, false); break; default: GDRNPP_RA_C(AL, 4, true); }
+  if (aligned) { GDRNPP_RA_V(true) } else { GDRNPP_RA_V(false) }
+#undef GDRNPP_RA_V
+#undef GDRNPP_RA_C
+#undef GDRNPP_RA
   return gdrnpp::check_launch("gdrnpp_roi_align");
 }

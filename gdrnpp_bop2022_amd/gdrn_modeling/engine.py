@@ -473,6 +473,14 @@ def default_compute_streams(model, cfg=None) -> int:
     return 2 if ours else 1
 
 
+def default_graph_streams(model, cfg=None) -> int:
+    """Compute streams for the hipGraph form of the step (``GraphedStepStreams``): 4 where steps may share the chip at all
+    (``default_compute_streams`` == 2) — a graph replay costs the host ~0.1 ms instead of ~3 ms of launches, so the host can keep
+    FOUR steps in flight, which is what HIP offers hardware queues for (a fifth stream shares a queue with one of the four:
+    profiles/r06_graph_streams.md; eager launches cannot feed more than two, profiles/r05r_compute_streams.txt) — else 1."""
+    return 4 if default_compute_streams(model, cfg) > 1 else 1
+
+
 _DEALER_TLS = threading.local()      # .dealer: the StepStreams whose next() context the calling host thread is inside
 
 
@@ -579,6 +587,12 @@ class StepStreams:
         n = len(self.streams)
         return hip_lib.SPLIT2_MIN_TILES // n if n > 1 else 0
 
+    def shared_min_rows(self):
+        """Fewest rows of a launch under that rule: the process default (4 096) for two streams — the eager schedule of rounds 5 / 6,
+        whose records this keeps — and 2 048 from three streams on (four hipGraphs in flight: 8 / 16 / 32 ROIs 3 305 -> 3 592,
+        4 533 -> 4 561, 5 107 -> 5 172 ROIs/s with 64 tiles, profiles/r06_graph_streams.md)."""
+        return 2048 if len(self.streams) > 2 else None
+
     def next(self):
         """Context manager: the body's launches go to the next compute stream (with n = 1: the caller's current stream) and, with
         n > 1, choose their GEMM kernels for a shared chip (``shared_min_tiles``: 4 248 -> 4 525 ROIs/s at 32 ROIs, neutral at 8 and
@@ -592,11 +606,12 @@ class StepStreams:
         def ctx():
             # the rule belongs to the calling HOST THREAD for the duration of this step's launches (hip_lib.shared_min_tiles_scope):
             # two threads with their own dealers do not see each other's; an explicit setting (tests, A/B runs, env var) wins
-            rule = self.shared_min_tiles() if hip_lib.shared_min_tiles() == 0 else None
+            explicit = hip_lib.shared_min_tiles() != 0
+            rule, rows = (None, None) if explicit else (self.shared_min_tiles(), self.shared_min_rows())
             prev = getattr(_DEALER_TLS, "dealer", None), getattr(_DEALER_TLS, "foreign_at_entry", None)
             _DEALER_TLS.dealer, _DEALER_TLS.foreign_at_entry = self, hip_layers.fallback_launches()
             try:
-                with hip_lib.shared_min_tiles_scope(rule), torch.cuda.stream(s_):    # torch.cuda.stream(None) is a no-op context
+                with hip_lib.shared_min_tiles_scope(rule, rows), torch.cuda.stream(s_):    # torch.cuda.stream(None) is a no-op context
                     yield s_
             finally:
                 _DEALER_TLS.dealer, _DEALER_TLS.foreign_at_entry = prev
@@ -804,10 +819,10 @@ class GraphedInference:
     not on every replay."""
 
     def __init__(self, model, post: GdrnHipPost, example_batch: dict, roi_ids: torch.Tensor | None = None,
-                 warmup: int = 3, stream=None, shared_min_tiles=None, sharing: bool = False):
+                 warmup: int = 3, stream=None, shared_min_tiles=None, sharing: bool = False, shared_min_rows=None):
         self.model, self.post = model, post
         self.stream = stream                                  # None = whatever stream is current when replay is called
-        self.shared_min_tiles, self.sharing = shared_min_tiles, bool(sharing)
+        self.shared_min_tiles, self.shared_min_rows, self.sharing = shared_min_tiles, shared_min_rows, bool(sharing)
         self.static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in example_batch.items()}
         self.roi_ids = roi_ids.clone() if roi_ids is not None else None
         self.captures = 0
@@ -832,7 +847,7 @@ class GraphedInference:
         side.wait_stream(torch.cuda.current_stream())
         if self.stream is not None:
             side.wait_stream(self.stream)
-        with torch.cuda.stream(side), hip_lib.shared_min_tiles_scope(self.shared_min_tiles):
+        with torch.cuda.stream(side), hip_lib.shared_min_tiles_scope(self.shared_min_tiles, self.shared_min_rows):
             inference_step(self.model, self.post, self.static, self.roi_ids)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -852,7 +867,7 @@ class GraphedInference:
         n_x3, n_foreign = hip_lib.x3_launch_count(), hip_layers.fallback_launches()
         self.x3_flag.zero_()
         torch.cuda.synchronize()
-        with hip_lib.x3_flag_scope(self.x3_flag), hip_lib.shared_min_tiles_scope(self.shared_min_tiles), \
+        with hip_lib.x3_flag_scope(self.x3_flag), hip_lib.shared_min_tiles_scope(self.shared_min_tiles, self.shared_min_rows), \
                 torch.cuda.graph(self.graph, stream=self.stream):
             self.records = run()
         self.uses_x3 = hip_lib.x3_launch_count() != n_x3     # the captured step holds three-product kernels
@@ -891,7 +906,7 @@ class GraphedInference:
             event.synchronize()
             words = hip_lib.range_words_of(self._host_words)
             if words:
-                with self._on_stream(), hip_lib.shared_min_tiles_scope(self.shared_min_tiles):
+                with self._on_stream(), hip_lib.shared_min_tiles_scope(self.shared_min_tiles, self.shared_min_rows):
                     rec = _six_product_rerun(_step_closure(self.model, self.post, self.static, self.roi_ids), words)
                     self._recapture()
                     self.records.copy_(rec)
@@ -936,8 +951,8 @@ class GraphedStepStreams:
     schedule; what disappears is the host's ~150 launches per step, which is what bounds 8-32 ROIs (the reference's own regime:
     one image per forward, gdrn_evaluator.py:697-750, demo/predictor_gdrn.py:133-143).
 
-        gs = GraphedStepStreams(model, post, [batch0, batch1])          # default_compute_streams(model) streams
-        h0 = gs.launch(0); h1 = gs.launch(1)                            # two steps in flight, ~0.1 ms of host time each
+        gs = GraphedStepStreams(model, post, [batch0, batch1, batch2, batch3])   # default_graph_streams(model) = 4 streams
+        h0 = gs.launch(0); h1 = gs.launch(1); ...                       # four steps in flight, ~0.1 ms of host time each
         rec0 = h0.result(); h2 = gs.launch(0, new_batch) ...            # (launching a slot again resolves its previous handle first)
 
     A model whose step launches kernels outside this library gets ONE stream (the static gate), and a capture that does so all
@@ -951,17 +966,18 @@ class GraphedStepStreams:
         if isinstance(compute_streams, StepStreams):
             self.dealer = compute_streams
         else:
-            n = default_compute_streams(model) if compute_streams is None else max(1, int(compute_streams))
+            n = default_graph_streams(model) if compute_streams is None else max(1, int(compute_streams))
             self.dealer = StepStreams(n, dev)
         streams = self.dealer.streams
         multi = len(streams) > 1
-        rule = self.dealer.shared_min_tiles() if multi and hip_lib.shared_min_tiles() == 0 else None
+        rule, rows = ((self.dealer.shared_min_tiles(), self.dealer.shared_min_rows()) if multi and hip_lib.shared_min_tiles() == 0
+                      else (None, None))
         ids = roi_ids if isinstance(roi_ids, (list, tuple)) else [roi_ids] * len(slot_batches)
         self.graphs = []
         for i, (bt, rid) in enumerate(zip(slot_batches, ids)):
             st = streams[i % len(streams)]      # None (StepStreams(1)): captured on a side stream, replayed on the caller's current one
             self.graphs.append(GraphedInference(model, post, bt, rid if rid is not None else bt.get("roi_id"), warmup=warmup, stream=st,
-                                                shared_min_tiles=rule, sharing=self.dealer.sharing()))
+                                                shared_min_tiles=rule, shared_min_rows=rows, sharing=self.dealer.sharing()))
 
     def launch(self, slot: int, batch: dict | None = None) -> GraphHandle:
         g = self.graphs[slot % len(self.graphs)]

@@ -750,21 +750,31 @@ def shared_min_tiles() -> int:
     return SPLIT2_SHARED_MIN_TILES if v is None else v
 
 
-class shared_min_tiles_scope:
-    """``with shared_min_tiles_scope(n):`` — launches of the calling host thread inside choose their GEMM kernels for a chip shared
-    with another step (three-product 256-row form from ``n`` tiles on); ``None`` = leave whatever is in force."""
+def shared_min_rows() -> int:
+    """Fewest rows of a launch that takes the three-product form under the shared-chip rule, for the calling host thread."""
+    v = getattr(_SHARED_TLS, "min_rows", None)
+    return SPLIT2_SHARED_MIN_ROWS if v is None else v
 
-    def __init__(self, n):
+
+class shared_min_tiles_scope:
+    """``with shared_min_tiles_scope(n, rows):`` — launches of the calling host thread inside choose their GEMM kernels for a chip
+    shared with other steps (three-product 256-row form from ``n`` tiles on, for launches of at least ``rows`` rows); ``None`` =
+    leave whatever is in force."""
+
+    def __init__(self, n, rows=None):
         self.n = None if n is None else int(n)
+        self.rows = None if rows is None else int(rows)
 
     def __enter__(self):
-        self.prev = getattr(_SHARED_TLS, "min_tiles", None)
+        self.prev = getattr(_SHARED_TLS, "min_tiles", None), getattr(_SHARED_TLS, "min_rows", None)
         if self.n is not None:
             _SHARED_TLS.min_tiles = self.n
+        if self.rows is not None:
+            _SHARED_TLS.min_rows = self.rows
         return self
 
     def __exit__(self, *exc):
-        _SHARED_TLS.min_tiles = self.prev
+        _SHARED_TLS.min_tiles, _SHARED_TLS.min_rows = self.prev
         return False
 
 
@@ -773,7 +783,7 @@ def split2_tiles_ok(m: int, n: int) -> bool:
     if n % 128:
         return False
     tiles = ((m + 255) // 256) * (n // 128)
-    return tiles >= SPLIT2_MIN_TILES or (0 < shared_min_tiles() <= tiles and m >= SPLIT2_SHARED_MIN_ROWS)
+    return tiles >= SPLIT2_MIN_TILES or (0 < shared_min_tiles() <= tiles and m >= shared_min_rows())
 
 
 # Range words of the three-product launches (include/gdrnpp_hip.h: GDRNPP_SPLIT2_NONFINITE | GDRNPP_SPLIT2_SMALL_ROWS).  Every

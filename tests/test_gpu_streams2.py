@@ -222,8 +222,8 @@ def test_step_streams_are_chosen_so_that_they_really_overlap(hip):
     assert engine.StepStreams(1, dev).streams == [None] and engine.StepStreams(1, dev).overlap_probe is None
 
 
-@pytest.mark.parametrize("b", [8, 64])
-def test_two_hipgraphs_in_flight_give_the_eager_two_stream_records(setup, b):
+@pytest.mark.parametrize("b,n_streams", [(8, 2), (64, 2), (16, 4)])
+def test_two_hipgraphs_in_flight_give_the_eager_two_stream_records(setup, b, n_streams):
     """engine.GraphedStepStreams: one captured hipGraph per slot, slots dealt to the dealer's two HIP streams — two steps in
     flight without per-launch host work (the reference's own batch sizes are host-bound: 146 launches through ctypes per step).
     The graphs are captured with the dealer's shared-chip kernel rule, so their records equal the EAGER two-stream schedule's
@@ -232,21 +232,23 @@ def test_two_hipgraphs_in_flight_give_the_eager_two_stream_records(setup, b):
     cfg, model, post, batches = setup
     bs = [{k: (v[:b].contiguous() if isinstance(v, torch.Tensor) and v.shape[:1] == batches[0]["roi_img"].shape[:1] else v) for k, v in bt.items()}
           for bt in batches]
-    order = [0, 1, 0, 1, 2, 1, 2, 0]                       # slot = i % 2; from step 4 on other batches are loaded into the slots
+    order = [0, 1, 0, 1, 2, 1, 2, 0]                       # slot = i % n_slots; from step 4 on other batches are loaded into the slots
+    n_slots = n_streams                                    # (four streams: four hipGraphs in flight, engine.default_graph_streams)
     eager, _ = _run(model, post, [bs[k] for k in order], len(order), 2)
     n0 = hip_lib.x3_launch_count()
-    gs = engine.GraphedStepStreams(model, post, bs[:2], compute_streams=2)
-    assert len(gs.dealer.streams) == 2 and gs.graphs[0].stream != gs.graphs[1].stream
+    gs = engine.GraphedStepStreams(model, post, [bs[order[j]] for j in range(n_slots)], compute_streams=n_streams)
+    assert len(gs.dealer.streams) == n_streams and len({g.stream for g in gs.graphs}) == n_streams
     assert all(g.captures == 1 and g.foreign_launches == 0 for g in gs.graphs)
     assert b < 64 or (gs.graphs[0].uses_x3 and hip_lib.x3_launch_count() > n0)
     for rep in range(3):
-        out, prev = [], None
+        out, pend = [], []
         for i, k in enumerate(order):
-            cur = gs.launch(i % 2, None if i < 2 and rep == 0 else bs[k])
-            if prev is not None:
-                out.append(prev.result())
-            prev = cur
-        out.append(prev.result())
+            cur = gs.launch(i % n_slots, None if i < n_slots and rep == 0 else bs[k])
+            pend.append(cur)
+            if len(pend) >= n_slots:
+                out.append(pend.pop(0).result())
+        while pend:
+            out.append(pend.pop(0).result())
         torch.cuda.synchronize()
         for i, (a, c) in enumerate(zip(eager, out)):
             assert torch.equal(a, c), f"rep {rep} step {i}: max |diff| {float((a - c).abs().max()):.3e}"
