@@ -830,6 +830,27 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             out["stream"] = {"images_per_s": None, "rois_per_image_mean": stream["rois_per_image"],
                              "images_pushed": next(stream["counter"]), "rois_per_step": b,
                              "note": "value / rois_per_image_mean = images per second; ROI-granular packing, an image's ROIs may straddle two steps"}
+        if do_cpu and not args.graph:
+            # what THIS box does with the instruction form the library is built without (round-5 verdict item 2c): the raw probe of
+            # tools/probe (every op_sel form of v_pk_add / v_pk_mul_f32 against the scalar instruction) beside the product's
+            # three-product GEMM on another stream.  Diagnostic code from tools/, never the product path; skipped when absent.
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import pk_hazard as PK
+                lib_ = PK.load_probe(build=False)
+                if lib_ is not None:
+                    torch.cuda.synchronize()
+                    alone = PK.raw_probe_beside(lib_, None, dev, reps=1)
+                    beside = PK.raw_probe_beside(lib_, PK.product_gemm_companion(dev), dev, reps=2)
+                    out["pk_hazard_probe"] = {"wrong_results": beside["wrong_results"], "wrong_results_alone": alone["wrong_results"],
+                                              "lanes": beside["lanes"], "v_pk_add_f32": beside["v_pk_add_f32"], "v_pk_mul_f32": beside["v_pk_mul_f32"],
+                                              "note": "raw probe (tools/probe/pk_probe2.hip) beside the product's three-product GEMM on another stream: wrong "
+                                                      "packed-fp32 results on this box; the product library holds no such instruction "
+                                                      "(tools/check_isa_hazards.py at link time, tests/test_gpu_stream_guard.py)"}
+                else:
+                    out["pk_hazard_probe"] = {"wrong_results": None, "note": "tools/probe/libpk_probe.so not built"}
+            except Exception as e:  # the headline line must not depend on a diagnostic
+                out["pk_hazard_probe"] = {"wrong_results": None, "error": repr(e)}
         if stream is not None and stream.get("yolox") is not None:
             y_ = stream["yolox"]
             torch.cuda.synchronize()
