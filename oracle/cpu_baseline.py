@@ -193,6 +193,19 @@ def main():
         stages["flow_reference_1thread"] = dict(value=None, note="oracle/_ref/libflow_ref.so not built (needs /root/reference)")
     for name in ("cv2.warpAffine (ROI crops, data_loader.py:773-797)", "cv2.solvePnPRansac / solvePnP (lib/pysixd/misc.py:153-208)"):
         stages[name] = dict(value=None, note="cv2 unavailable")
+    # ... but the ROI preparation stage is the CPU stage that caps an 8-GPU node, so its PORT is timed: the
+    # oracle's scalar-C restatement of the three warpAffine calls of read_data_test (u8 bilinear 256^2 x 3, f32 nearest 256^2,
+    # f32 bilinear 64^2 x 2) + the fp64 normalisation, per ROI of a 480 x 640 image.  NOT OpenCV's SIMD code: a floor for what a
+    # host core does to one ROI with this algorithm, beside the GPU crop kernel's ~0.45 us per ROI (profiles/*ops_microbench.json).
+    crng = np.random.default_rng(20220925 + 7)
+    c_img = crng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    c_dep = crng.uniform(0.3, 1.5, (480, 640)).astype(np.float32)
+    c_ctr = np.stack([crng.uniform(80, 560, 64), crng.uniform(80, 400, 64)], 1)
+    c_scl = crng.uniform(60, 300, 64)
+    done, dt = _loop(lambda i: P.crop_resize_roi(c_img, c_dep, c_ctr[i], float(c_scl[i])), 64, share / 2, 4)
+    stages["crop_resize_port_1thread"] = dict(value=done / dt, unit="ROIs/s", cores=1, kind="port",
+                                              sample=f"{done} ROI crops (3 warps + normalisation each) of one 480x640 image, oracle/warp_oracle.c, {dt:.2f} s",
+                                              note="scalar restatement of cv2.warpAffine's algorithm, not OpenCV itself (absent)")
 
     if args.forward_cfg:
         stages["forward_cpu_torch"] = forward_cpu_torch(args.forward_cfg, args.forward_seconds)

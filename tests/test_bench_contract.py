@@ -82,6 +82,42 @@ def test_round5_lines_carry_in_run_parity_and_live_traffic():
             assert h["h2d_overlapped_frac"] >= 0.5
 
 
+def test_round6_lines_carry_the_two_stream_guard_the_hazard_probe_and_the_detector_leg():
+    """Round 6: the driver line says by itself that nothing outside this library ran beside the MFMAs (`two_stream_guard`), what the
+    raw packed-fp32 probe does on the box of the run (`pk_hazard_probe`), how a host core fares on the ROI crops (`crop_resize_port`
+    stage); the configs[4] stream line starts from the detector's raw output (`yolox_post`); the small-batch lines hold four
+    hipGraphs in flight."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06*_bench_refine_b128.json")))
+    assert files, "no committed round-6 bench line under profiles/"
+    for f in files:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        g = d["two_stream_guard"]
+        assert g["launches_outside_this_library"] == 0 and g["dealer_stopped_sharing"] is None and g["allow_foreign"] is False
+        assert d["config"]["compute_streams"] == 2 and d["single_stream_mode"]["last_step_records_bit_equal_to_timed_region"] is True
+        pk = d["pk_hazard_probe"]
+        assert pk["wrong_results_alone"] == 0 and pk["wrong_results"] is not None
+        if pk["wrong_results"]:
+            assert pk["lanes"][0] >= 48 and all("op_sel:[0,1]" in x for x in pk["v_pk_add_f32"] + pk["v_pk_mul_f32"])
+        p_ = d["parity_in_run"]
+        assert p_["max_abs_dR"] <= 1e-4 and p_["max_abs_dt_m"] <= 1e-4 and p_["refine_vs_oracle"]["max_abs_dt_m"] <= 1e-5
+        crop = d["cpu_baseline"]["stages"]["crop_resize_port_1thread"]
+        assert crop["kind"] == "port" and crop["cores"] == 1 and crop["value"] > 0
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r06*_bench_*stream_hostfed_yolox.json"))):
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        y = d["yolox_post"]
+        assert y["images"] > 0 and y["detections"] > 3 * y["images"] and 0 < y["ms_per_image"] < 1.0 and 0 < y["host_ms_per_image"] < 2.0
+        assert d["config"]["host_fed"] is True and d["value"] >= 0.95 * d["host_fed"]["resident_pool_rois_per_s"]
+        assert d["two_stream_guard"]["dealer_stopped_sharing"] is None
+    small = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06*_small_batch.jsonl")))
+    assert small
+    for f in small:
+        rows = [json.loads(l) for l in open(f) if l.startswith("{")]
+        by = {(r["config"]["rois_per_gpu"], r["config"]["hipgraph"]): r for r in rows}
+        for b in (8, 16):
+            assert by[(b, True)]["config"]["compute_streams"] == 4
+            assert by[(b, True)]["value"] >= 1.2 * by[(b, False)]["value"]        # round-5 verdict item 3's bar, same box
+
+
 def test_gpus_flag_spawns_ranks_and_gathers_every_roi_once():
     """`python bench.py --gpus 2` without a launcher: spawn, rendezvous on 127.0.0.1, contiguous ROI shards, one all-gather
     of the records, ROI-id permutation check, MAX-over-ranks timing, one JSON line from rank 0 — on CPU through the gloo
