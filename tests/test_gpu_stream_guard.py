@@ -43,6 +43,8 @@ def _device_kernel_names(fn):
     for ev in prof.events():
         if str(ev.device_type).endswith("CUDA"):
             names.append(ev.name)
+    if not names:      # no device-side tracing on this box (roctracer not loadable / another tracer holds it): say so, do not pretend
+        pytest.skip("torch.profiler returned no device events here: the kernel-name whitelist cannot be checked on this box")
     return names
 
 

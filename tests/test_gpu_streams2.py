@@ -280,3 +280,86 @@ def test_a_graph_that_would_share_the_chip_refuses_foreign_kernels(hip):
         engine.GraphedInference(model, post, batch, warmup=1, stream=torch.cuda.Stream(), sharing=True)
     g1 = engine.GraphedInference(model, post, batch, warmup=1)           # alone on a stream it is fine
     assert g1.foreign_launches > 0 and torch.isfinite(g1.replay()).all()
+
+
+def test_a_graph_on_its_own_stream_that_leaves_the_range_is_repeated_there_and_captured_again(setup):
+    """Two hipGraphs on two streams; before the third replay ONE layer's input shrinks to the 1e-3 scale (its LayerNorm affine is
+    scaled in place): the graph whose replay trips SMALL_ROWS — read back asynchronously, looked at in GraphHandle.result() —
+    returns the records of the six-product mode (bit for bit), demotes the layer and captures again ON ITS STREAM; the other graph,
+    still holding the layer's three-product kernel, captures again before its next replay; after that both replay without repeats."""
+    cfg, model, post, batches = setup
+    blk = model.backbone.stages_2.blocks[9]
+    reruns0 = engine.range_reruns()
+    try:
+        with torch.no_grad():
+            gs = engine.GraphedStepStreams(model, post, batches[:2], compute_streams=2, warmup=1)
+            healthy = [gs.launch(0).result().clone(), gs.launch(1).result().clone()]
+            assert all(g.uses_x3 and g.captures == 1 for g in gs.graphs) and hip_layers.x3_demoted() == {}
+            w_ok, b_ok = blk.norm.weight.clone(), blk.norm.bias.clone()
+            blk.norm.weight.mul_(1e-3)
+            blk.norm.bias.mul_(1e-3)
+            with hip_layers.forced_gemm_products(6):
+                want = [engine.inference_step(model, post, batches[k]).clone() for k in range(2)]
+            h0, h1 = gs.launch(0), gs.launch(1)               # both in flight with the shrunken layer
+            r0, r1 = h0.result().clone(), h1.result().clone()
+            torch.cuda.synchronize()
+            assert engine.range_reruns() >= reruns0 + 1 and len(hip_layers.x3_demoted()) >= 1
+            assert torch.equal(r0, want[0]), "the flagged replay must return the six-product records"
+            assert (r1[:, :12] - want[1][:, :12]).abs().max().item() <= 1e-4      # second graph: repeated too, or replayed after the demotion
+            assert gs.graphs[0].captures == 2 and gs.graphs[0].stream == gs.dealer.streams[0]
+            n_rer = engine.range_reruns()
+            again = [gs.launch(0).result().clone(), gs.launch(1).result().clone()]
+            torch.cuda.synchronize()
+            assert engine.range_reruns() == n_rer and all(g.captures == 2 for g in gs.graphs)
+            for k in range(2):
+                assert (again[k][:, :12] - want[k][:, :12]).abs().max().item() <= 1e-4
+            assert not torch.equal(again[0], healthy[0])
+    finally:
+        with torch.no_grad():
+            blk.norm.weight.copy_(w_ok)
+            blk.norm.bias.copy_(b_ok)
+        hip_layers.reset_x3_demotions()
+        engine._X3_OVERFLOW_STEPS = 0
+
+
+def test_host_fed_images_report_when_their_pinned_source_may_be_overwritten(setup):
+    """(round-5 advice) RoiStreamScheduler copies a host image with non_blocking=True from the caller's PINNED buffer;
+    ``h2d_done_event(key)`` is what the caller waits for before recycling that buffer: overwriting it after the event gives the
+    records of the untouched run, bit for bit."""
+    cfg, model, post, _ = setup
+    rng = np.random.default_rng(21)
+    ext = np.asarray(S.make_models(21, np.random.default_rng(11), 2)[2])
+    g = torch.Generator(device=DEV).manual_seed(4)
+    dets, imgs = [], []
+    for i in range(6):
+        det = S.make_detections(24, 21, ext, rng)
+        x1y1 = det["roi_center"] - det["roi_wh"] / 2
+        dets.append(dict(bbox=np.concatenate([x1y1, x1y1 + det["roi_wh"]], 1).astype(np.float32), roi_cls=det["roi_cls"], score=det["score"],
+                         cam=S.YCBV_K.astype(np.float32), extents=ext))
+        imgs.append((torch.randint(0, 256, (S.IM_H, S.IM_W, 3), dtype=torch.uint8, device=DEV, generator=g).cpu(),
+                     (torch.rand((S.IM_H, S.IM_W), device=DEV, generator=g) + 0.5).cpu()))
+
+    def run(recycle):
+        sch = engine.RoiStreamScheduler(cfg, model, post, rois_per_step=64, device=torch.device(DEV, 0))
+        buf_i, buf_d = torch.empty_like(imgs[0][0]).pin_memory(), torch.empty_like(imgs[0][1]).pin_memory()
+        out = {}
+        for i, (im, dp) in enumerate(imgs):
+            if recycle:                                   # ONE pinned staging buffer for the whole stream
+                buf_i.copy_(im); buf_d.copy_(dp)
+                src = (buf_i, buf_d)
+            else:
+                src = (im.pin_memory(), dp.pin_memory())
+            for k, rec, _ in sch.push(i, src[0], src[1], dets[i]):
+                out[k] = rec
+            if recycle:
+                ev = sch.h2d_done_event(i)
+                if ev is not None:
+                    ev.synchronize()                      # ... now the next image may overwrite the buffer
+        for k, rec, _ in sch.flush():
+            out[k] = rec
+        return out
+
+    a, b = run(False), run(True)
+    assert sorted(a) == sorted(b) == list(range(6))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
