@@ -323,6 +323,62 @@ def record_large(ds, b, chunk32=32, chunk64=16, seed_shift=1):
     print("wrote", f"net_golden_{ds}_b{b}.npz")
 
 
+def record_large_alt(ds, b, chunk=32, seed_shift=1):
+    """A SECOND fp32 forward of the reference's module on the batch of record_large, on another fp32 backend of the same PyTorch:
+    oneDNN switched off (``torch.backends.mkldnn.flags(enabled=False)``: native im2col + BLAS convolutions, other summation
+    orders) — the closest this container gets to "the reference's CUDA path vs its CPU path".  Stored beside the first run
+    (``*_alt32``) in net_golden_<ds>_b<b>.npz, so that the tests can state how far two fp32 runs of the REFERENCE'S OWN CODE are from
+    each other per ROI: the yardstick for what "within 1e-4 of the reference" can mean at ill-conditioned ROIs."""
+    import time
+
+    torch.set_num_threads(os.cpu_count())
+    torch.set_grad_enabled(False)
+    hip_layers.set_enabled(False)
+    from core.gdrn_modeling.models import GDRN_double_mask as REFM
+    from core.gdrn_modeling.models import net_factory
+    from tests.netgolden import net_detections_large
+
+    net_factory.BACKBONES["timm/convnext_base"] = lambda model_name=None, **kw: create_backbone(type="timm/" + model_name, **kw)
+    raw = _refimport.load_ref_config(CONFIGS[ds])
+    cfg = Config(raw)
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.MODEL.POSE_NET.BACKBONE.INIT_CFG.pretrained = False
+    cfg.TEST.USE_DEPTH_REFINE = True
+    cfg.SOLVER.BASE_LR = cfg.SOLVER.OPTIMIZER_CFG["lr"]
+    model, _ = REFM.build_model_optimizer(cfg, is_test=True)
+    model.eval()
+    sd = model.state_dict()
+    model.load_state_dict(S.seeded_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], SEED, alias=norm_alias), strict=True)
+    C = cfg.MODEL.POSE_NET.NUM_CLASSES
+    path = os.path.join(HERE, f"net_golden_{ds}_b{b}.npz")
+    z = np.load(path)
+    rec = {k: z[k] for k in z.files}
+    x, det = net_image(b, SEED + seed_shift), net_detections_large(C, b)
+    assert np.array_equal(det["roi_cls"], rec["roi_cls"]) and np.array_equal(det["roi_center"], rec["roi_center"])
+    coord2d = S.coord2d_roi(det["roi_center"], det["scale"])
+    grab = {}
+    model.pnp_net.register_forward_hook(lambda m, i, o: grab.update(pred_rot_=o[0].clone(), pred_t_=o[1].clone()))
+    acc = {k: [] for k in ("rot", "trans", "pred_rot_", "pred_t_")}
+    t0 = time.time()
+    with torch.backends.mkldnn.flags(enabled=False):
+        for s in range(0, b, chunk):
+            sl = slice(s, s + chunk)
+            D = lambda a: torch.from_numpy(np.ascontiguousarray(a[sl]))   # noqa: E731
+            out = model(D(x), roi_classes=torch.from_numpy(det["roi_cls"][sl]), roi_cams=D(det["roi_cam"]), roi_whs=D(det["roi_wh"]),
+                        roi_centers=D(det["roi_center"]), resize_ratios=D(det["resize_ratio"]), roi_coord_2d=D(coord2d),
+                        roi_extents=D(det["roi_extent"]), do_loss=False)
+            acc["rot"].append(out["rot"].numpy()); acc["trans"].append(out["trans"].numpy())
+            acc["pred_rot_"].append(grab["pred_rot_"].numpy()); acc["pred_t_"].append(grab["pred_t_"].numpy())
+            print(ds, b, "alt fp32 chunk", s, f"{time.time() - t0:.0f} s", flush=True)
+    for k, v in acc.items():
+        rec[k + "_alt32"] = np.concatenate(v)
+        d = np.abs(rec[k + "_alt32"].astype(np.float64) - rec[k].astype(np.float64)).reshape(b, -1).max(1)
+        e = np.abs(rec[k + "_alt32"].astype(np.float64) - rec[k + "_f64"]).reshape(b, -1).max(1)
+        print(ds, b, k, "two fp32 runs of the reference: max distance", d.max(), "at ROI", int(d.argmax()), "| alt run vs fp64: max", e.max(), "at ROI", int(e.argmax()))
+    np.savez_compressed(path, **rec)
+    print("updated", path)
+
+
 def record_resnet34():
     """BASELINE configs[0]: models/GDRN.py built from configs/_base_/gdrn_base.py (NUM_CLASSES=1 for the single LM-O object;
     the base file's 13 gives the same graph — nothing in it is class-aware), 32 ROIs = the batch of configs[0].
@@ -422,7 +478,10 @@ def record_resnet34_f64(b=32):
 
 
 if __name__ == "__main__":
-    if "--large" in sys.argv:          # --large tless 1024 | --large ycbv 512
+    if "--large-alt" in sys.argv:      # --large-alt tless 1024: adds the second fp32 run (oneDNN off) to an existing fixture
+        i = sys.argv.index("--large-alt")
+        record_large_alt(sys.argv[i + 1], int(sys.argv[i + 2]))
+    elif "--large" in sys.argv:        # --large tless 1024 | --large ycbv 512
         i = sys.argv.index("--large")
         record_large(sys.argv[i + 1], int(sys.argv[i + 2]))
     elif "--b128-only" in sys.argv:
