@@ -45,7 +45,7 @@ int ensure_dynamic_lds(const void* kernel, int bytes) {
   return 0;
 }
 // tuning switches: written by gdrnpp_set_option, read by launches on any host thread
-static std::atomic<int> g_opt_glds{1}, g_opt_mi4{-1}, g_opt_pipe{3}, g_opt_pipe_conv{0}, g_opt_panel{4}, g_opt_big_tiles{256}, g_opt_dw_tile{-1}, g_opt_splitk_small{1}, g_opt_split2_wide{-1}, g_opt_mlp_fused_pipe{1}, g_opt_dw_lds_w{1}, g_opt_dw_lds_pad{0}, g_opt_roi_align_variant{0};
+static std::atomic<int> g_opt_glds{1}, g_opt_mi4{-1}, g_opt_pipe{3}, g_opt_pipe_conv{0}, g_opt_panel{4}, g_opt_big_tiles{256}, g_opt_dw_tile{-1}, g_opt_splitk_small{1}, g_opt_split2_wide{-1}, g_opt_mlp_fused_pipe{1}, g_opt_dw_lds_w{1}, g_opt_dw_lds_pad{0};
 int option_split_gemm_glds() { return g_opt_glds; }
 int option_split_gemm_pipe() { return g_opt_pipe; }
 int option_split_gemm_pipe_conv() { return g_opt_pipe_conv; }
@@ -58,7 +58,6 @@ int option_split2_wide() { return g_opt_split2_wide; }
 int option_mlp_fused_pipe() { return g_opt_mlp_fused_pipe; }
 int option_dwconv_lds_w() { return g_opt_dw_lds_w; }
 int option_dwconv_lds_pad() { return g_opt_dw_lds_pad; }
-int option_roi_align_variant() { return g_opt_roi_align_variant; }
 }  // namespace gdrnpp
 
 namespace {
@@ -123,7 +122,6 @@ int gdrnpp_set_option(const char* name, int value) {
   if (!strcmp(name, "dwconv_tile")) { gdrnpp::g_opt_dw_tile = (value >= 0 && value <= 2) ? value : -1; return 0; }
   if (!strcmp(name, "split2_wide")) { gdrnpp::g_opt_split2_wide = value < 0 ? -1 : (value != 0); return 0; }
   if (!strcmp(name, "mlp_fused_pipe")) { gdrnpp::g_opt_mlp_fused_pipe = value != 0; return 0; }
-  if (!strcmp(name, "roi_align_variant")) { gdrnpp::g_opt_roi_align_variant = value; return 0; }
   if (!strcmp(name, "dwconv_lds_w")) { gdrnpp::g_opt_dw_lds_w = value != 0; return 0; }
   if (!strcmp(name, "dwconv_lds_pad")) { gdrnpp::g_opt_dw_lds_pad = value < 0 ? 0 : (value > 112 * 1024 ? 112 * 1024 : value); return 0; }
   if (!strcmp(name, "split_gemm_mi4")) { gdrnpp::g_opt_mi4 = value < 0 ? -1 : (value != 0); return 0; }

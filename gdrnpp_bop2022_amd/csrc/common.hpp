@@ -77,7 +77,6 @@ int option_mlp_fused_pipe();    // 1 (default): software-pipelined tile loop of 
 int option_dwconv_tile();       // -1 (default): by launch size; 0 / 1 / 2: force the 2x8 / 2x4 / 1x4 pixel tile of dwconv7x7+LN
 int option_dwconv_lds_w();      // 1 (default): [49][C] weights in LDS + persistent workgroups where they fit; 0: weights through L1 / L2, no LDS (A/B:
                                 // a workgroup that needs 98 KB of LDS cannot start on a CU that holds one 80 KB GEMM workgroup of another stream)
-int option_roi_align_variant(); // A/B switch of gdrnpp_roi_align's launch shape (rows per thread / store kind)
 int option_dwconv_lds_pad();    // experiment only: dynamic LDS bytes the no-LDS form allocates all the same (profiles/r06_dwconv_shared.txt)
 
 }  // namespace gdrnpp

@@ -296,21 +296,17 @@ extern "C" int gdrnpp_roi_align(const float* x, const float* rois, float* out, i
   }
   const int cols = pooled_w > 128 ? 256 : (pooled_w > 64 ? 128 : 64);      // output columns per workgroup; 256 / cols row lanes
   const int col_tiles = (pooled_w + cols - 1) / cols;
-  const int variant = gdrnpp::option_roi_align_variant();     // A/B switch: 0 (default) 4 rows per thread, non-temporal stores / 1: 8 rows / 2: 16 rows / 3: 4 rows, plain stores
-  const int rows = variant == 1 ? 8 : (variant == 2 ? 16 : 4);
+  constexpr int rows = 4;                                     // output rows per thread (8 / 16 measured slower: fewer waves in flight)
   const long rows_per_wg = (long)rows * (256 / cols);
   const int ch = C >= 4 ? 4 : C;                              // channel planes per thread; full = no partial last chunk
   const bool full = C % ch == 0;
   GDRNPP_REQUIRE(((pooled_h + rows_per_wg - 1) / rows_per_wg) * col_tiles < (1l << 31), GDRNPP_ELIMIT, "gdrnpp_roi_align: output plane too large");
   const dim3 grid((unsigned)(((pooled_h + rows_per_wg - 1) / rows_per_wg) * col_tiles), (unsigned)((C + ch - 1) / ch), (unsigned)n_rois);
-#define GDRNPP_RA(AL, R, NT, CHV, FU) hipLaunchKernelGGL((roi_align_kernel<AL, R, NT, CHV, FU>), grid, dim3(256), 0, (hipStream_t)stream, x, rois, out, C, H, W, \
-                                                        pooled_h, pooled_w, spatial_scale, sampling_ratio, col_tiles, cols)
-#define GDRNPP_RA_C(AL, R, NT) do { if (ch == 1) GDRNPP_RA(AL, R, NT, 1, true); else if (ch == 2) GDRNPP_RA(AL, R, NT, 2, true); \
-    else if (ch == 3) GDRNPP_RA(AL, R, NT, 3, true); else if (full) GDRNPP_RA(AL, R, NT, 4, true); else GDRNPP_RA(AL, R, NT, 4, false); } while (0)
-#define GDRNPP_RA_V(AL) switch (variant) { case 1: GDRNPP_RA_C(AL, 8, false); break; case 2: GDRNPP_RA_C(AL, 16, false); break; \
-    case 3: GDRNPP_RA_C(AL, 4, false); break; default: GDRNPP_RA_C(AL, 4, true); }
-  if (aligned) { GDRNPP_RA_V(true) } else { GDRNPP_RA_V(false) }
-#undef GDRNPP_RA_V
+#define GDRNPP_RA(AL, CHV, FU) hipLaunchKernelGGL((roi_align_kernel<AL, rows, true, CHV, FU>), grid, dim3(256), 0, (hipStream_t)stream, x, rois, out, C, H, W, \
+                                                 pooled_h, pooled_w, spatial_scale, sampling_ratio, col_tiles, cols)
+#define GDRNPP_RA_C(AL) do { if (ch == 1) GDRNPP_RA(AL, 1, true); else if (ch == 2) GDRNPP_RA(AL, 2, true); \
+    else if (ch == 3) GDRNPP_RA(AL, 3, true); else if (full) GDRNPP_RA(AL, 4, true); else GDRNPP_RA(AL, 4, false); } while (0)
+  if (aligned) GDRNPP_RA_C(true); else GDRNPP_RA_C(false);
 #undef GDRNPP_RA_C
 #undef GDRNPP_RA
   return gdrnpp::check_launch("gdrnpp_roi_align");

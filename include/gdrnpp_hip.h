@@ -55,6 +55,10 @@ const char* gdrnpp_last_error(void);
  *   "mlp_fused_pipe"   0 / 1       fused stage-0 MLP (gdrnpp_convnext_mlp_f32_fused): software-pipelined tile loop (default 1) or the plain loop (A/B switch)
  *   "split2_wide"      0 / 1       three-product kernels (gdrnpp_*_split2): 256x256 block tiles whenever N % 256 == 0 (A/B switch,
  *                                   default 0: bitwise identical and measured slower than 256x128)
+ *   "dwconv_lds_w"     0 / 1       depthwise 7x7 + LayerNorm: [49][C] weights in LDS with persistent workgroups where they fit (default 1) or
+ *                                   through L1 / L2 without LDS (A/B switch: which of two kernels sharing the chip yields is decided by the LDS
+ *                                   a workgroup holds, profiles/r06_dwconv_shared.txt; bitwise identical)
+ *   "dwconv_lds_pad"   bytes       experiment only: dynamic LDS the no-LDS form allocates without using it (default 0)
  * unknown name -> GDRNPP_EINVAL. */
 int gdrnpp_set_option(const char* name, int value);
 

@@ -10,7 +10,7 @@ sys.path.insert(0, "$R")
 sys.path.insert(0, "$R/tools")
 import numpy as np, torch
 from gdrnpp_bop2022_amd import hip_lib, synthetic as S
-hip_lib.load(); hip_lib.set_option("roi_align_variant", $V)
+hip_lib.load()   # (the variant argument selected A/B builds of round 6; the library now holds the kept form only)
 dev = torch.device("cuda", 0); rng = np.random.default_rng(20220925); b = 128
 verts, faces, ext = S.make_models(21, np.random.default_rng(1), 2)
 det = S.make_detections(b, 21, ext, rng)

@@ -1,5 +1,6 @@
-"""A/B of gdrnpp_roi_align's launch shapes (gdrnpp_set_option("roi_align_variant", v)) on the ops microbenchmark's workload:
-128 ROIs of a [16,3,480,640] batch -> 3 x 256 x 256, adaptive sampling grid; bit-equality of every variant with variant 0."""
+"""gdrnpp_roi_align on the ops microbenchmark's workload: 128 ROIs of a [16,3,480,640] batch -> 3 x 256 x 256 and 3 x 64 x 64, adaptive
+sampling grid.  (The launch-shape variants of profiles/r06_roi_align.md were A/B builds of round 6 — rows per thread, store kind, LDS
+staging: tools/probe/roi_align_lds_experiment.hip.txt — the library keeps the one that won.)"""
 import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,14 +22,12 @@ def gpu_time(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e-3
 ref = None
-names = {0: "4 rows per thread, non-temporal stores (product)", 1: "8 rows, plain stores", 2: "16 rows, plain stores", 3: "4 rows, plain stores"}
+names = {0: "4 rows per thread, non-temporal stores (product)"}
 for out_res in (256, 64):
-    for v in range(4):
-        hip_lib.set_option("roi_align_variant", v)
+    for v in range(1):
         y = hip_lib.roi_align(x, rois, out_res)
         torch.cuda.synchronize()
         if v == 0: ref = y.clone()
         t = gpu_time(lambda: hip_lib.roi_align(x, rois, out_res))
         nb = b * 3 * out_res * out_res * 4
         print(json.dumps({"out": out_res, "variant": v, "shape": names[v], "us": t * 1e6, "GBs": nb / t / 1e9, "frac_of_8TBs": nb / t / 8e12, "bit_equal": bool(torch.equal(y, ref))}), flush=True)
-hip_lib.set_option("roi_align_variant", 0)
