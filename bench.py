@@ -466,8 +466,12 @@ def worker(args):
                                   if args.gemm_products == 3 else
                                   "fp32 operands split exactly into three bf16 values, six partial products, fp32 accumulation (exact to 2^-26)"),
                 "library_options": args.opt,
-                "timed_entry_point": ("engine.RoiStreamScheduler.launch_next (GPU crop + inference_step_async) + engine.gather_records"
-                                      if wname.endswith("stream") else "engine.inference_step_async / StepHandle.result + engine.gather_records"),
+                "timed_entry_point": (("engine.RoiStreamScheduler(graph_steps=True).launch_next (static-buffer fill + hipGraph replay of GPU crop + forward + post) + engine.gather_records"
+                                       if args.graph and wname == "stream" else
+                                       "engine.RoiStreamScheduler.launch_next (GPU crop + inference_step_async) + engine.gather_records")
+                                      if wname.endswith("stream") else
+                                      "engine.GraphedStepStreams.launch / GraphHandle.result + engine.gather_records" if args.graph else
+                                      "engine.inference_step_async / StepHandle.result + engine.gather_records"),
                 "stub_step": bool(args.stub_step)},
             "gather_ms": gather_ms, "collective": collective,
         }
@@ -568,7 +572,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                            K_crops=[p[2] for p in pair], meshes=meshes, verts=verts, faces=faces, C=C, graphs={}, ext=ext))
 
     if args.compute_streams <= 0:        # default: two steps in flight only where every kernel of a step is this library's
-        default_streams = E.default_graph_streams if (args.graph and not args.with_crop and wname != "lmo_upnp" and not wname.endswith("stream")) \
+        default_streams = E.default_graph_streams if (args.graph and not args.with_crop and wname not in ("lmo_upnp", "bop7_stream")) \
             else E.default_compute_streams            # hipGraph replays leave the host free to keep four steps in flight
         args.compute_streams = min(default_streams(m_["model"], m_["cfg"]) for m_ in models)
     else:                                # an explicit --compute-streams N is an A/B request: the dealer keeps sharing whatever a step launches
@@ -648,7 +652,7 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
 
             def make_sched(m_=m_, timed=args.host_fed):
                 return E.RoiStreamScheduler(m_["cfg"], m_["model"], m_["post"], rois_per_step=b, roi_id_base=lo, device=dev, time_h2d=timed,
-                                            compute_streams=sched_streams)
+                                            compute_streams=sched_streams, graph_steps=bool(args.graph) and wname == "stream")
             subs.append(dict(sched=make_sched(), feeder=make_feeder(host_pool if args.host_fed else pool), pool=pool, make_sched=make_sched,
                              make_feeder=make_feeder))
         stream = dict(subs=subs, counter=counter, h2d_bytes_warmup=0, yolox=yolox,

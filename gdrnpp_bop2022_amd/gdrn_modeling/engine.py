@@ -597,10 +597,16 @@ class StepStreams:
         """Context manager: the body's launches go to the next compute stream (with n = 1: the caller's current stream) and, with
         n > 1, choose their GEMM kernels for a shared chip (``shared_min_tiles``: 4 248 -> 4 525 ROIs/s at 32 ROIs, neutral at 8 and
         128, profiles/r05y_shared_chip_tile_rule.txt)."""
+        idx = self._i % len(self.streams)
+        self._i += 1
+        return self.on(idx)
+
+    def on(self, index: int):
+        """Context manager like ``next()`` for a GIVEN stream of the dealer, without advancing the round-robin (a hipGraph slot is
+        bound to the stream it was captured on)."""
         import contextlib
 
-        s_ = self.streams[0 if self.stopped_sharing is not None else self._i % len(self.streams)]
-        self._i += 1
+        s_ = self.streams[0 if self.stopped_sharing is not None else index % len(self.streams)]
 
         @contextlib.contextmanager
         def ctx():
@@ -789,11 +795,15 @@ class GraphHandle:
 
     def __init__(self, owner, event, rec):
         self._owner, self._event, self._rec = owner, event, rec
+        self.stream = owner.stream              # the stream the graph was replayed on (None: the caller's current one)
+        self.reran = False                      # result() repeated the step eagerly with six products
 
     def result(self) -> torch.Tensor:
         if self._owner is not None:
             owner, self._owner = self._owner, None
+            n0 = owner.reruns
             self._rec = owner._resolve(self._event, self._rec)
+            self.reran = owner.reruns != n0
             self._event = None
         return self._rec
 
@@ -819,15 +829,18 @@ class GraphedInference:
     not on every replay."""
 
     def __init__(self, model, post: GdrnHipPost, example_batch: dict, roi_ids: torch.Tensor | None = None,
-                 warmup: int = 3, stream=None, shared_min_tiles=None, sharing: bool = False, shared_min_rows=None):
+                 warmup: int = 3, stream=None, shared_min_tiles=None, sharing: bool = False, shared_min_rows=None, body=None):
         self.model, self.post = model, post
+        self.body = body                                      # callable(static) -> records: a step that is more than forward + post
+        self.reruns = 0                                       # (RoiStreamScheduler(graph_steps=True): crop + forward + post)
         self.stream = stream                                  # None = whatever stream is current when replay is called
         self.shared_min_tiles, self.shared_min_rows, self.sharing = shared_min_tiles, shared_min_rows, bool(sharing)
-        self.static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in example_batch.items()}
+        self.static = ({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in example_batch.items()} if body is None
+                       else example_batch)                    # with a body the caller owns the static inputs and fills them itself
         self.roi_ids = roi_ids.clone() if roi_ids is not None else None
         self.captures = 0
         self._pending = None                                  # the unresolved GraphHandle of the latest replay
-        dev = self.static["roi_img"].device
+        dev = next(v.device for v in self.static.values() if isinstance(v, torch.Tensor))
         for _ in range(max(warmup, 1)):                       # MIOpen find, hipFuncSetAttribute, allocator warm-up, weight packing and the
             self._eager_pass()                                # first range verdicts (demotions) happen outside capture
         self.x3_flag = torch.zeros((hip_lib.X3_SLOTS,), dtype=torch.int32, device=dev)   # the graph's own range words
@@ -848,9 +861,15 @@ class GraphedInference:
         if self.stream is not None:
             side.wait_stream(self.stream)
         with torch.cuda.stream(side), hip_lib.shared_min_tiles_scope(self.shared_min_tiles, self.shared_min_rows):
-            inference_step(self.model, self.post, self.static, self.roi_ids)
+            run_with_range_check(torch.no_grad()(self._step))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+
+    def _step(self):
+        """The work of one replay, as a callable of no arguments (eager passes, capture, the six-product repeat)."""
+        if self.body is not None:
+            return self.body(self.static)
+        return _step_closure(self.model, self.post, self.static, self.roi_ids)()
 
     def _recapture(self):
         for _ in range(4):          # an eager pass may itself demote a layer: repeat until the set is stable
@@ -862,7 +881,7 @@ class GraphedInference:
 
     @torch.no_grad()
     def _capture(self):
-        run = _step_closure(self.model, self.post, self.static, self.roi_ids)
+        run = self._step
         self.graph = torch.cuda.CUDAGraph()
         n_x3, n_foreign = hip_lib.x3_launch_count(), hip_layers.fallback_launches()
         self.x3_flag.zero_()
@@ -899,6 +918,7 @@ class GraphedInference:
         self._pending = GraphHandle(self, ev, rec)
         return self._pending
 
+    @torch.no_grad()
     def _resolve(self, event, rec) -> torch.Tensor:
         self._pending = None
         caller = torch.cuda.current_stream()
@@ -907,7 +927,8 @@ class GraphedInference:
             words = hip_lib.range_words_of(self._host_words)
             if words:
                 with self._on_stream(), hip_lib.shared_min_tiles_scope(self.shared_min_tiles, self.shared_min_rows):
-                    rec = _six_product_rerun(_step_closure(self.model, self.post, self.static, self.roi_ids), words)
+                    rec = _six_product_rerun(self._step, words)
+                    self.reruns += 1
                     self._recapture()
                     self.records.copy_(rec)
                     event = torch.cuda.Event()
@@ -1060,65 +1081,87 @@ def detections_from_bop_json(detections: dict, scene_im_ids, obj_ids, cam, exten
                 time=np.asarray(times, np.float32))
 
 
+def packed_layout(arrays: dict):
+    """Byte layout of ``upload_packed``'s staging buffer: -> ({key: (offset, nbytes, numpy dtype, shape)}, total bytes); every
+    array starts on a 16-byte boundary, dict order."""
+    import numpy as np
+
+    lay, total = {}, 0
+    for k, a in arrays.items():
+        a = np.asarray(a)
+        total = (total + 15) & ~15
+        lay[k] = (total, a.nbytes, a.dtype, a.shape)
+        total += a.nbytes
+    return lay, max(total, 16)
+
+
+def fill_packed(host_u8, arrays: dict, layout: dict) -> None:
+    """Write ``arrays`` into a staging buffer (a uint8 NumPy view) laid out by ``packed_layout``."""
+    import numpy as np
+
+    for k, (off, nbytes, dt, shape) in layout.items():
+        a = np.ascontiguousarray(arrays[k], dtype=dt)
+        if a.shape != tuple(shape):
+            raise ValueError(f"fill_packed: {k!r} has shape {a.shape}, the layout holds {tuple(shape)}")
+        if nbytes:
+            host_u8[off:off + nbytes] = a.reshape(-1).view(np.uint8)
+
+
+def packed_views(dev_u8: torch.Tensor, layout: dict) -> dict:
+    """Typed tensor views of a device copy of the staging buffer."""
+    import numpy as np
+
+    out = {}
+    for k, (off, nbytes, dt, shape) in layout.items():
+        tdt = torch.from_numpy(np.empty((0,), dt)).dtype
+        out[k] = dev_u8[off:off + nbytes].view(tdt).reshape(tuple(shape))
+    return out
+
+
 def upload_packed(arrays: dict, dev) -> dict:
     """The small per-ROI host arrays of a step -> device tensors through ONE pinned staging buffer and ONE asynchronous copy on the
     current stream.  A ``torch.from_numpy(a).to(dev)`` per array is a blocking pageable copy queued behind everything already on
     the stream: the host would sit out the step that is still running there before it could prepare the next one."""
-    import numpy as np
-
     dev = torch.device(dev)
-    arrs, offs, total = {}, {}, 0
-    for k, a in arrays.items():
-        a = np.ascontiguousarray(a)
-        arrs[k] = a
-        total = (total + 15) & ~15
-        offs[k] = total
-        total += a.nbytes
-    host = torch.empty((max(total, 16),), dtype=torch.uint8, pin_memory=dev.type == "cuda")
-    hv = host.numpy()
-    for k, a in arrs.items():
-        if a.nbytes:
-            hv[offs[k]:offs[k] + a.nbytes] = a.reshape(-1).view(np.uint8)
-    d = host.to(dev, non_blocking=True)
-    out = {}
-    for k, a in arrs.items():
-        dt = torch.from_numpy(np.empty((0,), a.dtype)).dtype
-        out[k] = d[offs[k]:offs[k] + a.nbytes].view(dt).reshape(a.shape)
-    return out
+    layout, total = packed_layout(arrays)
+    host = torch.empty((total,), dtype=torch.uint8, pin_memory=dev.type == "cuda")
+    fill_packed(host.numpy(), arrays, layout)
+    return packed_views(host.to(dev, non_blocking=True), layout)
 
 
-def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, device=None, sort_by_class: bool = False,
-                        roi_id_base: int = 0, extra_per_roi_keys=(), extra_global_keys=()) -> dict:
-    """``read_data_test`` + ``batch_data_test`` (data_loader.py:647-818, engine_utils.py:213-241) with the crops made
-    on the GPU.  images u8[n_im,H,W,3] (BGR, device), depths f32[n_im,H,W] or None, detections:
-    {"bbox": [n,4] xyxy, "im_idx": [n], "roi_cls": [n], "score": [n], "cam": [n,3,3] or [3,3], "extents": [C,3]}.
-    Returns the batch dict ``GDRN_Net.forward`` / ``GdrnHipPost`` consume (all tensors on the device).
-    ``sort_by_class``: ROIs are laid out in class order (SURVEY.md §8e) and ``batch["roi_id"]`` = ``roi_id_base`` + the
-    detection's original position (or the caller's ``detections["roi_id"]``), which ``inference_step`` writes into the records
-    (``records_in_roi_order`` restores it)."""
+def roi_host_arrays(cfg, detections: dict, H: int, W: int, sort_by_class: bool = False, roi_id_base: int = 0, extra_per_roi_keys=(),
+                    extra_global_keys=()) -> dict:
+    """The HOST half of ``batch_data_test_gpu``: detections -> the per-ROI NumPy arrays of a step (ROI parameters exactly as
+    read_data_test derives them, data_loader.py:754-769; class sort; ids), in the order ``upload_packed`` lays them out."""
     import numpy as np
 
-    dev = device or images.device
     roi_id = None
     if sort_by_class:
         detections, roi_id = sort_detections_by_class(detections, roi_id_base, extra_per_roi_keys, extra_global_keys)
     if "roi_id" in detections:        # the caller's own ids (RoiStreamScheduler: global stream ids), permuted with the rest
         roi_id = np.asarray(detections["roi_id"], np.int32)
-    net_cfg = cfg.MODEL.POSE_NET
-    n_im, H, W, _ = images.shape
-    r = rois_from_detections(detections["bbox"], H, W, cfg.INPUT.DZI_PAD_SCALE, net_cfg.OUTPUT_RES)
+    r = rois_from_detections(detections["bbox"], H, W, cfg.INPUT.DZI_PAD_SCALE, cfg.MODEL.POSE_NET.OUTPUT_RES)
     n = len(r["scale"])
     cls = np.asarray(detections["roi_cls"], np.int64)
     cam = np.asarray(detections["cam"], np.float32)
     cam = np.repeat(cam[None], n, 0) if cam.ndim == 2 else cam
-
     host = dict(center64=r["bbox_center"], scale64=r["scale"], im_idx=np.asarray(detections["im_idx"], np.int32), roi_cls=cls, roi_cam=cam,
                 roi_center=np.asarray(r["bbox_center"], np.float32), roi_wh=r["roi_wh"], scale=np.asarray(r["scale"], np.float32),
                 resize_ratio=np.asarray(r["resize_ratio"], np.float32), roi_extent=np.asarray(detections["extents"], np.float32)[cls],
                 score=np.asarray(detections.get("score", np.ones(n)), np.float32))
     if roi_id is not None:
         host["roi_id"] = np.asarray(roi_id, np.int32)
-    up = upload_packed(host, dev)                 # one pinned buffer, one asynchronous copy: the host never waits for the stream
+    return host
+
+
+def batch_from_uploaded(cfg, images: torch.Tensor, depths, up: dict, dev=None) -> dict:
+    """The DEVICE half: the uploaded per-ROI arrays (``upload_packed`` / ``packed_views`` of ``roi_host_arrays``) + the images ->
+    GPU crops (``gdrnpp_crop_resize_roi``) and the batch dict ``GDRN_Net.forward`` / ``GdrnHipPost`` consume.  Launches and tensor
+    views only — no host data: this half can be captured into a hipGraph (``RoiStreamScheduler(graph_steps=True)``)."""
+    dev = dev or images.device
+    net_cfg = cfg.MODEL.POSE_NET
+    n_im, H, W, _ = images.shape
+    n = up["scale"].shape[0]
     centers64, scales64 = up["center64"], up["scale64"]
     roi_img, roi_depth, roi_c2d = hip_lib.crop_resize_roi(
         images, depths, up["im_idx"], centers64, scales64,
@@ -1130,7 +1173,7 @@ def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, dev
         im_H=torch.full((n,), float(H), device=dev), im_W=torch.full((n,), float(W), device=dev))
     if roi_depth is not None:
         batch["roi_depth"] = roi_depth
-    if roi_id is not None:
+    if "roi_id" in up:
         batch["roi_id"] = up["roi_id"]
     if net_cfg.PNP_NET.COORD_2D_TYPE == "rel":
         # data_loader.py:799-804: (bbox_center - roi_coord_2d * (im_W, im_H)) / scale, float64 like NumPy, stored float32
@@ -1138,6 +1181,22 @@ def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, dev
         wh = torch.tensor([float(W), float(H)], dtype=torch.float64, device=dev).view(1, 2, 1, 1)
         batch["roi_coord_2d_rel"] = ((centers64.view(n, 2, 1, 1) - roi_c2d.double() * wh) / scales64.view(n, 1, 1, 1)).float()
     return batch
+
+
+def batch_data_test_gpu(cfg, images: torch.Tensor, depths, detections: dict, device=None, sort_by_class: bool = False,
+                        roi_id_base: int = 0, extra_per_roi_keys=(), extra_global_keys=()) -> dict:
+    """``read_data_test`` + ``batch_data_test`` (data_loader.py:647-818, engine_utils.py:213-241) with the crops made
+    on the GPU.  images u8[n_im,H,W,3] (BGR, device), depths f32[n_im,H,W] or None, detections:
+    {"bbox": [n,4] xyxy, "im_idx": [n], "roi_cls": [n], "score": [n], "cam": [n,3,3] or [3,3], "extents": [C,3]}.
+    Returns the batch dict ``GDRN_Net.forward`` / ``GdrnHipPost`` consume (all tensors on the device).
+    ``sort_by_class``: ROIs are laid out in class order (SURVEY.md §8e) and ``batch["roi_id"]`` = ``roi_id_base`` + the
+    detection's original position (or the caller's ``detections["roi_id"]``), which ``inference_step`` writes into the records
+    (``records_in_roi_order`` restores it).  = ``roi_host_arrays`` -> ``upload_packed`` (one pinned buffer, one asynchronous copy:
+    the host never waits for the stream) -> ``batch_from_uploaded``."""
+    dev = device or images.device
+    n_im, H, W, _ = images.shape
+    host = roi_host_arrays(cfg, detections, H, W, sort_by_class, roi_id_base, extra_per_roi_keys, extra_global_keys)
+    return batch_from_uploaded(cfg, images, depths, upload_packed(host, dev), dev)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -1295,6 +1354,11 @@ class RoiStreamScheduler:
     since admission runs one step ahead of the device the copies overlap the previous step's kernels.  ``time_h2d=True``
     brackets every image's copies with timing events (``h2d_ms()``).
 
+    ``graph_steps``: every FULL step replays a captured hipGraph of (GPU crop -> forward -> post-processing) instead of ~150 eager
+    launches — for small ``rois_per_step`` (the reference's own regime: a few ROIs at a time, low latency), where the host's launches
+    bound the eager schedule; the graphs sit in 2 x streams slots with static image / per-ROI buffers, ``default_graph_streams``
+    (4) steps in flight; records bit-equal to the eager scheduler with the same kernel rule; the tail step of ``flush`` runs eagerly.
+
     ``compute_streams`` (default: ``default_compute_streams(model)`` = 2 for the ConvNeXt configurations, whose every kernel is
     this library's): consecutive steps are launched on alternating HIP streams (``StepStreams``), so that with
     ``max_in_flight`` >= 2 two steps really are in flight on the device — one step's narrow tail under the next one's GEMMs —
@@ -1302,12 +1366,14 @@ class RoiStreamScheduler:
     that dealer, shared by several schedulers of one device (bench.py's seven-dataset stream)."""
 
     def __init__(self, cfg, model, post: GdrnHipPost, rois_per_step: int = 128, max_in_flight: int = 2, roi_id_base: int = 0,
-                 device=None, time_h2d: bool = False, compute_streams=None):
+                 device=None, time_h2d: bool = False, compute_streams=None, graph_steps: bool = False):
         import collections
 
         self.device = device
+        self.graph_steps = bool(graph_steps)    # full steps replay a captured hipGraph (crop + forward + post): small rois_per_step
+        self._slots = []                        # graph slots: static inputs + GraphedInference, bound to a compute stream each
         if compute_streams is None:
-            compute_streams = default_compute_streams(model)
+            compute_streams = default_graph_streams(model) if graph_steps else default_compute_streams(model)
         if isinstance(compute_streams, StepStreams):     # shared with other schedulers feeding the same device
             self._n_compute, self._dealer = len(compute_streams.streams), compute_streams
         else:
@@ -1323,6 +1389,8 @@ class RoiStreamScheduler:
         self.cfg, self.model, self.post = cfg, model, post
         self.packer = RoiPacker(rois_per_step, roi_id_base)
         self.max_in_flight = max(1, int(max_in_flight))
+        if self.graph_steps:                    # a graph replay costs the host ~0.1 ms: as many steps in flight as there are streams
+            self.max_in_flight = max(self.max_in_flight, self._n_compute)
         self._images = {}                       # key -> (image, depth, detections, arrival time)
         self._arrival = {}
         self._in_flight = collections.deque()   # (StepHandle, batch, done event) — the batch stays alive for a six-product repeat
@@ -1348,12 +1416,96 @@ class RoiStreamScheduler:
             dev = self.device if self.device is not None else self._images[keys[0]][0].device
             self._dealer = StepStreams(self._n_compute, dev)
         caller = torch.cuda.current_stream(self._dealer.device)
-        with self._dealer.next():               # this step's crop, forward and post-processing: the next compute stream
-            self._launch_on_current_stream(pack, keys, per_roi, cams, caller)
+        n_rois = sum(len(loc) for _, loc, _ in pack)
+        if self.graph_steps and n_rois == self.packer.rois_per_step:
+            n_slots = 2 * self._n_compute       # twice the streams: consecutive steps alternate streams, a slot is reused only after
+            k = self.steps_launched % n_slots   # max_in_flight (<= streams) younger steps were launched, i.e. after it was resolved
+            with self._dealer.on(k):
+                self._launch_graph_step(k, pack, keys, per_roi, cams, caller)
+        else:                                   # eager (the default; in graph mode: the short tail step of flush())
+            with self._dealer.next():           # this step's crop, forward and post-processing: the next compute stream
+                self._launch_on_current_stream(pack, keys, per_roi, cams, caller)
         for k in keys:                          # pixels are only read by the crop kernel just enqueued
             if self.packer.last_roi_dealt(k):
                 del self._images[k]
                 self._h2d_ready.pop(k, None)
+
+    def _step_detections(self, pack, keys, per_roi, cams) -> dict:
+        import numpy as np
+
+        return dict(
+            bbox=np.concatenate([per_roi(k, loc, "bbox", np.float32) for k, loc, _ in pack]),
+            roi_cls=np.concatenate([per_roi(k, loc, "roi_cls", np.int64) for k, loc, _ in pack]),
+            score=np.concatenate([per_roi(k, loc, "score", np.float32, np.ones) for k, loc, _ in pack]),
+            im_idx=np.concatenate([np.full(len(loc), i, np.int64) for i, (_, loc, _) in enumerate(pack)]),
+            roi_id=np.concatenate([ids for _, _, ids in pack]),
+            cam=np.concatenate([cams(k, loc) for k, loc, _ in pack]),
+            extents=self._images[keys[0]][2]["extents"])
+
+    def _launch_graph_step(self, k, pack, keys, per_roi, cams, caller) -> None:
+        """A full step as a hipGraph replay: the step's images are copied into the slot's static image block, its per-ROI arrays
+        through the slot's pinned buffer into the slot's packed device buffer (one asynchronous copy), then the slot's graph —
+        GPU crop, forward, post-processing, records — is replayed on the slot's stream.  The first use of a slot captures it."""
+        dev = self._dealer.device
+        cur = torch.cuda.current_stream(dev)
+        if cur != caller:
+            cur.wait_stream(caller)
+        for key in keys:
+            ev = self._h2d_ready.get(key)
+            if ev is not None:
+                cur.wait_event(ev)
+        im0, dp0 = self._images[keys[0]][0], self._images[keys[0]][1]
+        H, W = int(im0.shape[0]), int(im0.shape[1])
+        det = self._step_detections(pack, keys, per_roi, cams)
+        host = roi_host_arrays(self.cfg, det, H, W, sort_by_class=True)
+        while len(self._slots) <= k:
+            self._slots.append(None)
+        slot = self._slots[k]
+        if slot is None:
+            P = self.packer.rois_per_step       # a step of P ROIs touches at most P images
+            layout, total = packed_layout(host)
+            slot = dict(images=torch.zeros((P, H, W, 3), dtype=torch.uint8, device=dev),
+                        depths=torch.zeros((P, H, W), dtype=torch.float32, device=dev) if self._with_depth else None,
+                        packed=torch.zeros((total,), dtype=torch.uint8, device=dev),
+                        pinned=torch.zeros((total,), dtype=torch.uint8, pin_memory=True), layout=layout, graph=None)
+            self._slots[k] = slot
+        if slot["graph"] is not None and slot["graph"]._pending is not None:
+            slot["graph"]._pending.result()     # (cannot happen with max_in_flight <= streams; the pinned buffer must be free)
+        for i, key in enumerate(keys):          # device-to-device copies on the slot's stream (the images were produced / copied elsewhere)
+            im, dp = self._images[key][0], self._images[key][1]
+            im.record_stream(cur)
+            slot["images"][i].copy_(im, non_blocking=True)
+            if slot["depths"] is not None:
+                dp.record_stream(cur)
+                slot["depths"][i].copy_(dp, non_blocking=True)
+        fill_packed(slot["pinned"].numpy(), host, slot["layout"])
+        slot["packed"].copy_(slot["pinned"], non_blocking=True)
+        if self._time_h2d:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+        if slot["graph"] is None:
+            cfg, model, post = self.cfg, self.model, self.post
+
+            def body(static):
+                up = packed_views(static["packed"], slot["layout"])
+                batch = batch_from_uploaded(cfg, static["images"], static["depths"], up, dev)
+                return _step_closure(model, post, batch, batch["roi_id"])()
+
+            multi = len(self._dealer.streams) > 1
+            rule, rows = ((self._dealer.shared_min_tiles(), self._dealer.shared_min_rows()) if multi and hip_lib.shared_min_tiles() == 0
+                          else (None, None))
+            slot["graph"] = GraphedInference(model, post, dict(images=slot["images"], depths=slot["depths"], packed=slot["packed"]), None,
+                                             warmup=2, stream=cur, shared_min_tiles=rule, shared_min_rows=rows,
+                                             sharing=self._dealer.sharing(), body=body)
+        handle = slot["graph"].replay_async()
+        done = torch.cuda.Event()
+        done.record()
+        self._in_flight.append((handle, None, done))
+        if self._time_h2d:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()
+            self._step_timing.append((t0, t1))
+        self.steps_launched += 1
 
     def _launch_on_current_stream(self, pack, keys, per_roi, cams, caller) -> None:
         import numpy as np
@@ -1371,14 +1523,7 @@ class RoiStreamScheduler:
                     t.record_stream(cur)
         images = torch.stack([self._images[k][0] for k in keys])
         depths = torch.stack([self._images[k][1] for k in keys]) if self._with_depth else None
-        det = dict(
-            bbox=np.concatenate([per_roi(k, loc, "bbox", np.float32) for k, loc, _ in pack]),
-            roi_cls=np.concatenate([per_roi(k, loc, "roi_cls", np.int64) for k, loc, _ in pack]),
-            score=np.concatenate([per_roi(k, loc, "score", np.float32, np.ones) for k, loc, _ in pack]),
-            im_idx=np.concatenate([np.full(len(loc), i, np.int64) for i, (_, loc, _) in enumerate(pack)]),
-            roi_id=np.concatenate([ids for _, _, ids in pack]),
-            cam=np.concatenate([cams(k, loc) for k, loc, _ in pack]),
-            extents=self._images[keys[0]][2]["extents"])
+        det = self._step_detections(pack, keys, per_roi, cams)
         if self._time_h2d:
             t0 = torch.cuda.Event(enable_timing=True)
             t0.record()

@@ -363,3 +363,49 @@ def test_host_fed_images_report_when_their_pinned_source_may_be_overwritten(setu
     assert sorted(a) == sorted(b) == list(range(6))
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("host_fed", [False, True])
+def test_scheduler_with_graph_steps_returns_the_eager_schedulers_records(setup, host_fed):
+    """RoiStreamScheduler(graph_steps=True): every full step is a hipGraph replay of (GPU crop -> forward -> refine -> records) on
+    static image / per-ROI buffers, four steps in flight; the short tail step of flush() runs eagerly.  Per image the records
+    are those of the eager scheduler, bit for bit — from device images and from pinned host images; the slots are captured once."""
+    cfg, model, post, _ = setup
+    rng = np.random.default_rng(5)
+    g = torch.Generator(device=DEV).manual_seed(7)
+    ext = np.asarray(S.make_models(21, np.random.default_rng(11), 2)[2])
+    images = []
+    for i, n in enumerate([20, 7, 30, 0, 25, 13, 30, 4, 18, 29, 11, 30, 2, 16, 9, 22, 5, 27, 14, 30, 3, 19]):
+        det = S.make_detections(max(n, 1), 21, ext, rng)
+        x1y1 = det["roi_center"] - det["roi_wh"] / 2
+        d = dict(bbox=np.concatenate([x1y1, x1y1 + det["roi_wh"]], 1).astype(np.float32)[:n], roi_cls=det["roi_cls"][:n], score=det["score"][:n],
+                 cam=S.YCBV_K.astype(np.float32), extents=ext)
+        img = torch.randint(0, 256, (S.IM_H, S.IM_W, 3), dtype=torch.uint8, device=DEV, generator=g)
+        dep = torch.rand((S.IM_H, S.IM_W), device=DEV, generator=g) + 0.5
+        if host_fed:
+            img, dep = img.cpu().pin_memory(), dep.cpu().pin_memory()
+        images.append((f"s/{i}", img, dep, d))
+
+    def run(graph_steps, n_streams):
+        sch = engine.RoiStreamScheduler(cfg, model, post, rois_per_step=16, compute_streams=n_streams, graph_steps=graph_steps,
+                                        device=torch.device(DEV, 0))
+        out = {}
+        for key, img, dep, det in images:
+            for k, rec, _ in sch.push(key, img, dep, det):
+                out[k] = rec
+        for k, rec, _ in sch.flush():
+            out[k] = rec
+        torch.cuda.synchronize()
+        return out, sch
+
+    one, _ = run(False, 1)
+    for rep in range(2):
+        two, sch = run(True, 4)
+        assert len(sch._dealer.streams) == 4 and sch.max_in_flight == 4
+        slots = [s_ for s_ in sch._slots if s_ is not None]
+        assert len(slots) >= 4 and all(s_["graph"].captures == 1 and s_["graph"].foreign_launches == 0 for s_ in slots)
+        assert len({s_["graph"].stream for s_ in slots}) == 4
+        assert sorted(two) == sorted(one) == sorted(k for k, _, _, _ in images)
+        for k in one:
+            assert np.array_equal(one[k], two[k]), (rep, k)
+    assert all(np.isfinite(v).all() for v in one.values())
