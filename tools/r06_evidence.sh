@@ -31,6 +31,12 @@ S="--no-cpu-baseline --no-pmc"
 ( timeout 300 python bench.py --workload lmo_upnp --steps 30 --warmup 5 --no-pmc 2> $O/bench_lmo_upnp.err ) > $O/bench_lmo_upnp.json
 timeout 900 bash tools/bench_configs.sh $O/bench_configs.jsonl > $O/bench_configs.txt 2>&1
 timeout 900 bash tools/small_batch_lines.sh $O/small_batch.jsonl > $O/small_batch.md 2>&1
+# the image stream at the reference's own step sizes: eager scheduler (two streams) against graph-backed steps (four in flight)
+: > $O/stream_small_steps.jsonl
+for b in 8 16 32; do
+  python bench.py --workload stream --batch $b --steps 60 --warmup 4 $S --no-roofline-pass --no-other-mode-line 2>/dev/null | grep '^{' >> $O/stream_small_steps.jsonl
+  python bench.py --workload stream --graph --batch $b --steps 60 --warmup 4 $S --no-roofline-pass --no-other-mode-line 2>/dev/null | grep '^{' >> $O/stream_small_steps.jsonl
+done
 ( timeout 400 python tools/microbench_ops.py 2> $O/ops.err ) > $O/ops_microbench.json
 ( timeout 200 python tools/roi_align_variants.py 2>/dev/null ) > $O/roi_align_variants.jsonl
 ( timeout 400 python tools/b128_engine_errors.py 2>&1 | grep -v amdgpu.ids ) > $O/b128_engine_errors_vs_fp64.txt
