@@ -789,6 +789,9 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
             set_compute_streams(max(1, args.compute_streams))
 
     def after_warmup():
+        if stream is not None:
+            for s_ in stream["subs"]:
+                s_["sched"].latencies.clear()
         if stream is not None and stream.get("yolox") is not None:      # the warm-up's post-processing is not the timed region's
             torch.cuda.synchronize()
             stream["yolox"].update(events=[], host_s=0.0, images=0, dets=0)
@@ -831,7 +834,12 @@ def build_state(args, cfg_names, refine, wname, b, rank, dev, lo):
                                    "note": "whole process: hip_layers counts every layer that fell back to a PyTorch operator while the HIP path was on; "
                                            "a step that moves the counter inside a sharing dealer is repeated alone and the dealer drops to one stream"}
         if stream is not None:
+            lat = np.sort(np.concatenate([np.asarray(s_["sched"].latencies, np.float64) for s_ in stream["subs"]] or [np.zeros(0)])) * 1e3
             out["stream"] = {"images_per_s": None, "rois_per_image_mean": stream["rois_per_image"],
+                             "image_latency_ms": ({"p50": float(lat[len(lat) // 2]), "p95": float(lat[int(0.95 * (len(lat) - 1))]), "max": float(lat[-1]),
+                                                   "images": int(len(lat)),
+                                                   "note": "push() -> the image's records back on the host, timed region only: packing delay (waiting for "
+                                                           "enough ROIs to fill a step) + the steps in flight ahead of it + its own step"} if len(lat) else None),
                              "images_pushed": next(stream["counter"]), "rois_per_step": b,
                              "note": "value / rois_per_image_mean = images per second; ROI-granular packing, an image's ROIs may straddle two steps"}
         if do_cpu and not args.graph:

@@ -1396,6 +1396,7 @@ class RoiStreamScheduler:
         self._in_flight = collections.deque()   # (StepHandle, batch, done event) — the batch stays alive for a six-product repeat
         self._with_depth = None                 # fixed by the first image that has ROIs
         self._d2h_stream = None                 # side stream of the 8 KB record copies
+        self.latencies = collections.deque(maxlen=1 << 16)   # seconds from push to completed records, per image (newest 65 536)
         self.steps_launched = 0
 
     # -- one step ----------------------------------------------------------------------------------
@@ -1567,7 +1568,9 @@ class RoiStreamScheduler:
         import time
 
         now = time.perf_counter()
-        return [(k, r, now - self._arrival.pop(k)) for k, r in self.packer.pop_completed()]
+        done = [(k, r, now - self._arrival.pop(k)) for k, r in self.packer.pop_completed()]
+        self.latencies.extend(lat for _, r, lat in done if len(r))       # push -> records back on the host, images with ROIs
+        return done
 
     def _admit(self, key, image, depth, detections) -> None:
         import time
