@@ -831,3 +831,45 @@ def test_gather_records_dst_is_a_rank_of_the_group_gloo_world3():
     assert ret[0] is None and ret[1] is None
     got = ret[2]
     assert got.shape == (4, 16) and got[:, 14].tolist() == [10.0, 11.0, 20.0, engine.PAD_ROI_ID] and got[:, 15].tolist() == [1, 1, 1, 0]
+
+
+def test_packed_layout_is_fixed_by_shapes_and_fill_checks_them():
+    """RoiStreamScheduler(graph_steps=True) lays the per-ROI arrays of a step out ONCE (packed_layout) and refills the same pinned
+    buffer every step (fill_packed): the layout depends on shapes / dtypes only, arrays start on 16-byte boundaries, a step
+    with another ROI count is refused instead of silently overrunning, and packed_views of the buffer give the arrays back."""
+    rng = np.random.default_rng(0)
+
+    def arrays(n):
+        return dict(center64=rng.uniform(0, 640, (n, 2)), scale64=rng.uniform(10, 300, n), im_idx=rng.integers(0, 4, n).astype(np.int32),
+                    roi_cls=rng.integers(0, 21, n), roi_cam=np.tile(np.eye(3, dtype=np.float32), (n, 1, 1)),
+                    score=rng.uniform(0, 1, n).astype(np.float32), roi_id=np.arange(n, dtype=np.int32))
+
+    a, b = arrays(16), arrays(16)
+    la, ta = engine.packed_layout(a)
+    lb, tb = engine.packed_layout(b)
+    assert la == lb and ta == tb and all(off % 16 == 0 for off, _, _, _ in la.values())
+    buf = torch.zeros((ta,), dtype=torch.uint8)
+    engine.fill_packed(buf.numpy(), a, la)
+    got = engine.packed_views(buf, la)
+    assert all(np.array_equal(got[k].numpy(), a[k]) for k in a)
+    engine.fill_packed(buf.numpy(), b, la)                          # the same buffer, the next step
+    assert all(np.array_equal(engine.packed_views(buf, la)[k].numpy(), b[k]) for k in b)
+    with pytest.raises(ValueError, match="layout holds"):
+        engine.fill_packed(buf.numpy(), arrays(15), la)
+
+
+def test_roi_host_arrays_is_the_host_half_of_batch_data_test_gpu():
+    """roi_host_arrays: ROI parameters as read_data_test derives them + the class sort + the ids, as plain NumPy (no device): the
+    sorted order is stable, roi_id carries each detection's original position, per-class extents are looked up after the sort."""
+    from gdrnpp_bop2022_amd.gdrn_modeling.config import get_cfg
+
+    cfg = get_cfg("ycbv_convnext_a6")
+    ext = np.linspace(0.05, 0.25, 63, dtype=np.float32).reshape(21, 3)
+    det = dict(bbox=np.array([[10, 20, 110, 220], [300, 100, 360, 130], [50, 60, 70, 90], [200, 200, 400, 300]], np.float32),
+               roi_cls=np.array([7, 2, 7, 0]), score=np.array([0.9, 0.8, 0.7, 0.6], np.float32), im_idx=np.array([0, 0, 1, 1]),
+               cam=np.eye(3, dtype=np.float32), extents=ext)
+    h = engine.roi_host_arrays(cfg, det, 480, 640, sort_by_class=True, roi_id_base=100)
+    assert h["roi_cls"].tolist() == [0, 2, 7, 7] and h["roi_id"].tolist() == [103, 101, 100, 102] and h["im_idx"].tolist() == [1, 0, 0, 1]
+    assert np.array_equal(h["roi_extent"], ext[[0, 2, 7, 7]]) and h["roi_cam"].shape == (4, 3, 3)
+    assert np.allclose(h["scale64"], [min(200 * 1.5, 640), 60 * 1.5, 200 * 1.5, 30 * 1.5]) and h["center64"].dtype == np.float64
+    assert np.allclose(h["resize_ratio"], 64.0 / h["scale64"]) and h["roi_wh"].tolist() == [[200, 100], [60, 30], [100, 200], [20, 30]]
