@@ -207,6 +207,29 @@ def main():
                                               sample=f"{done} ROI crops (3 warps + normalisation each) of one 480x640 image, oracle/warp_oracle.c, {dt:.2f} s",
                                               note="scalar restatement of cv2.warpAffine's algorithm, not OpenCV itself (absent)")
 
+    # the same for the PnP stage of the TEST.USE_PNP branches: solvePnPRansac(EPNP, reprojErr 3, 100 iterations) on the 2D-3D
+    # correspondences of a ROI (misc.pnp_v2) — the oracle's NumPy restatement (oracle/epnp.py), not OpenCV
+    try:
+        from oracle import epnp as EP
+        prng = np.random.default_rng(20220925 + 9)
+        K_p = np.array([[1066.778, 0, 312.9869], [0, 1067.487, 241.3109], [0, 0, 1.0]])
+        probs = []
+        for _ in range(8):
+            pw = prng.uniform(-0.08, 0.08, (600, 3))
+            Rq, _ = np.linalg.qr(prng.standard_normal((3, 3)))
+            Rq = Rq * np.sign(np.linalg.det(Rq))
+            tq = np.array([prng.uniform(-0.1, 0.1), prng.uniform(-0.1, 0.1), prng.uniform(0.5, 1.2)])
+            cam_p = pw @ Rq.T + tq
+            uv = cam_p[:, :2] / cam_p[:, 2:] * np.array([K_p[0, 0], K_p[1, 1]]) + np.array([K_p[0, 2], K_p[1, 2]]) + prng.normal(0, 0.7, (600, 2))
+            uv[:60] += prng.uniform(-40, 40, (60, 2))                      # 10 % outliers
+            probs.append((pw, uv))
+        done, dt = _loop(lambda i: EP.solve_pnp_ransac_epnp(probs[i][0], probs[i][1], K_p, 3.0, 100), 8, share / 2, 2)
+        stages["pnp_ransac_epnp_port_1thread"] = dict(value=done / dt, unit="ROIs/s", cores=1, kind="port",
+                                                      sample=f"{done} RANSAC-EPnP solves (600 correspondences, 10 % outliers, 100 iterations max), oracle/epnp.py, {dt:.2f} s",
+                                                      note="NumPy restatement of cv2.solvePnPRansac(EPNP), not OpenCV itself (absent)")
+    except Exception as e:  # a baseline stage must not take the line down
+        stages["pnp_ransac_epnp_port_1thread"] = dict(value=None, note=repr(e))
+
     if args.forward_cfg:
         stages["forward_cpu_torch"] = forward_cpu_torch(args.forward_cfg, args.forward_seconds)
     top = dict(stages["refine_1thread"])
