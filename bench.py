@@ -334,7 +334,10 @@ def worker(args):
             rec = gather_records(pend.pop(0)(), b, dst=dst, single_rank_collective=args.force_dist)
         return rec
 
-    run_steps(max(args.warmup, 1) * len(cfg_names) * 2)   # MIOpen find, weight packing, first range verdicts, both batches of every model
+    n_warm = max(args.warmup, 1) * len(cfg_names) * 2      # MIOpen find, weight packing, first range verdicts, both batches of every model
+    if args.graph and state is not None:                  # ... and every hipGraph slot captured (the scheduler's graph steps: 2 x streams slots)
+        n_warm = max(n_warm, 2 * state["compute_streams"] + 2)
+    run_steps(n_warm)
     sync()
     if state is not None and state.get("after_warmup"):
         state["after_warmup"]()
